@@ -1,0 +1,386 @@
+"""CPU ORACLE for the PCGCv2 encode/decode hot path (numpy + oracle/libpcgc_oracle.so).
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg,
+never by the product package (pcgcv2_amd/).  Every function cites the reference lines it restates.
+
+Parity status (see also pcgc_oracle.c header and DESIGN.md):
+  pinned     entropy tables (G1), ordering/top-k (G2), PLY text (G3), D1 metric (G4), state-dict keys (G5)
+  unpinned   MinkowskiEngine conv/map/prune semantics, torchac range coder  (un-vendored third-party; restated)
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, 'libpcgc_oracle.so')
+
+
+def build():
+    subprocess.check_call(['make', '-s', '-C', _HERE])
+
+
+def _load():
+    if not os.path.exists(_SO):
+        build()
+    lib = C.CDLL(_SO)
+    i64, i32, vp = C.c_int64, C.c_int32, C.c_void_p
+    lib.orc_unique_first.restype = i64
+    lib.orc_unique_first.argtypes = [vp, i64, vp]
+    lib.orc_stride2_coords.restype = i64
+    lib.orc_stride2_coords.argtypes = [vp, i64, i32, vp, vp]
+    lib.orc_kmap_k3.argtypes = [vp, i64, i32, vp]
+    lib.orc_kmap_down.argtypes = [vp, i64, vp, i64, i32, vp]
+    lib.orc_children_coords.argtypes = [vp, i64, i32, vp]
+    lib.orc_conv_gather.argtypes = [vp, C.c_int, i64, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int]
+    lib.orc_conv_up2.argtypes = [i64, vp, C.c_int, vp, vp, vp, C.c_int]
+    lib.orc_likelihood.argtypes = [vp, C.c_int, C.c_float, C.c_float, vp]
+    lib.orc_cdf_float.argtypes = [vp, C.c_int, C.c_float, C.c_float, vp]
+    lib.orc_cdf_u16.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.orc_rc_encode.restype = i64
+    lib.orc_rc_encode.argtypes = [vp, C.c_int, C.c_int, vp, i64, vp, i64]
+    lib.orc_rc_decode.argtypes = [vp, C.c_int, C.c_int, vp, i64, vp, i64]
+    lib.orc_nn_sqdist_sum.restype = C.c_double
+    lib.orc_nn_sqdist_sum.argtypes = [vp, i64, vp, i64, vp]
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+# ------------------------------------------------------------------------------------------- coordinates
+def unique_first(coords):
+    """ME.SparseTensor dedup (data_utils.py:108,116): keep first occurrence, input order."""
+    coords = _c(coords, np.int32)
+    keep = np.zeros(len(coords), np.uint8)
+    lib().orc_unique_first(_p(coords), len(coords), _p(keep))
+    return coords[keep.astype(bool)]
+
+
+def stride2_coords(coords, stride_out):
+    coords = _c(coords, np.int32)
+    out = np.empty_like(coords)
+    parent = np.empty(len(coords), np.int32)
+    n = lib().orc_stride2_coords(_p(coords), len(coords), stride_out, _p(out), _p(parent))
+    return out[:n].copy(), parent
+
+
+def kmap_k3(coords, stride):
+    coords = _c(coords, np.int32)
+    nbr = np.empty((27, len(coords)), np.int32)
+    lib().orc_kmap_k3(_p(coords), len(coords), stride, _p(nbr))
+    return nbr
+
+
+def kmap_down(fine, coarse, stride_fine):
+    fine, coarse = _c(fine, np.int32), _c(coarse, np.int32)
+    nbr = np.empty((8, len(coarse)), np.int32)
+    lib().orc_kmap_down(_p(fine), len(fine), _p(coarse), len(coarse), stride_fine, _p(nbr))
+    return nbr
+
+
+def children_coords(coords, stride_in):
+    coords = _c(coords, np.int32)
+    out = np.empty((8 * len(coords), 4), np.int32)
+    lib().orc_children_coords(_p(coords), len(coords), stride_in, _p(out))
+    return out
+
+
+# ------------------------------------------------------------------------------------------- conv family
+def conv_gather(nbr, x, W, bias):
+    """out = fmaf-chain(k asc, ci asc) + bias.  W is ME's `kernel` [K,Cin,Cout] (2-D [Cin,Cout] for k=1)."""
+    x = _c(x, np.float32)
+    W = _c(W, np.float32)
+    if W.ndim == 2:
+        W = W[None]
+    K, Cin, Cout = W.shape
+    nbr = _c(nbr, np.int32)
+    n_out = nbr.shape[1]
+    out = np.empty((n_out, Cout), np.float32)
+    b = None if bias is None else _c(bias, np.float32).ravel()
+    lib().orc_conv_gather(_p(nbr), K, n_out, _p(x), Cin, x.shape[1], _p(W), None if b is None else _p(b), _p(out),
+                          Cout, Cout, 0)
+    return out
+
+
+def conv_k1(x, W, bias):
+    n = len(x)
+    return conv_gather(np.arange(n, dtype=np.int32)[None], x, W, bias)
+
+
+def conv_up2(x, W, bias):
+    x = _c(x, np.float32)
+    W = _c(W, np.float32)
+    K, Cin, Cout = W.shape
+    assert K == 8
+    out = np.empty((8 * len(x), Cout), np.float32)
+    b = None if bias is None else _c(bias, np.float32).ravel()
+    lib().orc_conv_up2(len(x), _p(x), Cin, _p(W), None if b is None else _p(b), _p(out), Cout)
+    return out
+
+
+def relu(x):
+    return np.maximum(x, np.float32(0))
+
+
+# ------------------------------------------------------------------------------------------- model (autoencoder.py)
+class Level:
+    """coords of one tensor stride + its cached k3 kernel map (ME caches kernel maps per coordinate key ‡)."""
+
+    def __init__(self, coords, stride):
+        self.C = _c(coords, np.int32)
+        self.stride = stride
+        self._k3 = None
+
+    @property
+    def k3(self):
+        if self._k3 is None:
+            self._k3 = kmap_k3(self.C, self.stride)
+        return self._k3
+
+    def __len__(self):
+        return len(self.C)
+
+
+def _conv3(sd, name, lvl, x):
+    return conv_gather(lvl.k3, x, sd[name + '.kernel'], sd[name + '.bias'])
+
+
+def _conv1(sd, name, x):
+    return conv_k1(x, sd[name + '.kernel'], sd[name + '.bias'])
+
+
+def inception_resnet(sd, name, lvl, x):
+    """autoencoder.py:52-57: cat(conv0_1(relu(conv0_0 x)), conv1_2(relu(conv1_1(relu(conv1_0 x))))) + x."""
+    out0 = _conv3(sd, name + '.conv0_1', lvl, relu(_conv3(sd, name + '.conv0_0', lvl, x)))
+    out1 = _conv1(sd, name + '.conv1_2', relu(_conv3(sd, name + '.conv1_1', lvl, relu(_conv1(sd, name + '.conv1_0', x)))))
+    return np.concatenate([out0, out1], axis=1) + x
+
+
+def _block(sd, name, lvl, x):
+    for i in range(3):                                   # make_layer(block_layers=3), autoencoder.py:59-66
+        x = inception_resnet(sd, f'{name}.{i}', lvl, x)
+    return x
+
+
+def _down(sd, name, fine, x):
+    cc, _ = stride2_coords(fine.C, fine.stride * 2)
+    coarse = Level(cc, fine.stride * 2)
+    nbr = kmap_down(fine.C, coarse.C, fine.stride)
+    return coarse, conv_gather(nbr, x, sd[name + '.kernel'], sd[name + '.bias'])
+
+
+def encoder_forward(sd, coords, feats, stride=1, prefix='encoder'):
+    """autoencoder.py:138-147.  Returns [(C8,F8), (C4,F4), (C2,F2)] like the reference's [out2,out1,out0]."""
+    l1 = Level(coords, stride)
+    x = relu(_conv3(sd, prefix + '.conv0', l1, feats))
+    l2, x = _down(sd, prefix + '.down0', l1, x)
+    out0 = _block(sd, prefix + '.block0', l2, relu(x))
+    x = relu(_conv3(sd, prefix + '.conv1', l2, out0))
+    l4, x = _down(sd, prefix + '.down1', l2, x)
+    out1 = _block(sd, prefix + '.block1', l4, relu(x))
+    x = relu(_conv3(sd, prefix + '.conv2', l4, out1))
+    l8, x = _down(sd, prefix + '.down2', l4, x)
+    out2 = _block(sd, prefix + '.block2', l8, relu(x))
+    out2 = _conv3(sd, prefix + '.conv3', l8, out2)
+    return [(l8.C, out2), (l4.C, out1), (l2.C, out0)]
+
+
+def topk_mask(vals, k):
+    """data_utils.py:77-89 istopk for one batch item; canonical tie rule: equal logits -> lower row index wins;
+    -0.0 == +0.0."""
+    v = np.asarray(vals, np.float32).ravel() + np.float32(0)
+    k = int(min(len(v), k))
+    order = np.argsort(-v, kind='stable')
+    mask = np.zeros(len(v), bool)
+    mask[order[:k]] = True
+    return mask
+
+
+def decoder_forward(sd, coords, feats, nums, stride=8, prefix='decoder', return_cls=False):
+    """autoencoder.py:251-273 with training=False: prune keeps the top-`nums[l]` logits (autoencoder.py:239-249);
+    ‡ MinkowskiPruning preserves row order."""
+    C_, x = _c(coords, np.int32), feats
+    cls_list = []
+    for l in range(3):
+        x = relu(conv_up2(x, sd[f'{prefix}.up{l}.kernel'], sd[f'{prefix}.up{l}.bias']))
+        lvl = Level(children_coords(C_, stride), stride // 2)
+        stride //= 2
+        x = relu(_conv3(sd, f'{prefix}.conv{l}', lvl, x))
+        x = _block(sd, f'{prefix}.block{l}', lvl, x)
+        cls = _conv3(sd, f'{prefix}.conv{l}_cls', lvl, x)
+        cls_list.append((lvl.C, cls))
+        mask = topk_mask(cls[:, 0], nums[l])
+        C_, x = lvl.C[mask], x[mask]
+    return (C_, x, cls_list) if return_cls else (C_, x)
+
+
+# ------------------------------------------------------------------------------------------- ordering (data_utils.py)
+def array2vector(array, step):
+    """data_utils.py:55-61."""
+    a = np.asarray(array).astype(np.int64)
+    step = int(step)
+    return sum(a[:, i] * (step ** i) for i in range(a.shape[-1]))
+
+
+def sort_zyx_perm(coords):
+    """data_utils.py:91-95 / coder.py:97-99: argsort of array2vector(C, C.max()+1)."""
+    coords = np.asarray(coords)
+    return np.argsort(array2vector(coords, coords.max() + 1), kind='stable')
+
+
+# ------------------------------------------------------------------------------------------- entropy model
+EB_SHAPES = [(8, 3, 1), (8, 3, 3), (8, 3, 3), (8, 1, 3)] + [(8, 3, 1)] * 3 + [(8, 1, 1)] + [(8, 3, 1)] * 3 + [(8, 1, 1)]
+EB_NAMES = [f'_matrices.{i}' for i in range(4)] + [f'_biases.{i}' for i in range(4)] + [f'_factors.{i}' for i in range(4)]
+
+
+def pack_eb_params(sd, prefix='entropy_bottleneck'):
+    return np.concatenate([_c(sd[f'{prefix}.{n}'], np.float32).ravel() for n in EB_NAMES])
+
+
+def likelihood(params, min_v, max_v):
+    L = int(max_v - min_v) + 1
+    out = np.empty((L, 8), np.float32)
+    params = _c(params, np.float32)
+    lib().orc_likelihood(_p(params), 8, float(min_v), float(max_v), _p(out))
+    return out
+
+
+def cdf_float(params, min_v, max_v):
+    L = int(max_v - min_v) + 1
+    out = np.empty((8, L + 1), np.float32)
+    params = _c(params, np.float32)
+    lib().orc_cdf_float(_p(params), 8, float(min_v), float(max_v), _p(out))
+    return out
+
+
+def cdf_u16(cdf):
+    cdf = _c(cdf, np.float32)
+    out = np.empty(cdf.shape, np.uint16)
+    lib().orc_cdf_u16(_p(cdf), cdf.shape[0], cdf.shape[1], _p(out))
+    return out
+
+
+def rc_encode(cdf16, sym):
+    cdf16 = _c(cdf16, np.uint16)
+    sym = _c(sym, np.int16).ravel()
+    cap = 4 * sym.size + 64
+    buf = np.empty(cap, np.uint8)
+    n = lib().orc_rc_encode(_p(cdf16), cdf16.shape[0], cdf16.shape[1], _p(sym), sym.size, _p(buf), cap)
+    assert n <= cap
+    return buf[:n].tobytes()
+
+
+def rc_decode(cdf16, data, n):
+    cdf16 = _c(cdf16, np.uint16)
+    src = np.frombuffer(data, np.uint8)
+    out = np.empty(n, np.int16)
+    lib().orc_rc_decode(_p(cdf16), cdf16.shape[0], cdf16.shape[1], _p(src), len(src), _p(out), n)
+    return out
+
+
+def eb_compress(params, feats):
+    """entropy_model.py:151-176.  Returns (bytes, min_v, max_v)."""
+    values = np.rint(np.asarray(feats, np.float32))              # torch.round == half-to-even
+    min_v, max_v = np.float32(values.min() + 0.0), np.float32(values.max() + 0.0)
+    sym = (values - min_v).astype(np.int16)
+    table = cdf_u16(cdf_float(params, min_v, max_v))
+    return rc_encode(table, sym), min_v, max_v
+
+
+def eb_decompress(params, data, min_v, max_v, shape):
+    """entropy_model.py:178-196."""
+    table = cdf_u16(cdf_float(params, min_v, max_v))
+    n = int(shape[0]) * int(shape[1])
+    return rc_decode(table, data, n).reshape(int(shape[0]), int(shape[1])).astype(np.float32) + np.float32(min_v)
+
+
+def header_bytes(shape, min_v, max_v):
+    """coder.py:51-55: int32[2] shape | int8 len(min_v)=1 | float32 min_v | float32 max_v  (17 bytes)."""
+    return (np.array(shape, np.int32).tobytes() + np.array(1, np.int8).tobytes() +
+            np.array([min_v], np.float32).tobytes() + np.array([max_v], np.float32).tobytes())
+
+
+# ------------------------------------------------------------------------------------------- Coder (coder.py:80-112)
+def encode(sd, coords):
+    """coder.py:80-91 minus the external tmc3 step.  coords: int32 [N,4] (deduped, stride 1).
+    Returns dict(F=bytes, H=bytes, num_points=bytes, coords8=int [N8,3] (y.C // 8 sorted z-major), yC, yF)."""
+    feats = np.ones((len(coords), 1), np.float32)
+    (c8, f8), (c4, _), (c2, _) = encoder_forward(sd, coords, feats)
+    perm = sort_zyx_perm(c8)
+    c8, f8 = c8[perm], f8[perm]
+    num_points = np.array([len(c4), len(c2), len(coords)], np.int32)
+    params = pack_eb_params(sd)
+    strings, min_v, max_v = eb_compress(params, f8)
+    return dict(F=strings, H=header_bytes(f8.shape, min_v, max_v), num_points=num_points.tobytes(),
+                coords8=(c8 // 8)[:, 1:].copy(), yC=c8, yF=f8)
+
+
+def decode(sd, coords8, F, H, num_points, rho=1.0):
+    """coder.py:93-112 minus tmc3.  coords8: int [N8,3] in any order."""
+    yC = np.concatenate([np.zeros((len(coords8), 1), np.int32), np.asarray(coords8, np.int32)], 1)
+    yC = yC[sort_zyx_perm(yC)]
+    shape = np.frombuffer(H[:8], np.int32)
+    assert np.frombuffer(H[8:9], np.int8)[0] == 1
+    min_v = np.frombuffer(H[9:13], np.float32)[0]
+    max_v = np.frombuffer(H[13:17], np.float32)[0]
+    yF = eb_decompress(pack_eb_params(sd), F, min_v, max_v, shape)
+    nums = np.frombuffer(num_points[:12], np.int32).tolist()
+    nums[-1] = int(rho * nums[-1])
+    outC, _ = decoder_forward(sd, yC * 8, yF, nums)
+    return outC
+
+
+# ------------------------------------------------------------------------------------------- PLY (data_utils.py:19-48)
+def read_ply_ascii_geo(path):
+    data = []
+    with open(path) as f:
+        for line in f:
+            words = line.split(' ')
+            try:
+                vals = [float(w) for w in words if w != '\n']
+            except ValueError:
+                continue
+            data.append(vals)
+    return np.array(data)[:, 0:3].astype('int')
+
+
+def ply_ascii_bytes(coords):
+    coords = np.asarray(coords).astype('int')
+    head = 'ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nend_header\n' % len(coords)
+    return (head + ''.join('%d %d %d\n' % (p[0], p[1], p[2]) for p in coords)).encode()
+
+
+# ------------------------------------------------------------------------------------------- D1 (pc_error.py:27-74)
+def d1_metrics(a, b, res):
+    """mpeg-pcc-dmetric 0.13.4 ‡ point-to-point: mse1 = mean_a min_b |a-b|^2, mse2 the reverse, mseF = max,
+    PSNR = 10 log10(3 * peak^2 / mse), peak = res-1 (pc_error.py:49 passes --resolution=res-1)."""
+    a = _c(a, np.int32)
+    b = _c(b, np.int32)
+    if len(a) * len(b) <= 4e8:
+        s1 = lib().orc_nn_sqdist_sum(_p(a), len(a), _p(b), len(b), None)
+        s2 = lib().orc_nn_sqdist_sum(_p(b), len(b), _p(a), len(a), None)
+    else:
+        from scipy.spatial import cKDTree
+        s1 = float((cKDTree(b).query(a)[0] ** 2).sum())
+        s2 = float((cKDTree(a).query(b)[0] ** 2).sum())
+    mse1, mse2 = s1 / len(a), s2 / len(b)
+    mse = max(mse1, mse2)
+    peak = float(res - 1)
+    psnr = lambda m: 10 * np.log10(3 * peak * peak / m) if m > 0 else float('inf')
+    return dict(mse1=mse1, mse2=mse2, mseF=mse, psnr1=psnr(mse1), psnr2=psnr(mse2), psnrF=psnr(mse))

@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the reference implementation.
+
+Runs ONLY in the authoring container (needs /root/reference).  The reference's Python
+never travels: this script imports the importable slices of it (with empty stub modules
+for the un-installed third-party packages MinkowskiEngine / torchac / h5py), feeds them
+seeded inputs and stores inputs + outputs as small .npz / .txt data files.
+
+Fixtures:
+  G1 entropy_tables.npz   EntropyBottleneck params -> _likelihood / pmf / cdf   (entropy_model.py:82-149)
+  G2 ordering.npz         array2vector keys / argsort, istopk masks            (data_utils.py:55-89)
+  G3 ply_format.npz       bytes written by write_ply_ascii_geo + read-back     (data_utils.py:19-48)
+  G4 d1_metric.npz        pc_error_d (mpeg-pcc-dmetric 0.13.4) outputs         (pc_error.py:27-74)
+  G5 state_dict_keys.txt  EntropyBottleneck state_dict names / shapes          (entropy_model.py:59-80)
+"""
+import os, sys, types, shutil, subprocess, tempfile
+import numpy as np
+import torch
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+for name in ('torchac', 'h5py', 'MinkowskiEngine'):
+    sys.modules.setdefault(name, types.ModuleType(name))
+sys.path.insert(0, REF)
+import entropy_model as ref_em      # noqa: E402
+import data_utils as ref_du         # noqa: E402
+import pc_error as ref_pe           # noqa: E402
+
+
+def pack_params(eb):
+    """Flatten the 12 unique parameter tensors in a fixed order: matrices 0..3, biases 0..3, factors 0..3."""
+    parts = []
+    for lst in (eb._matrices, eb._biases, eb._factors):
+        for p in lst:
+            parts.append(p.detach().numpy().astype(np.float32).ravel())
+    return np.concatenate(parts)
+
+
+def g1():
+    cases = {}
+    for ci, (seed, perturb, lo, hi) in enumerate([(1234, False, -8, 9), (7, True, -20, 20), (99, True, -3, 2),
+                                                  (5, True, 0, 0), (11, True, -40, 37)]):
+        np.random.seed(seed); torch.manual_seed(seed)
+        eb = ref_em.EntropyBottleneck(8)
+        if perturb:
+            with torch.no_grad():
+                for f in eb._factors:
+                    f.copy_(torch.empty_like(f).uniform_(-0.5, 0.5))
+                for m in eb._matrices:
+                    m.add_(torch.empty_like(m).uniform_(-0.3, 0.3))
+        min_v = torch.tensor(float(lo)); max_v = torch.tensor(float(hi))
+        symbols = torch.arange(min_v, max_v + 1).reshape(-1, 1).repeat(1, 8)
+        with torch.no_grad():
+            lik = eb._likelihood(symbols)                           # [L,8]
+            pmf = torch.clamp(lik, min=eb._likelihood_bound).permute(1, 0)
+            cdf = eb._pmf_to_cdf(pmf)                               # [8,L+1]
+        cases[f'c{ci}_params'] = pack_params(eb)
+        cases[f'c{ci}_minmax'] = np.array([lo, hi], np.float32)
+        cases[f'c{ci}_likelihood'] = lik.numpy()
+        cases[f'c{ci}_pmf'] = pmf.contiguous().numpy()
+        cases[f'c{ci}_cdf'] = cdf.contiguous().numpy()
+        if ci == 0:
+            with open(os.path.join(OUT, 'state_dict_keys.txt'), 'w') as f:
+                for k, v in eb.state_dict().items():
+                    f.write(f'{k} {list(v.shape)}\n')
+    cases['n_cases'] = np.array(5)
+    np.savez_compressed(os.path.join(OUT, 'entropy_tables.npz'), **cases)
+
+
+class _Duck:
+    """duck-typed stand-in for the ME.SparseTensor attributes istopk touches (data_utils.py:77-89)."""
+    def __init__(self, F):
+        self.F = F; self.device = F.device
+        self._batchwise_row_indices = [torch.arange(len(F))]
+    def __len__(self): return len(self.F)
+
+
+def g2():
+    rng = np.random.default_rng(2024)
+    out = {}
+    for i, (n, hi) in enumerate([(257, 128), (1000, 1024), (5000, 64)]):
+        c = rng.integers(0, hi, size=(n, 3)).astype(np.int32)
+        c = np.unique(c, axis=0); rng.shuffle(c)
+        c4 = np.concatenate([np.zeros((len(c), 1), np.int32), c], 1)
+        t = torch.tensor(c4)
+        key = ref_du.array2vector(t, t.max() + 1)
+        out[f's{i}_coords'] = c4
+        out[f's{i}_key'] = key.numpy()
+        out[f's{i}_argsort'] = np.argsort(key.numpy())
+    for i, (n, k) in enumerate([(64, 10), (1000, 391), (4096, 4096), (333, 1)]):
+        v = rng.permutation(n).astype(np.float32) * 0.37 - 50.0      # tie-free
+        m = ref_du.istopk(_Duck(torch.tensor(v).reshape(-1, 1)), [k])
+        out[f't{i}_vals'] = v; out[f't{i}_k'] = np.array(k); out[f't{i}_mask'] = m.numpy()
+    np.savez_compressed(os.path.join(OUT, 'ordering.npz'), **out)
+
+
+def g3():
+    rng = np.random.default_rng(3)
+    c = rng.integers(0, 1024, size=(37, 3)).astype(np.int64)
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, 'a.ply')
+        ref_du.write_ply_ascii_geo(p, c)
+        raw = open(p, 'rb').read()
+        back = ref_du.read_ply_ascii_geo(p)
+        # a PLY with extra header lines and float-formatted coords, as 8iVFB files have
+        p2 = os.path.join(d, 'b.ply')
+        with open(p2, 'w') as f:
+            f.write('ply\nformat ascii 1.0\ncomment made by hand\nelement vertex 3\nproperty float x\n'
+                    'property float y\nproperty float z\nproperty uchar red\nend_header\n'
+                    '1.000 2.000 3.000 255\n10 20 30 0\n7.0 8.0 9.0 1\n')
+        raw2 = open(p2, 'rb').read()
+        back2 = ref_du.read_ply_ascii_geo(p2)
+    np.savez_compressed(os.path.join(OUT, 'ply_format.npz'), coords=c, file_bytes=np.frombuffer(raw, np.uint8),
+                        read_back=back, file2_bytes=np.frombuffer(raw2, np.uint8), read_back2=back2)
+
+
+def g4():
+    rng = np.random.default_rng(4)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, 'pc_error_d'); shutil.copy(os.path.join(REF, 'pc_error_d'), exe); os.chmod(exe, 0o755)
+        ref_pe.rootdir = d
+        for i, (n, res, drop, jit) in enumerate([(2000, 64, 1, 0.3), (5000, 1024, 50, 0.5), (3000, 1024, 0, 0.0),
+                                                 (4000, 256, 400, 0.8)]):
+            a = np.unique(rng.integers(0, res, size=(n, 3)), axis=0)
+            b = a.copy()
+            if drop: b = np.delete(b, rng.choice(len(b), drop, replace=False), 0)
+            mv = rng.random(len(b)) < jit
+            b[mv] = np.clip(b[mv] + rng.integers(-2, 3, size=(mv.sum(), 3)), 0, res - 1)
+            b = np.unique(b, axis=0)
+            pa, pb = os.path.join(d, f'a{i}.ply'), os.path.join(d, f'b{i}.ply')
+            ref_du.write_ply_ascii_geo(pa, a); ref_du.write_ply_ascii_geo(pb, b)
+            df = ref_pe.pc_error(pa, pb, res=res)
+            out[f'p{i}_a'] = a.astype(np.int32); out[f'p{i}_b'] = b.astype(np.int32); out[f'p{i}_res'] = np.array(res)
+            for key in ('mse1      (p2point)', 'mse2      (p2point)', 'mseF      (p2point)', 'mseF,PSNR (p2point)',
+                        'mse1,PSNR (p2point)', 'mse2,PSNR (p2point)', 'h.        (p2point)'):
+                out[f'p{i}_' + key.replace(' ', '').replace(',', '_')] = np.array(df[key][0])
+    out['n_cases'] = np.array(4)
+    np.savez_compressed(os.path.join(OUT, 'd1_metric.npz'), **out)
+
+
+if __name__ == '__main__':
+    g1(); g2(); g3(); g4()
+    print('golden fixtures written to', OUT)
