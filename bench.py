@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — encode+decode throughput of the PCGCv2 hot path on MI355X.
+
+Metric (BASELINE.json): encode+decode Mpoints/s at fixed rate (r3 stand-in: synthetic weights), vox10 frame.
+A "step" = one full `Coder.encode` + `Coder.decode` of one vox10 frame per GPU (shell10, 786 632 points — the synthetic
+stand-in for longdress_vox10_1300.ply; real PLYs / checkpoints are external downloads), including the four bitstream
+files, exactly what coder.py:155-162 brackets.  The input coordinates are resident in HBM when the timer starts; all
+coordinate maps / kernel maps are rebuilt inside every step (nothing cached across steps).
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); frames are independent, so ranks shard
+frames with no data-path collective ("weak" scaling: 1 frame per GPU per step); the only collective is the final
+5-scalar all-reduce (bits, N_in, N_out, time) after the timed region.
+
+JSON line: see the round contract; extra objects `roofline` (dominant kernel = the k3 sparse-conv gather) and
+`cpu_baseline` (the CPU oracle timed on this host, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='shell10')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', default='shell9', help='bounded sample of the same workload for the CPU oracle')
+    ap.add_argument('--detail', default='', help='optional path for a per-kernel-shape JSON breakdown')
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f'bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks', file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from pcgcv2_amd import synthetic, ops
+    from pcgcv2_amd.pcc_model import PCCModel
+    from pcgcv2_amd.coder import Coder
+    from pcgcv2_amd.sparse import SparseTensor
+
+    # ---- inputs: one frame per rank (distinct clouds per rank, like the 8iVFB 4-sequence config) ----
+    variants = [args.workload] + [args.workload + s for s in ('_b', '_c', '_d') if args.workload + s in synthetic.SHELLS]
+    name = variants[rank % len(variants)]
+    pts = synthetic.shell(name, device=dev)
+    coords = torch.cat([torch.zeros((len(pts), 1), dtype=torch.int32, device=dev), pts], 1).contiguous()
+    feats = torch.ones((len(pts), 1), dtype=torch.float32, device=dev)
+    n_points = len(pts)
+    sd = synthetic.synthetic_state_dict()
+    model = PCCModel().to(dev)
+    model.load_state_dict(sd)
+    tmp = tempfile.mkdtemp(prefix=f'pcgc_bench_r{rank}_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+    coder = Coder(model, os.path.join(tmp, 'frame'))
+
+    def step():
+        x = SparseTensor(feats, coordinates=coords, tensor_stride=1, device=dev)     # rebuilds hash + dedup each step
+        coder.encode(x)
+        out = coder.decode()
+        return out
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    n_out = len(out)
+    bits = sum(os.path.getsize(os.path.join(tmp, 'frame' + p)) * 8 for p in ('_C.bin', '_F.bin', '_H.bin', '_num_points.bin'))
+
+    # ---- timed region: exactly K steps, with the dominant kernel bracketed by HIP events on its own stream ----
+    ops.PROFILE.reset(enabled=True)
+    barrier()
+    t0 = time.perf_counter()
+    enc_t = dec_t = 0.0
+    for _ in range(args.steps):
+        x = SparseTensor(feats, coordinates=coords, tensor_stride=1, device=dev)
+        a = time.perf_counter()
+        coder.encode(x)
+        torch.cuda.synchronize()
+        b = time.perf_counter()
+        coder.decode()
+        torch.cuda.synchronize()
+        c = time.perf_counter()
+        enc_t += b - a; dec_t += c - b
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.PROFILE.enabled = False
+    ops.PROFILE.counting = True          # untimed analysis pass: count kernel-map pairs per level for the byte formula
+    step()
+    ops.PROFILE.counting = False
+    torch.cuda.synchronize()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([float(n_points), float(n_out), float(bits)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_points, total_out, total_bits = [float(v) for v in tot.tolist()]
+    else:
+        total_points, total_out, total_bits = float(n_points), float(n_out), float(bits)
+
+    roof = ops.PROFILE.summary(HBM_PEAK_GBS)
+    if rank == 0:
+        value = total_points * args.steps / elapsed / 1e6
+        line = {
+            'metric': 'encode+decode Mpoints/sec at fixed bpp (r3 ckpt), vox10 frame',
+            'value': round(value, 4), 'unit': 'Mpoints/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.workload}: perturbed-sphere vox10 frame, {n_points} points/GPU, synthetic r3 stand-in '
+                                   f'weights (seed 1234, gain 50), 1 frame per GPU per step, encode+decode incl. bitstream files',
+                       'points_per_gpu': n_points, 'enc_ms': round(enc_t / args.steps * 1e3, 3),
+                       'dec_ms': round(dec_t / args.steps * 1e3, 3), 'bpp': round(total_bits / total_points, 5),
+                       'points_out': int(total_out), 'coord_codec': 'native-octree (tmc3 absent)'},
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.cpu_sample, sd)
+        if args.detail:
+            with open(args.detail, 'w') as f:
+                json.dump(ops.PROFILE.detail(), f, indent=1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sample, sd):
+    """The CPU oracle (oracle/: C restatement, OpenMP over output rows) on a bounded sample of the same workload.
+    kind = "port": MinkowskiEngine's CPU backend cannot be installed here (no network, un-vendored)."""
+    from pcgcv2_amd import synthetic
+    from oracle import pcgc_oracle as orc
+    sd_np = synthetic.state_dict_to_numpy(sd)
+    c = synthetic.shell(sample).numpy()
+    c4 = np.concatenate([np.zeros((len(c), 1), np.int32), c], 1)
+    t0 = time.perf_counter()
+    enc = orc.encode(sd_np, c4)
+    out = orc.decode(sd_np, enc['coords8'], enc['F'], enc['H'], enc['num_points'])
+    dt = time.perf_counter() - t0
+    assert len(out) == len(c4)
+    return {'value': round(len(c4) / dt / 1e6, 5), 'unit': 'Mpoints/s', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': f'{sample} ({len(c4)} points, one encode+decode, {dt:.1f} s; oracle C restatement with OpenMP on all cores; '
+                      'NOT MinkowskiEngine-CPU)'}
+
+
+if __name__ == '__main__':
+    main()

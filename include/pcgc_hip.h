@@ -1,0 +1,125 @@
+/*
+ * pcgc_hip.h — C-ABI of libpcgc_hip.so: the MI355X (gfx950) native operators under PCGCv2's encode/decode path.
+ *
+ * The reference (NJUVISION/PCGCv2) has no FFI layer of its own: its native code is reached through
+ * `import MinkowskiEngine` and `import torchac`.  Each entry point below replaces one of those Python->native call
+ * sites (cited as reference file:line); INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *   - every pointer marked [dev] is a device buffer owned by the caller (PyTorch-ROCm's allocator in our host code);
+ *     [host] is host memory.  The library never allocates a result the caller must free.
+ *   - variable-size results are two-phase: a count comes back through a [dev] int32, the caller sizes the output.
+ *   - `stream` is a hipStream_t passed as void*; every device call is asynchronous on that stream.
+ *   - return value: 0 = OK, <0 = error (message via pcgc_last_error()).
+ *   - coordinates: int32 [N,4] rows (batch, x, y, z), 0 <= x,y,z < 2^20, 0 <= batch < 16  (ME.SparseTensor.C layout).
+ *   - features: fp32 row-major, leading dimension given explicitly (`*_ld`, in floats) so concat / slices are views.
+ *   - kernel maps: int32 [K][N_out], entry = input row feeding output row o through kernel offset k, or -1.
+ *     offset order: k3 -> (k%3-1, (k/3)%3-1, k/9-1)*stride ; k2 -> (k&1, (k>>1)&1, k>>2)*stride  (x fastest, ME ‡).
+ *   - canonical arithmetic: out = ( fp32 fmaf chain over k ascending, ci ascending, from +0 ) + bias ; then
+ *     + residual ; then ReLU.   Bit-identical to oracle/pcgc_oracle.c.
+ */
+#ifndef PCGC_HIP_H
+#define PCGC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* pcgc_last_error(void);
+int pcgc_version(void);
+
+/* ---- coordinate hash map: replaces ME's CoordinateManager / coordinate map (ME.SparseTensor ctor at
+ *      data_utils.py:96,108,116 and coder.py:102).  Open addressing, 64-slot spatial blocks (4x4x4 voxels). ---- */
+int64_t pcgc_hash_capacity(int64_t n);                                   /* slots needed for n coordinates (pow2) */
+int pcgc_hash_clear(uint64_t* keys /*[dev cap]*/, int32_t* vals /*[dev cap]*/, int64_t cap, void* stream);
+/* `stride` = tensor stride of the level the table indexes (the spatial blocking works on the level's own lattice);
+ * insert, first_mask and the kmap builders of one table must all be given the same stride. */
+int pcgc_hash_insert(const int32_t* coords /*[dev n,4]*/, int64_t n, int32_t stride, uint64_t* keys, int32_t* vals,
+                     int64_t cap, void* stream);                         /* vals[slot] = smallest row with that key */
+int pcgc_hash_first_mask(const int32_t* coords, int64_t n, int32_t stride, const uint64_t* keys, const int32_t* vals,
+                         int64_t cap, uint8_t* keep /*[dev n]*/, void* stream);  /* keep[i] = row i is the first occurrence */
+
+/* ---- coordinate transforms ---- */
+/* output coords of MinkowskiConvolution(kernel_size=2, stride=2): floor(c / stride_out) * stride_out per row
+ * (autoencoder.py:78-84,97-103,116-122); dedup with the hash calls above. */
+int pcgc_coords_quantize(const int32_t* coords, int64_t n, int32_t stride_out, int32_t* out /*[dev n,4]*/, void* stream);
+/* output coords of MinkowskiGenerativeConvolutionTranspose(k=2,s=2): row 8*i+k = c_i + (k&1,(k>>1)&1,k>>2)*stride_in/2
+ * (autoencoder.py:155-161,182-188,209-215). */
+int pcgc_coords_children(const int32_t* coords, int64_t n, int32_t stride_in, int32_t* out /*[dev 8n,4]*/, void* stream);
+/* scale_sparse_tensor: round_half_even(float32(c) * float32(factor)) (data_utils.py:112-118); batch column kept. */
+int pcgc_coords_scale(const int32_t* coords, int64_t n, float factor, int32_t* out /*[dev n,4]*/, void* stream);
+
+/* ---- stream compaction (MinkowskiPruning, autoencoder.py:237,247; also dedup) ---- */
+size_t pcgc_scan_workspace_bytes(int64_t n);
+/* prefix[i] = number of set mask bytes before i; *total = number set. */
+int pcgc_mask_scan(const uint8_t* mask /*[dev n]*/, int64_t n, int32_t* prefix /*[dev n]*/, int32_t* total /*[dev 1]*/,
+                   void* workspace /*[dev]*/, size_t workspace_bytes, void* stream);
+int pcgc_compact_coords(const int32_t* coords, const uint8_t* mask, const int32_t* prefix, int64_t n,
+                        int32_t* out /*[dev total,4]*/, void* stream);
+int pcgc_compact_feats(const float* in, int C, int in_ld, const uint8_t* mask, const int32_t* prefix, int64_t n,
+                       float* out /*[dev total,C]*/, void* stream);
+
+/* ---- kernel maps (ME kernel maps, built once per coordinate level and reused by every conv on it) ---- */
+int pcgc_kmap_k3(const int32_t* coords, int64_t n, int32_t stride, const uint64_t* keys, const int32_t* vals,
+                 int64_t cap, int32_t* nbr /*[dev 27,n]*/, void* stream);
+int pcgc_kmap_down(const int32_t* coarse, int64_t n_coarse, int32_t stride_fine, const uint64_t* fine_keys,
+                   const int32_t* fine_vals, int64_t fine_cap, int32_t* nbr /*[dev 8,n_coarse]*/, void* stream);
+
+/* ---- sparse convolution family ---- */
+/* Gather convolution: MinkowskiConvolution k=3,s=1 (K=27), k=2,s=2 (K=8), k=1 (K=1, nbr may be NULL = identity)
+ * (autoencoder.py:13-48,71-134,162-234).  W = ME `kernel` [K,Cin,Cout]; bias [Cout] or NULL;
+ * residual (same row, columns res_coff..) or NULL (SparseTensor.__add__, autoencoder.py:55); relu = MinkowskiReLU. */
+int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const float* in, int Cin, int in_ld, int in_coff,
+                     const float* W, const float* bias, const float* residual, int res_ld, int res_coff, int relu,
+                     float* out, int Cout, int out_ld, int out_coff, void* stream);
+/* MinkowskiGenerativeConvolutionTranspose(k=2,s=2): out[8i+k] = in[i] @ W[k] + bias (+ReLU). */
+int pcgc_conv_up2(int64_t n_in, const float* in, int Cin, int in_ld, const float* W /*[8,Cin,Cout]*/, const float* bias,
+                  int relu, float* out /*[dev 8n,Cout]*/, int Cout, void* stream);
+
+/* ---- top-k pruning mask: istopk (data_utils.py:77-89).  mask[i]=1 for the k largest logits;
+ *      ties -> lower row index; -0.0 == +0.0. ---- */
+size_t pcgc_topk_workspace_bytes(int64_t n);
+int pcgc_topk_mask(const float* logits /*[dev n], stride ld*/, int ld, int64_t n, int64_t k, uint8_t* mask /*[dev n]*/,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- canonical ordering: sort_spare_tensor / array2vector (data_utils.py:55-61,91-101; coder.py:97-99):
+ *      perm = argsort of (z, y, x, batch) most-significant first. ---- */
+size_t pcgc_sort_workspace_bytes(int64_t n);
+int pcgc_sort_zyx(const int32_t* coords, int64_t n, int32_t* perm /*[dev n]*/, void* workspace, size_t workspace_bytes,
+                  void* stream);
+int pcgc_gather_rows_i32x4(const int32_t* in, const int32_t* perm, int64_t n, int32_t* out, void* stream);
+int pcgc_gather_rows_f32(const float* in, int C, const int32_t* perm, int64_t n, float* out, void* stream);
+
+/* ---- factorized entropy bottleneck (entropy_model.py:82-196) ---- */
+/* values = round_half_even(feats); minmax[0]=min, minmax[1]=max (fp32, -0 canonicalised to +0). */
+int pcgc_round_minmax(const float* feats, int64_t count, float* minmax /*[dev 2]*/, void* stream);
+/* sym = int16(round(feats) - min_v)  (entropy_model.py:161-163). */
+int pcgc_symbolize(const float* feats, int64_t count, float min_v, int16_t* sym /*[dev count]*/, void* stream);
+/* feats = float(sym) + min_v  (entropy_model.py:193-194). */
+int pcgc_desymbolize(const int16_t* sym, int64_t count, float min_v, float* feats, void* stream);
+/* fused CDF table: _likelihood -> clamp(1e-9) -> cumsum -> clamp(1) -> torchac 16-bit normalisation
+ * (entropy_model.py:112-149,165-170 + torchac ‡).  params: 352 fp32 packed matrices|biases|factors.
+ * cdf_u16 [C, L+1], L = max_v-min_v+1.  cdf_f32 (optional, may be NULL) receives the fp32 cdf [C, L+1]. */
+int pcgc_cdf_table(const float* params /*[dev 352]*/, int C, float min_v, float max_v, uint16_t* cdf_u16 /*[dev]*/,
+                   float* cdf_f32 /*[dev] or NULL*/, void* stream);
+
+/* ---- range coder, bit-compatible with torchac 0.9.3 ‡ encode_float_cdf / decode_float_cdf
+ *      (entropy_model.py:174,192).  HOST functions; symbols row-major [point, channel], one CDF row per channel. ---- */
+int64_t pcgc_rc_encode(const uint16_t* cdf /*[host C,Lp]*/, int C, int Lp, const int16_t* sym /*[host n]*/, int64_t n,
+                       uint8_t* out /*[host cap]*/, int64_t cap);          /* returns bytes, or -needed if cap too small */
+int pcgc_rc_decode(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int64_t nbytes, int16_t* sym, int64_t n);
+
+/* ---- native lossless coordinate codec for _C.bin when the external tmc3 binary (gpcc.py:6-41) is absent.
+ *      Occupancy-octree + adaptive range coder.  NOT interoperable with G-PCC; flagged by its magic "PCGO". HOST. ---- */
+int64_t pcgc_oct_encode(const int32_t* xyz /*[host n,3]*/, int64_t n, uint8_t* out, int64_t cap);   /* bytes or -needed */
+int64_t pcgc_oct_decode_count(const uint8_t* in, int64_t nbytes);                                   /* points or <0 */
+int pcgc_oct_decode(const uint8_t* in, int64_t nbytes, int32_t* xyz /*[host n,3]*/, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCGC_HIP_H */

@@ -1,0 +1,73 @@
+"""ctypes binding of libpcgc_hip.so (include/pcgc_hip.h).  There is NO fallback: if the HIP library is missing or a
+call fails, the product raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpcgc_hip.so')
+
+vp, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
+ci = C.c_int
+
+# name -> (restype, argtypes); mirrors include/pcgc_hip.h one to one
+SIGNATURES = {
+    'pcgc_last_error': (C.c_char_p, []),
+    'pcgc_version': (ci, []),
+    'pcgc_hash_capacity': (i64, [i64]),
+    'pcgc_hash_clear': (ci, [vp, vp, i64, vp]),
+    'pcgc_hash_insert': (ci, [vp, i64, i32, vp, vp, i64, vp]),
+    'pcgc_hash_first_mask': (ci, [vp, i64, i32, vp, vp, i64, vp, vp]),
+    'pcgc_coords_quantize': (ci, [vp, i64, i32, vp, vp]),
+    'pcgc_coords_children': (ci, [vp, i64, i32, vp, vp]),
+    'pcgc_coords_scale': (ci, [vp, i64, f32, vp, vp]),
+    'pcgc_scan_workspace_bytes': (sz, [i64]),
+    'pcgc_mask_scan': (ci, [vp, i64, vp, vp, vp, sz, vp]),
+    'pcgc_compact_coords': (ci, [vp, vp, vp, i64, vp, vp]),
+    'pcgc_compact_feats': (ci, [vp, ci, ci, vp, vp, i64, vp, vp]),
+    'pcgc_kmap_k3': (ci, [vp, i64, i32, vp, vp, i64, vp, vp]),
+    'pcgc_kmap_down': (ci, [vp, i64, i32, vp, vp, i64, vp, vp]),
+    'pcgc_conv_gather': (ci, [vp, ci, i64, vp, ci, ci, ci, vp, vp, vp, ci, ci, ci, vp, ci, ci, ci, vp]),
+    'pcgc_conv_up2': (ci, [i64, vp, ci, ci, vp, vp, ci, vp, ci, vp]),
+    'pcgc_topk_workspace_bytes': (sz, [i64]),
+    'pcgc_topk_mask': (ci, [vp, ci, i64, i64, vp, vp, sz, vp]),
+    'pcgc_sort_workspace_bytes': (sz, [i64]),
+    'pcgc_sort_zyx': (ci, [vp, i64, vp, vp, sz, vp]),
+    'pcgc_gather_rows_i32x4': (ci, [vp, vp, i64, vp, vp]),
+    'pcgc_gather_rows_f32': (ci, [vp, ci, vp, i64, vp, vp]),
+    'pcgc_round_minmax': (ci, [vp, i64, vp, vp]),
+    'pcgc_symbolize': (ci, [vp, i64, f32, vp, vp]),
+    'pcgc_desymbolize': (ci, [vp, i64, f32, vp, vp]),
+    'pcgc_cdf_table': (ci, [vp, ci, f32, f32, vp, vp, vp]),
+    'pcgc_rc_encode': (i64, [vp, ci, ci, vp, i64, vp, i64]),
+    'pcgc_rc_decode': (ci, [vp, ci, ci, vp, i64, vp, i64]),
+    'pcgc_oct_encode': (i64, [vp, i64, vp, i64]),
+    'pcgc_oct_decode_count': (i64, [vp, i64]),
+    'pcgc_oct_decode': (ci, [vp, i64, vp, i64]),
+}
+
+
+class PcgcError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the bound library.  Raises if it is not built: there is no CPU / eager fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PcgcError(f'{LIB_PATH} not found: run `python -c "import __graft_entry__ as g; g.build()"` '
+                            '(hipcc --offload-arch=gfx950). The HIP library is mandatory; there is no fallback path.')
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise PcgcError(f'{what or "pcgc call"} failed ({rc}): {lib().pcgc_last_error().decode()}')

@@ -1,0 +1,95 @@
+"""Encoder / Decoder of PCGCv2 (reference autoencoder.py:7-273) on the HIP operator set.
+
+Same module tree and attribute names as the reference (so state_dict keys match: encoder.conv0, encoder.block0.1.conv1_2,
+decoder.conv2_cls, ...), but the forward passes use fused epilogues: ReLU, bias, the InceptionResNet residual add and
+the channel concat are written by the producing kernel (ME.cat / MinkowskiReLU / SparseTensor.__add__ each cost ME an
+extra HBM round trip)."""
+import torch
+
+from . import ops
+from .nn import MinkowskiConvolution as Conv, MinkowskiGenerativeConvolutionTranspose as UpConv, MinkowskiPruning
+from .sparse import SparseTensor
+
+
+class InceptionResNet(torch.nn.Module):
+    """autoencoder.py:7-57: out = cat(conv0_1(relu(conv0_0 x)), conv1_2(relu(conv1_1(relu(conv1_0 x))))) + x."""
+
+    def __init__(self, channels):
+        super().__init__()
+        c = channels
+        self.conv0_0 = Conv(c, c // 4, 3)
+        self.conv0_1 = Conv(c // 4, c // 2, 3)
+        self.conv1_0 = Conv(c, c // 4, 1)
+        self.conv1_1 = Conv(c // 4, c // 4, 3)
+        self.conv1_2 = Conv(c // 4, c // 2, 1)
+
+    def forward(self, x):
+        c = x.F.shape[1]
+        out = torch.empty_like(x.F)
+        a = self.conv0_0(x, relu=True)
+        self.conv0_1(a, out=out[:, :c // 2], residual=x.F[:, :c // 2])          # cat slot 0 + residual
+        b = self.conv1_1(self.conv1_0(x, relu=True), relu=True)
+        self.conv1_2(b, out=out[:, c // 2:], residual=x.F[:, c // 2:])          # cat slot 1 + residual
+        return SparseTensor(out, coordinate_map=x.cmap)
+
+
+def make_layer(block, block_layers, channels):
+    return torch.nn.Sequential(*[block(channels=channels) for _ in range(block_layers)])
+
+
+class Encoder(torch.nn.Module):
+    """autoencoder.py:68-147."""
+
+    def __init__(self, channels=[1, 16, 32, 64, 32, 8]):
+        super().__init__()
+        ch = channels
+        self.conv0 = Conv(ch[0], ch[1], 3)
+        self.down0 = Conv(ch[1], ch[2], 2, 2)
+        self.block0 = make_layer(InceptionResNet, 3, ch[2])
+        self.conv1 = Conv(ch[2], ch[2], 3)
+        self.down1 = Conv(ch[2], ch[3], 2, 2)
+        self.block1 = make_layer(InceptionResNet, 3, ch[3])
+        self.conv2 = Conv(ch[3], ch[3], 3)
+        self.down2 = Conv(ch[3], ch[4], 2, 2)
+        self.block2 = make_layer(InceptionResNet, 3, ch[4])
+        self.conv3 = Conv(ch[4], ch[5], 3)
+
+    def forward(self, x):
+        out0 = self.block0(self.down0(self.conv0(x, relu=True), relu=True))
+        out1 = self.block1(self.down1(self.conv1(out0, relu=True), relu=True))
+        out2 = self.block2(self.down2(self.conv2(out1, relu=True), relu=True))
+        out2 = self.conv3(out2)
+        return [out2, out1, out0]
+
+
+class Decoder(torch.nn.Module):
+    """autoencoder.py:150-273 (inference: training=False, ground truth unused)."""
+
+    def __init__(self, channels=[8, 64, 32, 16]):
+        super().__init__()
+        ch = channels
+        for l in range(3):
+            setattr(self, f'up{l}', UpConv(ch[l], ch[l + 1], 2, 2))
+            setattr(self, f'conv{l}', Conv(ch[l + 1], ch[l + 1], 3))
+            setattr(self, f'block{l}', make_layer(InceptionResNet, 3, ch[l + 1]))
+            setattr(self, f'conv{l}_cls', Conv(ch[l + 1], 1, 3))
+        self.pruning = MinkowskiPruning()
+
+    def prune_voxel(self, data, data_cls, nums, ground_truth=None, training=False):
+        """autoencoder.py:239-249 with istopk (data_utils.py:77-89) on device; batch size 1."""
+        if training:
+            raise NotImplementedError('training-time pruning (top-k ∪ ground truth) is outside the encode/decode path')
+        k = int(min(len(data_cls), nums[0]))
+        mask = ops.topk_mask(data_cls.F, k)
+        return self.pruning(data, mask, n_keep=k)
+
+    def forward(self, x, nums_list, ground_truth_list=(None, None, None), training=False):
+        out, cls_list = x, []
+        for l in range(3):
+            out = getattr(self, f'up{l}')(out, relu=True)
+            out = getattr(self, f'conv{l}')(out, relu=True)
+            out = getattr(self, f'block{l}')(out)
+            cls = getattr(self, f'conv{l}_cls')(out)
+            cls_list.append(cls)
+            out = self.prune_voxel(out, cls, nums_list[l], ground_truth_list[l], training)
+        return cls_list, out

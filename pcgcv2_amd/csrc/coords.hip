@@ -1,0 +1,162 @@
+// Coordinate hash map, coordinate transforms and kernel-map construction.
+// Replaces MinkowskiEngine's CoordinateManager (reference call sites: data_utils.py:96,108,116; coder.py:102;
+// every MinkowskiConvolution in autoencoder.py builds/looks up a kernel map through it).
+#include <stdarg.h>
+#include "pcgc_common.h"
+
+static thread_local char g_err[512] = "";
+void pcgc_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char* pcgc_last_error(void) { return g_err; }
+extern "C" int pcgc_version(void) { return 1; }
+
+extern "C" int64_t pcgc_hash_capacity(int64_t n) {
+    int64_t cap = 1024;
+    while (cap < 2 * n) cap <<= 1;
+    return cap;
+}
+
+// The lattice shift used by the blocked hash: derived from the coordinates' stride.  Levels are inserted and probed
+// with the same shift; we fold it into the table by storing it nowhere — callers pass `stride` where needed and the
+// insert kernels below recover it from a kernel argument.
+__global__ void k_hash_clear(uint64_t* keys, int32_t* vals, int64_t cap) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) { keys[i] = PCGC_EMPTY_KEY; vals[i] = 0x7fffffff; }
+}
+
+__global__ void k_hash_insert(const int4* __restrict__ coords, int64_t n, int sh, uint64_t* keys, int32_t* vals, uint64_t cap_mask) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 c = coords[i];                               // (b, x, y, z)
+    if (!coord_in_range(c.x, c.y, c.z, c.w)) return;  // out-of-range rows are never found again; host validates
+    uint64_t key = coord_key(c.x, c.y, c.z, c.w);
+    uint64_t h = hash_slot(c.x, c.y, c.z, c.w, sh, cap_mask);
+    for (;;) {
+        unsigned long long prev = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)PCGC_EMPTY_KEY,
+                                            (unsigned long long)key);
+        if (prev == PCGC_EMPTY_KEY || prev == key) { atomicMin(&vals[h], (int32_t)i); return; }
+        h = (h + 1) & cap_mask;
+    }
+}
+
+__global__ void k_hash_first_mask(const int4* __restrict__ coords, int64_t n, int sh, const uint64_t* __restrict__ keys,
+                                  const int32_t* __restrict__ vals, uint64_t cap_mask, uint8_t* keep) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 c = coords[i];
+    keep[i] = hash_lookup(keys, vals, cap_mask, sh, c.x, c.y, c.z, c.w) == (int32_t)i;
+}
+
+extern "C" int pcgc_hash_clear(uint64_t* keys, int32_t* vals, int64_t cap, void* stream) {
+    PCGC_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "capacity must be a power of two");
+    hipLaunchKernelGGL(k_hash_clear, dim3(grid_for(cap, 256)), dim3(256), 0, S(stream), keys, vals, cap);
+    PCGC_CHECK_LAUNCH("hash_clear");
+    return 0;
+}
+static inline int stride_shift(int32_t stride) { int sh = 0; while ((2 << sh) <= stride) ++sh; return sh; }
+extern "C" int pcgc_hash_insert(const int32_t* coords, int64_t n, int32_t stride, uint64_t* keys, int32_t* vals, int64_t cap,
+                                void* stream) {
+    PCGC_REQUIRE(cap >= 2 * n && (cap & (cap - 1)) == 0, "capacity must be a power of two >= 2n");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_hash_insert, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n,
+                       stride_shift(stride), keys, vals, (uint64_t)(cap - 1));
+    PCGC_CHECK_LAUNCH("hash_insert");
+    return 0;
+}
+extern "C" int pcgc_hash_first_mask(const int32_t* coords, int64_t n, int32_t stride, const uint64_t* keys,
+                                    const int32_t* vals, int64_t cap, uint8_t* keep, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_hash_first_mask, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n,
+                       stride_shift(stride), keys, vals, (uint64_t)(cap - 1), keep);
+    PCGC_CHECK_LAUNCH("hash_first_mask");
+    return 0;
+}
+
+// ---- coordinate transforms ------------------------------------------------------------------------------------
+__global__ void k_coords_quantize(const int4* __restrict__ in, int64_t n, int32_t s, int4* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 c = in[i];
+    auto fl = [s](int32_t v) { return (v >= 0 ? v / s : -((-v + s - 1) / s)) * s; };
+    out[i] = make_int4(c.x, fl(c.y), fl(c.z), fl(c.w));
+}
+__global__ void k_coords_children(const int4* __restrict__ in, int64_t n, int32_t h, int4* out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per child row
+    if (t >= 8 * n) return;
+    int4 c = in[t >> 3]; int k = (int)(t & 7);
+    out[t] = make_int4(c.x, c.y + (k & 1) * h, c.z + ((k >> 1) & 1) * h, c.w + (k >> 2) * h);
+}
+__global__ void k_coords_scale(const int4* __restrict__ in, int64_t n, float f, int4* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 c = in[i];
+    out[i] = make_int4(c.x, (int32_t)rintf((float)c.y * f), (int32_t)rintf((float)c.z * f), (int32_t)rintf((float)c.w * f));
+}
+extern "C" int pcgc_coords_quantize(const int32_t* coords, int64_t n, int32_t stride_out, int32_t* out, void* stream) {
+    PCGC_REQUIRE(stride_out > 0, "stride must be positive");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_coords_quantize, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n,
+                       stride_out, (int4*)out);
+    PCGC_CHECK_LAUNCH("coords_quantize");
+    return 0;
+}
+extern "C" int pcgc_coords_children(const int32_t* coords, int64_t n, int32_t stride_in, int32_t* out, void* stream) {
+    PCGC_REQUIRE(stride_in >= 2 && (stride_in & 1) == 0, "input stride must be even");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_coords_children, dim3(grid_for(8 * n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n,
+                       stride_in / 2, (int4*)out);
+    PCGC_CHECK_LAUNCH("coords_children");
+    return 0;
+}
+extern "C" int pcgc_coords_scale(const int32_t* coords, int64_t n, float factor, int32_t* out, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_coords_scale, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n, factor,
+                       (int4*)out);
+    PCGC_CHECK_LAUNCH("coords_scale");
+    return 0;
+}
+
+// ---- kernel maps ----------------------------------------------------------------------------------------------
+// One thread per output site; the 27 probes are independent so the compiler keeps several loads in flight.
+// nbr is offset-major [27][n] so the conv kernels read it coalesced.
+__global__ void __launch_bounds__(256) k_kmap_k3(const int4* __restrict__ coords, int64_t n, int32_t s, int sh,
+                                                 const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
+                                                 uint64_t cap_mask, int32_t* __restrict__ nbr) {
+    int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n) return;
+    int4 c = coords[o];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        int dx = (k % 3 - 1) * s, dy = ((k / 3) % 3 - 1) * s, dz = (k / 9 - 1) * s;
+        int32_t r = (k == 13) ? (int32_t)o : hash_lookup(keys, vals, cap_mask, sh, c.x, c.y + dx, c.z + dy, c.w + dz);
+        nbr[(int64_t)k * n + o] = r;
+    }
+}
+__global__ void __launch_bounds__(256) k_kmap_down(const int4* __restrict__ coarse, int64_t n, int32_t s, int sh,
+                                                   const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
+                                                   uint64_t cap_mask, int32_t* __restrict__ nbr) {
+    int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n) return;
+    int4 c = coarse[o];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        nbr[(int64_t)k * n + o] = hash_lookup(keys, vals, cap_mask, sh, c.x, c.y + (k & 1) * s, c.z + ((k >> 1) & 1) * s,
+                                              c.w + (k >> 2) * s);
+}
+extern "C" int pcgc_kmap_k3(const int32_t* coords, int64_t n, int32_t stride, const uint64_t* keys, const int32_t* vals,
+                            int64_t cap, int32_t* nbr, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_kmap_k3, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n, stride,
+                       stride_shift(stride), keys, vals, (uint64_t)(cap - 1), nbr);
+    PCGC_CHECK_LAUNCH("kmap_k3");
+    return 0;
+}
+extern "C" int pcgc_kmap_down(const int32_t* coarse, int64_t n_coarse, int32_t stride_fine, const uint64_t* fine_keys,
+                              const int32_t* fine_vals, int64_t fine_cap, int32_t* nbr, void* stream) {
+    if (n_coarse == 0) return 0;
+    hipLaunchKernelGGL(k_kmap_down, dim3(grid_for(n_coarse, 256)), dim3(256), 0, S(stream), (const int4*)coarse, n_coarse,
+                       stride_fine, stride_shift(stride_fine), fine_keys, fine_vals, (uint64_t)(fine_cap - 1), nbr);
+    PCGC_CHECK_LAUNCH("kmap_down");
+    return 0;
+}

@@ -1,0 +1,117 @@
+// Factorized entropy bottleneck on device (reference entropy_model.py:82-196): quantisation, symbol range, and the
+// fused CDF table (likelihood MLP -> clamp -> cumsum -> torchac 16-bit normalisation).  The table is 8 x (L+1)
+// values: the point of doing it on device is that neither the latents nor an [N8,8,L+1] expansion
+// (entropy_model.py:173) ever exist; only int16 symbols and the 16-bit table cross PCIe.
+#include "pcgc_common.h"
+
+__device__ static inline int32_t f2ord(float f) { int32_t b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7fffffff; }
+__device__ static inline float ord2f(int32_t o) { return __int_as_float(o >= 0 ? o : o ^ 0x7fffffff); }
+
+// single block (count is N8*8 ~ 1e5..1e6): grid-stride inside the block, LDS tree for the 16 waves
+__global__ void __launch_bounds__(1024) k_round_minmax(const float* __restrict__ f, int64_t count, float* minmax) {
+    __shared__ int32_t smin[16], smax[16];
+    int32_t lo = 0x7fffffff, hi = (int32_t)0x80000000;
+    for (int64_t i = threadIdx.x; i < count; i += 1024) {
+        int32_t o = f2ord(rintf(f[i]) + 0.0f);
+        lo = min(lo, o); hi = max(hi, o);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { lo = min(lo, __shfl_xor(lo, d, 64)); hi = max(hi, __shfl_xor(hi, d, 64)); }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) { lo = min(lo, smin[i]); hi = max(hi, smax[i]); }
+        minmax[0] = ord2f(lo); minmax[1] = ord2f(hi);
+    }
+}
+__global__ void k_symbolize(const float* __restrict__ f, int64_t count, float min_v, int16_t* __restrict__ sym) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) sym[i] = (int16_t)(rintf(f[i]) - min_v);
+}
+__global__ void k_desymbolize(const int16_t* __restrict__ sym, int64_t count, float min_v, float* __restrict__ f) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) f[i] = (float)sym[i] + min_v;
+}
+extern "C" int pcgc_round_minmax(const float* feats, int64_t count, float* minmax, void* stream) {
+    PCGC_REQUIRE(count > 0, "empty latent");
+    hipLaunchKernelGGL(k_round_minmax, dim3(1), dim3(1024), 0, S(stream), feats, count, minmax);
+    PCGC_CHECK_LAUNCH("round_minmax");
+    return 0;
+}
+extern "C" int pcgc_symbolize(const float* feats, int64_t count, float min_v, int16_t* sym, void* stream) {
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(k_symbolize, dim3(grid_for(count, 256)), dim3(256), 0, S(stream), feats, count, min_v, sym);
+    PCGC_CHECK_LAUNCH("symbolize");
+    return 0;
+}
+extern "C" int pcgc_desymbolize(const int16_t* sym, int64_t count, float min_v, float* feats, void* stream) {
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(k_desymbolize, dim3(grid_for(count, 256)), dim3(256), 0, S(stream), sym, count, min_v, feats);
+    PCGC_CHECK_LAUNCH("desymbolize");
+    return 0;
+}
+
+// ---- fused CDF table ----------------------------------------------------------------------------------------
+// params packing (352 floats for C=8): matrices 0..3 [C,fo,fi] | biases 0..3 [C,fo,1] | factors 0..3 [C,fo,1],
+// filters (1,3,3,3,1).  Evaluated in fp64 from the fp32 parameters; rounded to fp32 where the reference holds fp32
+// tensors feeding a discontinuity (likelihood, clamp, running cumsum).
+__device__ static inline double eb_softplus(double x) { return x > 0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
+__device__ static inline double eb_sigmoid(double x) { return x >= 0 ? 1.0 / (1.0 + exp(-x)) : exp(x) / (1.0 + exp(x)); }
+__device__ static double eb_logits(const float* __restrict__ P, int C, int c, double v) {
+    const int F[5] = {1, 3, 3, 3, 1};
+    const float* M = P; const float* B = P + 24 * C; const float* Fa = B + 10 * C;
+    double h[3] = {v, 0, 0}, t[3];
+    int moff = 0, boff = 0;
+    for (int i = 0; i < 4; ++i) {
+        int fi = F[i], fo = F[i + 1];
+        const float* m = M + moff + c * fo * fi; const float* b = B + boff + c * fo; const float* f = Fa + boff + c * fo;
+        for (int r = 0; r < fo; ++r) {
+            double s = 0;
+            for (int q = 0; q < fi; ++q) s += eb_softplus((double)m[r * fi + q]) * h[q];
+            s += (double)b[r];
+            s += tanh((double)f[r]) * tanh(s);
+            t[r] = s;
+        }
+        for (int r = 0; r < fo; ++r) h[r] = t[r];
+        moff += C * fo * fi; boff += C * fo;
+    }
+    return h[0];
+}
+// phase 1: likelihood(c, s) -> cdf_f32[c][s+1] (temporarily holds the clamped pmf)
+__global__ void k_cdf_likelihood(const float* __restrict__ P, int C, int L, float min_v, float* __restrict__ cdf_f32) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= C * L) return;
+    int c = t / L, s = t % L;
+    double v = (double)min_v + s;
+    double lo = eb_logits(P, C, c, v - 0.5), up = eb_logits(P, C, c, v + 0.5);
+    double sum = lo + up, sign = sum > 0 ? -1.0 : (sum < 0 ? 1.0 : 0.0);
+    float p = (float)fabs(eb_sigmoid(sign * up) - eb_sigmoid(sign * lo));
+    cdf_f32[c * (L + 1) + s + 1] = p < 1e-9f ? 1e-9f : p;
+}
+// phase 2: one thread per channel: fp32 running sum (torch.cumsum on fp32), clamp(max=1), 16-bit normalisation
+__global__ void k_cdf_finish(int C, int L, float* __restrict__ cdf_f32, uint16_t* __restrict__ cdf_u16) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float* row = cdf_f32 + c * (L + 1);
+    uint16_t* q = cdf_u16 + c * (L + 1);
+    const float scale = 65536.0f - (float)L;            // 2^16 - (Lp - 1), Lp = L + 1
+    float run = 0.0f;
+    row[0] = 0.0f; q[0] = 0;
+    for (int s = 1; s <= L; ++s) {
+        run = run + row[s];
+        float v = run > 1.0f ? 1.0f : run;
+        row[s] = v;
+        q[s] = (uint16_t)((int32_t)rintf(v * scale) + s);
+    }
+}
+extern "C" int pcgc_cdf_table(const float* params, int C, float min_v, float max_v, uint16_t* cdf_u16, float* cdf_f32,
+                              void* stream) {
+    PCGC_REQUIRE(max_v >= min_v, "max_v < min_v");
+    PCGC_REQUIRE(cdf_f32 != nullptr, "cdf_f32 scratch/output buffer is required");
+    int L = (int)(max_v - min_v) + 1;
+    PCGC_REQUIRE(L >= 1 && L < 32768, "symbol alphabet out of int16 range");
+    hipLaunchKernelGGL(k_cdf_likelihood, dim3(grid_for((int64_t)C * L, 64)), dim3(64), 0, S(stream), params, C, L, min_v, cdf_f32);
+    hipLaunchKernelGGL(k_cdf_finish, dim3(1), dim3(64), 0, S(stream), C, L, cdf_f32, cdf_u16);
+    PCGC_CHECK_LAUNCH("cdf_table");
+    return 0;
+}

@@ -1,0 +1,274 @@
+// Host-side (sequential) entropy coding of the PCGCv2 bitstream:
+//   * pcgc_rc_encode / pcgc_rc_decode — the 32-bit range coder behind torchac 0.9.3 ‡ encode_float_cdf /
+//     decode_float_cdf (reference call sites entropy_model.py:174,192).  One 16-bit CDF row per channel instead of
+//     the reference's [N8, C, L+1] expansion (entropy_model.py:173).
+//   * pcgc_oct_encode / pcgc_oct_decode — native lossless codec for the stride-8 coordinates (`_C.bin`), used when
+//     the external G-PCC `tmc3` binary of gpcc.py:6-41 is not installed.  Not G-PCC interoperable (magic "PCGO").
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "../../include/pcgc_hip.h"
+
+// ------------------------------------------------------------------------------------------------ torchac-compatible
+namespace {
+
+struct BitSink {
+    uint8_t* out; int64_t cap; int64_t len = 0; uint32_t acc = 0; int nbits = 0;
+    inline void put(uint32_t bit) {
+        acc = (acc << 1) | bit;
+        if (++nbits == 8) { if (len < cap) out[len] = (uint8_t)acc; ++len; acc = 0; nbits = 0; }
+    }
+    inline void put_with_pending(uint32_t bit, uint64_t& pending) {
+        put(bit);
+        for (; pending > 0; --pending) put(bit ^ 1u);
+    }
+    inline void flush() { while (nbits != 0) put(0); }
+};
+
+struct BitSource {
+    const uint8_t* in; int64_t len; int64_t pos = 0; uint32_t cur = 0; int left = 0;
+    inline void shift_into(uint32_t& value) {
+        if (left == 0) {
+            if (pos == len) { value <<= 1; return; }      // past the end: zeros
+            cur = in[pos++]; left = 8;
+        }
+        value = (value << 1) | ((cur >> (left - 1)) & 1u);
+        --left;
+    }
+};
+
+}  // namespace
+
+extern "C" int64_t pcgc_rc_encode(const uint16_t* cdf, int C, int Lp, const int16_t* sym, int64_t n, uint8_t* out, int64_t cap) {
+    BitSink sink{out, cap};
+    uint32_t low = 0, high = 0xFFFFFFFFu;
+    uint64_t pending = 0;
+    const int top_symbol = Lp - 2;
+    int ch = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint16_t* row = cdf + (size_t)ch * Lp;
+        if (++ch == C) ch = 0;
+        const int s = sym[i];
+        if (s < 0 || s > top_symbol) return INT64_MIN;                       // symbol outside the table
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+        const uint32_t c_lo = row[s];
+        const uint32_t c_hi = (s == top_symbol) ? 0x10000u : row[s + 1];     // last boundary is pinned to 2^16
+        high = (low - 1) + (uint32_t)((span * c_hi) >> 16);
+        low = low + (uint32_t)((span * c_lo) >> 16);
+        for (;;) {
+            if (high < 0x80000000u) sink.put_with_pending(0, pending);
+            else if (low >= 0x80000000u) sink.put_with_pending(1, pending);
+            else if (low >= 0x40000000u && high < 0xC0000000u) {             // straddling the middle: defer the bit
+                ++pending;
+                low = (low << 1) & 0x7FFFFFFFu;
+                high = (high << 1) | 0x80000001u;
+                continue;
+            } else break;
+            low <<= 1;
+            high = (high << 1) | 1u;
+        }
+    }
+    ++pending;
+    sink.put_with_pending(low < 0x40000000u ? 0u : 1u, pending);
+    sink.flush();
+    return sink.len <= cap ? sink.len : -sink.len;
+}
+
+extern "C" int pcgc_rc_decode(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int64_t nbytes, int16_t* sym, int64_t n) {
+    BitSource src{in, nbytes};
+    uint32_t low = 0, high = 0xFFFFFFFFu, value = 0;
+    for (int i = 0; i < 32; ++i) src.shift_into(value);
+    const int top_symbol = Lp - 2;
+    int ch = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint16_t* row = cdf + (size_t)ch * Lp;
+        if (++ch == C) ch = 0;
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+        const uint16_t target = (uint16_t)((((uint64_t)value - (uint64_t)low + 1) * 0x10000ull - 1) / span);
+        // largest m in [0, top_symbol] with row[m] <= target (the wrapped last entry row[Lp-1] is never read)
+        int lo = 0, hi = top_symbol + 1;
+        while (lo + 1 < hi) {
+            const int mid = (lo + hi) >> 1;
+            const uint16_t v = row[mid];
+            if (v < target) lo = mid; else if (v > target) hi = mid; else { lo = mid; break; }
+        }
+        sym[i] = (int16_t)lo;
+        if (i == n - 1) break;
+        const uint32_t c_lo = row[lo];
+        const uint32_t c_hi = (lo == top_symbol) ? 0x10000u : row[lo + 1];
+        high = (low - 1) + (uint32_t)((span * c_hi) >> 16);
+        low = low + (uint32_t)((span * c_lo) >> 16);
+        for (;;) {
+            if (low >= 0x80000000u || high < 0x80000000u) {
+                low <<= 1; high = (high << 1) | 1u; src.shift_into(value);
+            } else if (low >= 0x40000000u && high < 0xC0000000u) {
+                low = (low << 1) & 0x7FFFFFFFu; high = (high << 1) | 0x80000001u;
+                value -= 0x40000000u; src.shift_into(value);
+            } else break;
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ octree codec
+// Breadth-first occupancy octree over the Morton-sorted points; each node's 8-bit child occupancy is coded as 8 binary
+// decisions with an adaptive binary range coder (12-bit probabilities, carry-propagating 32-bit range, LZMA-style).
+// Context of child bit j = (level bucket, bits already coded in this node, number of occupied face-neighbours of the
+// PARENT among the 6 same-level neighbours) — neighbour occupancy is what G-PCC exploits too; here it is a 0..6 count.
+namespace {
+
+struct BinEnc {
+    std::vector<uint8_t> out; uint64_t low = 0; uint32_t range = 0xFFFFFFFFu; uint8_t cache = 0; int64_t cache_size = 1;
+    void shift_low() {
+        if ((uint32_t)low < 0xFF000000u || (low >> 32) != 0) {
+            uint8_t carry = (uint8_t)(low >> 32);
+            uint8_t temp = cache;
+            do { out.push_back((uint8_t)(temp + carry)); temp = 0xFF; } while (--cache_size != 0);
+            cache = (uint8_t)((uint32_t)low >> 24);
+        }
+        ++cache_size;
+        low = (uint32_t)low << 8;
+    }
+    void encode(uint16_t& p, int bit) {
+        uint32_t bound = (range >> 12) * p;
+        if (bit == 0) { range = bound; p += (4096 - p) >> 4; }
+        else { low += bound; range -= bound; p -= p >> 4; }
+        while (range < (1u << 24)) { range <<= 8; shift_low(); }
+    }
+    void finish() { for (int i = 0; i < 5; ++i) shift_low(); }
+};
+struct BinDec {
+    const uint8_t* in; int64_t len; int64_t pos = 0; uint32_t range = 0xFFFFFFFFu, code = 0;
+    uint8_t next() { return pos < len ? in[pos++] : 0; }
+    void init() { next(); for (int i = 0; i < 4; ++i) code = (code << 8) | next(); }
+    int decode(uint16_t& p) {
+        uint32_t bound = (range >> 12) * p;
+        int bit;
+        if (code < bound) { range = bound; p += (4096 - p) >> 4; bit = 0; }
+        else { code -= bound; range -= bound; p -= p >> 4; bit = 1; }
+        while (range < (1u << 24)) { range <<= 8; code = (code << 8) | next(); }
+        return bit;
+    }
+};
+
+inline uint64_t morton3(uint32_t x, uint32_t y, uint32_t z) {
+    auto spread = [](uint64_t v) {
+        v &= 0x1FFFFF;
+        v = (v | v << 32) & 0x1F00000000FFFFull; v = (v | v << 16) & 0x1F0000FF0000FFull;
+        v = (v | v << 8) & 0x100F00F00F00F00Full; v = (v | v << 4) & 0x10C30C30C30C30C3ull;
+        v = (v | v << 2) & 0x1249249249249249ull; return v;
+    };
+    return spread(x) | (spread(y) << 1) | (spread(z) << 2);
+}
+inline void demorton3(uint64_t m, int32_t& x, int32_t& y, int32_t& z) {
+    auto compact = [](uint64_t v) {
+        v &= 0x1249249249249249ull;
+        v = (v ^ (v >> 2)) & 0x10C30C30C30C30C3ull; v = (v ^ (v >> 4)) & 0x100F00F00F00F00Full;
+        v = (v ^ (v >> 8)) & 0x1F0000FF0000FFull; v = (v ^ (v >> 16)) & 0x1F00000000FFFFull;
+        v = (v ^ (v >> 32)) & 0x1FFFFF; return (int32_t)v;
+    };
+    x = compact(m); y = compact(m >> 1); z = compact(m >> 2);
+}
+
+constexpr int kLevelBuckets = 4;       // root-side levels share statistics poorly; bucket by distance from the leaves
+constexpr int kNbrClasses = 7;         // 0..6 occupied face neighbours
+struct OctModel {
+    std::vector<uint16_t> p;
+    OctModel() : p((size_t)kLevelBuckets * kNbrClasses * 256, 2048) {}
+    inline uint16_t& at(int bucket, int nb, int node) { return p[((size_t)bucket * kNbrClasses + nb) * 256 + node]; }
+};
+
+// number of occupied 6-neighbours of node `code` (Morton code at the current level) within the sorted node list
+inline int face_neighbours(const std::vector<uint64_t>& nodes, uint64_t code, int level_bits) {
+    int32_t x, y, z; demorton3(code, x, y, z);
+    const int32_t lim = (level_bits >= 21) ? INT32_MAX : (1 << level_bits);
+    int cnt = 0;
+    const int d[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+    for (auto& o : d) {
+        int32_t nx = x + o[0], ny = y + o[1], nz = z + o[2];
+        if (nx < 0 || ny < 0 || nz < 0 || nx >= lim || ny >= lim || nz >= lim) continue;
+        cnt += std::binary_search(nodes.begin(), nodes.end(), morton3(nx, ny, nz));
+    }
+    return cnt;
+}
+
+constexpr uint8_t kMagic[4] = {'P', 'C', 'G', 'O'};
+
+}  // namespace
+
+extern "C" int64_t pcgc_oct_encode(const int32_t* xyz, int64_t n, uint8_t* out, int64_t cap) {
+    uint32_t maxc = 0;
+    for (int64_t i = 0; i < 3 * n; ++i) { if (xyz[i] < 0 || xyz[i] >= (1 << 21)) return INT64_MIN; maxc = std::max(maxc, (uint32_t)xyz[i]); }
+    int depth = 1; while ((1u << depth) <= maxc) ++depth;
+    std::vector<uint64_t> leaves((size_t)n);
+    for (int64_t i = 0; i < n; ++i) leaves[(size_t)i] = morton3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    std::sort(leaves.begin(), leaves.end());
+    leaves.erase(std::unique(leaves.begin(), leaves.end()), leaves.end());
+    const int64_t n_unique = (int64_t)leaves.size();
+
+    BinEnc enc; OctModel model;
+    std::vector<uint64_t> level_nodes, next;
+    if (n_unique > 0) level_nodes.push_back(0);
+    for (int lvl = 0; lvl < depth && !level_nodes.empty(); ++lvl) {
+        const int shift = 3 * (depth - 1 - lvl);                     // leaves >> shift = child code at level lvl+1
+        const int bucket = std::min(kLevelBuckets - 1, depth - 1 - lvl);
+        next.clear();
+        size_t cursor = 0;
+        for (uint64_t node : level_nodes) {
+            unsigned occ = 0;
+            while (cursor < leaves.size() && ((leaves[cursor] >> shift) >> 3) == node) { occ |= 1u << ((leaves[cursor] >> shift) & 7); ++cursor; }
+            const int nb = face_neighbours(level_nodes, node, lvl);
+            int tree = 1;
+            for (int j = 0; j < 8; ++j) {
+                int bit = (occ >> j) & 1;
+                enc.encode(model.at(bucket, nb, tree), bit);
+                tree = (tree << 1) | bit;
+                if (bit) next.push_back((node << 3) | (uint64_t)j);
+            }
+        }
+        level_nodes.swap(next);
+    }
+    enc.finish();
+    const int64_t total = 4 + 1 + 4 + (int64_t)enc.out.size();
+    if (total > cap) return -total;
+    std::memcpy(out, kMagic, 4);
+    out[4] = (uint8_t)depth;
+    uint32_t n32 = (uint32_t)n_unique; std::memcpy(out + 5, &n32, 4);
+    std::memcpy(out + 9, enc.out.data(), enc.out.size());
+    return total;
+}
+
+extern "C" int64_t pcgc_oct_decode_count(const uint8_t* in, int64_t nbytes) {
+    if (nbytes < 9 || std::memcmp(in, kMagic, 4) != 0) return -1;
+    uint32_t n32; std::memcpy(&n32, in + 5, 4);
+    return (int64_t)n32;
+}
+
+extern "C" int pcgc_oct_decode(const uint8_t* in, int64_t nbytes, int32_t* xyz, int64_t n) {
+    if (pcgc_oct_decode_count(in, nbytes) != n) return -1;
+    const int depth = in[4];
+    if (depth < 1 || depth > 21) return -1;
+    BinDec dec{in + 9, nbytes - 9}; dec.init();
+    OctModel model;
+    std::vector<uint64_t> level_nodes, next;
+    if (n > 0) level_nodes.push_back(0);
+    for (int lvl = 0; lvl < depth && !level_nodes.empty(); ++lvl) {
+        const int bucket = std::min(kLevelBuckets - 1, depth - 1 - lvl);
+        next.clear();
+        for (uint64_t node : level_nodes) {
+            const int nb = face_neighbours(level_nodes, node, lvl);
+            int tree = 1;
+            for (int j = 0; j < 8; ++j) {
+                int bit = dec.decode(model.at(bucket, nb, tree));
+                tree = (tree << 1) | bit;
+                if (bit) next.push_back((node << 3) | (uint64_t)j);
+            }
+        }
+        level_nodes.swap(next);
+        if ((int64_t)level_nodes.size() > n) return -2;              // corrupt stream
+    }
+    if ((int64_t)level_nodes.size() != n) return -2;
+    for (int64_t i = 0; i < n; ++i) demorton3(level_nodes[(size_t)i], xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    return 0;
+}

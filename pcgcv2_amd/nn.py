@@ -1,0 +1,65 @@
+"""Layer modules with MinkowskiEngine-compatible parameter names/shapes (`kernel`, `bias`) so that the reference's
+checkpoints (`torch.load(p)['model']`, coder.py:141-142) load with a strict load_state_dict:
+   k=3: kernel [27,Cin,Cout] · k=2: [8,Cin,Cout] · k=1: [Cin,Cout] (2-D) · bias [1,Cout]   (ME ‡ conventions)."""
+import math
+import torch
+
+from . import ops
+from .sparse import SparseTensor
+
+
+class _ConvBase(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, bias=True, dimension=3):
+        super().__init__()
+        assert dimension == 3
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = kernel_size, stride
+        vol = kernel_size ** 3
+        shape = (in_channels, out_channels) if vol == 1 else (vol, in_channels, out_channels)
+        self.kernel = torch.nn.Parameter(torch.empty(shape, dtype=torch.float32))
+        self.bias = torch.nn.Parameter(torch.empty((1, out_channels), dtype=torch.float32)) if bias else None
+        bound = 1.0 / math.sqrt(vol * in_channels)
+        with torch.no_grad():
+            self.kernel.uniform_(-bound, bound)
+            if self.bias is not None:
+                self.bias.zero_()
+
+    def extra_repr(self):
+        return f'in={self.in_channels}, out={self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}'
+
+
+class MinkowskiConvolution(_ConvBase):
+    """kernel_size 3 / stride 1, kernel_size 1, or kernel_size 2 / stride 2 (the three forms autoencoder.py uses)."""
+
+    def forward(self, x, relu=False, out=None, residual=None):
+        k, s = self.kernel_size, self.stride
+        if k == 3 and s == 1:
+            cmap, nbr = x.cmap, x.cmap.k3
+        elif k == 1 and s == 1:
+            cmap, nbr = x.cmap, None
+        elif k == 2 and s == 2:
+            cmap, nbr = x.cmap.down()
+        else:
+            raise NotImplementedError(f'MinkowskiConvolution(kernel_size={k}, stride={s}) is not on the PCGCv2 path')
+        y = ops.conv_gather(nbr, x.F, self.kernel, self.bias, out=out, residual=residual, relu=relu)
+        return SparseTensor(y, coordinate_map=cmap)
+
+
+class MinkowskiGenerativeConvolutionTranspose(_ConvBase):
+    def forward(self, x, relu=False):
+        assert self.kernel_size == 2 and self.stride == 2
+        y = ops.conv_up2(x.F, self.kernel, self.bias, relu=relu)
+        return SparseTensor(y, coordinate_map=x.cmap.up())
+
+
+class MinkowskiPruning(torch.nn.Module):
+    """Keep rows where mask is set, order preserved (autoencoder.py:237,247).  n_keep, when the caller knows it
+    (top-k), avoids a device->host sync."""
+
+    def forward(self, x, mask, n_keep=None):
+        from .sparse import CoordMap
+        prefix, total = ops.mask_scan(mask)
+        n = int(total.item()) if n_keep is None else int(n_keep)
+        coords = ops.compact_coords(x.C, mask, prefix, n)
+        feats = ops.compact_feats(x.F, mask, prefix, n)
+        return SparseTensor(feats, coordinate_map=CoordMap(coords, x.cmap.stride, unique=True))

@@ -1,0 +1,353 @@
+"""Thin functional layer over the C-ABI (include/pcgc_hip.h): torch tensors in, torch tensors out.
+
+PyTorch is used for device memory and streams only; all arithmetic happens in libpcgc_hip.so.  Every function
+requires ROCm device tensors and raises otherwise — there is no CPU path in the product.
+"""
+import numpy as np
+import torch
+
+from ._lib import lib, check, PcgcError
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _dev(t, dtype, what):
+    if not t.is_cuda:
+        raise PcgcError(f'{what}: expected a ROCm device tensor, got {t.device} (no CPU fallback exists)')
+    if t.dtype != dtype:
+        raise PcgcError(f'{what}: expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise PcgcError(f'{what}: tensor must be contiguous')
+    return t
+
+
+def _i32(t, what='coords'):
+    return _dev(t, torch.int32, what)
+
+
+def _f32(t, what='feats'):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise PcgcError(f'{what}: expected float32 device tensor, got {t.dtype} on {t.device}')
+    return t
+
+
+def _ld(t):
+    """leading dimension (row stride in floats) of a 2-D row-major view whose rows are contiguous."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise PcgcError('feature views must be 2-D with unit column stride')
+    return t.stride(0)
+
+
+# ------------------------------------------------------------------------------------------------ profiling hook
+class _Profile:
+    """Brackets every k3 gather-conv launch (the dominant kernel) with HIP events on the stream it is launched on, and
+    turns the timings into the `roofline` object of bench.py.  Algorithmic bytes per launch:
+    P*Cin*4 (gathered rows) + P*8 (int32 in/out pair indices) + N_out*Cout*4 (output rows), P = kernel-map pairs."""
+
+    def __init__(self):
+        self.reset(False)
+
+    def reset(self, enabled=False):
+        self.enabled = enabled
+        self.counting = False
+        self.records = []          # (K, Cin, Cout, n_out, ev0, ev1)
+        self.pairs = {}            # (K, n_out) -> P
+
+    def bracket(self, K, Cin, Cout, n_out):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.append((K, Cin, Cout, n_out, e0, e1))
+        return e0, e1
+
+    def count(self, nbr, K, n_out):
+        if (K, n_out) not in self.pairs:
+            self.pairs[(K, n_out)] = int((nbr >= 0).sum().item())
+
+    def detail(self):
+        rows = {}
+        for K, Cin, Cout, n_out, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            r = rows.setdefault((K, Cin, Cout, n_out), {'K': K, 'Cin': Cin, 'Cout': Cout, 'n_out': n_out, 'launches': 0, 'ms': 0.0})
+            r['launches'] += 1; r['ms'] += ms
+        out = []
+        for (K, Cin, Cout, n_out), r in rows.items():
+            P = self.pairs.get((K, n_out))
+            if P is not None:
+                r['pairs'] = P
+                r['alg_bytes_per_launch'] = P * Cin * 4 + P * 8 + n_out * Cout * 4
+                r['flops_per_launch'] = 2 * P * Cin * Cout
+                r['avg_us'] = r['ms'] / r['launches'] * 1e3
+                r['GBps'] = r['alg_bytes_per_launch'] / (r['ms'] / r['launches'] * 1e-3) / 1e9
+            out.append(r)
+        return sorted(out, key=lambda r: -r['ms'])
+
+    def summary(self, peak_gbs):
+        """Dominant kernel = the k3 gather conv; report its heaviest shape (most total time) as `achieved`, plus the
+        all-launch aggregate."""
+        d = [r for r in self.detail() if r['K'] == 27 and 'pairs' in r]
+        if not d:
+            return None
+        top = d[0]
+        tot_bytes = sum(r['alg_bytes_per_launch'] * r['launches'] for r in d)
+        tot_ms = sum(r['ms'] for r in d)
+        ach = top['GBps']
+        return {'bound': 'hbm', 'achieved': round(ach, 2), 'peak': peak_gbs, 'unit': 'GB/s', 'frac': round(ach / peak_gbs, 4),
+                'traffic': None,
+                'kernel': f"k3 sparse-conv gather, Cin={top['Cin']} Cout={top['Cout']} N_out={top['n_out']} pairs={top['pairs']}",
+                'alg_bytes_per_launch': top['alg_bytes_per_launch'], 'avg_launch_us': round(top['avg_us'], 2),
+                'launches_timed': top['launches'],
+                'all_k3_launches': {'achieved': round(tot_bytes / (tot_ms * 1e-3) / 1e9, 2), 'frac': round(tot_bytes / (tot_ms * 1e-3) / 1e9 / peak_gbs, 4),
+                                    'ms_per_step_share': round(tot_ms, 3), 'launches': sum(r['launches'] for r in d)}}
+
+
+PROFILE = _Profile()
+
+
+# ------------------------------------------------------------------------------------------------ hash / coords
+class HashTable:
+    """Coordinate hash of one level (keys/vals device buffers + the stride its spatial blocking was built with)."""
+
+    def __init__(self, coords, stride):
+        n = coords.shape[0]
+        self.cap = int(lib().pcgc_hash_capacity(n))
+        self.stride = int(stride)
+        self.keys = torch.empty(self.cap, dtype=torch.int64, device=coords.device)
+        self.vals = torch.empty(self.cap, dtype=torch.int32, device=coords.device)
+        check(lib().pcgc_hash_clear(_p(self.keys), _p(self.vals), self.cap, _stream()), 'hash_clear')
+        check(lib().pcgc_hash_insert(_p(_i32(coords)), n, self.stride, _p(self.keys), _p(self.vals), self.cap, _stream()),
+              'hash_insert')
+
+
+def first_occurrence_mask(coords, table):
+    n = coords.shape[0]
+    keep = torch.empty(n, dtype=torch.uint8, device=coords.device)
+    check(lib().pcgc_hash_first_mask(_p(_i32(coords)), n, table.stride, _p(table.keys), _p(table.vals), table.cap, _p(keep),
+                                     _stream()), 'hash_first_mask')
+    return keep
+
+
+def mask_scan(mask):
+    """-> (prefix int32 [n], total int32 [1] on device)."""
+    n = mask.shape[0]
+    prefix = torch.empty(n, dtype=torch.int32, device=mask.device)
+    total = torch.empty(1, dtype=torch.int32, device=mask.device)
+    ws_bytes = int(lib().pcgc_scan_workspace_bytes(n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mask.device)
+    check(lib().pcgc_mask_scan(_p(_dev(mask, torch.uint8, 'mask')), n, _p(prefix), _p(total), _p(ws), ws_bytes, _stream()),
+          'mask_scan')
+    return prefix, total
+
+
+def compact_coords(coords, mask, prefix, n_out):
+    out = torch.empty((n_out, 4), dtype=torch.int32, device=coords.device)
+    check(lib().pcgc_compact_coords(_p(_i32(coords)), _p(mask), _p(prefix), coords.shape[0], _p(out), _stream()),
+          'compact_coords')
+    return out
+
+
+def compact_feats(feats, mask, prefix, n_out):
+    _f32(feats)
+    C = feats.shape[1]
+    out = torch.empty((n_out, C), dtype=torch.float32, device=feats.device)
+    check(lib().pcgc_compact_feats(_p(feats), C, _ld(feats), _p(mask), _p(prefix), feats.shape[0], _p(out), _stream()),
+          'compact_feats')
+    return out
+
+
+def coords_quantize(coords, stride_out):
+    out = torch.empty_like(coords)
+    check(lib().pcgc_coords_quantize(_p(_i32(coords)), coords.shape[0], int(stride_out), _p(out), _stream()), 'coords_quantize')
+    return out
+
+
+def coords_children(coords, stride_in):
+    out = torch.empty((8 * coords.shape[0], 4), dtype=torch.int32, device=coords.device)
+    check(lib().pcgc_coords_children(_p(_i32(coords)), coords.shape[0], int(stride_in), _p(out), _stream()), 'coords_children')
+    return out
+
+
+def coords_scale(coords, factor):
+    out = torch.empty_like(coords)
+    check(lib().pcgc_coords_scale(_p(_i32(coords)), coords.shape[0], float(np.float32(factor)), _p(out), _stream()),
+          'coords_scale')
+    return out
+
+
+def kmap_k3(coords, stride, table):
+    n = coords.shape[0]
+    nbr = torch.empty((27, n), dtype=torch.int32, device=coords.device)
+    check(lib().pcgc_kmap_k3(_p(_i32(coords)), n, int(stride), _p(table.keys), _p(table.vals), table.cap, _p(nbr), _stream()),
+          'kmap_k3')
+    return nbr
+
+
+def kmap_down(coarse, stride_fine, fine_table):
+    n = coarse.shape[0]
+    nbr = torch.empty((8, n), dtype=torch.int32, device=coarse.device)
+    check(lib().pcgc_kmap_down(_p(_i32(coarse)), n, int(stride_fine), _p(fine_table.keys), _p(fine_table.vals), fine_table.cap,
+                               _p(nbr), _stream()), 'kmap_down')
+    return nbr
+
+
+# ------------------------------------------------------------------------------------------------ conv family
+def conv_gather(nbr, x, W, bias, out=None, residual=None, relu=False, n_out=None):
+    """out (view, may be a column slice) = relu?( fmaf-chain(nbr, x, W) + bias (+ residual) )."""
+    _f32(x, 'x'); _f32(W, 'W')
+    if W.dim() == 2:
+        K, (Cin, Cout) = 1, W.shape
+    else:
+        K, Cin, Cout = W.shape
+    if x.shape[1] != Cin:
+        raise PcgcError(f'conv_gather: input has {x.shape[1]} channels, kernel expects {Cin}')
+    if nbr is None:
+        n_out = x.shape[0]
+    else:
+        n_out = nbr.shape[1]
+        if nbr.shape[0] != K:
+            raise PcgcError('conv_gather: kernel map / kernel volume mismatch')
+    if out is None:
+        out = torch.empty((n_out, Cout), dtype=torch.float32, device=x.device)
+    res_p, res_ld = (None, 0) if residual is None else (_p(_f32(residual)), _ld(residual))
+    prof = PROFILE.enabled and K == 27
+    if prof:
+        e0, e1 = PROFILE.bracket(K, Cin, Cout, n_out)
+        e0.record()
+    check(lib().pcgc_conv_gather(_p(nbr), K, n_out, _p(x), Cin, _ld(x), 0, _p(W), _p(bias), res_p, res_ld, 0, int(relu),
+                                 _p(out), Cout, _ld(out), 0, _stream()), 'conv_gather')
+    if prof:
+        e1.record()
+    elif PROFILE.counting and K == 27:
+        PROFILE.count(nbr, K, n_out)
+    return out
+
+
+def conv_up2(x, W, bias, relu=False):
+    _f32(x, 'x'); _f32(W, 'W')
+    K, Cin, Cout = W.shape
+    out = torch.empty((8 * x.shape[0], Cout), dtype=torch.float32, device=x.device)
+    check(lib().pcgc_conv_up2(x.shape[0], _p(x), Cin, _ld(x), _p(W), _p(bias), int(relu), _p(out), Cout, _stream()), 'conv_up2')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ select / sort
+def topk_mask(logits, k):
+    """logits: [n,1] or [n] fp32 view -> uint8 mask [n] of the k largest (ties: lower row)."""
+    _f32(logits, 'logits')
+    n = logits.shape[0]
+    ld = logits.stride(0)
+    mask = torch.empty(n, dtype=torch.uint8, device=logits.device)
+    ws_bytes = int(lib().pcgc_topk_workspace_bytes(n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=logits.device)
+    check(lib().pcgc_topk_mask(_p(logits), ld, n, int(k), _p(mask), _p(ws), ws_bytes, _stream()), 'topk_mask')
+    return mask
+
+
+def sort_zyx(coords):
+    n = coords.shape[0]
+    perm = torch.empty(n, dtype=torch.int32, device=coords.device)
+    ws_bytes = int(lib().pcgc_sort_workspace_bytes(n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=coords.device)
+    check(lib().pcgc_sort_zyx(_p(_i32(coords)), n, _p(perm), _p(ws), ws_bytes, _stream()), 'sort_zyx')
+    return perm
+
+
+def gather_coords(coords, perm):
+    out = torch.empty_like(coords)
+    check(lib().pcgc_gather_rows_i32x4(_p(_i32(coords)), _p(perm), coords.shape[0], _p(out), _stream()), 'gather_rows_i32x4')
+    return out
+
+
+def gather_feats(feats, perm):
+    feats = _f32(feats).contiguous()
+    out = torch.empty_like(feats)
+    check(lib().pcgc_gather_rows_f32(_p(feats), feats.shape[1], _p(perm), feats.shape[0], _p(out), _stream()), 'gather_rows_f32')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ entropy
+def round_minmax(feats):
+    feats = _f32(feats).contiguous()
+    mm = torch.empty(2, dtype=torch.float32, device=feats.device)
+    check(lib().pcgc_round_minmax(_p(feats), feats.numel(), _p(mm), _stream()), 'round_minmax')
+    return mm
+
+
+def symbolize(feats, min_v):
+    feats = _f32(feats).contiguous()
+    sym = torch.empty(feats.shape, dtype=torch.int16, device=feats.device)
+    check(lib().pcgc_symbolize(_p(feats), feats.numel(), float(min_v), _p(sym), _stream()), 'symbolize')
+    return sym
+
+
+def desymbolize(sym, min_v):
+    out = torch.empty(sym.shape, dtype=torch.float32, device=sym.device)
+    check(lib().pcgc_desymbolize(_p(_dev(sym, torch.int16, 'sym')), sym.numel(), float(min_v), _p(out), _stream()), 'desymbolize')
+    return out
+
+
+def cdf_table(params, C, min_v, max_v):
+    """-> (cdf_u16 as int16-typed tensor [C, L+1] holding the uint16 bit patterns, cdf_f32 [C, L+1])."""
+    L = int(max_v - min_v) + 1
+    q = torch.empty((C, L + 1), dtype=torch.int16, device=params.device)
+    f = torch.empty((C, L + 1), dtype=torch.float32, device=params.device)
+    check(lib().pcgc_cdf_table(_p(_f32(params, 'params')), C, float(min_v), float(max_v), _p(q), _p(f), _stream()), 'cdf_table')
+    return q, f
+
+
+# ------------------------------------------------------------------------------------------------ host codecs (numpy)
+def _np(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def rc_encode(cdf_u16, sym):
+    cdf = _np(cdf_u16, np.uint16)
+    sym = _np(sym, np.int16).ravel()
+    C, Lp = cdf.shape
+    cap = sym.size * 2 + 64
+    while True:
+        buf = np.empty(cap, np.uint8)
+        n = int(lib().pcgc_rc_encode(cdf.ctypes.data, C, Lp, sym.ctypes.data, sym.size, buf.ctypes.data, cap))
+        if n >= 0:
+            return buf[:n].tobytes()
+        if n == -(2 ** 63):
+            raise PcgcError('rc_encode: symbol outside the CDF table')
+        cap = -n
+
+
+def rc_decode(cdf_u16, data, n):
+    cdf = _np(cdf_u16, np.uint16)
+    C, Lp = cdf.shape
+    src = np.frombuffer(data, np.uint8)
+    out = np.empty(n, np.int16)
+    check(lib().pcgc_rc_decode(cdf.ctypes.data, C, Lp, src.ctypes.data, src.size, out.ctypes.data, n), 'rc_decode')
+    return out
+
+
+def oct_encode(xyz):
+    xyz = _np(xyz, np.int32)
+    if xyz.ndim != 2 or xyz.shape[1] != 3:
+        raise PcgcError('oct_encode: expected [n,3] coordinates')
+    cap = 64 + 4 * len(xyz)
+    while True:
+        buf = np.empty(cap, np.uint8)
+        n = int(lib().pcgc_oct_encode(xyz.ctypes.data, len(xyz), buf.ctypes.data, cap))
+        if n >= 0:
+            return buf[:n].tobytes()
+        if n == -(2 ** 63):
+            raise PcgcError('oct_encode: coordinates must be in [0, 2^21)')
+        cap = -n
+
+
+def oct_decode(data):
+    src = np.frombuffer(data, np.uint8)
+    n = int(lib().pcgc_oct_decode_count(src.ctypes.data, src.size))
+    if n < 0:
+        raise PcgcError('oct_decode: not a PCGO stream')
+    out = np.empty((n, 3), np.int32)
+    check(lib().pcgc_oct_decode(src.ctypes.data, src.size, out.ctypes.data, n), 'oct_decode')
+    return out

@@ -1,0 +1,134 @@
+"""SparseTensor + coordinate levels: the part of MinkowskiEngine's tensor / coordinate-manager surface that PCGCv2's
+encode/decode path touches: `.C .F .tensor_stride .device len()`.
+
+A `CoordMap` is one coordinate level (ME: a coordinate-map key inside the coordinate manager).  It owns the level's
+hash table and caches the kernel maps built on it, so all convolutions of a level share one k3 map — ME does the same.
+"""
+import torch
+
+from . import ops
+from ._lib import PcgcError
+
+
+def require_gpu(device):
+    device = torch.device(device)
+    if device.type != 'cuda':
+        raise PcgcError(f'pcgcv2_amd runs on an MI355X (torch device "cuda" on ROCm); got "{device}". '
+                        'There is no CPU execution path.')
+    return device
+
+
+class CoordMap:
+    def __init__(self, coords, stride, unique=False):
+        """coords: int32 [N,4] device (batch,x,y,z).  unique=True promises there are no duplicate rows."""
+        self.C = coords
+        self.stride = int(stride)
+        self._table = None
+        self._k3 = None
+        self._down = None
+        self._up = None
+        self._unique = unique
+
+    def __len__(self):
+        return self.C.shape[0]
+
+    @property
+    def table(self):
+        if self._table is None:
+            self._table = ops.HashTable(self.C, self.stride)
+        return self._table
+
+    @property
+    def k3(self):
+        """[27, N] kernel map of MinkowskiConvolution(kernel_size=3, stride=1) on this level."""
+        if self._k3 is None:
+            self._k3 = ops.kmap_k3(self.C, self.stride, self.table)
+        return self._k3
+
+    def down(self):
+        """-> (coarse CoordMap at 2*stride, [8, N_coarse] kernel map): MinkowskiConvolution(kernel_size=2, stride=2)."""
+        if self._down is None:
+            q = ops.coords_quantize(self.C, 2 * self.stride)
+            qt = ops.HashTable(q, 2 * self.stride)
+            keep = ops.first_occurrence_mask(q, qt)
+            prefix, total = ops.mask_scan(keep)
+            n_coarse = int(total.item())                       # host sync: sizes the coarse level
+            coarse = CoordMap(ops.compact_coords(q, keep, prefix, n_coarse), 2 * self.stride, unique=True)
+            self._down = (coarse, ops.kmap_down(coarse.C, self.stride, self.table))
+        return self._down
+
+    def up(self):
+        """-> children CoordMap at stride/2, rows 8*i+k: MinkowskiGenerativeConvolutionTranspose(k=2, stride=2)."""
+        if self._up is None:
+            self._up = CoordMap(ops.coords_children(self.C, self.stride), self.stride // 2, unique=True)
+        return self._up
+
+    def drop_caches(self):
+        self._table = self._k3 = self._down = self._up = None
+
+
+def dedup(coords, feats, stride):
+    """ME.SparseTensor construction collapses duplicate coordinates; canonical: keep the first occurrence."""
+    table = ops.HashTable(coords, stride)
+    keep = ops.first_occurrence_mask(coords, table)
+    prefix, total = ops.mask_scan(keep)
+    n = int(total.item())
+    if n == coords.shape[0]:
+        return coords, feats
+    return ops.compact_coords(coords, keep, prefix, n), ops.compact_feats(feats.contiguous(), keep, prefix, n)
+
+
+class SparseTensor:
+    """Drop-in for the ME.SparseTensor uses in coder.py / data_utils.py (ctor: data_utils.py:96,108,116; coder.py:102)."""
+
+    def __init__(self, features, coordinates=None, tensor_stride=1, device=None, coordinate_map=None, assume_unique=False):
+        if isinstance(tensor_stride, (list, tuple)):
+            tensor_stride = tensor_stride[0]
+        if coordinate_map is not None:
+            self.cmap = coordinate_map
+            dev = coordinate_map.C.device
+            self.F = features if features.device == dev else features.to(dev)
+        else:
+            dev = require_gpu(device if device is not None else coordinates.device)
+            coords = coordinates.to(device=dev, dtype=torch.int32).contiguous()
+            feats = features.to(device=dev, dtype=torch.float32).contiguous()
+            if coords.dim() != 2 or coords.shape[1] != 4:
+                raise PcgcError('coordinates must be [N,4] (batch, x, y, z)')
+            if coords.shape[0] != feats.shape[0]:
+                raise PcgcError('coordinates / features length mismatch')
+            if not assume_unique and coords.shape[0] > 0:
+                coords, feats = dedup(coords, feats, int(tensor_stride))
+            self.cmap = CoordMap(coords, int(tensor_stride), unique=True)
+            self.F = feats
+
+    @property
+    def C(self):
+        return self.cmap.C
+
+    @property
+    def tensor_stride(self):
+        return [self.cmap.stride] * 3
+
+    @property
+    def device(self):
+        return self.cmap.C.device
+
+    @property
+    def shape(self):
+        return self.F.shape
+
+    def __len__(self):
+        return self.cmap.C.shape[0]
+
+    def __repr__(self):
+        return f'SparseTensor(N={len(self)}, C={self.F.shape[1]}, stride={self.cmap.stride}, device={self.device})'
+
+
+def sparse_collate(coords_list, feats_list):
+    """ME.utils.sparse_collate (data_utils.py:107,115): prepend the batch index column."""
+    cs, fs = [], []
+    for b, (c, f) in enumerate(zip(coords_list, feats_list)):
+        c = torch.as_tensor(c).int()
+        cs.append(torch.cat([torch.full((len(c), 1), b, dtype=torch.int32, device=c.device), c], dim=1))
+        fs.append(torch.as_tensor(f))
+    return torch.cat(cs, 0), torch.cat(fs, 0)

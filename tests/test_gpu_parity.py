@@ -1,0 +1,273 @@
+"""GPU parity tests: every HIP operator and the full encode/decode path against the CPU oracle, through the C-ABI.
+Bit-exact for coordinates, masks, permutations, symbols, bitstreams AND for the fp32 conv outputs (the canonical
+fmaf chain makes them reproducible); the entropy tables are additionally pinned to the reference golden (G1)."""
+import os
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pcgc_oracle as orc
+from pcgcv2_amd import ops, synthetic
+from pcgcv2_amd.sparse import SparseTensor, CoordMap
+
+DEV = torch.device('cuda:0')
+
+
+def _t(a, dt=None):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(DEV)
+
+
+def _coords(name):
+    c = synthetic.shell(name).numpy()
+    return np.concatenate([np.zeros((len(c), 1), np.int32), c], 1)
+
+
+@pytest.fixture(scope='module')
+def sd():
+    return synthetic.synthetic_state_dict()
+
+
+@pytest.fixture(scope='module')
+def sd_np(sd):
+    return synthetic.state_dict_to_numpy(sd)
+
+
+# ------------------------------------------------------------------------------------------------ coordinate ops
+def test_dedup_keeps_first_occurrence():
+    rng = np.random.default_rng(0)
+    c = rng.integers(0, 40, size=(20000, 3)).astype(np.int32)                 # many duplicates
+    c4 = np.concatenate([np.zeros((len(c), 1), np.int32), c], 1)
+    f = rng.standard_normal((len(c), 4)).astype(np.float32)
+    x = SparseTensor(_t(f), coordinates=_t(c4), tensor_stride=1, device=DEV)
+    want = orc.unique_first(c4)
+    np.testing.assert_array_equal(x.C.cpu().numpy(), want)
+    # features follow their (first-occurrence) rows
+    first = {tuple(r): i for i, r in reversed(list(enumerate(map(tuple, c4))))}
+    idx = np.array([first[tuple(r)] for r in want])
+    np.testing.assert_array_equal(x.F.cpu().numpy(), f[idx])
+
+
+@pytest.mark.parametrize('name', ['shell6', 'shell8'])
+def test_pyramid_and_kernel_maps(name):
+    c4 = _coords(name)
+    lvl = CoordMap(_t(c4), 1, unique=True)
+    fine_np, stride = c4, 1
+    for _ in range(3):
+        np.testing.assert_array_equal(lvl.k3.cpu().numpy(), orc.kmap_k3(fine_np, stride))
+        coarse, nbr8 = lvl.down()
+        want_c, _ = orc.stride2_coords(fine_np, 2 * stride)
+        np.testing.assert_array_equal(coarse.C.cpu().numpy(), want_c)
+        np.testing.assert_array_equal(nbr8.cpu().numpy(), orc.kmap_down(fine_np, want_c, stride))
+        lvl, fine_np, stride = coarse, want_c, 2 * stride
+    kids = lvl.up()
+    np.testing.assert_array_equal(kids.C.cpu().numpy(), orc.children_coords(fine_np, stride))
+    np.testing.assert_array_equal(kids.k3.cpu().numpy(), orc.kmap_k3(kids.C.cpu().numpy(), stride // 2))
+
+
+def test_kmap_at_volume_border_and_empty():
+    c4 = np.array([[0, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 1], [0, 1048575, 1048575, 1048575]], np.int32)
+    lvl = CoordMap(_t(c4), 1, unique=True)
+    np.testing.assert_array_equal(lvl.k3.cpu().numpy(), orc.kmap_k3(c4, 1))
+    e = CoordMap(torch.zeros((0, 4), dtype=torch.int32, device=DEV), 1, unique=True)
+    assert e.k3.shape == (27, 0)
+
+
+def test_scale_coords_half_even():
+    rng = np.random.default_rng(3)
+    c = rng.integers(0, 4096, size=(5000, 4)).astype(np.int32); c[:, 0] = 0
+    for factor in (0.375, 1.0 / 0.375, 0.5):
+        got = ops.coords_scale(_t(c), factor).cpu().numpy()
+        want = c.copy()
+        want[:, 1:] = torch.tensor(c[:, 1:]).mul(factor).round().int().numpy()       # data_utils.py:113 semantics
+        np.testing.assert_array_equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------ conv family
+CONV_SHAPES = [(27, 1, 16), (27, 16, 16), (27, 32, 8), (27, 8, 16), (27, 8, 8), (27, 32, 32), (27, 64, 16), (27, 16, 32),
+               (27, 16, 4), (27, 4, 8), (27, 4, 4), (27, 64, 64), (27, 32, 1), (27, 16, 1), (27, 64, 1), (27, 32, 8),
+               (8, 16, 32), (8, 32, 64), (8, 64, 32), (1, 32, 8), (1, 8, 16), (1, 64, 16), (1, 16, 32), (1, 16, 4), (1, 4, 8)]
+
+
+@pytest.mark.parametrize('K,cin,cout', CONV_SHAPES)
+def test_conv_gather_bit_exact(K, cin, cout):
+    rng = np.random.default_rng(K * 1000 + cin * 10 + cout)
+    c4 = _coords('shell7')
+    n = len(c4)
+    if K == 27:
+        nbr = orc.kmap_k3(c4, 1)
+    elif K == 8:
+        coarse, _ = orc.stride2_coords(c4, 2)
+        nbr = orc.kmap_down(c4, coarse, 1)
+    else:
+        nbr = None
+    x = rng.standard_normal((n, cin)).astype(np.float32)
+    W = (rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+    b = rng.standard_normal((1, cout)).astype(np.float32)
+    want = orc.conv_gather(nbr if nbr is not None else np.arange(n, dtype=np.int32)[None], x, W, b)
+    Wt = _t(W[0] if K == 1 else W)
+    got = ops.conv_gather(None if nbr is None else _t(nbr), _t(x), Wt, _t(b))
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    # fused epilogue: residual + relu into a column slice of a wider buffer
+    n_out = want.shape[0]
+    res = rng.standard_normal((n_out, 2 * cout)).astype(np.float32)
+    buf = torch.zeros((n_out, 2 * cout), device=DEV)
+    res_t = _t(res)
+    ops.conv_gather(None if nbr is None else _t(nbr), _t(x), Wt, _t(b), out=buf[:, cout:], residual=res_t[:, cout:], relu=True)
+    np.testing.assert_array_equal(buf[:, cout:].cpu().numpy(), np.maximum(want + res[:, cout:], np.float32(0)))
+    assert not buf[:, :cout].any()
+
+
+@pytest.mark.parametrize('cin,cout', [(8, 64), (64, 32), (32, 16)])
+def test_conv_up2_bit_exact(cin, cout):
+    rng = np.random.default_rng(cin + cout)
+    x = rng.standard_normal((3001, cin)).astype(np.float32)
+    W = (rng.standard_normal((8, cin, cout)) / np.sqrt(8 * cin)).astype(np.float32)
+    b = rng.standard_normal((1, cout)).astype(np.float32)
+    got = ops.conv_up2(_t(x), _t(W), _t(b), relu=True).cpu().numpy()
+    np.testing.assert_array_equal(got, orc.relu(orc.conv_up2(x, W, b)))
+
+
+# ------------------------------------------------------------------------------------------------ select / sort
+@pytest.mark.parametrize('n,k', [(1, 1), (100, 0), (1000, 391), (4097, 4097), (250000, 100003), (2048, 1)])
+def test_topk_mask_with_ties(n, k):
+    rng = np.random.default_rng(n + k)
+    v = np.round(rng.standard_normal(n) * 3).astype(np.float32) / 2          # heavy ties, includes +-0
+    v[rng.random(n) < 0.05] = -0.0
+    got = ops.topk_mask(_t(v).reshape(-1, 1), k).cpu().numpy().astype(bool)
+    np.testing.assert_array_equal(got, orc.topk_mask(v, k))
+    assert got.sum() == min(n, k)
+
+
+def test_topk_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'ordering.npz'))
+    for i in range(4):
+        got = ops.topk_mask(_t(g[f't{i}_vals']).reshape(-1, 1), int(g[f't{i}_k'])).cpu().numpy().astype(bool)
+        np.testing.assert_array_equal(got, g[f't{i}_mask'])
+
+
+def test_sort_zyx_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'ordering.npz'))
+    for i in range(3):
+        c = g[f's{i}_coords']
+        np.testing.assert_array_equal(ops.sort_zyx(_t(c)).cpu().numpy(), g[f's{i}_argsort'])
+
+
+def test_mask_scan_and_compaction():
+    rng = np.random.default_rng(9)
+    for n in (1, 7, 2048, 2049, 300001):
+        m = (rng.random(n) < 0.4).astype(np.uint8)
+        prefix, total = ops.mask_scan(_t(m))
+        np.testing.assert_array_equal(prefix.cpu().numpy(), np.cumsum(m) - m)
+        assert int(total.item()) == m.sum()
+        f = rng.standard_normal((n, 8)).astype(np.float32)
+        got = ops.compact_feats(_t(f), _t(m), prefix, int(m.sum())).cpu().numpy()
+        np.testing.assert_array_equal(got, f[m.astype(bool)])
+
+
+# ------------------------------------------------------------------------------------------------ entropy model
+def test_cdf_table_vs_oracle_and_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'entropy_tables.npz'))
+    for ci in range(int(g['n_cases'])):
+        params = g[f'c{ci}_params']
+        lo, hi = g[f'c{ci}_minmax']
+        q, f = ops.cdf_table(_t(params), 8, lo, hi)
+        q = q.cpu().numpy().view(np.uint16); f = f.cpu().numpy()
+        want_f = orc.cdf_float(params, lo, hi)
+        np.testing.assert_array_equal(f, want_f)                              # fp32 cdf: bit-exact vs oracle
+        np.testing.assert_array_equal(q, orc.cdf_u16(want_f))                 # 16-bit table: bit-exact vs oracle
+        np.testing.assert_allclose(f, g[f'c{ci}_cdf'], rtol=0, atol=5e-7)     # reference (torch-CPU fp32) golden
+
+
+def test_quantise_symbolize_roundtrip():
+    rng = np.random.default_rng(2)
+    f = (rng.standard_normal((5000, 8)) * 4).astype(np.float32)
+    f[0, 0] = 2.5; f[0, 1] = 3.5; f[0, 2] = -0.5; f[0, 3] = -0.2                # half-even and -0 cases
+    mm = ops.round_minmax(_t(f)).cpu().numpy()
+    r = np.rint(f)
+    assert mm[0] == r.min() and mm[1] == r.max()
+    sym = ops.symbolize(_t(f), mm[0])
+    np.testing.assert_array_equal(sym.cpu().numpy(), (r - mm[0]).astype(np.int16))
+    np.testing.assert_array_equal(ops.desymbolize(sym, mm[0]).cpu().numpy(), r + np.float32(0))
+
+
+# ------------------------------------------------------------------------------------------------ model / coder
+def _model(sd):
+    from pcgcv2_amd.pcc_model import PCCModel
+    m = PCCModel().to(DEV)
+    m.load_state_dict(sd)
+    return m
+
+
+def test_encoder_decoder_layers_bit_exact(sd, sd_np):
+    c4 = _coords('shell7')
+    m = _model(sd)
+    x = SparseTensor(torch.ones((len(c4), 1)), coordinates=_t(c4), tensor_stride=1, device=DEV)
+    with torch.no_grad():
+        ys = m.encoder(x)
+    want = orc.encoder_forward(sd_np, c4, np.ones((len(c4), 1), np.float32))
+    for got, (wc, wf) in zip(ys, want):
+        np.testing.assert_array_equal(got.C.cpu().numpy(), wc)
+        np.testing.assert_array_equal(got.F.cpu().numpy(), wf)
+    # decoder from the (unsorted is fine) latent
+    nums = [len(want[1][0]), len(want[2][0]), len(c4)]
+    with torch.no_grad():
+        cls_list, out = m.decoder(ys[0], [[n] for n in nums])
+    wC, wF, wcls = orc.decoder_forward(sd_np, want[0][0], want[0][1], nums, return_cls=True)
+    for got, (cc, cf) in zip(cls_list, wcls):
+        np.testing.assert_array_equal(got.C.cpu().numpy(), cc)
+        np.testing.assert_array_equal(got.F.cpu().numpy(), cf)
+    np.testing.assert_array_equal(out.C.cpu().numpy(), wC)
+    np.testing.assert_array_equal(out.F.cpu().numpy(), wF)
+
+
+@pytest.mark.parametrize('name,rho', [('shell6', 1.0), ('shell8', 1.0), ('shell8', 0.6), ('shell8', 2.0)])
+def test_coder_files_and_decode_match_oracle(name, rho, sd, sd_np, tmp_path):
+    from pcgcv2_amd.coder import Coder
+    c4 = _coords(name)
+    m = _model(sd)
+    x = SparseTensor(torch.ones((len(c4), 1)), coordinates=_t(c4), tensor_stride=1, device=DEV)
+    coder = Coder(m, str(tmp_path / name))
+    y = coder.encode(x, postfix='_r3')
+    ref = orc.encode(sd_np, c4)
+    for k in ('F', 'H', 'num_points'):
+        assert (tmp_path / f'{name}_r3_{k}.bin').read_bytes() == ref[k], k
+    np.testing.assert_array_equal(y.C.cpu().numpy(), ref['yC'])
+    np.testing.assert_array_equal(y.F.cpu().numpy(), ref['yF'])
+    dec_c = coder.coordinate_coder.decode(postfix='_r3')
+    key = lambda a: a[np.lexsort((a[:, 0], a[:, 1], a[:, 2]))]
+    np.testing.assert_array_equal(key(dec_c), key(ref['coords8']))
+    out = coder.decode(rho=rho, postfix='_r3')
+    want = orc.decode(sd_np, ref['coords8'], ref['F'], ref['H'], ref['num_points'], rho=rho)
+    np.testing.assert_array_equal(out.C.cpu().numpy(), want)
+    assert out.tensor_stride[0] == 1
+
+
+def test_full_size_frame_properties(sd, tmp_path):
+    """shell10 (786 632 points, the bench workload): size-independent properties instead of the (slow) oracle."""
+    from pcgcv2_amd.coder import Coder
+    c4 = _coords('shell10')
+    m = _model(sd)
+    x = SparseTensor(torch.ones((len(c4), 1)), coordinates=_t(c4), tensor_stride=1, device=DEV)
+    coder = Coder(m, str(tmp_path / 'full'))
+    y = coder.encode(x)
+    files = {k: (tmp_path / f'full_{k}.bin').read_bytes() for k in ('C', 'F', 'H', 'num_points')}
+    n4, n2, n1 = np.frombuffer(files['num_points'], np.int32)
+    assert (n1, n2, n4, len(y)) == (786632, 255692, 71216, 18732)              # pyramid sizes probed in SURVEY §8
+    yc = y.C.cpu().numpy()
+    keyv = orc.array2vector(yc, yc.max() + 1)
+    assert np.all(np.diff(keyv) > 0)                                           # sortedness in the reference's key
+    out = coder.decode()
+    oc = out.C.cpu().numpy()
+    assert len(oc) == n1 and len(np.unique(oc, axis=0)) == n1                  # rho=1: exactly N1 distinct voxels
+    assert oc[:, 1:].min() >= 0 and (oc[:, 0] == 0).all()
+    # idempotence: a second encode of the same tensor gives the same bitstream; decode is deterministic
+    coder2 = Coder(m, str(tmp_path / 'again'))
+    coder2.encode(x)
+    for k in files:
+        assert (tmp_path / f'again_{k}.bin').read_bytes() == files[k], k
+    np.testing.assert_array_equal(coder2.decode().C.cpu().numpy(), oc)
+    # the entropy-coded latent round-trips exactly
+    yF = coder.feature_coder.decode(device=DEV)
+    np.testing.assert_array_equal(yF.cpu().numpy(), np.rint(y.F.cpu().numpy()) + np.float32(0))

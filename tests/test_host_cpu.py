@@ -1,0 +1,159 @@
+"""CPU-side checks (no GPU): C-ABI exports, host codecs against the oracle, file formats, checkpoint layout."""
+import os
+import re
+import numpy as np
+import pytest
+import torch
+
+from oracle import pcgc_oracle as orc
+from pcgcv2_amd import ops, synthetic, PcgcError
+from pcgcv2_amd._lib import lib, SIGNATURES, LIB_PATH
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'pcgc_hip.h')).read()
+    body = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    declared = set(re.findall(r'\b(pcgc_\w+)\s*\(', body))
+    assert len(declared) >= 30
+    l = lib()
+    for name in declared:
+        assert hasattr(l, name), f'{name} declared in include/pcgc_hip.h but not exported by {LIB_PATH}'
+    assert declared == set(SIGNATURES), declared ^ set(SIGNATURES)
+    assert l.pcgc_version() >= 1
+
+
+def test_range_coder_matches_oracle_bit_for_bit(golden_dir):
+    rng = np.random.default_rng(1)
+    g = np.load(os.path.join(golden_dir, 'entropy_tables.npz'))
+    for case, (lo, hi) in [('c1', (-20, 20)), ('c0', (-8, 9)), ('c3', (0, 0)), ('c2', (-3, 2))]:
+        table = orc.cdf_u16(orc.cdf_float(g[f'{case}_params'], lo, hi))
+        L = hi - lo + 1
+        for n in (1, 3, 257, 5000):
+            # peaked symbol distribution like real latents
+            sym = np.clip(np.rint(rng.normal(L / 2, max(L / 8, 0.3), size=(n, 8))), 0, L - 1).astype(np.int16)
+            a = ops.rc_encode(table, sym)
+            b = orc.rc_encode(table, sym)
+            assert a == b
+            np.testing.assert_array_equal(ops.rc_decode(table, a, sym.size), sym.ravel())
+            np.testing.assert_array_equal(orc.rc_decode(table, a, sym.size), sym.ravel())
+
+
+def test_range_coder_rejects_out_of_table_symbol():
+    table = orc.cdf_u16(np.array([[0, .25, .5, 1.0]] * 8, np.float32))
+    with pytest.raises(PcgcError):
+        ops.rc_encode(table, np.full((2, 8), 3, np.int16))
+
+
+@pytest.mark.parametrize('case', ['empty', 'single', 'random', 'shell', 'dense', 'big_coords'])
+def test_octree_codec_roundtrip(case):
+    rng = np.random.default_rng(5)
+    if case == 'empty':
+        pts = np.zeros((0, 3), np.int32)
+    elif case == 'single':
+        pts = np.array([[5, 0, 127]], np.int32)
+    elif case == 'random':
+        pts = np.unique(rng.integers(0, 128, size=(3000, 3)), axis=0).astype(np.int32)
+    elif case == 'dense':
+        g = np.arange(8)
+        pts = np.stack(np.meshgrid(g, g, g, indexing='ij'), -1).reshape(-1, 3).astype(np.int32)
+    elif case == 'big_coords':
+        pts = np.unique(rng.integers(0, 1 << 20, size=(500, 3)), axis=0).astype(np.int32)
+    else:
+        pts = np.unique(synthetic.shell('shell8').numpy() // 8, axis=0).astype(np.int32)
+    rng.shuffle(pts)
+    data = ops.oct_encode(pts)
+    back = ops.oct_decode(data)
+    assert data[:4] == b'PCGO'
+    key = lambda a: a[np.lexsort((a[:, 0], a[:, 1], a[:, 2]))]
+    np.testing.assert_array_equal(key(back), key(pts))
+    if case == 'shell':
+        bits_per_point = 8 * len(data) / len(pts)
+        assert bits_per_point < 4.0, bits_per_point
+
+
+def test_octree_rejects_foreign_stream():
+    with pytest.raises(PcgcError):
+        ops.oct_decode(b'not a stream at all')
+
+
+def test_state_dict_layout_matches_reference(golden_dir):
+    from pcgcv2_amd.pcc_model import PCCModel
+    m = PCCModel()
+    sd = m.state_dict()
+    assert len(sd) == 227                                       # 106 convs x 2 + 15 entropy tensors
+    want = {}
+    for line in open(os.path.join(golden_dir, 'state_dict_keys.txt')):
+        k, shape = line.split(' ', 1)
+        want['entropy_bottleneck.' + k] = eval(shape)
+    for k, shape in want.items():
+        assert list(sd[k].shape) == shape, k
+    assert list(sd['encoder.conv0.kernel'].shape) == [27, 1, 16]
+    assert list(sd['encoder.conv0.bias'].shape) == [1, 16]
+    assert list(sd['encoder.down0.kernel'].shape) == [8, 16, 32]
+    assert list(sd['encoder.block0.1.conv1_0.kernel'].shape) == [32, 8]        # k=1 kernels are 2-D in ME
+    assert list(sd['decoder.up0.kernel'].shape) == [8, 8, 64]
+    assert list(sd['decoder.conv2_cls.kernel'].shape) == [27, 16, 1]
+    assert sum(p.numel() for p in m.encoder.parameters()) == 408008
+    assert sum(p.numel() for p in m.decoder.parameters()) == 370127
+    # a checkpoint in the reference's layout loads strictly, aliases included
+    syn = synthetic.synthetic_state_dict()
+    m.load_state_dict(syn, strict=True)
+    assert m.entropy_bottleneck.matrix is m.entropy_bottleneck._matrices[3]
+    np.testing.assert_array_equal(orc.pack_eb_params(synthetic.state_dict_to_numpy(syn)),
+                                  m.entropy_bottleneck.packed_params(torch.device('cpu')).numpy())
+
+
+def test_ply_io_matches_reference_format(golden_dir, tmp_path):
+    from pcgcv2_amd.data_utils import read_ply_ascii_geo, write_ply_ascii_geo
+    g = np.load(os.path.join(golden_dir, 'ply_format.npz'))
+    p = tmp_path / 'w.ply'
+    write_ply_ascii_geo(str(p), g['coords'])
+    assert p.read_bytes() == g['file_bytes'].tobytes()
+    np.testing.assert_array_equal(read_ply_ascii_geo(str(p)), g['read_back'])
+    p2 = tmp_path / 'b.ply'
+    p2.write_bytes(g['file2_bytes'].tobytes())
+    np.testing.assert_array_equal(read_ply_ascii_geo(str(p2)), g['read_back2'])
+
+
+def test_native_d1_matches_pc_error_d(golden_dir, tmp_path):
+    from pcgcv2_amd.pc_error import d1_psnr, pc_error
+    from pcgcv2_amd.data_utils import write_ply_ascii_geo
+    g = np.load(os.path.join(golden_dir, 'd1_metric.npz'))
+    for i in range(int(g['n_cases'])):
+        m = d1_psnr(g[f'p{i}_a'], g[f'p{i}_b'], int(g[f'p{i}_res']))
+        assert m['mseF      (p2point)'] == pytest.approx(float(g[f'p{i}_mseF(p2point)']), rel=1e-5, abs=1e-9)
+        assert m['h.        (p2point)'] == pytest.approx(float(g[f'p{i}_h.(p2point)']), rel=1e-5, abs=1e-9)
+        if m['mseF      (p2point)'] > 0:
+            assert m['mseF,PSNR (p2point)'] == pytest.approx(float(g[f'p{i}_mseF_PSNR(p2point)']), abs=2e-4)
+    a, b = tmp_path / 'a.ply', tmp_path / 'b.ply'
+    write_ply_ascii_geo(str(a), g['p0_a']); write_ply_ascii_geo(str(b), g['p0_b'])
+    df = pc_error(str(a), str(b), res=int(g['p0_res']))
+    assert df['mseF,PSNR (p2point)'][0] == pytest.approx(float(g['p0_mseF_PSNR(p2point)']), abs=2e-4)
+
+
+def test_product_refuses_cpu_tensors():
+    from pcgcv2_amd.sparse import SparseTensor
+    with pytest.raises(PcgcError):
+        SparseTensor(torch.ones(4, 1), coordinates=torch.zeros(4, 4, dtype=torch.int32), device='cpu')
+    with pytest.raises(PcgcError):
+        ops.conv_gather(None, torch.ones(4, 4), torch.ones(4, 4), None)
+
+
+def test_oracle_roundtrip_small_shell():
+    """encode -> decode of the oracle itself on shell6: decoded point count follows coder.py:105-112."""
+    sd = synthetic.state_dict_to_numpy(synthetic.synthetic_state_dict())
+    c = synthetic.shell('shell6').numpy()
+    c4 = np.concatenate([np.zeros((len(c), 1), np.int32), c], 1)
+    enc = orc.encode(sd, c4)
+    assert len(enc['H']) == 17 and len(enc['num_points']) == 12
+    n4, n2, n1 = np.frombuffer(enc['num_points'], np.int32)
+    assert n1 == len(c4) and n4 < n2 < n1
+    out = orc.decode(sd, enc['coords8'], enc['F'], enc['H'], enc['num_points'])
+    assert len(out) == n1 and len(np.unique(out, axis=0)) == n1
+    out_half = orc.decode(sd, enc['coords8'][::-1], enc['F'], enc['H'], enc['num_points'], rho=0.5)
+    assert len(out_half) == int(0.5 * n1)
+    # latent symbols use a realistic alphabet with the synthetic gain
+    hdr_min, hdr_max = np.frombuffer(enc['H'][9:17], np.float32)
+    assert 4 <= hdr_max - hdr_min <= 200
