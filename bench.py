@@ -38,6 +38,7 @@ def parse():
     ap.add_argument('--workload', default='shell10')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', default='shell9', help='bounded sample of the same workload for the CPU oracle')
+    ap.add_argument('--no-events', action='store_true', help='do not bracket the dominant kernel with HIP events')
     ap.add_argument('--detail', default='', help='optional path for a per-kernel-shape JSON breakdown')
     return ap.parse_args()
 
@@ -95,7 +96,7 @@ def main():
     bits = sum(os.path.getsize(os.path.join(tmp, 'frame' + p)) * 8 for p in ('_C.bin', '_F.bin', '_H.bin', '_num_points.bin'))
 
     # ---- timed region: exactly K steps, with the dominant kernel bracketed by HIP events on its own stream ----
-    ops.PROFILE.reset(enabled=True)
+    ops.PROFILE.reset(enabled=not args.no_events)
     barrier()
     t0 = time.perf_counter()
     enc_t = dec_t = 0.0

@@ -41,7 +41,8 @@ int pcgc_hash_clear(uint64_t* keys /*[dev cap]*/, int32_t* vals /*[dev cap]*/, i
 int pcgc_hash_insert(const int32_t* coords /*[dev n,4]*/, int64_t n, int32_t stride, uint64_t* keys, int32_t* vals,
                      int64_t cap, void* stream);                         /* vals[slot] = smallest row with that key */
 int pcgc_hash_first_mask(const int32_t* coords, int64_t n, int32_t stride, const uint64_t* keys, const int32_t* vals,
-                         int64_t cap, uint8_t* keep /*[dev n]*/, void* stream);  /* keep[i] = row i is the first occurrence */
+                         int64_t cap, uint8_t* keep /*[dev n]*/, int32_t* first_row /*[dev n] or NULL*/, void* stream);
+                         /* keep[i] = row i is the first occurrence of its coordinate; first_row[i] = that first row */
 
 /* ---- coordinate transforms ---- */
 /* output coords of MinkowskiConvolution(kernel_size=2, stride=2): floor(c / stride_out) * stride_out per row
@@ -68,6 +69,24 @@ int pcgc_kmap_k3(const int32_t* coords, int64_t n, int32_t stride, const uint64_
                  int64_t cap, int32_t* nbr /*[dev 27,n]*/, void* stream);
 int pcgc_kmap_down(const int32_t* coarse, int64_t n_coarse, int32_t stride_fine, const uint64_t* fine_keys,
                    const int32_t* fine_vals, int64_t fine_cap, int32_t* nbr /*[dev 8,n_coarse]*/, void* stream);
+
+/* Hierarchical kernel maps: a level's 27-neighbourhood is a gather through its PARENT level's map (octree relation), so
+ * only the coarsest level of a pyramid probes the hash.  (ME rebuilds a hash-probed map per level ‡.) */
+/* children of a generative transpose (all 8 children exist, rows 8*i+j):  [27, 8*n_parent] from [27, n_parent] */
+int pcgc_kmap_k3_children(const int32_t* parent_nbr, int64_t n_parent, int32_t* nbr /*[dev 27,8n]*/, void* stream);
+/* pruned level: surviving rows orig[r] of a candidate level, neighbours renumbered through mask/prefix */
+int pcgc_kmap_k3_prune(const int32_t* cand_nbr /*[27,n_cand]*/, int64_t n_cand, const uint8_t* mask, const int32_t* prefix,
+                       const int32_t* orig /*[n_out]*/, int64_t n_out, int32_t* nbr /*[dev 27,n_out]*/, void* stream);
+/* strided pyramid (encoder): fine level from the coarse level's map + the down map + each fine row's parent row */
+int pcgc_kmap_k3_from_coarse(const int32_t* fine /*[n_fine,4]*/, int64_t n_fine, int32_t stride_fine,
+                             const int32_t* parent_of /*[n_fine]*/, const int32_t* coarse_nbr /*[27,n_coarse]*/,
+                             const int32_t* down /*[8,n_coarse]*/, int64_t n_coarse, int32_t* nbr /*[dev 27,n_fine]*/,
+                             void* stream);
+/* parent_of[c] = prefix[first_row[c]]; down[slot(c)][parent_of[c]] = c — the k2s2 kernel map without hash probes */
+int pcgc_down_maps(const int32_t* fine, const int32_t* first_row, const int32_t* prefix, int64_t n_fine, int32_t stride_fine,
+                   int64_t n_coarse, int32_t* parent_of /*[dev n_fine]*/, int32_t* down /*[dev 8,n_coarse]*/, void* stream);
+/* orig[prefix[i]] = i for set mask bytes (row indices that survive a compaction) */
+int pcgc_compact_index(const uint8_t* mask, const int32_t* prefix, int64_t n, int32_t* orig /*[dev total]*/, void* stream);
 
 /* ---- sparse convolution family ---- */
 /* Gather convolution: MinkowskiConvolution k=3,s=1 (K=27), k=2,s=2 (K=8), k=1 (K=1, nbr may be NULL = identity)

@@ -29,17 +29,26 @@
  * coordinate keys.  coords are int32 [N,4] = (batch, x, y, z) as ME.SparseTensor.C
  * (reference call sites: data_utils.py:107-108, coder.py:102).
  * ---------------------------------------------------------------------------------------------- */
-static inline int64_t pack_key(int32_t b, int32_t x, int32_t y, int32_t z) {
-    /* 16 bits per field, biased so that -1 neighbours still order correctly */
-    return ((int64_t)(b & 0xffff) << 48) | ((int64_t)((z + 1) & 0xffff) << 32) |
-           ((int64_t)((y + 1) & 0xffff) << 16) | (int64_t)((x + 1) & 0xffff);
+typedef struct { int64_t hi, lo; } ckey_t;                 /* full-width fields: (batch, z+1) | (y+1, x+1) */
+static inline ckey_t pack_key(int32_t b, int32_t x, int32_t y, int32_t z) {
+    ckey_t k;
+    k.hi = ((int64_t)b << 32) | (int64_t)(uint32_t)(z + 1);
+    k.lo = ((int64_t)(uint32_t)(y + 1) << 32) | (int64_t)(uint32_t)(x + 1);
+    return k;
 }
+static inline int key_cmp(ckey_t a, ckey_t b) {
+    if (a.hi != b.hi) return a.hi < b.hi ? -1 : 1;
+    if (a.lo != b.lo) return a.lo < b.lo ? -1 : 1;
+    return 0;
+}
+static inline int key_eq(ckey_t a, ckey_t b) { return a.hi == b.hi && a.lo == b.lo; }
 
-typedef struct { int64_t key; int32_t row; } kv_t;
+typedef struct { ckey_t key; int32_t row; } kv_t;
 
 static int kv_cmp(const void* a, const void* b) {
     const kv_t* p = (const kv_t*)a; const kv_t* q = (const kv_t*)b;
-    if (p->key != q->key) return p->key < q->key ? -1 : 1;
+    int c = key_cmp(p->key, q->key);
+    if (c) return c;
     return p->row < q->row ? -1 : (p->row > q->row);
 }
 
@@ -53,10 +62,10 @@ static kv_t* build_sorted(const int32_t* coords, int64_t n) {
     return kv;
 }
 
-static int32_t find_row(const kv_t* kv, int64_t n, int64_t key) {
+static int32_t find_row(const kv_t* kv, int64_t n, ckey_t key) {
     int64_t lo = 0, hi = n;
-    while (lo < hi) { int64_t m = (lo + hi) >> 1; if (kv[m].key < key) lo = m + 1; else hi = m; }
-    return (lo < n && kv[lo].key == key) ? kv[lo].row : -1;
+    while (lo < hi) { int64_t m = (lo + hi) >> 1; if (key_cmp(kv[m].key, key) < 0) lo = m + 1; else hi = m; }
+    return (lo < n && key_eq(kv[lo].key, key)) ? kv[lo].row : -1;
 }
 
 /* ME.SparseTensor construction dedups coordinates (data_utils.py:108,116; coder.py:102).  ‡ ME keeps one row
@@ -67,7 +76,7 @@ int64_t orc_unique_first(const int32_t* coords, int64_t n, uint8_t* keep) {
     int64_t cnt = 0;
     memset(keep, 0, (size_t)n);
     for (int64_t i = 0; i < n; ++i)
-        if (i == 0 || kv[i].key != kv[i - 1].key) { keep[kv[i].row] = 1; ++cnt; }
+        if (i == 0 || !key_eq(kv[i].key, kv[i - 1].key)) { keep[kv[i].row] = 1; ++cnt; }
     free(kv);
     return cnt;
 }
@@ -92,7 +101,7 @@ int64_t orc_stride2_coords(const int32_t* coords, int64_t n, int32_t stride_out,
     int32_t* rank_of_first = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
     for (int64_t i = 0; i < n; ++i) rank_of_first[i] = -1;
     for (int64_t i = 0; i < n;) {
-        int64_t j = i; while (j < n && kv[j].key == kv[i].key) ++j;
+        int64_t j = i; while (j < n && key_eq(kv[j].key, kv[i].key)) ++j;
         for (int64_t t = i; t < j; ++t) first_row[kv[t].row] = kv[i].row;     /* kv sorted by (key,row): kv[i].row is min */
         i = j;
     }

@@ -16,7 +16,7 @@ SIGNATURES = {
     'pcgc_hash_capacity': (i64, [i64]),
     'pcgc_hash_clear': (ci, [vp, vp, i64, vp]),
     'pcgc_hash_insert': (ci, [vp, i64, i32, vp, vp, i64, vp]),
-    'pcgc_hash_first_mask': (ci, [vp, i64, i32, vp, vp, i64, vp, vp]),
+    'pcgc_hash_first_mask': (ci, [vp, i64, i32, vp, vp, i64, vp, vp, vp]),
     'pcgc_coords_quantize': (ci, [vp, i64, i32, vp, vp]),
     'pcgc_coords_children': (ci, [vp, i64, i32, vp, vp]),
     'pcgc_coords_scale': (ci, [vp, i64, f32, vp, vp]),
@@ -26,6 +26,11 @@ SIGNATURES = {
     'pcgc_compact_feats': (ci, [vp, ci, ci, vp, vp, i64, vp, vp]),
     'pcgc_kmap_k3': (ci, [vp, i64, i32, vp, vp, i64, vp, vp]),
     'pcgc_kmap_down': (ci, [vp, i64, i32, vp, vp, i64, vp, vp]),
+    'pcgc_kmap_k3_children': (ci, [vp, i64, vp, vp]),
+    'pcgc_kmap_k3_prune': (ci, [vp, i64, vp, vp, vp, i64, vp, vp]),
+    'pcgc_kmap_k3_from_coarse': (ci, [vp, i64, i32, vp, vp, vp, i64, vp, vp]),
+    'pcgc_down_maps': (ci, [vp, vp, vp, i64, i32, i64, vp, vp, vp]),
+    'pcgc_compact_index': (ci, [vp, vp, i64, vp, vp]),
     'pcgc_conv_gather': (ci, [vp, ci, i64, vp, ci, ci, ci, vp, vp, vp, ci, ci, ci, vp, ci, ci, ci, vp]),
     'pcgc_conv_up2': (ci, [i64, vp, ci, ci, vp, vp, ci, vp, ci, vp]),
     'pcgc_topk_workspace_bytes': (sz, [i64]),

@@ -116,9 +116,59 @@ k_conv_up2(int64_t n_in, const float* __restrict__ in, int Cin, int in_ld, const
         *(float4*)(y + co) = v;
     }
 }
+// Coalesced form for the model's three shapes: one thread per (output row, 4-column chunk); consecutive lanes store
+// consecutive 16-byte chunks (pure streaming write, the op is write-bandwidth bound: 8N*Cout*4 bytes), the 8 weight
+// slices sit in LDS and the parent row is a broadcast read.
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256)
+k_conv_up2_rows(int64_t n_in, const float* __restrict__ in, int in_ld, const float* __restrict__ W,
+                const float* __restrict__ bias, int relu, float* __restrict__ out) {
+    extern __shared__ float4 w_lds[];                       // [8][CIN][COUT/4]
+    constexpr int CH = COUT / 4;
+    for (int t = threadIdx.x; t < 8 * CIN * CH; t += 256) w_lds[t] = ((const float4*)W)[t];
+    __syncthreads();
+    const int64_t total = 8 * n_in * CH;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        int64_t r = t / CH; int c = (int)(t % CH);
+        int64_t i = r >> 3; int k = (int)(r & 7);
+        const float4* x = (const float4*)(in + i * in_ld);
+        const float4* w = w_lds + (k * CIN) * CH + c;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int q = 0; q < CIN / 4; ++q) {
+            float4 xv = x[q];
+            float4 w0 = w[(4 * q + 0) * CH], w1 = w[(4 * q + 1) * CH], w2 = w[(4 * q + 2) * CH], w3 = w[(4 * q + 3) * CH];
+            acc.x = fmaf(xv.x, w0.x, acc.x); acc.y = fmaf(xv.x, w0.y, acc.y); acc.z = fmaf(xv.x, w0.z, acc.z); acc.w = fmaf(xv.x, w0.w, acc.w);
+            acc.x = fmaf(xv.y, w1.x, acc.x); acc.y = fmaf(xv.y, w1.y, acc.y); acc.z = fmaf(xv.y, w1.z, acc.z); acc.w = fmaf(xv.y, w1.w, acc.w);
+            acc.x = fmaf(xv.z, w2.x, acc.x); acc.y = fmaf(xv.z, w2.y, acc.y); acc.z = fmaf(xv.z, w2.z, acc.z); acc.w = fmaf(xv.z, w2.w, acc.w);
+            acc.x = fmaf(xv.w, w3.x, acc.x); acc.y = fmaf(xv.w, w3.y, acc.y); acc.z = fmaf(xv.w, w3.z, acc.z); acc.w = fmaf(xv.w, w3.w, acc.w);
+        }
+        if (bias) { float4 b = ((const float4*)bias)[c]; acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w; }
+        if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+        ((float4*)out)[t] = acc;
+    }
+}
+template <int CIN, int COUT>
+static int launch_up2_rows(int64_t n_in, const float* in, int in_ld, const float* W, const float* bias, int relu, float* out,
+                           hipStream_t s) {
+    size_t lds = (size_t)8 * CIN * COUT * sizeof(float);
+    int64_t total = 8 * n_in * (COUT / 4);
+    unsigned g = grid_for(total, 256); if (g > 256 * 8) g = 256 * 8;
+    hipLaunchKernelGGL((k_conv_up2_rows<CIN, COUT>), dim3(g), dim3(256), lds, s, n_in, in, in_ld, W, bias, relu, out);
+    return 0;
+}
+
 extern "C" int pcgc_conv_up2(int64_t n_in, const float* in, int Cin, int in_ld, const float* W, const float* bias, int relu,
                              float* out, int Cout, void* stream) {
     if (n_in == 0) return 0;
+    if ((in_ld & 3) == 0 && (((uintptr_t)in | (uintptr_t)W | (uintptr_t)out | (uintptr_t)bias) & 15) == 0) {
+        bool done = true;
+        if (Cin == 8 && Cout == 64) launch_up2_rows<8, 64>(n_in, in, in_ld, W, bias, relu, out, S(stream));
+        else if (Cin == 64 && Cout == 32) launch_up2_rows<64, 32>(n_in, in, in_ld, W, bias, relu, out, S(stream));
+        else if (Cin == 32 && Cout == 16) launch_up2_rows<32, 16>(n_in, in, in_ld, W, bias, relu, out, S(stream));
+        else done = false;
+        if (done) { PCGC_CHECK_LAUNCH("conv_up2_rows"); return 0; }
+    }
     dim3 g(grid_for(n_in, 256), 8), b(256);
     switch (Cout) {
         case 16: hipLaunchKernelGGL((k_conv_up2<16>), g, b, 0, S(stream), n_in, in, Cin, in_ld, W, bias, relu, out); break;

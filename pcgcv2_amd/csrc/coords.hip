@@ -41,11 +41,13 @@ __global__ void k_hash_insert(const int4* __restrict__ coords, int64_t n, int sh
 }
 
 __global__ void k_hash_first_mask(const int4* __restrict__ coords, int64_t n, int sh, const uint64_t* __restrict__ keys,
-                                  const int32_t* __restrict__ vals, uint64_t cap_mask, uint8_t* keep) {
+                                  const int32_t* __restrict__ vals, uint64_t cap_mask, uint8_t* keep, int32_t* first_row) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int4 c = coords[i];
-    keep[i] = hash_lookup(keys, vals, cap_mask, sh, c.x, c.y, c.z, c.w) == (int32_t)i;
+    int32_t f = hash_lookup(keys, vals, cap_mask, sh, c.x, c.y, c.z, c.w);
+    keep[i] = f == (int32_t)i;
+    if (first_row) first_row[i] = f;
 }
 
 extern "C" int pcgc_hash_clear(uint64_t* keys, int32_t* vals, int64_t cap, void* stream) {
@@ -65,10 +67,10 @@ extern "C" int pcgc_hash_insert(const int32_t* coords, int64_t n, int32_t stride
     return 0;
 }
 extern "C" int pcgc_hash_first_mask(const int32_t* coords, int64_t n, int32_t stride, const uint64_t* keys,
-                                    const int32_t* vals, int64_t cap, uint8_t* keep, void* stream) {
+                                    const int32_t* vals, int64_t cap, uint8_t* keep, int32_t* first_row, void* stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_hash_first_mask, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n,
-                       stride_shift(stride), keys, vals, (uint64_t)(cap - 1), keep);
+                       stride_shift(stride), keys, vals, (uint64_t)(cap - 1), keep, first_row);
     PCGC_CHECK_LAUNCH("hash_first_mask");
     return 0;
 }
@@ -158,5 +160,123 @@ extern "C" int pcgc_kmap_down(const int32_t* coarse, int64_t n_coarse, int32_t s
     hipLaunchKernelGGL(k_kmap_down, dim3(grid_for(n_coarse, 256)), dim3(256), 0, S(stream), (const int4*)coarse, n_coarse,
                        stride_fine, stride_shift(stride_fine), fine_keys, fine_vals, (uint64_t)(fine_cap - 1), nbr);
     PCGC_CHECK_LAUNCH("kmap_down");
+    return 0;
+}
+
+// ---- hierarchical kernel maps ---------------------------------------------------------------------------------
+// A fine voxel at child slot j = (jx,jy,jz) of its parent, displaced by d in {-1,0,1}^3, lands in the parent displaced
+// by p = floor((j+d)/2) at child slot (j+d)&1 — so the fine level's 27-neighbourhood is a pure gather through the
+// coarse level's kernel map (8x smaller, cache resident).  Only the coarsest level of a pyramid probes the hash.
+__device__ static inline void child_offset(int j, int k, int& kp, int& jn) {
+    int tx = (j & 1) + (k % 3 - 1), ty = ((j >> 1) & 1) + ((k / 3) % 3 - 1), tz = (j >> 2) + (k / 9 - 1);
+    int px = tx < 0 ? -1 : (tx > 1 ? 1 : 0), py = ty < 0 ? -1 : (ty > 1 ? 1 : 0), pz = tz < 0 ? -1 : (tz > 1 ? 1 : 0);
+    kp = (px + 1) + 3 * (py + 1) + 9 * (pz + 1);
+    jn = (tx & 1) | ((ty & 1) << 1) | ((tz & 1) << 2);
+}
+
+// generative-transpose children (all 8 exist, rows 8*i+j): nbr[k][8i+j] = 8 * pnbr[kp][i] + j'
+__global__ void __launch_bounds__(256) k_kmap_children(const int32_t* __restrict__ pnbr, int64_t np, int32_t* __restrict__ nbr) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n = 8 * np;
+    if (c >= n) return;
+    int64_t i = c >> 3; int j = (int)(c & 7);
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        int kp, jn; child_offset(j, k, kp, jn);
+        int32_t pn = pnbr[(int64_t)kp * np + i];
+        nbr[(int64_t)k * n + c] = pn < 0 ? -1 : 8 * pn + jn;
+    }
+}
+// pruned level: rows orig[r] of the candidate level survive; neighbours are renumbered through mask/prefix
+__global__ void __launch_bounds__(256) k_kmap_prune(const int32_t* __restrict__ cand, int64_t n_cand,
+                                                    const uint8_t* __restrict__ mask, const int32_t* __restrict__ prefix,
+                                                    const int32_t* __restrict__ orig, int64_t n_out, int32_t* __restrict__ nbr) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_out) return;
+    int64_t o = orig[r];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        int32_t m = cand[(int64_t)k * n_cand + o];
+        nbr[(int64_t)k * n_out + r] = (m >= 0 && mask[m]) ? prefix[m] : -1;
+    }
+}
+// strided pyramid (encoder): fine row c has parent row parent_of[c]; down[j][p] = fine row at slot j of coarse row p
+__global__ void __launch_bounds__(256) k_kmap_from_coarse(const int4* __restrict__ fine, int64_t nf, int32_t stride_f,
+                                                          const int32_t* __restrict__ parent_of,
+                                                          const int32_t* __restrict__ pnbr, const int32_t* __restrict__ down,
+                                                          int64_t nc, int32_t* __restrict__ nbr) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nf) return;
+    int4 q = fine[c];
+    int j = ((q.y / stride_f) & 1) | (((q.z / stride_f) & 1) << 1) | (((q.w / stride_f) & 1) << 2);
+    int64_t p = parent_of[c];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        int32_t r;
+        if (k == 13) r = (int32_t)c;
+        else {
+            int kp, jn; child_offset(j, k, kp, jn);
+            int32_t pn = pnbr[(int64_t)kp * nc + p];
+            r = pn < 0 ? -1 : down[(int64_t)jn * nc + pn];
+        }
+        nbr[(int64_t)k * nf + c] = r;
+    }
+}
+// parent_of[c] = prefix[first_row[c]] ; down[slot(c)][parent_of[c]] = c   (down pre-filled with -1)
+__global__ void k_down_maps(const int4* __restrict__ fine, const int32_t* __restrict__ first_row,
+                            const int32_t* __restrict__ prefix, int64_t nf, int32_t stride_f, int64_t nc,
+                            int32_t* __restrict__ parent_of, int32_t* __restrict__ down) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nf) return;
+    int4 q = fine[c];
+    int j = ((q.y / stride_f) & 1) | (((q.z / stride_f) & 1) << 1) | (((q.w / stride_f) & 1) << 2);
+    int32_t p = prefix[first_row[c]];
+    parent_of[c] = p;
+    down[(int64_t)j * nc + p] = (int32_t)c;
+}
+__global__ void k_compact_index(const uint8_t* __restrict__ mask, const int32_t* __restrict__ prefix, int64_t n, int32_t* orig) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && mask[i]) orig[prefix[i]] = (int32_t)i;
+}
+
+extern "C" int pcgc_kmap_k3_children(const int32_t* parent_nbr, int64_t n_parent, int32_t* nbr, void* stream) {
+    if (n_parent == 0) return 0;
+    hipLaunchKernelGGL(k_kmap_children, dim3(grid_for(8 * n_parent, 256)), dim3(256), 0, S(stream), parent_nbr, n_parent, nbr);
+    PCGC_CHECK_LAUNCH("kmap_k3_children");
+    return 0;
+}
+extern "C" int pcgc_kmap_k3_prune(const int32_t* cand_nbr, int64_t n_cand, const uint8_t* mask, const int32_t* prefix,
+                                  const int32_t* orig, int64_t n_out, int32_t* nbr, void* stream) {
+    if (n_out == 0) return 0;
+    hipLaunchKernelGGL(k_kmap_prune, dim3(grid_for(n_out, 256)), dim3(256), 0, S(stream), cand_nbr, n_cand, mask, prefix, orig,
+                       n_out, nbr);
+    PCGC_CHECK_LAUNCH("kmap_k3_prune");
+    return 0;
+}
+extern "C" int pcgc_kmap_k3_from_coarse(const int32_t* fine, int64_t n_fine, int32_t stride_fine, const int32_t* parent_of,
+                                        const int32_t* coarse_nbr, const int32_t* down, int64_t n_coarse, int32_t* nbr,
+                                        void* stream) {
+    if (n_fine == 0) return 0;
+    hipLaunchKernelGGL(k_kmap_from_coarse, dim3(grid_for(n_fine, 256)), dim3(256), 0, S(stream), (const int4*)fine, n_fine,
+                       stride_fine, parent_of, coarse_nbr, down, n_coarse, nbr);
+    PCGC_CHECK_LAUNCH("kmap_k3_from_coarse");
+    return 0;
+}
+extern "C" int pcgc_down_maps(const int32_t* fine, const int32_t* first_row, const int32_t* prefix, int64_t n_fine,
+                              int32_t stride_fine, int64_t n_coarse, int32_t* parent_of, int32_t* down, void* stream) {
+    if (n_coarse > 0) {
+        hipError_t e = hipMemsetAsync(down, 0xFF, (size_t)n_coarse * 8 * sizeof(int32_t), S(stream));
+        if (e != hipSuccess) { pcgc_set_error("down_maps: %s", hipGetErrorString(e)); return -1; }
+    }
+    if (n_fine == 0) return 0;
+    hipLaunchKernelGGL(k_down_maps, dim3(grid_for(n_fine, 256)), dim3(256), 0, S(stream), (const int4*)fine, first_row, prefix,
+                       n_fine, stride_fine, n_coarse, parent_of, down);
+    PCGC_CHECK_LAUNCH("down_maps");
+    return 0;
+}
+extern "C" int pcgc_compact_index(const uint8_t* mask, const int32_t* prefix, int64_t n, int32_t* orig, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_compact_index, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), mask, prefix, n, orig);
+    PCGC_CHECK_LAUNCH("compact_index");
     return 0;
 }

@@ -62,4 +62,5 @@ class MinkowskiPruning(torch.nn.Module):
         n = int(total.item()) if n_keep is None else int(n_keep)
         coords = ops.compact_coords(x.C, mask, prefix, n)
         feats = ops.compact_feats(x.F, mask, prefix, n)
-        return SparseTensor(feats, coordinate_map=CoordMap(coords, x.cmap.stride, unique=True))
+        return SparseTensor(feats, coordinate_map=CoordMap(coords, x.cmap.stride, unique=True,
+                                                           origin=('pruned', x.cmap, mask, prefix)))

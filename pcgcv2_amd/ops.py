@@ -102,7 +102,7 @@ class _Profile:
                 'alg_bytes_per_launch': top['alg_bytes_per_launch'], 'avg_launch_us': round(top['avg_us'], 2),
                 'launches_timed': top['launches'],
                 'all_k3_launches': {'achieved': round(tot_bytes / (tot_ms * 1e-3) / 1e9, 2), 'frac': round(tot_bytes / (tot_ms * 1e-3) / 1e9 / peak_gbs, 4),
-                                    'ms_per_step_share': round(tot_ms, 3), 'launches': sum(r['launches'] for r in d)}}
+                                    'ms_total_timed': round(tot_ms, 3), 'launches': sum(r['launches'] for r in d)}}
 
 
 PROFILE = _Profile()
@@ -123,12 +123,53 @@ class HashTable:
               'hash_insert')
 
 
-def first_occurrence_mask(coords, table):
+def first_occurrence_mask(coords, table, want_rows=False):
+    """-> keep uint8 [n] (and, if want_rows, first_row int32 [n]: the first row holding each row's coordinate)."""
     n = coords.shape[0]
     keep = torch.empty(n, dtype=torch.uint8, device=coords.device)
+    first = torch.empty(n, dtype=torch.int32, device=coords.device) if want_rows else None
     check(lib().pcgc_hash_first_mask(_p(_i32(coords)), n, table.stride, _p(table.keys), _p(table.vals), table.cap, _p(keep),
-                                     _stream()), 'hash_first_mask')
-    return keep
+                                     _p(first), _stream()), 'hash_first_mask')
+    return (keep, first) if want_rows else keep
+
+
+def down_maps(fine, first_row, prefix, stride_fine, n_coarse):
+    """-> (parent_of int32 [n_fine], down int32 [8, n_coarse]) of the k2s2 down-sampling, no hash probes."""
+    n = fine.shape[0]
+    parent_of = torch.empty(n, dtype=torch.int32, device=fine.device)
+    down = torch.empty((8, n_coarse), dtype=torch.int32, device=fine.device)
+    check(lib().pcgc_down_maps(_p(_i32(fine)), _p(first_row), _p(prefix), n, int(stride_fine), n_coarse, _p(parent_of), _p(down),
+                               _stream()), 'down_maps')
+    return parent_of, down
+
+
+def compact_index(mask, prefix, n_out):
+    orig = torch.empty(n_out, dtype=torch.int32, device=mask.device)
+    check(lib().pcgc_compact_index(_p(mask), _p(prefix), mask.shape[0], _p(orig), _stream()), 'compact_index')
+    return orig
+
+
+def kmap_k3_children(parent_nbr):
+    n_parent = parent_nbr.shape[1]
+    nbr = torch.empty((27, 8 * n_parent), dtype=torch.int32, device=parent_nbr.device)
+    check(lib().pcgc_kmap_k3_children(_p(parent_nbr), n_parent, _p(nbr), _stream()), 'kmap_k3_children')
+    return nbr
+
+
+def kmap_k3_prune(cand_nbr, mask, prefix, orig):
+    n_out = orig.shape[0]
+    nbr = torch.empty((27, n_out), dtype=torch.int32, device=cand_nbr.device)
+    check(lib().pcgc_kmap_k3_prune(_p(cand_nbr), cand_nbr.shape[1], _p(mask), _p(prefix), _p(orig), n_out, _p(nbr), _stream()),
+          'kmap_k3_prune')
+    return nbr
+
+
+def kmap_k3_from_coarse(fine, stride_fine, parent_of, coarse_nbr, down):
+    n = fine.shape[0]
+    nbr = torch.empty((27, n), dtype=torch.int32, device=fine.device)
+    check(lib().pcgc_kmap_k3_from_coarse(_p(_i32(fine)), n, int(stride_fine), _p(parent_of), _p(coarse_nbr), _p(down),
+                                         coarse_nbr.shape[1], _p(nbr), _stream()), 'kmap_k3_from_coarse')
+    return nbr
 
 
 def mask_scan(mask):

@@ -18,14 +18,25 @@ def require_gpu(device):
     return device
 
 
+HASH_LEVEL_MAX = 1 << 15     # levels up to this many sites probe the hash for their k3 map; larger ones derive it
+
+
 class CoordMap:
-    def __init__(self, coords, stride, unique=False):
-        """coords: int32 [N,4] device (batch,x,y,z).  unique=True promises there are no duplicate rows."""
+    """One coordinate level.  `origin` records how the level was produced, which decides how its k3 kernel map is
+    built: hash probes only for small / root levels; otherwise a gather through the parent level's map.
+         None                                  raw coordinates (root): hash if small, else via its own strided pyramid
+         ('children', parent)                  rows 8*i+j of a generative transpose
+         ('pruned', cand, mask, prefix)        surviving rows of `cand` (MinkowskiPruning)
+    """
+
+    def __init__(self, coords, stride, unique=False, origin=None):
         self.C = coords
         self.stride = int(stride)
+        self.origin = origin
         self._table = None
         self._k3 = None
         self._down = None
+        self._parent_of = None
         self._up = None
         self._unique = unique
 
@@ -42,29 +53,44 @@ class CoordMap:
     def k3(self):
         """[27, N] kernel map of MinkowskiConvolution(kernel_size=3, stride=1) on this level."""
         if self._k3 is None:
-            self._k3 = ops.kmap_k3(self.C, self.stride, self.table)
+            kind = self.origin[0] if self.origin else None
+            if len(self) == 0:
+                self._k3 = torch.empty((27, 0), dtype=torch.int32, device=self.C.device)
+            elif kind == 'children':
+                self._k3 = ops.kmap_k3_children(self.origin[1].k3)
+            elif kind == 'pruned':
+                _, cand, mask, prefix = self.origin
+                self._k3 = ops.kmap_k3_prune(cand.k3, mask, prefix, ops.compact_index(mask, prefix, len(self)))
+            elif len(self) > HASH_LEVEL_MAX and self.stride <= (1 << 18):
+                coarse, down = self.down()
+                self._k3 = ops.kmap_k3_from_coarse(self.C, self.stride, self._parent_of, coarse.k3, down)
+            else:
+                self._k3 = ops.kmap_k3(self.C, self.stride, self.table)
         return self._k3
 
     def down(self):
-        """-> (coarse CoordMap at 2*stride, [8, N_coarse] kernel map): MinkowskiConvolution(kernel_size=2, stride=2)."""
+        """-> (coarse CoordMap at 2*stride, [8, N_coarse] kernel map): MinkowskiConvolution(kernel_size=2, stride=2).
+        One hash insert + one probe per fine row (the dedup of the quantised coordinates); the map itself is a scatter."""
         if self._down is None:
             q = ops.coords_quantize(self.C, 2 * self.stride)
             qt = ops.HashTable(q, 2 * self.stride)
-            keep = ops.first_occurrence_mask(q, qt)
+            keep, first_row = ops.first_occurrence_mask(q, qt, want_rows=True)
             prefix, total = ops.mask_scan(keep)
             n_coarse = int(total.item())                       # host sync: sizes the coarse level
             coarse = CoordMap(ops.compact_coords(q, keep, prefix, n_coarse), 2 * self.stride, unique=True)
-            self._down = (coarse, ops.kmap_down(coarse.C, self.stride, self.table))
+            self._parent_of, down = ops.down_maps(self.C, first_row, prefix, self.stride, n_coarse)
+            self._down = (coarse, down)
         return self._down
 
     def up(self):
         """-> children CoordMap at stride/2, rows 8*i+k: MinkowskiGenerativeConvolutionTranspose(k=2, stride=2)."""
         if self._up is None:
-            self._up = CoordMap(ops.coords_children(self.C, self.stride), self.stride // 2, unique=True)
+            self._up = CoordMap(ops.coords_children(self.C, self.stride), self.stride // 2, unique=True,
+                                origin=('children', self))
         return self._up
 
     def drop_caches(self):
-        self._table = self._k3 = self._down = self._up = None
+        self._table = self._k3 = self._down = self._up = self._parent_of = None
 
 
 def dedup(coords, feats, stride):

@@ -66,6 +66,28 @@ def test_pyramid_and_kernel_maps(name):
     np.testing.assert_array_equal(kids.k3.cpu().numpy(), orc.kmap_k3(kids.C.cpu().numpy(), stride // 2))
 
 
+def test_hierarchical_kmaps_equal_oracle(monkeypatch):
+    """Force the derived (parent-gather) kernel maps at every level, incl. children and pruned levels."""
+    from pcgcv2_amd import sparse
+    monkeypatch.setattr(sparse, 'HASH_LEVEL_MAX', 64)
+    c4 = _coords('shell8')
+    lvl = CoordMap(_t(c4), 1, unique=True)
+    np.testing.assert_array_equal(lvl.k3.cpu().numpy(), orc.kmap_k3(c4, 1))                 # strided pyramid, recursive
+    l8 = lvl.down()[0].down()[0].down()[0]
+    kids = l8.up()
+    kc = kids.C.cpu().numpy()
+    np.testing.assert_array_equal(kids.k3.cpu().numpy(), orc.kmap_k3(kc, 4))                # children of a transpose
+    rng = np.random.default_rng(0)
+    m = (rng.random(len(kc)) < 0.45).astype(np.uint8)
+    mask = _t(m)
+    prefix, _ = ops.mask_scan(mask)
+    pruned = CoordMap(ops.compact_coords(kids.C, mask, prefix, int(m.sum())), 4, unique=True,
+                      origin=('pruned', kids, mask, prefix))
+    np.testing.assert_array_equal(pruned.k3.cpu().numpy(), orc.kmap_k3(kc[m.astype(bool)], 4))     # pruned level
+    grand = pruned.up()
+    np.testing.assert_array_equal(grand.k3.cpu().numpy(), orc.kmap_k3(grand.C.cpu().numpy(), 2))  # and its children
+
+
 def test_kmap_at_volume_border_and_empty():
     c4 = np.array([[0, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 1], [0, 1048575, 1048575, 1048575]], np.int32)
     lvl = CoordMap(_t(c4), 1, unique=True)
