@@ -92,9 +92,12 @@ int pcgc_compact_index(const uint8_t* mask, const int32_t* prefix, int64_t n, in
 /* Gather convolution: MinkowskiConvolution k=3,s=1 (K=27), k=2,s=2 (K=8), k=1 (K=1, nbr may be NULL = identity)
  * (autoencoder.py:13-48,71-134,162-234).  W = ME `kernel` [K,Cin,Cout]; bias [Cout] or NULL;
  * residual (same row, columns res_coff..) or NULL (SparseTensor.__add__, autoencoder.py:55); relu = MinkowskiReLU. */
-int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const float* in, int Cin, int in_ld, int in_coff,
-                     const float* W, const float* bias, const float* residual, int res_ld, int res_coff, int relu,
-                     float* out, int Cout, int out_ld, int out_coff, void* stream);
+int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in /*rows of `in`*/, int Cin,
+                     int in_ld, int in_coff, const float* W, const float* bias, const float* residual, int res_ld,
+                     int res_coff, int relu, float* out, int Cout, int out_ld, int out_coff, void* stream);
+/* kernel selection for the gather conv: -1 auto (default), 0 = v0 direct-load kernel, 1 = v1 LDS-DMA kernel where eligible.
+ * Both produce bit-identical results; the switch exists for A/B measurements and tests. */
+int pcgc_set_conv_impl(int impl);
 /* MinkowskiGenerativeConvolutionTranspose(k=2,s=2): out[8i+k] = in[i] @ W[k] + bias (+ReLU). */
 int pcgc_conv_up2(int64_t n_in, const float* in, int Cin, int in_ld, const float* W /*[8,Cin,Cout]*/, const float* bias,
                   int relu, float* out /*[dev 8n,Cout]*/, int Cout, void* stream);

@@ -69,13 +69,176 @@ static void launch_valu(const int32_t* nbr, int K, int64_t n_out, const float* i
                        in_coff, W, bias, res, res_ld, res_coff, relu, out, out_ld, out_coff);
 }
 
-extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const float* in, int Cin, int in_ld, int in_coff,
-                                const float* W, const float* bias, const float* residual, int res_ld, int res_coff, int relu,
-                                float* out, int Cout, int out_ld, int out_coff, void* stream) {
+
+// ----------------------------------------------------------------------------------------------------------------
+// v1 kernel: LDS-DMA gather.  One wave = one tile of 64 output rows (lane = row, accumulators in VGPRs, weights as
+// scalar operands).  What changes vs v0 is how the gathered rows reach the lanes:
+//   * the tile's K x 64 kernel-map entries are staged in LDS once (buffer_load_dword ... lds),
+//   * per sub-step (offset k, 32-channel block) the 64 neighbour rows are fetched by `buffer_load_dwordx4 ... lds`
+//     with CH = CB/4 ADJACENT lanes per row, so one row = one contiguous 16*CH-byte request instead of CH separate
+//     per-lane requests (v0 was bound by the texture-addresser line rate, not by FMAs);  absent neighbours use an
+//     out-of-range buffer offset: no fetch, EXEC stays full, so the number of VMEM instructions per sub-step is static
+//     and the double buffering can use counted `s_waitcnt vmcnt(CH)` (the next sub-step's DMA stays in flight);
+//   * the LDS image is row-major [64][CH] 16-byte slots, written lane-linear by the DMA; the SOURCE chunk index is
+//     XOR-swizzled (slot p of row r holds chunk p ^ s(r), s(r) = (r*CH/16) % CH) and the per-lane row read-back
+//     applies the same XOR, which makes the ds_read_b128 of 64 different rows bank-conflict free.
+// Numerics: identical fmaf chain (k ascending, ci ascending) — only the data path differs.
+// ----------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+template <int N>
+__device__ static inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256)
+k_conv_gather_dma(const int32_t* __restrict__ nbr, int K, int64_t n_out, const float* __restrict__ in, int64_t n_in,
+                  int in_ld, const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ res,
+                  int res_ld, int relu, float* __restrict__ out, int out_ld) {
+    constexpr int CB = CIN < 32 ? CIN : 32;        // channels per sub-step
+    constexpr int NB = CIN / CB;                   // sub-steps per kernel offset
+    constexpr int CH = CB / 4;                     // 16-byte chunks per row per sub-step: 2, 4, 8
+    constexpr int RPI = 64 / CH;                   // rows covered by one DMA instruction
+    constexpr int SH = (CH == 2) ? 3 : (CH == 4 ? 2 : 1);      // s(r) = (r >> SH) & (CH-1)
+    constexpr int WAVE_F4 = 2 * 64 * CH;           // float4 slots of the two row buffers
+    constexpr int WAVE_LDS_BYTES = WAVE_F4 * 16 + 27 * 64 * 4;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* wbase = lds_raw + (size_t)wave * WAVE_LDS_BYTES;
+    float4* rowbuf = (float4*)wbase;                                  // [2][64*CH]
+    int32_t* idx_lds = (int32_t*)(wbase + WAVE_F4 * 16);              // [K][64]
+
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    if (row0 >= n_out) return;                                        // whole wave idle (wave-uniform)
+    const int64_t my_row = row0 + lane;
+    const bool valid = my_row < n_out;
+
+    const __amdgpu_buffer_rsrc_t rs_nbr = __builtin_amdgcn_make_buffer_rsrc((void*)nbr, 0, (int)((int64_t)K * n_out * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(n_in * in_ld * 4), 0x00020000);
+
+    // ---- stage the tile's kernel-map rows: idx_lds[k][lane] = nbr[k][row0 + lane]
+    for (int k = 0; k < K; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_nbr, (lds_void_ptr)(idx_lds + k * 64), 4,
+                                                 (int)(((int64_t)k * n_out + my_row) * 4), 0, 0, 0);
+    wait_vmcnt<0>();
+
+    // DMA lane roles: in instruction i this lane fetches row (i*RPI + lane/CH), LDS slot p = lane%CH <- chunk p ^ s(row)
+    const int dma_row_lo = lane / CH, dma_p = lane % CH;
+    auto issue = [&](int t) {
+        const int k = t / NB, cb = t % NB;
+        float4* dst = rowbuf + (t & 1) * (64 * CH);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int r = i * RPI + dma_row_lo;
+            const int rid = idx_lds[k * 64 + r];
+            const int chunk = dma_p ^ ((r >> SH) & (CH - 1));
+            const unsigned voff = rid >= 0 ? (unsigned)(((int64_t)rid * in_ld + cb * CB + chunk * 4) * 4) : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_ptr)(dst + i * 64), 16, (int)voff, 0, 0, 0);
+        }
+    };
+
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
+
+    const int T = K * NB;
+    const int my_swz = (lane >> SH) & (CH - 1);
+    issue(0);
+    for (int t = 0; t < T; ++t) {
+        const int k = t / NB, cb = t % NB;
+        if (t + 1 < T) { issue(t + 1); wait_vmcnt<CH>(); }            // leave the next sub-step's CH DMAs in flight
+        else wait_vmcnt<0>();
+        const int rid = valid ? idx_lds[k * 64 + lane] : -1;
+        const float4* src = rowbuf + (t & 1) * (64 * CH) + lane * CH;
+        float4 x[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) x[c] = src[c ^ my_swz];
+        if (rid >= 0) {
+            const float* w = W + ((int64_t)k * CIN + cb * CB) * COUT;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const float* w0 = w + (4 * c) * COUT;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(x[c].x, w0[co], acc[co]);
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(x[c].y, w0[COUT + co], acc[co]);
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(x[c].z, w0[2 * COUT + co], acc[co]);
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(x[c].w, w0[3 * COUT + co], acc[co]);
+            }
+        }
+        asm volatile("" ::: "memory");               // the row buffer read above must not sink below the next issue()
+    }
+    if (!valid) return;
+    float* y = out + my_row * out_ld;
+    const float* rr = res ? res + my_row * res_ld : nullptr;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        float v = acc[co];
+        if (bias) v = v + bias[co];
+        if (rr) v = v + rr[co];
+        if (relu) v = fmaxf(v, 0.0f);
+        y[co] = v;
+    }
+}
+
+template <int CIN, int COUT>
+static void launch_dma(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int in_ld, const float* W,
+                       const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld, hipStream_t s) {
+    constexpr int CB = CIN < 32 ? CIN : 32;
+    constexpr int CH = CB / 4;
+    constexpr size_t lds = 4 * (size_t)(2 * 64 * CH * 16 + 27 * 64 * 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_conv_gather_dma<CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_conv_gather_dma<CIN, COUT>), dim3(grid_for(n_out, 256)), dim3(256), lds, s, nbr, K, n_out, in, n_in,
+                       in_ld, W, bias, res, res_ld, relu, out, out_ld);
+}
+
+template <int CIN>
+static bool dispatch_dma_cout(int Cout, const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int in_ld,
+                              const float* W, const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld,
+                              hipStream_t s) {
+    switch (Cout) {
+#define PCGC_DMA(C) case C: launch_dma<CIN, C>(nbr, K, n_out, in, n_in, in_ld, W, bias, res, res_ld, relu, out, out_ld, s); return true;
+        PCGC_DMA(1) PCGC_DMA(4) PCGC_DMA(8) PCGC_DMA(16) PCGC_DMA(32) PCGC_DMA(64)
+#undef PCGC_DMA
+    }
+    return false;
+}
+
+static int g_conv_impl = -1;        // -1 auto, 0 force v0 (VALU direct loads), 1 force v1 (LDS-DMA gather) where eligible
+extern "C" int pcgc_set_conv_impl(int impl) { g_conv_impl = impl; return 0; }
+
+extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int Cin, int in_ld,
+                                int in_coff, const float* W, const float* bias, const float* residual, int res_ld, int res_coff,
+                                int relu, float* out, int Cout, int out_ld, int out_coff, void* stream) {
     PCGC_REQUIRE(K >= 1 && Cin >= 1, "bad K / Cin");
     PCGC_REQUIRE(nbr != nullptr || K == 1, "identity map only for K == 1");
     if (n_out == 0) return 0;
     hipStream_t s = S(stream);
+    // v1 (LDS-DMA gather) eligibility: gathered maps, 8..64 input channels, 16-byte aligned rows, 32-bit buffer offsets
+    const float* in0 = in + in_coff;
+    const bool aligned = (((uintptr_t)in0 | (uintptr_t)W) & 15) == 0 && (in_ld & 3) == 0;
+    const bool small = n_in * in_ld * 4 < (int64_t)0xFFFFFFF0 && (int64_t)K * n_out * 4 < (int64_t)0xFFFFFFF0;
+    // auto: v1 pays where the op is gather-bound (few output channels per gathered row); measured per shape on MI355X
+    // (tools/conv_ab.py): Cin>=16 & Cout<=8 -> 1.5-3.8x faster; Cout>=16 -> v0 (v1's LDS footprint limits occupancy there).
+    const bool v1_eligible = nbr != nullptr && K <= 27 && aligned && small && (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64);
+    const bool v1_wanted = g_conv_impl == 1 || (g_conv_impl < 0 && Cin >= 16 && Cout <= 8);
+    if (v1_eligible && v1_wanted) {
+        const float* res0 = residual ? residual + res_coff : nullptr;
+        float* out0 = out + out_coff;
+        bool ok = false;
+        if (Cin == 8) ok = dispatch_dma_cout<8>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        else if (Cin == 16) ok = dispatch_dma_cout<16>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        else if (Cin == 32) ok = dispatch_dma_cout<32>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        else ok = dispatch_dma_cout<64>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        if (ok) { PCGC_CHECK_LAUNCH("conv_gather_dma"); return 0; }
+    }
 #define PCGC_CASE(C) case C: launch_valu<C>(nbr, K, n_out, in, Cin, in_ld, in_coff, W, bias, residual, res_ld, res_coff, relu, out, out_ld, out_coff, s); break;
     switch (Cout) {
         PCGC_CASE(1) PCGC_CASE(4) PCGC_CASE(8) PCGC_CASE(16) PCGC_CASE(32) PCGC_CASE(64)

@@ -13,33 +13,48 @@
 // ------------------------------------------------------------------------------------------------ torchac-compatible
 namespace {
 
+// MSB-first bit writer with a 64-bit staging word (the reference implementation appends one bit at a time).
 struct BitSink {
-    uint8_t* out; int64_t cap; int64_t len = 0; uint32_t acc = 0; int nbits = 0;
-    inline void put(uint32_t bit) {
-        acc = (acc << 1) | bit;
-        if (++nbits == 8) { if (len < cap) out[len] = (uint8_t)acc; ++len; acc = 0; nbits = 0; }
+    uint8_t* out; int64_t cap; int64_t len = 0; uint64_t acc = 0; int nbits = 0;
+    inline void put(uint32_t v, int n) {                    // n <= 32 low bits of v, MSB first
+        if (n == 0) return;
+        acc = (acc << n) | (uint64_t)(n == 32 ? v : (v & ((1u << n) - 1u)));
+        nbits += n;
+        while (nbits >= 8) {
+            nbits -= 8;
+            if (len < cap) out[len] = (uint8_t)(acc >> nbits);
+            ++len;
+        }
     }
-    inline void put_with_pending(uint32_t bit, uint64_t& pending) {
-        put(bit);
-        for (; pending > 0; --pending) put(bit ^ 1u);
+    inline void put_run(uint32_t bit, uint64_t count) {     // `count` copies of `bit`
+        const uint32_t word = bit ? 0xFFFFFFFFu : 0u;
+        while (count >= 32) { put(word, 32); count -= 32; }
+        put(word, (int)count);
     }
-    inline void flush() { while (nbits != 0) put(0); }
+    inline void flush() { if (nbits) put(0, 8 - nbits); }
 };
 
+// MSB-first bit reader; past the end of the stream it yields zeros (as the reference's `get` does).
 struct BitSource {
-    const uint8_t* in; int64_t len; int64_t pos = 0; uint32_t cur = 0; int left = 0;
-    inline void shift_into(uint32_t& value) {
-        if (left == 0) {
-            if (pos == len) { value <<= 1; return; }      // past the end: zeros
-            cur = in[pos++]; left = 8;
-        }
-        value = (value << 1) | ((cur >> (left - 1)) & 1u);
-        --left;
+    const uint8_t* in; int64_t len; int64_t pos = 0; uint64_t acc = 0; int nbits = 0;
+    inline uint32_t take(int n) {                           // n <= 32
+        if (n == 0) return 0;
+        while (nbits < n) { acc = (acc << 8) | (uint64_t)(pos < len ? in[pos] : 0); ++pos; nbits += 8; }
+        nbits -= n;
+        return (uint32_t)((acc >> nbits) & ((n == 32) ? 0xFFFFFFFFull : ((1ull << n) - 1ull)));
     }
 };
+
+inline int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 
 }  // namespace
 
+// Renormalisation in runs instead of single bits.  After coding a symbol:
+//   (1) low and high share n = clz(low ^ high) leading bits -> emit them (the first one releases the pending
+//       opposite bits), shift both by n;
+//   (2) then low = 01.., high = 10..: the E3 "near convergence" case repeats m = min(leading ones of low<<1,
+//       leading zeros of high<<1) times -> pending += m, low/high shifted by m with their MSBs pinned to 0 / 1.
+// After (2) neither case applies again, exactly as in the bit-serial loop of torchac ‡.
 extern "C" int64_t pcgc_rc_encode(const uint16_t* cdf, int C, int Lp, const int16_t* sym, int64_t n, uint8_t* out, int64_t cap) {
     BitSink sink{out, cap};
     uint32_t low = 0, high = 0xFFFFFFFFu;
@@ -56,56 +71,85 @@ extern "C" int64_t pcgc_rc_encode(const uint16_t* cdf, int C, int Lp, const int1
         const uint32_t c_hi = (s == top_symbol) ? 0x10000u : row[s + 1];     // last boundary is pinned to 2^16
         high = (low - 1) + (uint32_t)((span * c_hi) >> 16);
         low = low + (uint32_t)((span * c_lo) >> 16);
-        for (;;) {
-            if (high < 0x80000000u) sink.put_with_pending(0, pending);
-            else if (low >= 0x80000000u) sink.put_with_pending(1, pending);
-            else if (low >= 0x40000000u && high < 0xC0000000u) {             // straddling the middle: defer the bit
-                ++pending;
-                low = (low << 1) & 0x7FFFFFFFu;
-                high = (high << 1) | 0x80000001u;
-                continue;
-            } else break;
-            low <<= 1;
-            high = (high << 1) | 1u;
+        const int nshare = clz32(low ^ high);
+        if (nshare) {
+            const uint32_t bits = nshare == 32 ? low : (low >> (32 - nshare));
+            if (pending) {
+                const uint32_t first = (bits >> (nshare - 1)) & 1u;
+                sink.put(first, 1);
+                sink.put_run(first ^ 1u, pending);
+                pending = 0;
+                sink.put(bits, nshare - 1);
+            } else sink.put(bits, nshare);
+            if (nshare == 32) { low = 0; high = 0xFFFFFFFFu; }
+            else { low <<= nshare; high = (high << nshare) | ((1u << nshare) - 1u); }
+        }
+        while (low >= 0x40000000u && high < 0xC0000000u) {
+            int m = clz32(~(low << 1));
+            const int mz = clz32(high << 1);
+            if (mz < m) m = mz;
+            if (m > 31) m = 31;
+            pending += (uint64_t)m;
+            low = (low << m) & 0x7FFFFFFFu;
+            high = (high << m) | 0x80000000u | ((1u << m) - 1u);
         }
     }
     ++pending;
-    sink.put_with_pending(low < 0x40000000u ? 0u : 1u, pending);
+    const uint32_t last = low < 0x40000000u ? 0u : 1u;
+    sink.put(last, 1);
+    sink.put_run(last ^ 1u, pending);
     sink.flush();
     return sink.len <= cap ? sink.len : -sink.len;
 }
 
 extern "C" int pcgc_rc_decode(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int64_t nbytes, int16_t* sym, int64_t n) {
     BitSource src{in, nbytes};
-    uint32_t low = 0, high = 0xFFFFFFFFu, value = 0;
-    for (int i = 0; i < 32; ++i) src.shift_into(value);
+    uint32_t low = 0, high = 0xFFFFFFFFu;
+    uint32_t value = src.take(32);
     const int top_symbol = Lp - 2;
+    // search seed: for each channel and each high byte b of the 16-bit target, the largest m with row[m] <= (b << 8);
+    // the true symbol is found by walking forward from there (latent pmfs are peaked: usually 0-2 steps).
+    std::vector<int16_t> seed((size_t)C * 256);
+    for (int c = 0; c < C; ++c) {
+        const uint16_t* row = cdf + (size_t)c * Lp;
+        int m = 0;
+        for (int b = 0; b < 256; ++b) {
+            const uint32_t t = (uint32_t)b << 8;
+            while (m < top_symbol && row[m + 1] <= t) ++m;
+            seed[(size_t)c * 256 + b] = (int16_t)m;
+        }
+    }
     int ch = 0;
     for (int64_t i = 0; i < n; ++i) {
         const uint16_t* row = cdf + (size_t)ch * Lp;
+        const int16_t* sd = seed.data() + (size_t)ch * 256;
         if (++ch == C) ch = 0;
         const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
-        const uint16_t target = (uint16_t)((((uint64_t)value - (uint64_t)low + 1) * 0x10000ull - 1) / span);
-        // largest m in [0, top_symbol] with row[m] <= target (the wrapped last entry row[Lp-1] is never read)
-        int lo = 0, hi = top_symbol + 1;
-        while (lo + 1 < hi) {
-            const int mid = (lo + hi) >> 1;
-            const uint16_t v = row[mid];
-            if (v < target) lo = mid; else if (v > target) hi = mid; else { lo = mid; break; }
-        }
-        sym[i] = (int16_t)lo;
+        const uint32_t target = (uint16_t)((((uint64_t)value - (uint64_t)low + 1) * 0x10000ull - 1) / span);
+        int s = sd[target >> 8];                                             // row[s] <= target guaranteed
+        while (s < top_symbol && row[s + 1] <= target) ++s;                  // the wrapped entry row[Lp-1] is never read
+        sym[i] = (int16_t)s;
         if (i == n - 1) break;
-        const uint32_t c_lo = row[lo];
-        const uint32_t c_hi = (lo == top_symbol) ? 0x10000u : row[lo + 1];
+        const uint32_t c_lo = row[s];
+        const uint32_t c_hi = (s == top_symbol) ? 0x10000u : row[s + 1];
         high = (low - 1) + (uint32_t)((span * c_hi) >> 16);
         low = low + (uint32_t)((span * c_lo) >> 16);
-        for (;;) {
-            if (low >= 0x80000000u || high < 0x80000000u) {
-                low <<= 1; high = (high << 1) | 1u; src.shift_into(value);
-            } else if (low >= 0x40000000u && high < 0xC0000000u) {
-                low = (low << 1) & 0x7FFFFFFFu; high = (high << 1) | 0x80000001u;
-                value -= 0x40000000u; src.shift_into(value);
-            } else break;
+        const int nshare = clz32(low ^ high);
+        if (nshare) {
+            if (nshare == 32) { low = 0; high = 0xFFFFFFFFu; value = src.take(32); }
+            else {
+                low <<= nshare; high = (high << nshare) | ((1u << nshare) - 1u);
+                value = (value << nshare) | src.take(nshare);
+            }
+        }
+        while (low >= 0x40000000u && high < 0xC0000000u) {
+            int m = clz32(~(low << 1));
+            const int mz = clz32(high << 1);
+            if (mz < m) m = mz;
+            if (m > 31) m = 31;
+            low = (low << m) & 0x7FFFFFFFu;
+            high = (high << m) | 0x80000000u | ((1u << m) - 1u);
+            value = ((value << m) | src.take(m)) ^ 0x80000000u;              // m steps of (v - 2^30) << 1 | bit
         }
     }
     return 0;
@@ -179,19 +223,35 @@ struct OctModel {
     inline uint16_t& at(int bucket, int nb, int node) { return p[((size_t)bucket * kNbrClasses + nb) * 256 + node]; }
 };
 
-// number of occupied 6-neighbours of node `code` (Morton code at the current level) within the sorted node list
-inline int face_neighbours(const std::vector<uint64_t>& nodes, uint64_t code, int level_bits) {
-    int32_t x, y, z; demorton3(code, x, y, z);
-    const int32_t lim = (level_bits >= 21) ? INT32_MAX : (1 << level_bits);
-    int cnt = 0;
-    const int d[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
-    for (auto& o : d) {
-        int32_t nx = x + o[0], ny = y + o[1], nz = z + o[2];
-        if (nx < 0 || ny < 0 || nz < 0 || nx >= lim || ny >= lim || nz >= lim) continue;
-        cnt += std::binary_search(nodes.begin(), nodes.end(), morton3(nx, ny, nz));
+// Occupancy of one octree level for the neighbour contexts: a Morton-indexed bitmap while the level has at most 2^24
+// cells (2 MiB), binary search in the sorted node list beyond that.
+struct LevelOcc {
+    const std::vector<uint64_t>* nodes = nullptr; int level_bits = 0; bool use_bitmap = false;
+    std::vector<uint64_t> bits;
+    void build(const std::vector<uint64_t>& n, int lb) {
+        nodes = &n; level_bits = lb; use_bitmap = 3 * lb <= 24;
+        if (use_bitmap) {
+            bits.assign(((size_t)1 << (3 * lb)) / 64 + 1, 0);
+            for (uint64_t c : n) bits[c >> 6] |= 1ull << (c & 63);
+        }
     }
-    return cnt;
-}
+    inline bool has(uint64_t c) const {
+        return use_bitmap ? ((bits[c >> 6] >> (c & 63)) & 1ull) != 0 : std::binary_search(nodes->begin(), nodes->end(), c);
+    }
+    // number of occupied face neighbours (0..6) of node `code`
+    inline int face_neighbours(uint64_t code) const {
+        int32_t x, y, z; demorton3(code, x, y, z);
+        const int32_t lim = (level_bits >= 21) ? INT32_MAX : (1 << level_bits);
+        int cnt = 0;
+        if (x > 0) cnt += has(morton3(x - 1, y, z));
+        if (x + 1 < lim) cnt += has(morton3(x + 1, y, z));
+        if (y > 0) cnt += has(morton3(x, y - 1, z));
+        if (y + 1 < lim) cnt += has(morton3(x, y + 1, z));
+        if (z > 0) cnt += has(morton3(x, y, z - 1));
+        if (z + 1 < lim) cnt += has(morton3(x, y, z + 1));
+        return cnt;
+    }
+};
 
 constexpr uint8_t kMagic[4] = {'P', 'C', 'G', 'O'};
 
@@ -207,18 +267,19 @@ extern "C" int64_t pcgc_oct_encode(const int32_t* xyz, int64_t n, uint8_t* out, 
     leaves.erase(std::unique(leaves.begin(), leaves.end()), leaves.end());
     const int64_t n_unique = (int64_t)leaves.size();
 
-    BinEnc enc; OctModel model;
+    BinEnc enc; OctModel model; LevelOcc occ_map;
     std::vector<uint64_t> level_nodes, next;
     if (n_unique > 0) level_nodes.push_back(0);
     for (int lvl = 0; lvl < depth && !level_nodes.empty(); ++lvl) {
         const int shift = 3 * (depth - 1 - lvl);                     // leaves >> shift = child code at level lvl+1
         const int bucket = std::min(kLevelBuckets - 1, depth - 1 - lvl);
         next.clear();
+        occ_map.build(level_nodes, lvl);
         size_t cursor = 0;
         for (uint64_t node : level_nodes) {
             unsigned occ = 0;
             while (cursor < leaves.size() && ((leaves[cursor] >> shift) >> 3) == node) { occ |= 1u << ((leaves[cursor] >> shift) & 7); ++cursor; }
-            const int nb = face_neighbours(level_nodes, node, lvl);
+            const int nb = occ_map.face_neighbours(node);
             int tree = 1;
             for (int j = 0; j < 8; ++j) {
                 int bit = (occ >> j) & 1;
@@ -250,14 +311,15 @@ extern "C" int pcgc_oct_decode(const uint8_t* in, int64_t nbytes, int32_t* xyz, 
     const int depth = in[4];
     if (depth < 1 || depth > 21) return -1;
     BinDec dec{in + 9, nbytes - 9}; dec.init();
-    OctModel model;
+    OctModel model; LevelOcc occ_map;
     std::vector<uint64_t> level_nodes, next;
     if (n > 0) level_nodes.push_back(0);
     for (int lvl = 0; lvl < depth && !level_nodes.empty(); ++lvl) {
         const int bucket = std::min(kLevelBuckets - 1, depth - 1 - lvl);
         next.clear();
+        occ_map.build(level_nodes, lvl);
         for (uint64_t node : level_nodes) {
-            const int nb = face_neighbours(level_nodes, node, lvl);
+            const int nb = occ_map.face_neighbours(node);
             int tree = 1;
             for (int j = 0; j < 8; ++j) {
                 int bit = dec.decode(model.at(bucket, nb, tree));

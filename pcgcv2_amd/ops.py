@@ -236,6 +236,11 @@ def kmap_down(coarse, stride_fine, fine_table):
 
 
 # ------------------------------------------------------------------------------------------------ conv family
+def set_conv_impl(impl):
+    """-1 auto, 0 = v0 direct-load gather kernel, 1 = v1 LDS-DMA gather kernel (bit-identical results)."""
+    check(lib().pcgc_set_conv_impl(int(impl)), 'set_conv_impl')
+
+
 def conv_gather(nbr, x, W, bias, out=None, residual=None, relu=False, n_out=None):
     """out (view, may be a column slice) = relu?( fmaf-chain(nbr, x, W) + bias (+ residual) )."""
     _f32(x, 'x'); _f32(W, 'W')
@@ -258,7 +263,7 @@ def conv_gather(nbr, x, W, bias, out=None, residual=None, relu=False, n_out=None
     if prof:
         e0, e1 = PROFILE.bracket(K, Cin, Cout, n_out)
         e0.record()
-    check(lib().pcgc_conv_gather(_p(nbr), K, n_out, _p(x), Cin, _ld(x), 0, _p(W), _p(bias), res_p, res_ld, 0, int(relu),
+    check(lib().pcgc_conv_gather(_p(nbr), K, n_out, _p(x), x.shape[0], Cin, _ld(x), 0, _p(W), _p(bias), res_p, res_ld, 0, int(relu),
                                  _p(out), Cout, _ld(out), 0, _stream()), 'conv_gather')
     if prof:
         e1.record()

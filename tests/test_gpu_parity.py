@@ -112,8 +112,15 @@ CONV_SHAPES = [(27, 1, 16), (27, 16, 16), (27, 32, 8), (27, 8, 16), (27, 8, 8), 
                (8, 16, 32), (8, 32, 64), (8, 64, 32), (1, 32, 8), (1, 8, 16), (1, 64, 16), (1, 16, 32), (1, 16, 4), (1, 4, 8)]
 
 
+@pytest.fixture(params=[0, 1], ids=['v0_direct', 'v1_ldsdma'])
+def conv_impl(request):
+    ops.set_conv_impl(request.param)
+    yield request.param
+    ops.set_conv_impl(-1)
+
+
 @pytest.mark.parametrize('K,cin,cout', CONV_SHAPES)
-def test_conv_gather_bit_exact(K, cin, cout):
+def test_conv_gather_bit_exact(K, cin, cout, conv_impl):
     rng = np.random.default_rng(K * 1000 + cin * 10 + cout)
     c4 = _coords('shell7')
     n = len(c4)
