@@ -60,6 +60,8 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
+    import pcgcv2_amd
+    pcgcv2_amd.configure_host_threads()
     from pcgcv2_amd import synthetic, ops
     from pcgcv2_amd.pcc_model import PCCModel
     from pcgcv2_amd.coder import Coder
@@ -92,6 +94,11 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
+    # Python's cyclic GC stays enabled, but the ~1e6 long-lived objects created by importing torch & friends are moved
+    # to the permanent generation so that full collections do not re-traverse them (tens of ms each) mid-measurement.
+    import gc
+    gc.collect()
+    gc.freeze()
     n_out = len(out)
     bits = sum(os.path.getsize(os.path.join(tmp, 'frame' + p)) * 8 for p in ('_C.bin', '_F.bin', '_H.bin', '_num_points.bin'))
 
@@ -100,6 +107,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     enc_t = dec_t = 0.0
+    step_ms = []
     for _ in range(args.steps):
         x = SparseTensor(feats, coordinates=coords, tensor_stride=1, device=dev)
         a = time.perf_counter()
@@ -110,6 +118,7 @@ def main():
         torch.cuda.synchronize()
         c = time.perf_counter()
         enc_t += b - a; dec_t += c - b
+        step_ms.append(round((c - a) * 1e3, 2))
     barrier()
     elapsed = time.perf_counter() - t0
     ops.PROFILE.enabled = False
@@ -140,7 +149,7 @@ def main():
                                    f'weights (seed 1234, gain 50), 1 frame per GPU per step, encode+decode incl. bitstream files',
                        'points_per_gpu': n_points, 'enc_ms': round(enc_t / args.steps * 1e3, 3),
                        'dec_ms': round(dec_t / args.steps * 1e3, 3), 'bpp': round(total_bits / total_points, 5),
-                       'points_out': int(total_out), 'coord_codec': 'native-octree (tmc3 absent)'},
+                       'points_out': int(total_out), 'coord_codec': 'native-octree (tmc3 absent)', 'step_ms_rank0': step_ms},
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -156,7 +165,10 @@ def main():
 def cpu_baseline(sample, sd):
     """The CPU oracle (oracle/: C restatement, OpenMP over output rows) on a bounded sample of the same workload.
     kind = "port": MinkowskiEngine's CPU backend cannot be installed here (no network, un-vendored)."""
+    import pcgcv2_amd
     from pcgcv2_amd import synthetic
+    cores = pcgcv2_amd.effective_cpus()                     # cgroup quota, not os.cpu_count()
+    os.environ['OMP_NUM_THREADS'] = str(cores)
     from oracle import pcgc_oracle as orc
     sd_np = synthetic.state_dict_to_numpy(sd)
     c = synthetic.shell(sample).numpy()
@@ -166,8 +178,8 @@ def cpu_baseline(sample, sd):
     out = orc.decode(sd_np, enc['coords8'], enc['F'], enc['H'], enc['num_points'])
     dt = time.perf_counter() - t0
     assert len(out) == len(c4)
-    return {'value': round(len(c4) / dt / 1e6, 5), 'unit': 'Mpoints/s', 'cores': os.cpu_count(), 'kind': 'port',
-            'sample': f'{sample} ({len(c4)} points, one encode+decode, {dt:.1f} s; oracle C restatement with OpenMP on all cores; '
+    return {'value': round(len(c4) / dt / 1e6, 5), 'unit': 'Mpoints/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{sample} ({len(c4)} points, one encode+decode, {dt:.1f} s; oracle C restatement, OpenMP threads = the container CPU quota; '
                       'NOT MinkowskiEngine-CPU)'}
 
 

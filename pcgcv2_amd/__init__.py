@@ -3,3 +3,31 @@ pcc_model.py API and bitstream.  Hot ops live in libpcgc_hip.so (hand-written HI
 from ._lib import PcgcError, LIB_PATH  # noqa: F401
 
 __all__ = ['PcgcError', 'LIB_PATH']
+
+
+def effective_cpus():
+    """CPUs this process may actually use: min(affinity, cgroup cpu.max quota).  Containers often advertise all host
+    cores (os.cpu_count()) while a CFS quota allows far fewer; sizing thread pools from cpu_count then gets the process
+    throttled for the rest of every 100 ms period."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def configure_host_threads(max_threads=4):
+    """The host side of the codec is a single-threaded launcher + sequential entropy coder; keep torch's CPU thread pool
+    small so its workers do not spin away the container's CPU quota."""
+    import torch
+    torch.set_num_threads(max(1, min(max_threads, effective_cpus())))

@@ -97,16 +97,18 @@ class Coder():
         with open(self.filename + postfix + '_num_points.bin', 'wb') as f:
             f.write(np.array(num_points, dtype=np.int32).tobytes())
         self.feature_coder.encode(y.F, postfix=postfix)
-        self.coordinate_coder.encode((y.C // y.tensor_stride[0]).detach().cpu()[:, 1:], postfix=postfix)
+        self.coordinate_coder.encode(y.C.detach().cpu().numpy()[:, 1:] // y.tensor_stride[0], postfix=postfix)
         return y
 
     @torch.no_grad()
     def decode(self, rho=1, postfix=''):
         dev = require_gpu(next(self.model.decoder.parameters()).device)
         y_C = self.coordinate_coder.decode(postfix=postfix)
-        y_C = torch.cat((torch.zeros((len(y_C), 1)).int(), torch.tensor(y_C).int()), dim=-1)
-        # coder.py:97-99 sorts on the host with array2vector; here the (tiny) coordinate list is sorted on device
-        y_C = (y_C * 8).to(dev)
+        # coder.py:96-99: prepend the batch column and sort with array2vector on the host; here the (tiny) list goes to the
+        # device in one copy and is sorted there (same (z,y,x,batch) order)
+        y_C4 = np.zeros((len(y_C), 4), dtype=np.int32)
+        y_C4[:, 1:] = np.asarray(y_C, dtype=np.int32) * 8
+        y_C = torch.from_numpy(y_C4).to(dev)
         y_C = ops.gather_coords(y_C, ops.sort_zyx(y_C))
         y_F = self.feature_coder.decode(postfix=postfix, device=dev)
         y = SparseTensor(features=y_F, coordinates=y_C, tensor_stride=8, device=dev, assume_unique=True)

@@ -71,17 +71,20 @@ static void launch_valu(const int32_t* nbr, int K, int64_t n_out, const float* i
 
 
 // ----------------------------------------------------------------------------------------------------------------
-// v1 kernel: LDS-DMA gather.  One wave = one tile of 64 output rows (lane = row, accumulators in VGPRs, weights as
-// scalar operands).  What changes vs v0 is how the gathered rows reach the lanes:
-//   * the tile's K x 64 kernel-map entries are staged in LDS once (buffer_load_dword ... lds),
-//   * per sub-step (offset k, 32-channel block) the 64 neighbour rows are fetched by `buffer_load_dwordx4 ... lds`
-//     with CH = CB/4 ADJACENT lanes per row, so one row = one contiguous 16*CH-byte request instead of CH separate
-//     per-lane requests (v0 was bound by the texture-addresser line rate, not by FMAs);  absent neighbours use an
-//     out-of-range buffer offset: no fetch, EXEC stays full, so the number of VMEM instructions per sub-step is static
-//     and the double buffering can use counted `s_waitcnt vmcnt(CH)` (the next sub-step's DMA stays in flight);
-//   * the LDS image is row-major [64][CH] 16-byte slots, written lane-linear by the DMA; the SOURCE chunk index is
+// v1 kernel: LDS-DMA gather.  One wave = one tile of 64 output rows x CT output channels (lane = row, accumulators in
+// VGPRs, weights as scalar operands).  What changes vs v0 is how the gathered rows reach the lanes:
+//   * per sub-step (offset k, <=32-channel block) the 64 neighbour rows are fetched by `buffer_load_dwordx4 ... lds`
+//     with CH = CB/4 ADJACENT lanes per row, so one row is one contiguous 16*CH-byte request instead of CH separate
+//     per-lane requests (v0 is bound by the texture-addresser request rate, not by FMAs).  Absent neighbours use an
+//     out-of-range buffer offset: no fetch, EXEC stays full, the VMEM instruction count per sub-step is static, so the
+//     DMA can be awaited with a counted `s_waitcnt vmcnt(1)` that leaves the NEXT offset's kernel-map load in flight;
+//   * the kernel-map entry of each lane's own row lives in a VGPR (prefetched one offset ahead); the DMA lanes get
+//     the entries of the rows they fetch by ds_bpermute — no LDS staging of the map;
+//   * the LDS image is row-major [64][CH] 16-byte slots written lane-linear by the DMA; the SOURCE chunk index is
 //     XOR-swizzled (slot p of row r holds chunk p ^ s(r), s(r) = (r*CH/16) % CH) and the per-lane row read-back
-//     applies the same XOR, which makes the ds_read_b128 of 64 different rows bank-conflict free.
+//     applies the same XOR => the ds_read_b128 of 64 different rows is bank-conflict free;
+//   * only 1-8 KiB of LDS per wave and no intra-wave double buffering: latency is hidden by 4-8 waves per SIMD
+//     (measured: the double-buffered variant with staged maps needed 15-23 KiB per wave and was DMA-latency bound).
 // Numerics: identical fmaf chain (k ascending, ci ascending) — only the data path differs.
 // ----------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -89,125 +92,116 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 template <int N>
 __device__ static inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int CIN, int COUT>
+template <int CIN, int CT>
 __global__ void __launch_bounds__(256)
 k_conv_gather_dma(const int32_t* __restrict__ nbr, int K, int64_t n_out, const float* __restrict__ in, int64_t n_in,
-                  int in_ld, const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ res,
-                  int res_ld, int relu, float* __restrict__ out, int out_ld) {
+                  int in_ld, const float* __restrict__ W, int Cout, const float* __restrict__ bias,
+                  const float* __restrict__ res, int res_ld, int relu, float* __restrict__ out, int out_ld) {
     constexpr int CB = CIN < 32 ? CIN : 32;        // channels per sub-step
     constexpr int NB = CIN / CB;                   // sub-steps per kernel offset
     constexpr int CH = CB / 4;                     // 16-byte chunks per row per sub-step: 2, 4, 8
     constexpr int RPI = 64 / CH;                   // rows covered by one DMA instruction
     constexpr int SH = (CH == 2) ? 3 : (CH == 4 ? 2 : 1);      // s(r) = (r >> SH) & (CH-1)
-    constexpr int WAVE_F4 = 2 * 64 * CH;           // float4 slots of the two row buffers
-    constexpr int WAVE_LDS_BYTES = WAVE_F4 * 16 + 27 * 64 * 4;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned char* wbase = lds_raw + (size_t)wave * WAVE_LDS_BYTES;
-    float4* rowbuf = (float4*)wbase;                                  // [2][64*CH]
-    int32_t* idx_lds = (int32_t*)(wbase + WAVE_F4 * 16);              // [K][64]
+    float4* rowbuf = (float4*)lds_raw + (size_t)wave * (64 * CH);      // [64][CH] 16-byte slots, private to the wave
 
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
-    if (row0 >= n_out) return;                                        // whole wave idle (wave-uniform)
+    if (row0 >= n_out) return;                                         // wave-uniform
+    const int co0 = blockIdx.y * CT;
     const int64_t my_row = row0 + lane;
     const bool valid = my_row < n_out;
-
-    const __amdgpu_buffer_rsrc_t rs_nbr = __builtin_amdgcn_make_buffer_rsrc((void*)nbr, 0, (int)((int64_t)K * n_out * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(n_in * in_ld * 4), 0x00020000);
 
-    // ---- stage the tile's kernel-map rows: idx_lds[k][lane] = nbr[k][row0 + lane]
-    for (int k = 0; k < K; ++k)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_nbr, (lds_void_ptr)(idx_lds + k * 64), 4,
-                                                 (int)(((int64_t)k * n_out + my_row) * 4), 0, 0, 0);
-    wait_vmcnt<0>();
-
-    // DMA lane roles: in instruction i this lane fetches row (i*RPI + lane/CH), LDS slot p = lane%CH <- chunk p ^ s(row)
     const int dma_row_lo = lane / CH, dma_p = lane % CH;
-    auto issue = [&](int t) {
-        const int k = t / NB, cb = t % NB;
-        float4* dst = rowbuf + (t & 1) * (64 * CH);
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int r = i * RPI + dma_row_lo;
-            const int rid = idx_lds[k * 64 + r];
-            const int chunk = dma_p ^ ((r >> SH) & (CH - 1));
-            const unsigned voff = rid >= 0 ? (unsigned)(((int64_t)rid * in_ld + cb * CB + chunk * 4) * 4) : 0xFFFFFFF0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_ptr)(dst + i * 64), 16, (int)voff, 0, 0, 0);
-        }
-    };
-
-    float acc[COUT];
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
-
-    const int T = K * NB;
     const int my_swz = (lane >> SH) & (CH - 1);
-    issue(0);
-    for (int t = 0; t < T; ++t) {
-        const int k = t / NB, cb = t % NB;
-        if (t + 1 < T) { issue(t + 1); wait_vmcnt<CH>(); }            // leave the next sub-step's CH DMAs in flight
-        else wait_vmcnt<0>();
-        const int rid = valid ? idx_lds[k * 64 + lane] : -1;
-        const float4* src = rowbuf + (t & 1) * (64 * CH) + lane * CH;
-        float4 x[CH];
+
+    float acc[CT];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) x[c] = src[c ^ my_swz];
-        if (rid >= 0) {
-            const float* w = W + ((int64_t)k * CIN + cb * CB) * COUT;
+    for (int co = 0; co < CT; ++co) acc[co] = 0.0f;
+
+    int idx_cur = valid ? nbr[my_row] : -1;
+    for (int k = 0; k < K; ++k) {
+        int idx_nxt = -1;
 #pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const float* w0 = w + (4 * c) * COUT;
+        for (int cb = 0; cb < NB; ++cb) {
+            // ---- gather: CH DMA instructions, each fetching RPI rows as CH adjacent 16-byte chunks
 #pragma unroll
-                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(x[c].x, w0[co], acc[co]);
-#pragma unroll
-                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(x[c].y, w0[COUT + co], acc[co]);
-#pragma unroll
-                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(x[c].z, w0[2 * COUT + co], acc[co]);
-#pragma unroll
-                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(x[c].w, w0[3 * COUT + co], acc[co]);
+            for (int i = 0; i < CH; ++i) {
+                const int r = i * RPI + dma_row_lo;
+                const int rid = __shfl(idx_cur, r, 64);
+                const int chunk = dma_p ^ ((r >> SH) & (CH - 1));
+                const unsigned voff = rid >= 0 ? (unsigned)(((int64_t)rid * in_ld + cb * CB + chunk * 4) * 4) : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_ptr)(rowbuf + i * 64), 16, (int)voff, 0, 0, 0);
             }
+            asm volatile("" ::: "memory");                       // keep the map prefetch BEHIND the DMA in the VMEM queue
+            if (cb == NB - 1 && k + 1 < K) {
+                if (valid) idx_nxt = nbr[(int64_t)(k + 1) * n_out + my_row];   // newest VMEM op: stays in flight
+                asm volatile("" ::: "memory");
+                wait_vmcnt<1>();                                                // everything older (the DMA) has landed
+            } else wait_vmcnt<0>();
+            float4 x[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) x[c] = rowbuf[lane * CH + (c ^ my_swz)];
+            if (idx_cur >= 0) {
+                const float* w = W + ((int64_t)k * CIN + cb * CB) * Cout + co0;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const float* w0 = w + (int64_t)(4 * c) * Cout;
+#pragma unroll
+                    for (int co = 0; co < CT; ++co) acc[co] = fmaf(x[c].x, w0[co], acc[co]);
+#pragma unroll
+                    for (int co = 0; co < CT; ++co) acc[co] = fmaf(x[c].y, w0[Cout + co], acc[co]);
+#pragma unroll
+                    for (int co = 0; co < CT; ++co) acc[co] = fmaf(x[c].z, w0[2 * Cout + co], acc[co]);
+#pragma unroll
+                    for (int co = 0; co < CT; ++co) acc[co] = fmaf(x[c].w, w0[3 * Cout + co], acc[co]);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // row buffer fully read before the next DMA overwrites it
         }
-        asm volatile("" ::: "memory");               // the row buffer read above must not sink below the next issue()
+        idx_cur = idx_nxt;
     }
     if (!valid) return;
-    float* y = out + my_row * out_ld;
-    const float* rr = res ? res + my_row * res_ld : nullptr;
+    float* y = out + my_row * out_ld + co0;
+    const float* rr = res ? res + my_row * res_ld + co0 : nullptr;
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) {
+    for (int co = 0; co < CT; ++co) {
         float v = acc[co];
-        if (bias) v = v + bias[co];
+        if (bias) v = v + bias[co0 + co];
         if (rr) v = v + rr[co];
         if (relu) v = fmaxf(v, 0.0f);
         y[co] = v;
     }
 }
 
-template <int CIN, int COUT>
+template <int CIN, int CT>
 static void launch_dma(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int in_ld, const float* W,
-                       const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld, hipStream_t s) {
+                       int Cout, const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld,
+                       hipStream_t s) {
     constexpr int CB = CIN < 32 ? CIN : 32;
-    constexpr int CH = CB / 4;
-    constexpr size_t lds = 4 * (size_t)(2 * 64 * CH * 16 + 27 * 64 * 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_conv_gather_dma<CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((k_conv_gather_dma<CIN, COUT>), dim3(grid_for(n_out, 256)), dim3(256), lds, s, nbr, K, n_out, in, n_in,
-                       in_ld, W, bias, res, res_ld, relu, out, out_ld);
+    constexpr size_t lds = 4 * (size_t)(64 * (CB / 4) * 16);
+    hipLaunchKernelGGL((k_conv_gather_dma<CIN, CT>), dim3(grid_for(n_out, 256), Cout / CT), dim3(256), lds, s, nbr, K, n_out, in,
+                       n_in, in_ld, W, Cout, bias, res, res_ld, relu, out, out_ld);
 }
 
+// output-channel tile per wave: whole Cout up to 16; 16 or 32 beyond (smaller tiles on small levels = more waves)
 template <int CIN>
 static bool dispatch_dma_cout(int Cout, const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int in_ld,
                               const float* W, const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld,
                               hipStream_t s) {
+#define PCGC_DMA(CTILE) launch_dma<CIN, CTILE>(nbr, K, n_out, in, n_in, in_ld, W, Cout, bias, res, res_ld, relu, out, out_ld, s); return true;
     switch (Cout) {
-#define PCGC_DMA(C) case C: launch_dma<CIN, C>(nbr, K, n_out, in, n_in, in_ld, W, bias, res, res_ld, relu, out, out_ld, s); return true;
-        PCGC_DMA(1) PCGC_DMA(4) PCGC_DMA(8) PCGC_DMA(16) PCGC_DMA(32) PCGC_DMA(64)
-#undef PCGC_DMA
+        case 1: PCGC_DMA(1)
+        case 4: PCGC_DMA(4)
+        case 8: PCGC_DMA(8)
+        case 16: PCGC_DMA(16)
+        case 32: if (n_out < 200000) { PCGC_DMA(16) } else { PCGC_DMA(32) }
+        case 64: if (n_out < 200000) { PCGC_DMA(16) } else { PCGC_DMA(32) }
     }
+#undef PCGC_DMA
     return false;
 }
 
@@ -225,10 +219,10 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
     const float* in0 = in + in_coff;
     const bool aligned = (((uintptr_t)in0 | (uintptr_t)W) & 15) == 0 && (in_ld & 3) == 0;
     const bool small = n_in * in_ld * 4 < (int64_t)0xFFFFFFF0 && (int64_t)K * n_out * 4 < (int64_t)0xFFFFFFF0;
-    // auto: v1 pays where the op is gather-bound (few output channels per gathered row); measured per shape on MI355X
-    // (tools/conv_ab.py): Cin>=16 & Cout<=8 -> 1.5-3.8x faster; Cout>=16 -> v0 (v1's LDS footprint limits occupancy there).
+    // auto: measured per shape on MI355X (tools/conv_ab.py): v1 is 2-6x faster on the gather-bound shapes (Cout <= 8) and
+    // on par (0.9-1.4x) on the FMA-bound ones; v0 only wins on tiny levels (< ~30k rows) where launch geometry dominates.
     const bool v1_eligible = nbr != nullptr && K <= 27 && aligned && small && (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64);
-    const bool v1_wanted = g_conv_impl == 1 || (g_conv_impl < 0 && Cin >= 16 && Cout <= 8);
+    const bool v1_wanted = g_conv_impl == 1 || (g_conv_impl < 0 && n_out >= 30000);
     if (v1_eligible && v1_wanted) {
         const float* res0 = residual ? residual + res_coff : nullptr;
         float* out0 = out + out_coff;

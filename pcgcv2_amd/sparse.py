@@ -37,7 +37,6 @@ class CoordMap:
         self._k3 = None
         self._down = None
         self._parent_of = None
-        self._up = None
         self._unique = unique
 
     def __len__(self):
@@ -83,14 +82,13 @@ class CoordMap:
         return self._down
 
     def up(self):
-        """-> children CoordMap at stride/2, rows 8*i+k: MinkowskiGenerativeConvolutionTranspose(k=2, stride=2)."""
-        if self._up is None:
-            self._up = CoordMap(ops.coords_children(self.C, self.stride), self.stride // 2, unique=True,
-                                origin=('children', self))
-        return self._up
+        """-> children CoordMap at stride/2, rows 8*i+k: MinkowskiGenerativeConvolutionTranspose(k=2, stride=2).
+        Not cached on the parent: the child keeps a strong reference to its parent (to derive its kernel map), and a
+        back-reference would form a cycle that keeps hundreds of MB of maps alive until Python's cyclic GC runs."""
+        return CoordMap(ops.coords_children(self.C, self.stride), self.stride // 2, unique=True, origin=('children', self))
 
     def drop_caches(self):
-        self._table = self._k3 = self._down = self._up = self._parent_of = None
+        self._table = self._k3 = self._down = self._parent_of = None
 
 
 def dedup(coords, feats, stride):
