@@ -1,0 +1,110 @@
+"""Multi-GPU sharding of the encode/decode path (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm).
+
+The reference is single-device (coder.py:5).  Frames — and octant blocks of one large cloud — are coded independently
+(each unit is its own `Coder.encode/decode` with its own `postfix` file set, the mechanism test.py:38 uses for rates), so
+the data path needs NO collective.  The only exchange is the final reduction of five scalars per rank
+    [bits, N_in, N_out, sum d^2(A->B), sum d^2(B->A)]
+for the aggregate bpp / D1 (one all-reduce of 40 bytes), plus an optional variable-length all-gather of decoded
+coordinates when an exact global D1 over block borders is wanted.
+"""
+import math
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_units(n_units, rank=None, world_size=None):
+    """Round-robin assignment of independent units (frames / blocks) to ranks -> list of unit indices of this rank."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    return list(range(rank, n_units, world_size))
+
+
+def split_octants(coords, levels=1):
+    """Split a cloud into 8**levels blocks by the top `levels` bits of (x,y,z) of its bounding power-of-two cube.
+    coords: int array/tensor [N,3] or [N,4] (batch first).  -> list of index arrays (numpy), empty blocks dropped.
+    (BASELINE config 5: 8 blocks of the scaled vox12 cloud, one per GPU.)"""
+    c = coords.detach().cpu().numpy() if isinstance(coords, torch.Tensor) else np.asarray(coords)
+    xyz = c[:, -3:].astype(np.int64)
+    span = int(xyz.max()) + 1 if len(xyz) else 1
+    bits = max(levels, int(math.ceil(math.log2(max(span, 2)))))
+    sh = bits - levels
+    key = np.zeros(len(xyz), np.int64)
+    for d in range(3):
+        key |= (xyz[:, d] >> sh) << (levels * d)
+    order = np.argsort(key, kind='stable')
+    bounds = np.flatnonzero(np.diff(key[order])) + 1
+    return [blk for blk in np.split(order, bounds) if len(blk)]
+
+
+class Stats:
+    """Additive per-unit statistics; `reduce()` sums them over ranks (RCCL all-reduce on GPU, gloo on CPU)."""
+    FIELDS = ('bits', 'n_in', 'n_out', 'sse_ab', 'sse_ba')
+
+    def __init__(self, device='cpu'):
+        self.v = torch.zeros(len(self.FIELDS), dtype=torch.float64, device=device)
+
+    def add(self, bits=0, n_in=0, n_out=0, sse_ab=0.0, sse_ba=0.0):
+        self.v += torch.tensor([bits, n_in, n_out, sse_ab, sse_ba], dtype=torch.float64, device=self.v.device)
+        return self
+
+    def reduce(self):
+        if world()[1] > 1:
+            dist.all_reduce(self.v, op=dist.ReduceOp.SUM)
+        return self
+
+    def summary(self, res):
+        bits, n_in, n_out, ab, ba = [float(x) for x in self.v.tolist()]
+        mse = max(ab / max(n_in, 1), ba / max(n_out, 1))
+        peak = float(res - 1)
+        return {'bits': bits, 'n_in': int(n_in), 'n_out': int(n_out), 'bpp': bits / max(n_in, 1),
+                'd1_mse': mse, 'd1_psnr': float(10 * math.log10(3 * peak * peak / mse)) if mse > 0 else float('inf')}
+
+
+def gather_varlen(rows, dst=0):
+    """All ranks contribute an int32 [n_i, C] tensor; rank `dst` gets the concatenation (others get None).
+    Sizes are exchanged first, then one padded all-gather (xGMI: a single large transfer beats many small ones)."""
+    rank, w = world()
+    if w == 1:
+        return rows
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+    sizes = [torch.zeros_like(n) for _ in range(w)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(sizes)
+    pad = torch.zeros((m, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+    pad[:rows.shape[0]] = rows
+    bufs = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(bufs, pad)
+    if rank != dst:
+        return None
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
+
+
+def code_units(coder, units, rho=1.0, res=1024, with_d1=False):
+    """Encode+decode this rank's share of `units` = list of (name, SparseTensor) and return (Stats, {name: decoded}).
+    Each unit uses postfix '_<name>' so its four files never collide."""
+    import os
+    from .pc_error import d1_sums
+    stats = Stats(device=units[0][1].device if units else 'cpu')
+    outs = {}
+    for idx in shard_units(len(units)):
+        name, x = units[idx]
+        post = '_' + str(name)
+        coder.encode(x, postfix=post)
+        out = coder.decode(rho=rho, postfix=post)
+        bits = sum(os.path.getsize(coder.filename + post + s) * 8 for s in ('_C.bin', '_F.bin', '_H.bin', '_num_points.bin'))
+        ab = ba = 0.0
+        if with_d1:
+            a, b = x.C[:, 1:].cpu().numpy(), out.C[:, 1:].cpu().numpy()
+            ab, ba = d1_sums(a, b)[0], d1_sums(b, a)[0]
+        stats.add(bits=bits, n_in=len(x), n_out=len(out), sse_ab=ab, sse_ba=ba)
+        outs[name] = out
+    return stats, outs
