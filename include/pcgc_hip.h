@@ -98,6 +98,12 @@ int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const float* in, 
 /* kernel selection for the gather conv: -1 auto (default), 0 = v0 direct-load kernel, 1 = v1 LDS-DMA kernel where eligible.
  * Both produce bit-identical results; the switch exists for A/B measurements and tests. */
 int pcgc_set_conv_impl(int impl);
+/* Fused InceptionResNet block (autoencoder.py:7-57):  out = cat(conv0_1(relu(conv0_0 x)), conv1_2(relu(conv1_1(relu(conv1_0 x))))) + x
+ * in two gather passes.  params[10] = {conv0_0.kernel, .bias, conv0_1.kernel, .bias, conv1_0.kernel, .bias, conv1_1.kernel,
+ * .bias, conv1_2.kernel, .bias} (ME layouts).  t_scratch: [n, C/2] fp32 workspace.  Bit-identical to the five
+ * pcgc_conv_gather calls it replaces. */
+int pcgc_irn_block(const int32_t* nbr /*[27,n]*/, int64_t n, const float* x /*[n,C], ld x_ld*/, int C, int x_ld,
+                   const float* const* params, float* t_scratch, float* out, int out_ld, void* stream);
 /* MinkowskiGenerativeConvolutionTranspose(k=2,s=2): out[8i+k] = in[i] @ W[k] + bias (+ReLU). */
 int pcgc_conv_up2(int64_t n_in, const float* in, int Cin, int in_ld, const float* W /*[8,Cin,Cout]*/, const float* bias,
                   int relu, float* out /*[dev 8n,Cout]*/, int Cout, void* stream);

@@ -25,6 +25,9 @@ class InceptionResNet(torch.nn.Module):
 
     def forward(self, x):
         c = x.F.shape[1]
+        if ops.irn_eligible(x.F):                           # two fused gather passes (pcgc_irn_block)
+            params = [p for m in (self.conv0_0, self.conv0_1, self.conv1_0, self.conv1_1, self.conv1_2) for p in (m.kernel, m.bias)]
+            return SparseTensor(ops.irn_block(x.cmap.k3, x.F, params), coordinate_map=x.cmap)
         out = torch.empty_like(x.F)
         a = self.conv0_0(x, relu=True)
         self.conv0_1(a, out=out[:, :c // 2], residual=x.F[:, :c // 2])          # cat slot 0 + residual

@@ -205,6 +205,202 @@ static bool dispatch_dma_cout(int Cout, const int32_t* nbr, int K, int64_t n_out
     return false;
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------
+// Fused InceptionResNet block (autoencoder.py:52-57) in two gather passes, built on the same LDS-DMA row gather:
+//   A:  t[:, 0:Q]  = relu(conv0_0(x))   k3  C -> Q        t[:, Q:2Q] = relu(conv1_0(x))   k1  C -> Q   (Q = C/4)
+//       the k1 conv reads the site's own row, which is exactly the gathered row of the centre offset (k = 13).
+//   B:  out[:, 0:2Q]  = conv0_1(t[:, 0:Q]) + x[:, 0:2Q]                        k3  Q -> 2Q
+//       out[:, 2Q:4Q] = conv1_2(relu(conv1_1(t[:, Q:2Q]))) + x[:, 2Q:4Q]       k3  Q -> Q, then k1  Q -> 2Q in registers
+//       ONE gather of the 2Q-wide rows of t feeds both k3 convs (the unfused form gathers two Q-wide tensors).
+// 5 launches / 3 gathers / 2 pointwise passes become 2 launches / 2 gathers; every fmaf chain is unchanged.
+// ----------------------------------------------------------------------------------------------------------------
+template <int CH>
+struct RowGather {                                   // one wave, 64 rows, CH 16-byte chunks per row
+    static constexpr int RPI = 64 / CH;
+    static constexpr int SH = (CH == 2) ? 3 : (CH == 4 ? 2 : 1);
+    __device__ static inline void fetch(const __amdgpu_buffer_rsrc_t& rs, float4* rowbuf, int idx_cur, int in_ld, int col0, int lane) {
+        const int dma_row_lo = lane / CH, dma_p = lane % CH;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int r = i * RPI + dma_row_lo;
+            const int rid = __shfl(idx_cur, r, 64);
+            const int chunk = dma_p ^ ((r >> SH) & (CH - 1));
+            const unsigned voff = rid >= 0 ? (unsigned)(((int64_t)rid * in_ld + col0 + chunk * 4) * 4) : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)(rowbuf + i * 64), 16, (int)voff, 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+    }
+    __device__ static inline void read(const float4* rowbuf, int lane, float4 (&x)[CH]) {
+        const int swz = (lane >> SH) & (CH - 1);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) x[c] = rowbuf[lane * CH + (c ^ swz)];
+    }
+};
+
+// acc[0..NO) += x4 (4 consecutive input channels) * w[4][ldw] rows, channel order preserved
+template <int NO>
+__device__ static inline void fma4(float (&acc)[NO], const float4& x, const float* __restrict__ w, int ldw) {
+#pragma unroll
+    for (int co = 0; co < NO; ++co) acc[co] = fmaf(x.x, w[co], acc[co]);
+#pragma unroll
+    for (int co = 0; co < NO; ++co) acc[co] = fmaf(x.y, w[ldw + co], acc[co]);
+#pragma unroll
+    for (int co = 0; co < NO; ++co) acc[co] = fmaf(x.z, w[2 * ldw + co], acc[co]);
+#pragma unroll
+    for (int co = 0; co < NO; ++co) acc[co] = fmaf(x.w, w[3 * ldw + co], acc[co]);
+}
+
+template <int C>
+__global__ void __launch_bounds__(256)
+k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x, int x_ld,
+        const float* __restrict__ W00, const float* __restrict__ b00, const float* __restrict__ W10,
+        const float* __restrict__ b10, float* __restrict__ t /*[n, C/2]*/) {
+    constexpr int Q = C / 4;
+    constexpr int CB = C < 32 ? C : 32, NB = C / CB, CH = CB / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4* rowbuf = (float4*)lds_raw + (size_t)wave * (64 * CH);
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    if (row0 >= n) return;
+    const int64_t my_row = row0 + lane;
+    const bool valid = my_row < n;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(n * x_ld * 4), 0x00020000);
+    float acc0[Q], acc1[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+    int idx_cur = valid ? nbr[my_row] : -1;
+    for (int k = 0; k < 27; ++k) {
+        int idx_nxt = -1;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            RowGather<CH>::fetch(rs, rowbuf, idx_cur, x_ld, cb * CB, lane);
+            if (cb == NB - 1 && k + 1 < 27) {
+                if (valid) idx_nxt = nbr[(int64_t)(k + 1) * n + my_row];
+                asm volatile("" ::: "memory");
+                wait_vmcnt<1>();
+            } else wait_vmcnt<0>();
+            float4 xv[CH];
+            RowGather<CH>::read(rowbuf, lane, xv);
+            if (idx_cur >= 0) {
+                const float* w = W00 + ((int64_t)k * C + cb * CB) * Q;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) fma4<Q>(acc0, xv[c], w + (4 * c) * Q, Q);
+                if (k == 13) {                                       // own row: the k1 branch conv1_0
+                    const float* w1 = W10 + (int64_t)(cb * CB) * Q;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) fma4<Q>(acc1, xv[c], w1 + (4 * c) * Q, Q);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        idx_cur = idx_nxt;
+    }
+    if (!valid) return;
+    float* y = t + my_row * (2 * Q);
+#pragma unroll
+    for (int i = 0; i < Q; ++i) y[i] = fmaxf(acc0[i] + b00[i], 0.0f);
+#pragma unroll
+    for (int i = 0; i < Q; ++i) y[Q + i] = fmaxf(acc1[i] + b10[i], 0.0f);
+}
+
+template <int C>
+__global__ void __launch_bounds__(256)
+k_irn_b(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ t /*[n, C/2]*/, const float* __restrict__ x,
+        int x_ld, const float* __restrict__ W01, const float* __restrict__ b01, const float* __restrict__ W11,
+        const float* __restrict__ b11, const float* __restrict__ W12, const float* __restrict__ b12,
+        float* __restrict__ out, int out_ld) {
+    constexpr int Q = C / 4, H = C / 2;
+    constexpr int CH = H / 4;                        // gathered row = H floats: 2, 4 or 8 chunks
+    constexpr int CQ = Q / 4;                        // chunks per branch: 1, 2 or 4
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4* rowbuf = (float4*)lds_raw + (size_t)wave * (64 * CH);
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    if (row0 >= n) return;
+    const int64_t my_row = row0 + lane;
+    const bool valid = my_row < n;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)t, 0, (int)(n * H * 4), 0x00020000);
+    float acc0[H], acc1[Q];
+#pragma unroll
+    for (int i = 0; i < H; ++i) acc0[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) acc1[i] = 0.0f;
+    int idx_cur = valid ? nbr[my_row] : -1;
+    for (int k = 0; k < 27; ++k) {
+        int idx_nxt = -1;
+        RowGather<CH>::fetch(rs, rowbuf, idx_cur, H, 0, lane);
+        if (k + 1 < 27) {
+            if (valid) idx_nxt = nbr[(int64_t)(k + 1) * n + my_row];
+            asm volatile("" ::: "memory");
+            wait_vmcnt<1>();
+        } else wait_vmcnt<0>();
+        float4 tv[CH];
+        RowGather<CH>::read(rowbuf, lane, tv);
+        if (idx_cur >= 0) {
+            const float* w0 = W01 + (int64_t)k * Q * H;              // [Q][H]
+            const float* w1 = W11 + (int64_t)k * Q * Q;              // [Q][Q]
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) fma4<H>(acc0, tv[c], w0 + (4 * c) * H, H);
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) fma4<Q>(acc1, tv[CQ + c], w1 + (4 * c) * Q, Q);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        idx_cur = idx_nxt;
+    }
+    if (!valid) return;
+    // conv1_2 (k1, Q -> H) on u = relu(conv1_1 + bias), in registers
+    float acc2[H];
+#pragma unroll
+    for (int i = 0; i < H; ++i) acc2[i] = 0.0f;
+#pragma unroll
+    for (int ci = 0; ci < Q; ++ci) {
+        const float u = fmaxf(acc1[ci] + b11[ci], 0.0f);
+#pragma unroll
+        for (int co = 0; co < H; ++co) acc2[co] = fmaf(u, W12[ci * H + co], acc2[co]);
+    }
+    const float* xr = x + my_row * x_ld;
+    float* y = out + my_row * out_ld;
+#pragma unroll
+    for (int co = 0; co < H; co += 4) {
+        float4 r0 = *(const float4*)(xr + co), r1 = *(const float4*)(xr + H + co), o0, o1;
+        o0.x = (acc0[co] + b01[co]) + r0.x; o0.y = (acc0[co + 1] + b01[co + 1]) + r0.y;
+        o0.z = (acc0[co + 2] + b01[co + 2]) + r0.z; o0.w = (acc0[co + 3] + b01[co + 3]) + r0.w;
+        o1.x = (acc2[co] + b12[co]) + r1.x; o1.y = (acc2[co + 1] + b12[co + 1]) + r1.y;
+        o1.z = (acc2[co + 2] + b12[co + 2]) + r1.z; o1.w = (acc2[co + 3] + b12[co + 3]) + r1.w;
+        *(float4*)(y + co) = o0; *(float4*)(y + H + co) = o1;
+    }
+}
+
+template <int C>
+static void launch_irn(const int32_t* nbr, int64_t n, const float* x, int x_ld, const float* const* P, float* t, float* out,
+                       int out_ld, hipStream_t s) {
+    constexpr int CBA = C < 32 ? C : 32;
+    const size_t lds_a = 4 * (size_t)(64 * (CBA / 4) * 16), lds_b = 4 * (size_t)(64 * (C / 8) * 16);
+    hipLaunchKernelGGL((k_irn_a<C>), dim3(grid_for(n, 256)), dim3(256), lds_a, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
+    hipLaunchKernelGGL((k_irn_b<C>), dim3(grid_for(n, 256)), dim3(256), lds_b, s, nbr, n, t, x, x_ld, P[2], P[3], P[6], P[7],
+                       P[8], P[9], out, out_ld);
+}
+
+// params: {W00,b00, W01,b01, W10,b10, W11,b11, W12,b12} = conv0_0, conv0_1, conv1_0, conv1_1, conv1_2 (kernel, bias)
+extern "C" int pcgc_irn_block(const int32_t* nbr, int64_t n, const float* x, int C, int x_ld, const float* const* params,
+                              float* t_scratch, float* out, int out_ld, void* stream) {
+    PCGC_REQUIRE(nbr && x && params && t_scratch && out, "null argument");
+    PCGC_REQUIRE(C == 16 || C == 32 || C == 64, "channels must be 16, 32 or 64");
+    PCGC_REQUIRE((x_ld & 3) == 0 && (out_ld & 3) == 0, "leading dimensions must be multiples of 4");
+    PCGC_REQUIRE(n * (int64_t)x_ld * 4 < (int64_t)0xFFFFFFF0, "tensor too large for 32-bit buffer offsets");
+    for (int i = 0; i < 10; ++i) PCGC_REQUIRE(params[i] != nullptr, "null parameter tensor");
+    PCGC_REQUIRE((((uintptr_t)x | (uintptr_t)t_scratch | (uintptr_t)out) & 15) == 0, "buffers must be 16-byte aligned");
+    if (n == 0) return 0;
+    if (C == 16) launch_irn<16>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, S(stream));
+    else if (C == 32) launch_irn<32>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, S(stream));
+    else launch_irn<64>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, S(stream));
+    PCGC_CHECK_LAUNCH("irn_block");
+    return 0;
+}
+
 static int g_conv_impl = -1;        // -1 auto, 0 force v0 (VALU direct loads), 1 force v1 (LDS-DMA gather) where eligible
 extern "C" int pcgc_set_conv_impl(int impl) { g_conv_impl = impl; return 0; }
 

@@ -120,20 +120,18 @@ extern "C" int pcgc_coords_scale(const int32_t* coords, int64_t n, float factor,
 }
 
 // ---- kernel maps ----------------------------------------------------------------------------------------------
-// One thread per output site; the 27 probes are independent so the compiler keeps several loads in flight.
+// One thread per (offset, site) pair, site fastest: 27x more threads than sites — this kernel only runs on the coarsest
+// levels (<= 32k sites), where a thread-per-site version is latency-bound (27 serial probe chains on ~70 workgroups).
 // nbr is offset-major [27][n] so the conv kernels read it coalesced.
 __global__ void __launch_bounds__(256) k_kmap_k3(const int4* __restrict__ coords, int64_t n, int32_t s, int sh,
                                                  const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
                                                  uint64_t cap_mask, int32_t* __restrict__ nbr) {
-    int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= n) return;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 27 * n) return;
+    int k = (int)(t / n); int64_t o = t - (int64_t)k * n;
     int4 c = coords[o];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-        int dx = (k % 3 - 1) * s, dy = ((k / 3) % 3 - 1) * s, dz = (k / 9 - 1) * s;
-        int32_t r = (k == 13) ? (int32_t)o : hash_lookup(keys, vals, cap_mask, sh, c.x, c.y + dx, c.z + dy, c.w + dz);
-        nbr[(int64_t)k * n + o] = r;
-    }
+    int dx = (k % 3 - 1) * s, dy = ((k / 3) % 3 - 1) * s, dz = (k / 9 - 1) * s;
+    nbr[t] = (k == 13) ? (int32_t)o : hash_lookup(keys, vals, cap_mask, sh, c.x, c.y + dx, c.z + dy, c.w + dz);
 }
 __global__ void __launch_bounds__(256) k_kmap_down(const int4* __restrict__ coarse, int64_t n, int32_t s, int sh,
                                                    const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
@@ -149,7 +147,7 @@ __global__ void __launch_bounds__(256) k_kmap_down(const int4* __restrict__ coar
 extern "C" int pcgc_kmap_k3(const int32_t* coords, int64_t n, int32_t stride, const uint64_t* keys, const int32_t* vals,
                             int64_t cap, int32_t* nbr, void* stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_kmap_k3, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n, stride,
+    hipLaunchKernelGGL(k_kmap_k3, dim3(grid_for(27 * n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n, stride,
                        stride_shift(stride), keys, vals, (uint64_t)(cap - 1), nbr);
     PCGC_CHECK_LAUNCH("kmap_k3");
     return 0;

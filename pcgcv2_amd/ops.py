@@ -272,6 +272,25 @@ def conv_gather(nbr, x, W, bias, out=None, residual=None, relu=False, n_out=None
     return out
 
 
+FUSE_IRN = True           # tests flip this to compare the fused block against its five-conv composition
+
+
+def irn_block(nbr, x, params):
+    """Fused InceptionResNet block; params = [conv0_0.kernel, .bias, conv0_1.kernel, .bias, conv1_0..., conv1_1..., conv1_2...]."""
+    import ctypes
+    _f32(x, 'x')
+    n, C = x.shape
+    t = torch.empty((n, C // 2), dtype=torch.float32, device=x.device)
+    out = torch.empty((n, C), dtype=torch.float32, device=x.device)
+    arr = (ctypes.c_void_p * 10)(*[p.data_ptr() for p in params])
+    check(lib().pcgc_irn_block(_p(nbr), n, _p(x), C, _ld(x), arr, _p(t), _p(out), C, _stream()), 'irn_block')
+    return out
+
+
+def irn_eligible(x):
+    return FUSE_IRN and x.shape[1] in (16, 32, 64) and x.shape[0] >= 30000 and x.shape[0] * x.shape[1] * 4 < 0xFFFFFFF0
+
+
 def conv_up2(x, W, bias, relu=False):
     _f32(x, 'x'); _f32(W, 'W')
     K, Cin, Cout = W.shape

@@ -148,6 +148,33 @@ def test_conv_gather_bit_exact(K, cin, cout, conv_impl):
     assert not buf[:, :cout].any()
 
 
+@pytest.mark.parametrize('C', [16, 32, 64])
+def test_fused_inception_resnet_bit_exact(C):
+    """pcgc_irn_block (2 gather passes) == the oracle's five-conv InceptionResNet == the unfused HIP composition."""
+    from pcgcv2_amd.autoencoder import InceptionResNet
+    rng = np.random.default_rng(C)
+    c4 = _coords('shell8')
+    lvl = CoordMap(_t(c4), 1, unique=True)
+    blk = InceptionResNet(C).to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.from_numpy(rng.standard_normal(tuple(p.shape)).astype(np.float32) * 0.2))
+    x = rng.standard_normal((len(c4), C)).astype(np.float32)
+    xs = SparseTensor(_t(x), coordinate_map=lvl)
+    sd = {'b.' + k: v.detach().cpu().numpy() for k, v in blk.state_dict().items()}
+    want = orc.inception_resnet(sd, 'b', orc.Level(c4, 1), x)
+    assert ops.irn_eligible(xs.F)
+    with torch.no_grad():
+        fused = blk(xs).F.cpu().numpy()
+        ops.FUSE_IRN = False
+        try:
+            unfused = blk(xs).F.cpu().numpy()
+        finally:
+            ops.FUSE_IRN = True
+    np.testing.assert_array_equal(unfused, want)
+    np.testing.assert_array_equal(fused, want)
+
+
 @pytest.mark.parametrize('cin,cout', [(8, 64), (64, 32), (32, 16)])
 def test_conv_up2_bit_exact(cin, cout):
     rng = np.random.default_rng(cin + cout)
