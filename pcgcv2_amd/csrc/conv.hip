@@ -89,6 +89,14 @@ static void launch_valu(const int32_t* nbr, int K, int64_t n_out, const float* i
 // ----------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
+// XCD-aware tile order: workgroup b is observed to run on XCD b % 8 (each XCD has its own 4 MiB L2).  Remap so every XCD
+// walks a contiguous slab of tiles: neighbouring tiles gather overlapping rows, which then hit the same L2.  Bijective
+// for any grid size; placement only affects speed, never results.
+__device__ static inline unsigned xcd_tile(unsigned b, unsigned nb) {
+    const unsigned q = nb >> 3, r = nb & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
 template <int N>
 __device__ static inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -108,7 +116,7 @@ k_conv_gather_dma(const int32_t* __restrict__ nbr, int K, int64_t n_out, const f
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4* rowbuf = (float4*)lds_raw + (size_t)wave * (64 * CH);      // [64][CH] 16-byte slots, private to the wave
 
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * 64;
     if (row0 >= n_out) return;                                         // wave-uniform
     const int co0 = blockIdx.y * CT;
     const int64_t my_row = row0 + lane;
@@ -207,6 +215,163 @@ static bool dispatch_dma_cout(int Cout, const int32_t* nbr, int K, int64_t n_out
 
 
 // ----------------------------------------------------------------------------------------------------------------
+// v2 kernel: LDS-DMA gather + fp32 MFMA channel GEMM, for Cin in {16,32,64} and Cout a multiple of 16.
+// One wave = 64 output rows (4 M-tiles of 16) x CT = 16*NT output channels.  Per sub-step (offset k, 16 input channels):
+//   * gather: 4 `buffer_load_dwordx4 ... lds` (4 adjacent lanes = one 64-byte row segment); lanes whose neighbour is
+//     absent write a zero slot themselves (MFMA cannot mask rows; fma(0, w, acc) == acc keeps the chain exact);
+//   * A fragments: `v_mfma_f32_16x16x4_f32` wants A[row = lane&15][k = lane>>4].  Lane (i,q) reads the 16-byte chunk q of
+//     row 16m+i with ONE ds_read_b128 — slot q ^ f(i>>2) of the source-swizzled image, f = (0,2,3,1), which puts the
+//     four hardware lane groups of a b128 read on 16 distinct 16-byte slots (conflict-free) — and the 4x4 (lane-quarter x
+//     component) transpose that turns "4 consecutive channels" into "channel 4j+q" is two v_permlane32_swap + two
+//     v_permlane16_swap per M-tile;
+//   * B fragments: W[k][16cb + 4j + q][16n + (lane&15)], one dword per lane per (j, n), straight from L1/L2;
+//   * 16*NT MFMAs per sub-step, j outermost so consecutive MFMAs hit different accumulators (40-cycle dependent
+//     latency vs 32-cycle issue); per accumulator the channel order stays ascending => bitwise the canonical fmaf chain.
+// ----------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte zero store to LDS that the compiler does not see as an LDS access: a plain store would make hipcc wait
+// `vmcnt(0)` for the in-flight LDS-DMA (possible alias) and serialise the four gathers of a sub-step.  The slot belongs
+// to this lane only (its DMA element is out of range and is not written), and the reader waits lgkmcnt(0) first.
+__device__ static inline void lds_zero16(float4* p) {
+    const unsigned addr = (unsigned)(uintptr_t)(lds_void_ptr)p;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(z) : "memory");
+}
+
+__device__ static inline void lane_transpose4(float4& v) {
+    // in: lane-quarter q holds components (c = 0..3) = element [q][c]; out: component c of quarter q = element [c][q]
+    unsigned x = __float_as_uint(v.x), y = __float_as_uint(v.y), z = __float_as_uint(v.z), w = __float_as_uint(v.w);
+    auto r0 = __builtin_amdgcn_permlane32_swap(x, z, false, false); x = r0[0]; z = r0[1];   // quarter bit 1 <-> component bit 1
+    auto r1 = __builtin_amdgcn_permlane32_swap(y, w, false, false); y = r1[0]; w = r1[1];
+    auto r2 = __builtin_amdgcn_permlane16_swap(x, y, false, false); x = r2[0]; y = r2[1];   // quarter bit 0 <-> component bit 0
+    auto r3 = __builtin_amdgcn_permlane16_swap(z, w, false, false); z = r3[0]; w = r3[1];
+    v = make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w));
+}
+
+template <int CIN, int NT>
+__global__ void __launch_bounds__(256)
+k_conv_gather_mfma(const int32_t* __restrict__ nbr, int K, int64_t n_out, const float* __restrict__ in, int64_t n_in,
+                   int in_ld, const float* __restrict__ W, int Cout, const float* __restrict__ bias,
+                   const float* __restrict__ res, int res_ld, int relu, float* __restrict__ out, int out_ld) {
+    constexpr int NB = CIN / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4* rowbuf = (float4*)lds_raw + (size_t)wave * 256;            // [64 rows][4 slots]
+    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * 64;
+    if (row0 >= n_out) return;
+    const int co0 = blockIdx.y * (16 * NT);
+    const int64_t my_row = row0 + lane;
+    const bool valid = my_row < n_out;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(n_in * in_ld * 4), 0x00020000);
+
+    const int mi = lane & 15, mq = lane >> 4;
+    // f(0)=0, f(1)=2, f(2)=3, f(3)=1  ->  bits: f(3)f(2)f(1)f(0) = 01 11 10 00 = 0x78
+    const int f_a = (0x78 >> (2 * (mi >> 2))) & 3;
+    const int dma_row_lo = lane >> 2, dma_p = lane & 3;                // DMA: 16 rows per instruction, 4 lanes per row
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int idx_cur = valid ? nbr[my_row] : -1;
+    for (int k = 0; k < K; ++k) {
+        int idx_nxt = -1;
+        if (k + 1 < K && valid) idx_nxt = nbr[(int64_t)(k + 1) * n_out + my_row];
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            // ---- gather 64 rows x 16 channels
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = i * 16 + dma_row_lo;                     // tile row; (r>>2)&3 == (dma_row_lo>>2)&3
+                const int rid = __shfl(idx_cur, r, 64);
+                const int chunk = dma_p ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3);
+                const unsigned voff = rid >= 0 ? (unsigned)(((int64_t)rid * in_ld + cb * 16 + chunk * 4) * 4) : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_ptr)(rowbuf + i * 64), 16, (int)voff, 0, 0, 0);
+                if (rid < 0) lds_zero16(rowbuf + i * 64 + lane);       // inline asm: must not be ordered against the DMA
+            }
+            // ---- B fragments for this (k, cb): [j][n]
+            float b[4][NT];
+            const float* wk = W + ((int64_t)k * CIN + cb * 16 + mq) * Cout + co0 + mi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) b[j][n] = wk[(int64_t)(4 * j) * Cout + 16 * n];
+            asm volatile("" ::: "memory");
+            wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // zero-slot writes landed
+            // ---- A fragments
+            float4 a[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                a[m] = rowbuf[(16 * m + mi) * 4 + (mq ^ f_a)];
+                lane_transpose4(a[m]);
+            }
+            // ---- MFMA: j outermost, accumulators rotate
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, b[0][n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, b[1][n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, b[2][n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, b[3][n], acc[m][n], 0, 0, 0);
+            asm volatile("" ::: "memory");
+        }
+        idx_cur = idx_nxt;
+    }
+    // ---- epilogue: D[row = 16m + 4*mq + r][col = 16n + mi]
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 16 * m + 4 * mq + r;
+            if (row >= n_out) continue;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int col = co0 + 16 * n + mi;
+                float v = acc[m][n][r];
+                if (bias) v = v + bias[col];
+                if (res) v = v + res[row * res_ld + col];
+                if (relu) v = fmaxf(v, 0.0f);
+                out[row * out_ld + col] = v;
+            }
+        }
+}
+
+template <int CIN, int NT>
+static void launch_mfma(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int in_ld, const float* W,
+                        int Cout, const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld,
+                        hipStream_t s) {
+    hipLaunchKernelGGL((k_conv_gather_mfma<CIN, NT>), dim3(grid_for(n_out, 256), Cout / (16 * NT)), dim3(256), 4 * 4096, s, nbr,
+                       K, n_out, in, n_in, in_ld, W, Cout, bias, res, res_ld, relu, out, out_ld);
+}
+template <int CIN>
+static bool dispatch_mfma(int Cout, const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int in_ld,
+                          const float* W, const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld,
+                          hipStream_t s) {
+#define PCGC_MF(NTILES) launch_mfma<CIN, NTILES>(nbr, K, n_out, in, n_in, in_ld, W, Cout, bias, res, res_ld, relu, out, out_ld, s); return true;
+    switch (Cout) {
+        case 16: PCGC_MF(1)
+        case 32: if (n_out < 200000) { PCGC_MF(1) } else { PCGC_MF(2) }
+        case 64: if (n_out < 200000) { PCGC_MF(1) } else { PCGC_MF(2) }
+    }
+#undef PCGC_MF
+    return false;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // Fused InceptionResNet block (autoencoder.py:52-57) in two gather passes, built on the same LDS-DMA row gather:
 //   A:  t[:, 0:Q]  = relu(conv0_0(x))   k3  C -> Q        t[:, Q:2Q] = relu(conv1_0(x))   k1  C -> Q   (Q = C/4)
 //       the k1 conv reads the site's own row, which is exactly the gathered row of the centre offset (k = 13).
@@ -262,7 +427,7 @@ k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x,
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4* rowbuf = (float4*)lds_raw + (size_t)wave * (64 * CH);
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * 64;
     if (row0 >= n) return;
     const int64_t my_row = row0 + lane;
     const bool valid = my_row < n;
@@ -318,7 +483,7 @@ k_irn_b(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ t 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4* rowbuf = (float4*)lds_raw + (size_t)wave * (64 * CH);
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * 64;
     if (row0 >= n) return;
     const int64_t my_row = row0 + lane;
     const bool valid = my_row < n;
@@ -401,7 +566,8 @@ extern "C" int pcgc_irn_block(const int32_t* nbr, int64_t n, const float* x, int
     return 0;
 }
 
-static int g_conv_impl = -1;        // -1 auto, 0 force v0 (VALU direct loads), 1 force v1 (LDS-DMA gather) where eligible
+static int g_conv_impl = -1;        // -1 auto, 0 force v0 (direct loads), 1 force v1 (LDS-DMA + VALU), 2 force v2 (LDS-DMA + MFMA)
+static int g_auto_mfma = 1;         // auto mode uses the MFMA kernel for its eligible shapes once A/B says so
 extern "C" int pcgc_set_conv_impl(int impl) { g_conv_impl = impl; return 0; }
 
 extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int Cin, int in_ld,
@@ -419,6 +585,16 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
     // on par (0.9-1.4x) on the FMA-bound ones; v0 only wins on tiny levels (< ~30k rows) where launch geometry dominates.
     const bool v1_eligible = nbr != nullptr && K <= 27 && aligned && small && (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64);
     const bool v1_wanted = g_conv_impl == 1 || (g_conv_impl < 0 && n_out >= 30000);
+    const bool mfma_eligible = v1_eligible && (Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 16 || Cout == 32 || Cout == 64);
+    if (mfma_eligible && (g_conv_impl == 2 || (g_conv_impl < 0 && g_auto_mfma && n_out >= 30000))) {
+        const float* res0 = residual ? residual + res_coff : nullptr;
+        float* out0 = out + out_coff;
+        bool ok = false;
+        if (Cin == 16) ok = dispatch_mfma<16>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        else if (Cin == 32) ok = dispatch_mfma<32>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        else ok = dispatch_mfma<64>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        if (ok) { PCGC_CHECK_LAUNCH("conv_gather_mfma"); return 0; }
+    }
     if (v1_eligible && v1_wanted) {
         const float* res0 = residual ? residual + res_coff : nullptr;
         float* out0 = out + out_coff;

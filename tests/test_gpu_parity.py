@@ -112,7 +112,7 @@ CONV_SHAPES = [(27, 1, 16), (27, 16, 16), (27, 32, 8), (27, 8, 16), (27, 8, 8), 
                (8, 16, 32), (8, 32, 64), (8, 64, 32), (1, 32, 8), (1, 8, 16), (1, 64, 16), (1, 16, 32), (1, 16, 4), (1, 4, 8)]
 
 
-@pytest.fixture(params=[0, 1], ids=['v0_direct', 'v1_ldsdma'])
+@pytest.fixture(params=[0, 1, 2], ids=['v0_direct', 'v1_ldsdma', 'v2_mfma'])
 def conv_impl(request):
     ops.set_conv_impl(request.param)
     yield request.param
