@@ -16,8 +16,11 @@ from .data_utils import (array2vector, istopk, sort_spare_tensor, load_sparse_te
                          write_ply_ascii_geo, read_ply_ascii_geo)
 from .pc_error import pc_error
 from .pcc_model import PCCModel
-from .sparse import SparseTensor, require_gpu
+from concurrent.futures import ThreadPoolExecutor
+from .sparse import SparseTensor, CoordMap, require_gpu
 from . import ops
+
+_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix='pcgc-coord')
 
 device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
 
@@ -91,26 +94,38 @@ class Coder():
 
     @torch.no_grad()
     def encode(self, x, postfix=''):
-        y_list = self.model.encoder(x)
-        y = sort_spare_tensor(y_list[0])
+        """coder.py:80-91.  Same outputs, different schedule: the geometry pyramid (N1 -> N2 -> N4 -> N8) is built first, so
+        the stride-8 coordinates — all the coordinate coder needs — are on the host before the convolutions are even
+        enqueued, and the (sequential, host-side) coordinate coding overlaps the GPU's encoder pass."""
+        c8 = x.cmap
+        for _ in range(3):
+            c8 = c8.down()[0]                                   # cached on the levels: the encoder reuses these maps
+        perm = ops.sort_zyx(c8.C)
+        y_C = ops.gather_coords(c8.C, perm)
+        coords8 = y_C.cpu().numpy()[:, 1:] // c8.stride         # tiny D2H (N8 x 16 B)
+        y_list = self.model.encoder(x)                          # asynchronous: ~60 kernel launches
+        self.coordinate_coder.encode(coords8, postfix=postfix)  # runs on the host while the GPU computes
+        y = SparseTensor(ops.gather_feats(y_list[0].F, perm), coordinate_map=CoordMap(y_C, c8.stride, unique=True))
         num_points = [len(ground_truth) for ground_truth in y_list[1:] + [x]]
         with open(self.filename + postfix + '_num_points.bin', 'wb') as f:
             f.write(np.array(num_points, dtype=np.int32).tobytes())
         self.feature_coder.encode(y.F, postfix=postfix)
-        self.coordinate_coder.encode(y.C.detach().cpu().numpy()[:, 1:] // y.tensor_stride[0], postfix=postfix)
         return y
 
     @torch.no_grad()
     def decode(self, rho=1, postfix=''):
         dev = require_gpu(next(self.model.decoder.parameters()).device)
-        y_C = self.coordinate_coder.decode(postfix=postfix)
+        # the two bitstreams are independent: decode the coordinates on a helper thread while this thread range-decodes
+        # the features (both are native calls that release the GIL)
+        fut_C = _POOL.submit(self.coordinate_coder.decode, postfix)
+        y_F = self.feature_coder.decode(postfix=postfix, device=dev)
+        y_C = fut_C.result()
         # coder.py:96-99: prepend the batch column and sort with array2vector on the host; here the (tiny) list goes to the
         # device in one copy and is sorted there (same (z,y,x,batch) order)
         y_C4 = np.zeros((len(y_C), 4), dtype=np.int32)
         y_C4[:, 1:] = np.asarray(y_C, dtype=np.int32) * 8
         y_C = torch.from_numpy(y_C4).to(dev)
         y_C = ops.gather_coords(y_C, ops.sort_zyx(y_C))
-        y_F = self.feature_coder.decode(postfix=postfix, device=dev)
         y = SparseTensor(features=y_F, coordinates=y_C, tensor_stride=8, device=dev, assume_unique=True)
         with open(self.filename + postfix + '_num_points.bin', 'rb') as fin:
             num_points = np.frombuffer(fin.read(4 * 3), dtype=np.int32).tolist()

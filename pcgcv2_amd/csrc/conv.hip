@@ -100,6 +100,48 @@ __device__ static inline unsigned xcd_tile(unsigned b, unsigned nb) {
 template <int N>
 __device__ static inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+template <int CH>
+struct RowGather {                                   // one wave, 64 rows, CH 16-byte chunks per row
+    static constexpr int RPI = 64 / CH;
+    static constexpr int SH = (CH == 2) ? 3 : (CH == 4 ? 2 : 1);
+    __device__ static inline void fetch(const __amdgpu_buffer_rsrc_t& rs, float4* rowbuf, int idx_cur, int in_ld, int col0, int lane) {
+        const int dma_row_lo = lane / CH, dma_p = lane % CH;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int r = i * RPI + dma_row_lo;
+            const int rid = __shfl(idx_cur, r, 64);
+            const int chunk = dma_p ^ ((r >> SH) & (CH - 1));
+            const unsigned voff = rid >= 0 ? (unsigned)(((int64_t)rid * in_ld + col0 + chunk * 4) * 4) : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)(rowbuf + i * 64), 16, (int)voff, 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+    }
+    __device__ static inline void read(const float4* rowbuf, int lane, float4 (&x)[CH]) {
+        const int swz = (lane >> SH) & (CH - 1);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) x[c] = rowbuf[lane * CH + (c ^ swz)];
+    }
+};
+
+// acc[0..NO) += x4 (4 consecutive input channels) * w[4][ldw] rows, channel order preserved.
+// Notes from measurements on MI355X (tools/ubench/fma_rate.hip): v_fma_f32 (vgpr) 100 TF, v_fmac_f32 with an SGPR
+// operand 62 TF, v_pk_fma_f32 with an SGPR pair + op_sel broadcast 123 TF.  hipcc's SLP vectoriser turns these loops into
+// v_pk_fma_f32 (+ two v_mov per instruction for the broadcast).  Two "obvious" improvements were tried and REJECTED:
+// -fno-slp-vectorize (plain v_fmac with SGPR operands: 14.7 -> 16.8 ms per frame) and hand-emitted
+// `v_pk_fma_f32 ... op_sel` via inline asm (the compiler then meters the weight s_loads in x8 chunks with a wait before
+// every 4 FMAs: 14.7 -> 18.9 ms).  The compiler's own schedule (all s_load_dwordx16 of a sub-step up front) wins.
+template <int NO>
+__device__ static inline void fma4(float (&acc)[NO], const float4& x, const float* __restrict__ w, int ldw) {
+#pragma unroll
+    for (int co = 0; co < NO; ++co) acc[co] = fmaf(x.x, w[co], acc[co]);
+#pragma unroll
+    for (int co = 0; co < NO; ++co) acc[co] = fmaf(x.y, w[ldw + co], acc[co]);
+#pragma unroll
+    for (int co = 0; co < NO; ++co) acc[co] = fmaf(x.z, w[2 * ldw + co], acc[co]);
+#pragma unroll
+    for (int co = 0; co < NO; ++co) acc[co] = fmaf(x.w, w[3 * ldw + co], acc[co]);
+}
+
 template <int CIN, int CT>
 __global__ void __launch_bounds__(256)
 k_conv_gather_dma(const int32_t* __restrict__ nbr, int K, int64_t n_out, const float* __restrict__ in, int64_t n_in,
@@ -126,7 +168,7 @@ k_conv_gather_dma(const int32_t* __restrict__ nbr, int K, int64_t n_out, const f
     const int dma_row_lo = lane / CH, dma_p = lane % CH;
     const int my_swz = (lane >> SH) & (CH - 1);
 
-    float acc[CT];
+    __attribute__((aligned(8))) float acc[CT];
 #pragma unroll
     for (int co = 0; co < CT; ++co) acc[co] = 0.0f;
 
@@ -156,17 +198,7 @@ k_conv_gather_dma(const int32_t* __restrict__ nbr, int K, int64_t n_out, const f
             if (idx_cur >= 0) {
                 const float* w = W + ((int64_t)k * CIN + cb * CB) * Cout + co0;
 #pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    const float* w0 = w + (int64_t)(4 * c) * Cout;
-#pragma unroll
-                    for (int co = 0; co < CT; ++co) acc[co] = fmaf(x[c].x, w0[co], acc[co]);
-#pragma unroll
-                    for (int co = 0; co < CT; ++co) acc[co] = fmaf(x[c].y, w0[Cout + co], acc[co]);
-#pragma unroll
-                    for (int co = 0; co < CT; ++co) acc[co] = fmaf(x[c].z, w0[2 * Cout + co], acc[co]);
-#pragma unroll
-                    for (int co = 0; co < CT; ++co) acc[co] = fmaf(x[c].w, w0[3 * Cout + co], acc[co]);
-                }
+                for (int c = 0; c < CH; ++c) fma4<CT>(acc, x[c], w + (int64_t)(4 * c) * Cout, Cout);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // row buffer fully read before the next DMA overwrites it
         }
@@ -213,6 +245,201 @@ static bool dispatch_dma_cout(int Cout, const int32_t* nbr, int K, int64_t n_out
     return false;
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------
+// Tile-local maps.  A 64-row tile touches 64 x ~18 neighbour rows but only ~150-250 DISTINCT ones (neighbouring sites
+// share neighbours; measured reuse 7x on the decoder's hierarchically ordered levels).  Per level we therefore build,
+// once, for every tile t:   U[t][0..ucount)  the distinct source rows,   L[t][k][lane]  uint8 index into U (255 = absent).
+// The conv kernels then fetch U's rows into LDS ONCE per 16-channel block and run all 27 offsets out of LDS, instead of
+// one latency-bound global gather per offset.  Tiles with more than 255 distinct rows keep ucount > 255 and take the
+// per-offset path inside the same kernel.
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int TL_UMAX = 256;          // LDS rows per tile (16 KiB per 16-channel block); ids 0..254 usable, 255 = absent
+constexpr int TL_HASH = 2048;         // per-wave dedup table (>= 64*27 so it can never fill up)
+
+__global__ void __launch_bounds__(256) k_tilemap_build(const int32_t* __restrict__ nbr, int64_t n, int32_t* __restrict__ U,
+                                                       uint8_t* __restrict__ L, int32_t* __restrict__ ucount) {
+    __shared__ int32_t keys_s[4][TL_HASH];
+    __shared__ uint16_t ids_s[4][TL_HASH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t row = tile * 64 + lane;
+    int32_t* keys = keys_s[wave];
+    uint16_t* ids = ids_s[wave];
+    for (int i = lane; i < TL_HASH; i += 64) keys[i] = -1;
+    __builtin_amdgcn_wave_barrier();
+    if (tile * 64 >= n) return;
+    int slot[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        const int32_t r = row < n ? nbr[(int64_t)k * n + row] : -1;
+        int h = -1;
+        if (r >= 0) {
+            h = (int)(((uint32_t)r * 2654435761u) >> 21);                 // 11 bits
+            for (;;) {
+                const int32_t prev = atomicCAS(&keys[h], -1, r);
+                if (prev == -1 || prev == r) break;
+                h = (h + 1) & (TL_HASH - 1);
+            }
+        }
+        slot[k] = h;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // number the occupied slots: each lane owns 32 consecutive slots
+    int cnt = 0;
+    const int base = lane * (TL_HASH / 64);
+#pragma unroll 8
+    for (int i = 0; i < TL_HASH / 64; ++i) cnt += keys[base + i] >= 0;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    const int total = __shfl(incl, 63, 64);
+    int id = incl - cnt;
+    for (int i = 0; i < TL_HASH / 64; ++i) {
+        const int32_t key = keys[base + i];
+        if (key >= 0) {
+            ids[base + i] = (uint16_t)id;
+            if (id < TL_UMAX) U[tile * TL_UMAX + id] = key;
+            ++id;
+        }
+    }
+    if (lane == 0) ucount[tile] = total;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        const int v = slot[k] >= 0 ? (int)ids[slot[k]] : 255;
+        L[(tile * 27 + k) * 64 + lane] = (uint8_t)(v > 255 ? 255 : v);    // meaningless (never read) when total > 255
+    }
+}
+
+extern "C" int pcgc_tilemap_build(const int32_t* nbr, int64_t n, int32_t* U, uint8_t* L, int32_t* ucount, void* stream) {
+    if (n == 0) return 0;
+    const int64_t tiles = (n + 63) / 64;
+    hipLaunchKernelGGL(k_tilemap_build, dim3(grid_for(tiles, 4)), dim3(256), 0, S(stream), nbr, n, U, L, ucount);
+    PCGC_CHECK_LAUNCH("tilemap_build");
+    return 0;
+}
+
+// Shared pieces of the tile-local kernels -------------------------------------------------------------------------
+// LDS layout per wave: rows [TL_UMAX][4] 16-byte slots (one 16-channel block of every distinct row), then the tile's
+// local index table [27][64] bytes.  Slot p of local row u holds chunk p ^ ((u>>2) & 3), so the 16-byte slot hit by a
+// reader depends on 4 bits of u and 64 arbitrary rows spread over all 16 slots of a bank row.
+constexpr int TL_WAVE_LDS = TL_UMAX * 64 + 27 * 64;
+
+// fetch the 16-channel block `cb` of every distinct row of the tile: ceil(ucnt/16) DMA instructions, all in flight
+__device__ static inline void tl_fetch_rows(const __amdgpu_buffer_rsrc_t& rs, float4* rows, const int32_t* __restrict__ Ut,
+                                            int ucnt, int in_ld, int col0, int lane) {
+    const int p = lane & 3;
+    for (int i = 0; i * 16 < ucnt; ++i) {
+        const int u = i * 16 + (lane >> 2);
+        const int rid = u < ucnt ? Ut[u] : -1;
+        const int chunk = p ^ ((u >> 2) & 3);
+        const unsigned voff = rid >= 0 ? (unsigned)(((int64_t)rid * in_ld + col0 + chunk * 4) * 4) : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)(rows + i * 64), 16, (int)voff, 0, 0, 0);
+    }
+}
+__device__ static inline void tl_fetch_index(const __amdgpu_buffer_rsrc_t& rsL, uint8_t* lidx, int64_t tile, int lane) {
+    // 27*64 bytes = 432 dwords: 7 DMA instructions of 64 dwords (the last one partially out of range -> no fetch)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int d = i * 64 + lane;
+        const unsigned voff = d < 432 ? (unsigned)((tile * 432 + d) * 4) : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, (lds_void_ptr)((uint32_t*)lidx + i * 64), 4, (int)voff, 0, 0, 0);
+    }
+}
+
+// VALU gather conv on tile-local maps (lane = output row).  Fallback for overflow tiles: the per-offset DMA path.
+template <int CIN, int CT>
+__global__ void __launch_bounds__(256)
+k_conv_tl(const int32_t* __restrict__ nbr, const int32_t* __restrict__ U, const uint8_t* __restrict__ L,
+          const int32_t* __restrict__ ucount, int64_t n_out, const float* __restrict__ in, int64_t n_in, int in_ld,
+          const float* __restrict__ W, int Cout, const float* __restrict__ bias, const float* __restrict__ res, int res_ld,
+          int relu, float* __restrict__ out, int out_ld) {
+    // One 16-channel block only: with several blocks, "fetch block, run 27 offsets" would reorder the canonical chain
+    // (k-major over ALL input channels).  Wider gathers keep the per-offset kernels until the chain order is revisited.
+    static_assert(CIN == 16, "tile-local fast path is defined for 16-channel gathers");
+    constexpr int NB = CIN / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* wbase = lds_raw + (size_t)wave * TL_WAVE_LDS;
+    float4* rows = (float4*)wbase;
+    uint8_t* lidx = wbase + TL_UMAX * 64;
+    const int64_t tile = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave;
+    const int64_t row0 = tile * 64;
+    if (row0 >= n_out) return;
+    const int co0 = blockIdx.y * CT;
+    const int64_t my_row = row0 + lane;
+    const bool valid = my_row < n_out;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(n_in * in_ld * 4), 0x00020000);
+    const int64_t n_tiles = (n_out + 63) / 64;
+    const __amdgpu_buffer_rsrc_t rs_L = __builtin_amdgcn_make_buffer_rsrc((void*)L, 0, (int)(n_tiles * 27 * 64), 0x00020000);
+
+    __attribute__((aligned(8))) float acc[CT];
+#pragma unroll
+    for (int co = 0; co < CT; ++co) acc[co] = 0.0f;
+    const int ucnt = __builtin_amdgcn_readfirstlane(ucount[tile]);
+
+    if (ucnt <= 255) {
+        tl_fetch_index(rs_L, lidx, tile, lane);
+#pragma unroll 1
+        for (int cb = 0; cb < NB; ++cb) {
+            if (cb > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // previous block fully read
+            tl_fetch_rows(rs_in, rows, U + tile * TL_UMAX, ucnt, in_ld, cb * 16, lane);
+            wait_vmcnt<0>();
+#pragma unroll 1
+            for (int k = 0; k < 27; ++k) {
+                const int li = valid ? (int)lidx[k * 64 + lane] : 255;
+                if (li != 255) {
+                    const float4* src = rows + li * 4;
+                    const int sw = (li >> 2) & 3;
+                    const float* w = W + ((int64_t)k * CIN + cb * 16) * Cout + co0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float4 x = src[c ^ sw];
+                        fma4<CT>(acc, x, w + (int64_t)(4 * c) * Cout, Cout);
+                    }
+                }
+            }
+        }
+    } else {
+        // overflow tile: per-offset gather (same arithmetic order: k ascending, then ci ascending within k ... see note)
+        float4* rowbuf = rows;
+        int idx_cur = valid ? nbr[my_row] : -1;
+        for (int k = 0; k < 27; ++k) {
+            int idx_nxt = -1;
+#pragma unroll 1
+            for (int cb = 0; cb < NB; ++cb) {
+                RowGather<4>::fetch(rs_in, rowbuf, idx_cur, in_ld, cb * 16, lane);
+                if (cb == NB - 1 && k + 1 < 27) {
+                    if (valid) idx_nxt = nbr[(int64_t)(k + 1) * n_out + my_row];
+                    asm volatile("" ::: "memory");
+                    wait_vmcnt<1>();
+                } else wait_vmcnt<0>();
+                float4 xv[4];
+                RowGather<4>::read(rowbuf, lane, xv);
+                if (idx_cur >= 0) {
+                    const float* w = W + ((int64_t)k * CIN + cb * 16) * Cout + co0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) fma4<CT>(acc, xv[c], w + (int64_t)(4 * c) * Cout, Cout);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            idx_cur = idx_nxt;
+        }
+    }
+    if (!valid) return;
+    float* y = out + my_row * out_ld + co0;
+    const float* rr = res ? res + my_row * res_ld + co0 : nullptr;
+#pragma unroll
+    for (int co = 0; co < CT; ++co) {
+        float v = acc[co];
+        if (bias) v = v + bias[co0 + co];
+        if (rr) v = v + rr[co];
+        if (relu) v = fmaxf(v, 0.0f);
+        y[co] = v;
+    }
+}
 
 // ----------------------------------------------------------------------------------------------------------------
 // v2 kernel: LDS-DMA gather + fp32 MFMA channel GEMM, for Cin in {16,32,64} and Cout a multiple of 16.
@@ -380,42 +607,6 @@ static bool dispatch_mfma(int Cout, const int32_t* nbr, int K, int64_t n_out, co
 //       ONE gather of the 2Q-wide rows of t feeds both k3 convs (the unfused form gathers two Q-wide tensors).
 // 5 launches / 3 gathers / 2 pointwise passes become 2 launches / 2 gathers; every fmaf chain is unchanged.
 // ----------------------------------------------------------------------------------------------------------------
-template <int CH>
-struct RowGather {                                   // one wave, 64 rows, CH 16-byte chunks per row
-    static constexpr int RPI = 64 / CH;
-    static constexpr int SH = (CH == 2) ? 3 : (CH == 4 ? 2 : 1);
-    __device__ static inline void fetch(const __amdgpu_buffer_rsrc_t& rs, float4* rowbuf, int idx_cur, int in_ld, int col0, int lane) {
-        const int dma_row_lo = lane / CH, dma_p = lane % CH;
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int r = i * RPI + dma_row_lo;
-            const int rid = __shfl(idx_cur, r, 64);
-            const int chunk = dma_p ^ ((r >> SH) & (CH - 1));
-            const unsigned voff = rid >= 0 ? (unsigned)(((int64_t)rid * in_ld + col0 + chunk * 4) * 4) : 0xFFFFFFF0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)(rowbuf + i * 64), 16, (int)voff, 0, 0, 0);
-        }
-        asm volatile("" ::: "memory");
-    }
-    __device__ static inline void read(const float4* rowbuf, int lane, float4 (&x)[CH]) {
-        const int swz = (lane >> SH) & (CH - 1);
-#pragma unroll
-        for (int c = 0; c < CH; ++c) x[c] = rowbuf[lane * CH + (c ^ swz)];
-    }
-};
-
-// acc[0..NO) += x4 (4 consecutive input channels) * w[4][ldw] rows, channel order preserved
-template <int NO>
-__device__ static inline void fma4(float (&acc)[NO], const float4& x, const float* __restrict__ w, int ldw) {
-#pragma unroll
-    for (int co = 0; co < NO; ++co) acc[co] = fmaf(x.x, w[co], acc[co]);
-#pragma unroll
-    for (int co = 0; co < NO; ++co) acc[co] = fmaf(x.y, w[ldw + co], acc[co]);
-#pragma unroll
-    for (int co = 0; co < NO; ++co) acc[co] = fmaf(x.z, w[2 * ldw + co], acc[co]);
-#pragma unroll
-    for (int co = 0; co < NO; ++co) acc[co] = fmaf(x.w, w[3 * ldw + co], acc[co]);
-}
-
 template <int C>
 __global__ void __launch_bounds__(256)
 k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x, int x_ld,
@@ -432,7 +623,8 @@ k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x,
     const int64_t my_row = row0 + lane;
     const bool valid = my_row < n;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(n * x_ld * 4), 0x00020000);
-    float acc0[Q], acc1[Q];
+    __attribute__((aligned(8))) float acc0[Q];
+    __attribute__((aligned(8))) float acc1[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
     int idx_cur = valid ? nbr[my_row] : -1;
@@ -488,7 +680,8 @@ k_irn_b(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ t 
     const int64_t my_row = row0 + lane;
     const bool valid = my_row < n;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)t, 0, (int)(n * H * 4), 0x00020000);
-    float acc0[H], acc1[Q];
+    __attribute__((aligned(8))) float acc0[H];
+    __attribute__((aligned(8))) float acc1[Q];
 #pragma unroll
     for (int i = 0; i < H; ++i) acc0[i] = 0.0f;
 #pragma unroll
@@ -563,6 +756,36 @@ extern "C" int pcgc_irn_block(const int32_t* nbr, int64_t n, const float* x, int
     else if (C == 32) launch_irn<32>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, S(stream));
     else launch_irn<64>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, S(stream));
     PCGC_CHECK_LAUNCH("irn_block");
+    return 0;
+}
+
+extern "C" int pcgc_conv_gather_tl(const int32_t* nbr, const int32_t* U, const uint8_t* L, const int32_t* ucount, int64_t n_out,
+                                   const float* in, int64_t n_in, int Cin, int in_ld, const float* W, const float* bias,
+                                   const float* residual, int res_ld, int relu, float* out, int Cout, int out_ld, void* stream) {
+    PCGC_REQUIRE(Cin == 16, "tile-local gather conv: Cin must be 16");
+    PCGC_REQUIRE((in_ld & 3) == 0 && (((uintptr_t)in | (uintptr_t)W) & 15) == 0, "unaligned input");
+    PCGC_REQUIRE(n_in * (int64_t)in_ld * 4 < (int64_t)0xFFFFFFF0, "tensor too large for 32-bit buffer offsets");
+    if (n_out == 0) return 0;
+    const size_t lds = 4 * (size_t)TL_WAVE_LDS;
+    dim3 g(grid_for(n_out, 256), 1), b(256);
+#define PCGC_TL(CTILE)                                                                                                          \
+    {                                                                                                                           \
+        static bool once = false;                                                                                               \
+        if (!once) { (void)hipFuncSetAttribute((const void*)k_conv_tl<16, CTILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } \
+        g.y = Cout / CTILE;                                                                                                     \
+        hipLaunchKernelGGL((k_conv_tl<16, CTILE>), g, b, lds, S(stream), nbr, U, L, ucount, n_out, in, n_in, in_ld, W, Cout, bias,  \
+                           residual, res_ld, relu, out, out_ld);                                                               \
+    }
+    switch (Cout) {
+        case 1: PCGC_TL(1) break;
+        case 4: PCGC_TL(4) break;
+        case 8: PCGC_TL(8) break;
+        case 16: PCGC_TL(16) break;
+        case 32: PCGC_TL(16) break;
+        default: pcgc_set_error("conv_gather_tl: unsupported Cout %d", Cout); return -2;
+    }
+#undef PCGC_TL
+    PCGC_CHECK_LAUNCH("conv_gather_tl");
     return 0;
 }
 

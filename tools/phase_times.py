@@ -3,6 +3,8 @@
 import os, sys, tempfile, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+import pcgcv2_amd
+pcgcv2_amd.configure_host_threads()
 from pcgcv2_amd import synthetic, ops
 from pcgcv2_amd.pcc_model import PCCModel
 from pcgcv2_amd.coder import Coder
