@@ -137,7 +137,7 @@ def main():
     else:
         total_points, total_out, total_bits = float(n_points), float(n_out), float(bits)
 
-    roof = ops.PROFILE.summary(HBM_PEAK_GBS)
+    roof = ops.PROFILE.summary(HBM_PEAK_GBS, args.steps)
     if rank == 0:
         value = total_points * args.steps / elapsed / 1e6
         line = {
@@ -152,6 +152,8 @@ def main():
                        'points_out': int(total_out), 'coord_codec': 'native-octree (tmc3 absent)', 'step_ms_rank0': step_ms},
             'roofline': roof,
         }
+        if roof is not None:
+            attach_pmc_traffic(roof)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.cpu_sample, sd)
         if args.detail:
@@ -160,6 +162,25 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def attach_pmc_traffic(roof):
+    """`traffic`: HBM bytes per launch of the dominant kernel from rocprofv3 PMC counters (FETCH_SIZE and WRITE_SIZE in
+    separate passes; FETCH_SIZE doubled for 16-byte-per-lane reads as MI355X_MICROARCH.md prescribes for gfx950).  The
+    counters cannot be read from inside the process, so they come from the committed collection of the same command
+    (tools/pmc_traffic.sh -> profiles/pmc_traffic.json); null if no entry matches the dominant kernel + shape."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if not os.path.exists(path):
+        return
+    try:
+        table = json.load(open(path))
+    except ValueError:
+        return
+    for e in table.get('kernels', []):
+        if e['kernel'] in roof['kernel'] and abs(e.get('grid_rows', roof['n_out']) - roof['n_out']) < 256:
+            roof['traffic'] = e['hbm_bytes_per_launch']
+            roof['traffic_detail'] = {k: e[k] for k in ('fetch_bytes_raw', 'fetch_bytes_corrected', 'write_bytes', 'source') if k in e}
+            return
 
 
 def cpu_baseline(sample, sd):

@@ -113,6 +113,10 @@ int pcgc_conv_gather_tl(const int32_t* nbr, const int32_t* U, const uint8_t* L, 
  * pcgc_conv_gather calls it replaces. */
 int pcgc_irn_block(const int32_t* nbr /*[27,n]*/, int64_t n, const float* x /*[n,C], ld x_ld*/, int C, int x_ld,
                    const float* const* params, float* t_scratch, float* out, int out_ld, void* stream);
+/* the two gather passes of pcgc_irn_block separately (pass 1 = A: x -> t_scratch, pass 2 = B: t_scratch, x -> out);
+ * same arguments; used to time the passes individually. */
+int pcgc_irn_pass(const int32_t* nbr, int64_t n, const float* x, int C, int x_ld, const float* const* params,
+                  float* t_scratch, float* out, int out_ld, int pass, void* stream);
 /* MinkowskiGenerativeConvolutionTranspose(k=2,s=2): out[8i+k] = in[i] @ W[k] + bias (+ReLU). */
 int pcgc_conv_up2(int64_t n_in, const float* in, int Cin, int in_ld, const float* W /*[8,Cin,Cout]*/, const float* bias,
                   int relu, float* out /*[dev 8n,Cout]*/, int Cout, void* stream);

@@ -36,6 +36,7 @@ SIGNATURES = {
     'pcgc_tilemap_build': (ci, [vp, i64, vp, vp, vp, vp]),
     'pcgc_conv_gather_tl': (ci, [vp, vp, vp, vp, i64, vp, i64, ci, ci, vp, vp, vp, ci, ci, vp, ci, ci, vp]),
     'pcgc_irn_block': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, ci, vp]),
+    'pcgc_irn_pass': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, ci, ci, vp]),
     'pcgc_conv_up2': (ci, [i64, vp, ci, ci, vp, vp, ci, vp, ci, vp]),
     'pcgc_topk_workspace_bytes': (sz, [i64]),
     'pcgc_topk_mask': (ci, [vp, ci, i64, i64, vp, vp, sz, vp]),

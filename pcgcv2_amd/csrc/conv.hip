@@ -732,19 +732,33 @@ k_irn_b(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ t 
     }
 }
 
+// phase: 1 = pass A only, 2 = pass B only, 3 = both
 template <int C>
 static void launch_irn(const int32_t* nbr, int64_t n, const float* x, int x_ld, const float* const* P, float* t, float* out,
-                       int out_ld, hipStream_t s) {
+                       int out_ld, int phase, hipStream_t s) {
     constexpr int CBA = C < 32 ? C : 32;
     const size_t lds_a = 4 * (size_t)(64 * (CBA / 4) * 16), lds_b = 4 * (size_t)(64 * (C / 8) * 16);
-    hipLaunchKernelGGL((k_irn_a<C>), dim3(grid_for(n, 256)), dim3(256), lds_a, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
-    hipLaunchKernelGGL((k_irn_b<C>), dim3(grid_for(n, 256)), dim3(256), lds_b, s, nbr, n, t, x, x_ld, P[2], P[3], P[6], P[7],
-                       P[8], P[9], out, out_ld);
+    if (phase & 1)
+        hipLaunchKernelGGL((k_irn_a<C>), dim3(grid_for(n, 256)), dim3(256), lds_a, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
+    if (phase & 2)
+        hipLaunchKernelGGL((k_irn_b<C>), dim3(grid_for(n, 256)), dim3(256), lds_b, s, nbr, n, t, x, x_ld, P[2], P[3], P[6], P[7],
+                           P[8], P[9], out, out_ld);
 }
 
 // params: {W00,b00, W01,b01, W10,b10, W11,b11, W12,b12} = conv0_0, conv0_1, conv1_0, conv1_1, conv1_2 (kernel, bias)
+static int irn_launch(const int32_t* nbr, int64_t n, const float* x, int C, int x_ld, const float* const* params,
+                      float* t_scratch, float* out, int out_ld, int phase, void* stream);
 extern "C" int pcgc_irn_block(const int32_t* nbr, int64_t n, const float* x, int C, int x_ld, const float* const* params,
                               float* t_scratch, float* out, int out_ld, void* stream) {
+    return irn_launch(nbr, n, x, C, x_ld, params, t_scratch, out, out_ld, 3, stream);
+}
+extern "C" int pcgc_irn_pass(const int32_t* nbr, int64_t n, const float* x, int C, int x_ld, const float* const* params,
+                             float* t_scratch, float* out, int out_ld, int pass, void* stream) {
+    PCGC_REQUIRE(pass == 1 || pass == 2, "pass must be 1 (A) or 2 (B)");
+    return irn_launch(nbr, n, x, C, x_ld, params, t_scratch, out, out_ld, pass, stream);
+}
+static int irn_launch(const int32_t* nbr, int64_t n, const float* x, int C, int x_ld, const float* const* params,
+                      float* t_scratch, float* out, int out_ld, int phase, void* stream) {
     PCGC_REQUIRE(nbr && x && params && t_scratch && out, "null argument");
     PCGC_REQUIRE(C == 16 || C == 32 || C == 64, "channels must be 16, 32 or 64");
     PCGC_REQUIRE((x_ld & 3) == 0 && (out_ld & 3) == 0, "leading dimensions must be multiples of 4");
@@ -752,9 +766,9 @@ extern "C" int pcgc_irn_block(const int32_t* nbr, int64_t n, const float* x, int
     for (int i = 0; i < 10; ++i) PCGC_REQUIRE(params[i] != nullptr, "null parameter tensor");
     PCGC_REQUIRE((((uintptr_t)x | (uintptr_t)t_scratch | (uintptr_t)out) & 15) == 0, "buffers must be 16-byte aligned");
     if (n == 0) return 0;
-    if (C == 16) launch_irn<16>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, S(stream));
-    else if (C == 32) launch_irn<32>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, S(stream));
-    else launch_irn<64>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, S(stream));
+    if (C == 16) launch_irn<16>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
+    else if (C == 32) launch_irn<32>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
+    else launch_irn<64>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
     PCGC_CHECK_LAUNCH("irn_block");
     return 0;
 }

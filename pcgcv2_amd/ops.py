@@ -46,9 +46,11 @@ def _ld(t):
 
 # ------------------------------------------------------------------------------------------------ profiling hook
 class _Profile:
-    """Brackets every k3 gather-conv launch (the dominant kernel) with HIP events on the stream it is launched on, and
-    turns the timings into the `roofline` object of bench.py.  Algorithmic bytes per launch:
-    P*Cin*4 (gathered rows) + P*8 (int32 in/out pair indices) + N_out*Cout*4 (output rows), P = kernel-map pairs."""
+    """Brackets the gather kernels with HIP events on the stream they are launched on, and turns the timings into the
+    `roofline` object of bench.py.  Algorithmic bytes per launch follow SURVEY.md §8d with P = kernel-map pairs of the level
+    (counted from the map):   k3 conv: P*Cin*4 (gathered rows) + P*8 (int32 in/out pair indices) + N*Cout*4 (output rows);
+    k1 conv: N*(Cin+Cout)*4.  A fused InceptionResNet pass is charged the sum of the convs it computes:
+        pass A (k_irn_a<C>): k3 C->C/4  +  k1 C->C/4           pass B (k_irn_b<C>): k3 C/4->C/2 + k3 C/4->C/4 + k1 C/4->C/2."""
 
     def __init__(self):
         self.reset(False)
@@ -56,40 +58,38 @@ class _Profile:
     def reset(self, enabled=False):
         self.enabled = enabled
         self.counting = False
-        self.records = []          # (K, Cin, Cout, n_out, ev0, ev1)
-        self.pairs = {}            # (K, n_out) -> P
+        self.records = {}          # key -> dict(kernel, n, bytes(P), flops(P), events=[(e0,e1)])
+        self.pairs = {}            # n_out -> P of the level's k3 map
 
-    def bracket(self, K, Cin, Cout, n_out):
+    def bracket(self, key, kernel, n, bytes_fn, flops_fn):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.records.append((K, Cin, Cout, n_out, e0, e1))
+        r = self.records.setdefault(key, {'kernel': kernel, 'n': n, 'bytes': bytes_fn, 'flops': flops_fn, 'events': []})
+        r['events'].append((e0, e1))
         return e0, e1
 
-    def count(self, nbr, K, n_out):
-        if (K, n_out) not in self.pairs:
-            self.pairs[(K, n_out)] = int((nbr >= 0).sum().item())
+    def count(self, nbr):
+        n = nbr.shape[1]
+        if n not in self.pairs:
+            self.pairs[n] = int((nbr >= 0).sum().item())
 
     def detail(self):
-        rows = {}
-        for K, Cin, Cout, n_out, e0, e1 in self.records:
-            ms = e0.elapsed_time(e1)
-            r = rows.setdefault((K, Cin, Cout, n_out), {'K': K, 'Cin': Cin, 'Cout': Cout, 'n_out': n_out, 'launches': 0, 'ms': 0.0})
-            r['launches'] += 1; r['ms'] += ms
         out = []
-        for (K, Cin, Cout, n_out), r in rows.items():
-            P = self.pairs.get((K, n_out))
+        for key, r in self.records.items():
+            ms = sum(e0.elapsed_time(e1) for e0, e1 in r['events'])
+            d = {'kernel': r['kernel'], 'n_out': r['n'], 'launches': len(r['events']), 'ms': ms, 'avg_us': ms / len(r['events']) * 1e3}
+            P = self.pairs.get(r['n'])
             if P is not None:
-                r['pairs'] = P
-                r['alg_bytes_per_launch'] = P * Cin * 4 + P * 8 + n_out * Cout * 4
-                r['flops_per_launch'] = 2 * P * Cin * Cout
-                r['avg_us'] = r['ms'] / r['launches'] * 1e3
-                r['GBps'] = r['alg_bytes_per_launch'] / (r['ms'] / r['launches'] * 1e-3) / 1e9
-            out.append(r)
-        return sorted(out, key=lambda r: -r['ms'])
+                d['pairs'] = P
+                d['alg_bytes_per_launch'] = r['bytes'](P)
+                d['flops_per_launch'] = r['flops'](P)
+                d['GBps'] = d['alg_bytes_per_launch'] / (d['avg_us'] * 1e-6) / 1e9
+                d['TFLOPs'] = d['flops_per_launch'] / (d['avg_us'] * 1e-6) / 1e12
+            out.append(d)
+        return sorted(out, key=lambda d: -d['ms'])
 
-    def summary(self, peak_gbs):
-        """Dominant kernel = the k3 gather conv; report its heaviest shape (most total time) as `achieved`, plus the
-        all-launch aggregate."""
-        d = [r for r in self.detail() if r['K'] == 27 and 'pairs' in r]
+    def summary(self, peak_gbs, steps):
+        """`achieved` = the heaviest (kernel, shape) by total time; `all_gather_launches` aggregates every bracketed launch."""
+        d = [r for r in self.detail() if 'pairs' in r]
         if not d:
             return None
         top = d[0]
@@ -97,12 +97,12 @@ class _Profile:
         tot_ms = sum(r['ms'] for r in d)
         ach = top['GBps']
         return {'bound': 'hbm', 'achieved': round(ach, 2), 'peak': peak_gbs, 'unit': 'GB/s', 'frac': round(ach / peak_gbs, 4),
-                'traffic': None,
-                'kernel': f"k3 sparse-conv gather, Cin={top['Cin']} Cout={top['Cout']} N_out={top['n_out']} pairs={top['pairs']}",
+                'traffic': None, 'kernel': top['kernel'], 'n_out': top['n_out'], 'pairs': top['pairs'],
                 'alg_bytes_per_launch': top['alg_bytes_per_launch'], 'avg_launch_us': round(top['avg_us'], 2),
-                'launches_timed': top['launches'],
-                'all_k3_launches': {'achieved': round(tot_bytes / (tot_ms * 1e-3) / 1e9, 2), 'frac': round(tot_bytes / (tot_ms * 1e-3) / 1e9 / peak_gbs, 4),
-                                    'ms_total_timed': round(tot_ms, 3), 'launches': sum(r['launches'] for r in d)}}
+                'launches_timed': top['launches'], 'tflops_fp32': round(top['TFLOPs'], 2),
+                'all_gather_launches': {'achieved': round(tot_bytes / (tot_ms * 1e-3) / 1e9, 2),
+                                        'frac': round(tot_bytes / (tot_ms * 1e-3) / 1e9 / peak_gbs, 4),
+                                        'ms_per_step': round(tot_ms / steps, 3), 'launches_per_step': sum(r['launches'] for r in d) // steps}}
 
 
 PROFILE = _Profile()
@@ -261,14 +261,16 @@ def conv_gather(nbr, x, W, bias, out=None, residual=None, relu=False, n_out=None
     res_p, res_ld = (None, 0) if residual is None else (_p(_f32(residual)), _ld(residual))
     prof = PROFILE.enabled and K == 27
     if prof:
-        e0, e1 = PROFILE.bracket(K, Cin, Cout, n_out)
+        e0, e1 = PROFILE.bracket(('conv', Cin, Cout, n_out), f'k3 gather conv Cin={Cin} Cout={Cout} (k_conv_gather_mfma/dma)', n_out,
+                                 lambda P, a=Cin, b=Cout, n=n_out: P * a * 4 + P * 8 + n * b * 4,
+                                 lambda P, a=Cin, b=Cout: 2 * P * a * b)
         e0.record()
     check(lib().pcgc_conv_gather(_p(nbr), K, n_out, _p(x), x.shape[0], Cin, _ld(x), 0, _p(W), _p(bias), res_p, res_ld, 0, int(relu),
                                  _p(out), Cout, _ld(out), 0, _stream()), 'conv_gather')
     if prof:
         e1.record()
     elif PROFILE.counting and K == 27:
-        PROFILE.count(nbr, K, n_out)
+        PROFILE.count(nbr)
     return out
 
 
@@ -308,7 +310,20 @@ def irn_block(nbr, x, params):
     t = torch.empty((n, C // 2), dtype=torch.float32, device=x.device)
     out = torch.empty((n, C), dtype=torch.float32, device=x.device)
     arr = (ctypes.c_void_p * 10)(*[p.data_ptr() for p in params])
-    check(lib().pcgc_irn_block(_p(nbr), n, _p(x), C, _ld(x), arr, _p(t), _p(out), C, _stream()), 'irn_block')
+    if PROFILE.counting:
+        PROFILE.count(nbr)
+    if not PROFILE.enabled:
+        check(lib().pcgc_irn_block(_p(nbr), n, _p(x), C, _ld(x), arr, _p(t), _p(out), C, _stream()), 'irn_block')
+        return out
+    Q = C // 4
+    passes = ((1, f'k_irn_a<{C}>', lambda P, n=n: (P * C * 4 + P * 8 + n * Q * 4) + n * (C + Q) * 4, lambda P, n=n: 2 * P * C * Q + 2 * n * C * Q),
+              (2, f'k_irn_b<{C}>', lambda P, n=n: (P * Q * 4 + P * 8 + n * 2 * Q * 4) + (P * Q * 4 + P * 8 + n * Q * 4) + n * 3 * Q * 4,
+               lambda P, n=n: 2 * P * Q * 2 * Q + 2 * P * Q * Q + 2 * n * Q * 2 * Q))
+    for ps, name, bf, ff in passes:
+        e0, e1 = PROFILE.bracket((name, n), name, n, bf, ff)
+        e0.record()
+        check(lib().pcgc_irn_pass(_p(nbr), n, _p(x), C, _ld(x), arr, _p(t), _p(out), C, ps, _stream()), 'irn_pass')
+        e1.record()
     return out
 
 
