@@ -52,13 +52,19 @@ def main():
         if world == 1 and args.gpus > 1:
             print(f'bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks', file=sys.stderr)
             sys.exit(2)
+    local = local % max(1, torch.cuda.device_count())      # (test mode: several ranks may share one GPU)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    backend = os.environ.get('PCGC_DIST_BACKEND', 'nccl')      # 'nccl' = RCCL over xGMI; 'gloo' only to test the path on 1 GPU
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = dev if backend == 'nccl' else torch.device('cpu')
 
     import pcgcv2_amd
     pcgcv2_amd.configure_host_threads()
@@ -128,10 +134,10 @@ def main():
     torch.cuda.synchronize()
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([float(n_points), float(n_out), float(bits)], dtype=torch.float64, device=dev)
+        tot = torch.tensor([float(n_points), float(n_out), float(bits)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_points, total_out, total_bits = [float(v) for v in tot.tolist()]
     else:

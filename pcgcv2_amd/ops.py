@@ -328,7 +328,7 @@ def irn_block(nbr, x, params):
 
 
 def irn_eligible(x):
-    return FUSE_IRN and x.shape[1] in (16, 32, 64) and x.shape[0] >= 30000 and x.shape[0] * x.shape[1] * 4 < 0xFFFFFFF0
+    return FUSE_IRN and x.shape[1] in (16, 32, 64) and x.shape[0] * x.shape[1] * 4 < 0xFFFFFFF0
 
 
 def conv_up2(x, W, bias, relu=False):

@@ -27,21 +27,30 @@ def shard_units(n_units, rank=None, world_size=None):
     return list(range(rank, n_units, world_size))
 
 
-def split_octants(coords, levels=1):
-    """Split a cloud into 8**levels blocks by the top `levels` bits of (x,y,z) of its bounding power-of-two cube.
-    coords: int array/tensor [N,3] or [N,4] (batch first).  -> list of index arrays (numpy), empty blocks dropped.
-    (BASELINE config 5: 8 blocks of the scaled vox12 cloud, one per GPU.)"""
+def split_octants(coords, levels=1, align=8):
+    """Split a cloud into 8**levels spatial blocks for block-parallel coding (BASELINE config 5: 8 blocks, one per GPU).
+    Each level halves the set along x, then y, then z at the MEDIAN coordinate rounded to a multiple of `align` (= the
+    coarsest tensor stride, so no stride-8 cell is shared by two blocks): blocks are balanced in point count whatever
+    the cloud's position inside its cube.  coords: int array/tensor [N,3] or [N,4] (batch first).
+    -> list of index arrays (numpy, ascending), empty blocks dropped."""
     c = coords.detach().cpu().numpy() if isinstance(coords, torch.Tensor) else np.asarray(coords)
     xyz = c[:, -3:].astype(np.int64)
-    span = int(xyz.max()) + 1 if len(xyz) else 1
-    bits = max(levels, int(math.ceil(math.log2(max(span, 2)))))
-    sh = bits - levels
-    key = np.zeros(len(xyz), np.int64)
-    for d in range(3):
-        key |= (xyz[:, d] >> sh) << (levels * d)
-    order = np.argsort(key, kind='stable')
-    bounds = np.flatnonzero(np.diff(key[order])) + 1
-    return [blk for blk in np.split(order, bounds) if len(blk)]
+    parts = [np.arange(len(xyz))]
+    for _ in range(levels):
+        for d in range(3):
+            nxt = []
+            for idx in parts:
+                if len(idx) == 0:
+                    continue
+                v = xyz[idx, d]
+                cut = int(np.median(v))
+                cut = ((cut + align // 2) // align) * align          # nearest lattice plane
+                if cut <= v.min():
+                    cut += align
+                lo = v < cut
+                nxt += [idx[lo], idx[~lo]]
+            parts = nxt
+    return [p for p in parts if len(p)]
 
 
 class Stats:

@@ -358,3 +358,55 @@ def test_full_size_frame_properties(sd, tmp_path):
     # the entropy-coded latent round-trips exactly
     yF = coder.feature_coder.decode(device=DEV)
     np.testing.assert_array_equal(yF.cpu().numpy(), np.rint(y.F.cpu().numpy()) + np.float32(0))
+
+
+@pytest.mark.parametrize('name,n_expect', [('shell11', None)])
+def test_vox11_frame_roundtrip_properties(name, n_expect, sd, tmp_path):
+    """BASELINE config 4 shape (dancer vox11, res 2048, ~2.6 M points): the stand-in shell11 through encode/decode."""
+    from pcgcv2_amd.coder import Coder
+    pts = synthetic.shell(name, device=DEV)
+    coords = torch.cat([torch.zeros((len(pts), 1), dtype=torch.int32, device=DEV), pts], 1).contiguous()
+    assert 2_400_000 < len(pts) < 2_800_000
+    m = _model(sd)
+    x = SparseTensor(torch.ones((len(pts), 1), device=DEV), coordinates=coords, tensor_stride=1, device=DEV)
+    coder = Coder(m, str(tmp_path / name))
+    outs = []
+    for post in ('_r1', '_r2'):                                   # two "rates" = two postfixes, like test.py:38
+        y = coder.encode(x, postfix=post)
+        out = coder.decode(postfix=post)
+        oc = out.C.cpu().numpy()
+        assert len(oc) == len(pts) and len(np.unique(oc, axis=0)) == len(pts)
+        outs.append(oc)
+    np.testing.assert_array_equal(outs[0], outs[1])
+    n4, n2, n1 = np.frombuffer((tmp_path / f'{name}_r1_num_points.bin').read_bytes(), np.int32)
+    assert n1 == len(pts) and n4 < n2 < n1 and len(y) < n4
+
+
+def test_vox12_scaled_octant_blocks(sd, tmp_path):
+    """BASELINE config 5 shape: a vox12-size cloud down-scaled by 0.375 (data_utils.py:112-118), split into 8 octant
+    blocks coded independently with per-block postfixes, decoded, merged and scaled back (coder.py:149-166)."""
+    from pcgcv2_amd.coder import Coder
+    from pcgcv2_amd.data_utils import scale_sparse_tensor
+    from pcgcv2_amd import shard
+    pts = synthetic.shell('shell11', device=DEV) * 2                      # vox12-range coordinates, 2.6 M points
+    coords = torch.cat([torch.zeros((len(pts), 1), dtype=torch.int32, device=DEV), pts], 1).contiguous()
+    x = SparseTensor(torch.ones((len(pts), 1), device=DEV), coordinates=coords, tensor_stride=1, device=DEV)
+    x_in = scale_sparse_tensor(x, 0.375)
+    # oracle check of the scaling + dedup semantics on the host
+    want = np.unique(torch.tensor(pts.cpu().numpy()).mul(0.375).round().int().numpy(), axis=0)
+    got = x_in.C.cpu().numpy()[:, 1:]
+    assert len(got) == len(want)
+    np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], want[np.lexsort(want.T[::-1])])
+    blocks = shard.split_octants(x_in.C, levels=1)
+    assert len(blocks) == 8 and sum(len(b) for b in blocks) == len(x_in)
+    m = _model(sd)
+    coder = Coder(m, str(tmp_path / 'blk'))
+    total_out = 0
+    for i, idx in enumerate(blocks):
+        c = x_in.C[torch.as_tensor(idx, device=DEV)]
+        xb = SparseTensor(torch.ones((len(c), 1), device=DEV), coordinates=c, tensor_stride=1, device=DEV)
+        coder.encode(xb, postfix=f'_b{i}')
+        ob = coder.decode(postfix=f'_b{i}')
+        assert len(ob) == len(xb)
+        total_out += len(scale_sparse_tensor(ob, 1.0 / 0.375))
+    assert total_out > 0

@@ -57,12 +57,19 @@ def test_shard_units_single_process_and_explicit_ranks():
 
 
 def test_split_octants_partitions_the_cloud():
-    pts = synthetic.shell('shell7').numpy()
+    pts = synthetic.shell('shell8').numpy()
     blocks = shard.split_octants(pts, levels=1)
     assert len(blocks) == 8
     allidx = np.sort(np.concatenate(blocks))
     np.testing.assert_array_equal(allidx, np.arange(len(pts)))
-    for b in blocks:                                     # each block lies in one octant of the 128^3 cube
-        o = pts[b] >> 6
-        assert (o == o[0]).all()
+    sizes = np.array([len(b) for b in blocks])
+    assert sizes.min() > 0.5 * sizes.mean() and sizes.max() < 1.6 * sizes.mean()      # balanced (lattice-aligned cuts)
+    boxes = [(pts[b].min(0), pts[b].max(0)) for b in blocks]
+    for i in range(8):                                   # blocks are disjoint boxes ...
+        for j in range(i + 1, 8):
+            assert any(boxes[i][1][d] < boxes[j][0][d] or boxes[j][1][d] < boxes[i][0][d] for d in range(3))
+    cells = [set(map(tuple, (pts[b] >> 3).tolist())) for b in blocks]                    # ... that share no stride-8 cell
+    assert sum(len(c) for c in cells) == len(set().union(*cells))
+    off = pts + np.array([704, 8, 96])                   # position inside the cube does not matter (lattice-aligned shift)
+    assert [len(b) for b in shard.split_octants(off, 1)] == [len(b) for b in blocks]
     assert len(shard.split_octants(pts[:0], 1)) == 0
