@@ -607,6 +607,11 @@ static bool dispatch_mfma(int Cout, const int32_t* nbr, int K, int64_t n_out, co
 //       ONE gather of the 2Q-wide rows of t feeds both k3 convs (the unfused form gathers two Q-wide tensors).
 // 5 launches / 3 gathers / 2 pointwise passes become 2 launches / 2 gathers; every fmaf chain is unchanged.
 // ----------------------------------------------------------------------------------------------------------------
+// kernel offsets gathered per wait (27 = 9 x 3): more gathers in flight per wave.  Pays only while the extra row buffers do
+// not cut occupancy: measured irn_b<16> 194 -> 167 us, but irn_b<32> 127 -> 160 us and irn_b<64> 196 -> 433 us with 3.
+template <int C> struct IrnKG { static constexpr int value = (C == 16) ? 3 : 1; };       // pass B
+template <int C> struct IrnKGA { static constexpr int value = 1; };                     // pass A: 227 vs 212 us with 3 at C=16
+
 template <int C>
 __global__ void __launch_bounds__(256)
 k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x, int x_ld,
@@ -617,7 +622,7 @@ k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x,
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float4* rowbuf = (float4*)lds_raw + (size_t)wave * (64 * CH);
+    float4* rowbuf = (float4*)lds_raw + (size_t)wave * (IrnKGA<C>::value * 64 * CH);
     const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * 64;
     if (row0 >= n) return;
     const int64_t my_row = row0 + lane;
@@ -627,6 +632,39 @@ k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x,
     __attribute__((aligned(8))) float acc1[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+    if constexpr (NB == 1 && IrnKGA<C>::value > 1) {
+        constexpr int KG = IrnKGA<C>::value;
+        int idx[KG];
+#pragma unroll
+        for (int g = 0; g < KG; ++g) idx[g] = valid ? nbr[(int64_t)g * n + my_row] : -1;
+        for (int k0 = 0; k0 < 27; k0 += KG) {
+#pragma unroll
+            for (int g = 0; g < KG; ++g) RowGather<CH>::fetch(rs, rowbuf + g * (64 * CH), idx[g], x_ld, 0, lane);
+            int idx_n[KG];
+#pragma unroll
+            for (int g = 0; g < KG; ++g) idx_n[g] = (valid && k0 + KG + g < 27) ? nbr[(int64_t)(k0 + KG + g) * n + my_row] : -1;
+            asm volatile("" ::: "memory");
+            wait_vmcnt<KG>();
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                float4 xv[CH];
+                RowGather<CH>::read(rowbuf + g * (64 * CH), lane, xv);
+                if (idx[g] >= 0) {
+                    const int k = k0 + g;
+                    const float* w = W00 + (int64_t)k * C * Q;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) fma4<Q>(acc0, xv[c], w + (4 * c) * Q, Q);
+                    if (k == 13) {
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) fma4<Q>(acc1, xv[c], W10 + (4 * c) * Q, Q);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int g = 0; g < KG; ++g) idx[g] = idx_n[g];
+        }
+    } else {
     int idx_cur = valid ? nbr[my_row] : -1;
     for (int k = 0; k < 27; ++k) {
         int idx_nxt = -1;
@@ -654,6 +692,7 @@ k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x,
         }
         idx_cur = idx_nxt;
     }
+    }
     if (!valid) return;
     float* y = t + my_row * (2 * Q);
 #pragma unroll
@@ -671,10 +710,11 @@ k_irn_b(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ t 
     constexpr int Q = C / 4, H = C / 2;
     constexpr int CH = H / 4;                        // gathered row = H floats: 2, 4 or 8 chunks
     constexpr int CQ = Q / 4;                        // chunks per branch: 1, 2 or 4
+    constexpr int KG = IrnKG<C>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float4* rowbuf = (float4*)lds_raw + (size_t)wave * (64 * CH);
+    float4* rowbuf = (float4*)lds_raw + (size_t)wave * (KG * 64 * CH);
     const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * 64;
     if (row0 >= n) return;
     const int64_t my_row = row0 + lane;
@@ -686,27 +726,35 @@ k_irn_b(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ t 
     for (int i = 0; i < H; ++i) acc0[i] = 0.0f;
 #pragma unroll
     for (int i = 0; i < Q; ++i) acc1[i] = 0.0f;
-    int idx_cur = valid ? nbr[my_row] : -1;
-    for (int k = 0; k < 27; ++k) {
-        int idx_nxt = -1;
-        RowGather<CH>::fetch(rs, rowbuf, idx_cur, H, 0, lane);
-        if (k + 1 < 27) {
-            if (valid) idx_nxt = nbr[(int64_t)(k + 1) * n + my_row];
-            asm volatile("" ::: "memory");
-            wait_vmcnt<1>();
-        } else wait_vmcnt<0>();
-        float4 tv[CH];
-        RowGather<CH>::read(rowbuf, lane, tv);
-        if (idx_cur >= 0) {
-            const float* w0 = W01 + (int64_t)k * Q * H;              // [Q][H]
-            const float* w1 = W11 + (int64_t)k * Q * Q;              // [Q][Q]
+    // KG kernel offsets per wait: KG row buffers, KG gathers in flight per wave (27 = 9 x 3)
+    int idx[KG];
 #pragma unroll
-            for (int c = 0; c < CQ; ++c) fma4<H>(acc0, tv[c], w0 + (4 * c) * H, H);
+    for (int g = 0; g < KG; ++g) idx[g] = valid ? nbr[(int64_t)g * n + my_row] : -1;
+    for (int k0 = 0; k0 < 27; k0 += KG) {
 #pragma unroll
-            for (int c = 0; c < CQ; ++c) fma4<Q>(acc1, tv[CQ + c], w1 + (4 * c) * Q, Q);
+        for (int g = 0; g < KG; ++g) RowGather<CH>::fetch(rs, rowbuf + g * (64 * CH), idx[g], H, 0, lane);
+        int idx_n[KG];
+#pragma unroll
+        for (int g = 0; g < KG; ++g) idx_n[g] = (valid && k0 + KG + g < 27) ? nbr[(int64_t)(k0 + KG + g) * n + my_row] : -1;
+        asm volatile("" ::: "memory");
+        wait_vmcnt<KG>();                                        // the KG map prefetches may stay in flight
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            float4 tv[CH];
+            RowGather<CH>::read(rowbuf + g * (64 * CH), lane, tv);
+            if (idx[g] >= 0) {
+                const int k = k0 + g;
+                const float* w0 = W01 + (int64_t)k * Q * H;          // [Q][H]
+                const float* w1 = W11 + (int64_t)k * Q * Q;          // [Q][Q]
+#pragma unroll
+                for (int c = 0; c < CQ; ++c) fma4<H>(acc0, tv[c], w0 + (4 * c) * H, H);
+#pragma unroll
+                for (int c = 0; c < CQ; ++c) fma4<Q>(acc1, tv[CQ + c], w1 + (4 * c) * Q, Q);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        idx_cur = idx_nxt;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) idx[g] = idx_n[g];
     }
     if (!valid) return;
     // conv1_2 (k1, Q -> H) on u = relu(conv1_1 + bias), in registers
@@ -737,7 +785,7 @@ template <int C>
 static void launch_irn(const int32_t* nbr, int64_t n, const float* x, int x_ld, const float* const* P, float* t, float* out,
                        int out_ld, int phase, hipStream_t s) {
     constexpr int CBA = C < 32 ? C : 32;
-    const size_t lds_a = 4 * (size_t)(64 * (CBA / 4) * 16), lds_b = 4 * (size_t)(64 * (C / 8) * 16);
+    const size_t lds_a = 4 * (size_t)(IrnKGA<C>::value * 64 * (CBA / 4) * 16), lds_b = 4 * (size_t)(IrnKG<C>::value * 64 * (C / 8) * 16);
     if (phase & 1)
         hipLaunchKernelGGL((k_irn_a<C>), dim3(grid_for(n, 256)), dim3(256), lds_a, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
     if (phase & 2)
