@@ -12,144 +12,105 @@
 
 // ------------------------------------------------------------------------------------------------ torchac-compatible
 namespace {
-
-// MSB-first bit writer with a 64-bit staging word (the reference implementation appends one bit at a time).
-struct BitSink {
-    uint8_t* out; int64_t cap; int64_t len = 0; uint64_t acc = 0; int nbits = 0;
-    inline void put(uint32_t v, int n) {                    // n <= 32 low bits of v, MSB first
-        if (n == 0) return;
+inline int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
+// MSB-first bit writer: bits are staged in a 64-bit word and flushed 32 at a time with one byte-swapped store (the
+// reference appends one bit at a time).
+struct Sink {
+    uint8_t* out; int64_t cap; int64_t len = 0; uint64_t acc = 0; int nbits = 0;   // nbits < 32 between calls
+    inline void put(uint32_t v, int n) {            // n <= 32
         acc = (acc << n) | (uint64_t)(n == 32 ? v : (v & ((1u << n) - 1u)));
         nbits += n;
-        while (nbits >= 8) {
-            nbits -= 8;
-            if (len < cap) out[len] = (uint8_t)(acc >> nbits);
-            ++len;
+        if (nbits >= 32) {
+            nbits -= 32;
+            const uint32_t w = __builtin_bswap32((uint32_t)(acc >> nbits));
+            if (len + 4 <= cap) std::memcpy(out + len, &w, 4);
+            len += 4;
         }
     }
-    inline void put_run(uint32_t bit, uint64_t count) {     // `count` copies of `bit`
-        const uint32_t word = bit ? 0xFFFFFFFFu : 0u;
-        while (count >= 32) { put(word, 32); count -= 32; }
-        put(word, (int)count);
-    }
-    inline void flush() { if (nbits) put(0, 8 - nbits); }
+    inline void put_run(uint32_t bit, uint64_t count) { const uint32_t word = bit ? 0xFFFFFFFFu : 0u; while (count >= 32) { put(word, 32); count -= 32; } put(word, (int)count); }
+    inline void flush() { while (nbits > 0) { int take = nbits >= 8 ? 8 : nbits; uint8_t b = (uint8_t)((nbits >= 8 ? (acc >> (nbits - 8)) : (acc << (8 - nbits))) & 0xff); if (len < cap) out[len] = b; ++len; nbits -= take; } }
 };
-
-// MSB-first bit reader; past the end of the stream it yields zeros (as the reference's `get` does).
-struct BitSource {
-    const uint8_t* in; int64_t len; int64_t pos = 0; uint64_t acc = 0; int nbits = 0;
-    inline uint32_t take(int n) {                           // n <= 32
-        if (n == 0) return 0;
-        while (nbits < n) { acc = (acc << 8) | (uint64_t)(pos < len ? in[pos] : 0); ++pos; nbits += 8; }
+// MSB-first bit reader over a zero-padded copy of the stream (past the end the reference's reader yields zeros too);
+// refills 32 bits at a time.
+struct Source {
+    const uint8_t* in; int64_t pos = 0; uint64_t acc = 0; int nbits = 0;
+    inline uint32_t take(int n) {
+        if (nbits < n) { uint32_t w; std::memcpy(&w, in + pos, 4); pos += 4; acc = (acc << 32) | __builtin_bswap32(w); nbits += 32; }
         nbits -= n;
-        return (uint32_t)((acc >> nbits) & ((n == 32) ? 0xFFFFFFFFull : ((1ull << n) - 1ull)));
+        return n == 0 ? 0u : (uint32_t)((acc >> nbits) & ((n == 32) ? 0xFFFFFFFFull : ((1ull << n) - 1ull)));
     }
 };
-
-inline int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
-
-}  // namespace
-
+}
 // Renormalisation in runs instead of single bits.  After coding a symbol:
 //   (1) low and high share n = clz(low ^ high) leading bits -> emit them (the first one releases the pending
 //       opposite bits), shift both by n;
 //   (2) then low = 01.., high = 10..: the E3 "near convergence" case repeats m = min(leading ones of low<<1,
 //       leading zeros of high<<1) times -> pending += m, low/high shifted by m with their MSBs pinned to 0 / 1.
-// After (2) neither case applies again, exactly as in the bit-serial loop of torchac ‡.
+// After (2) neither case applies again, exactly as in the bit-serial loop of torchac ‡.  The CDF rows are widened to
+// 32 bits with the last boundary pinned to 2^16 (torchac hard-codes c_high = 0x10000 for the top symbol), which removes
+// the per-symbol special case; the decoder seeds its symbol search from the target's high byte.
 extern "C" int64_t pcgc_rc_encode(const uint16_t* cdf, int C, int Lp, const int16_t* sym, int64_t n, uint8_t* out, int64_t cap) {
-    BitSink sink{out, cap};
-    uint32_t low = 0, high = 0xFFFFFFFFu;
-    uint64_t pending = 0;
+    Sink sink{out, cap};
+    uint32_t low = 0, high = 0xFFFFFFFFu; uint64_t pending = 0;
     const int top_symbol = Lp - 2;
+    std::vector<uint32_t> rows((size_t)C * Lp);
+    for (int c = 0; c < C; ++c) { for (int j = 0; j < Lp - 1; ++j) rows[(size_t)c * Lp + j] = cdf[(size_t)c * Lp + j]; rows[(size_t)c * Lp + Lp - 1] = 0x10000u; }
     int ch = 0;
     for (int64_t i = 0; i < n; ++i) {
-        const uint16_t* row = cdf + (size_t)ch * Lp;
+        const uint32_t* row = rows.data() + (size_t)ch * Lp;
         if (++ch == C) ch = 0;
         const int s = sym[i];
-        if (s < 0 || s > top_symbol) return INT64_MIN;                       // symbol outside the table
+        if ((unsigned)s > (unsigned)top_symbol) return INT64_MIN;
         const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
-        const uint32_t c_lo = row[s];
-        const uint32_t c_hi = (s == top_symbol) ? 0x10000u : row[s + 1];     // last boundary is pinned to 2^16
-        high = (low - 1) + (uint32_t)((span * c_hi) >> 16);
-        low = low + (uint32_t)((span * c_lo) >> 16);
+        high = (low - 1) + (uint32_t)((span * row[s + 1]) >> 16);
+        low = low + (uint32_t)((span * row[s]) >> 16);
         const int nshare = clz32(low ^ high);
         if (nshare) {
-            const uint32_t bits = nshare == 32 ? low : (low >> (32 - nshare));
+            const uint32_t bits = low >> (32 - nshare);
             if (pending) {
                 const uint32_t first = (bits >> (nshare - 1)) & 1u;
-                sink.put(first, 1);
-                sink.put_run(first ^ 1u, pending);
-                pending = 0;
-                sink.put(bits, nshare - 1);
+                sink.put(first, 1); sink.put_run(first ^ 1u, pending); pending = 0; sink.put(bits, nshare - 1);
             } else sink.put(bits, nshare);
-            if (nshare == 32) { low = 0; high = 0xFFFFFFFFu; }
-            else { low <<= nshare; high = (high << nshare) | ((1u << nshare) - 1u); }
+            low <<= nshare; high = (high << nshare) | ((1u << nshare) - 1u);
         }
         while (low >= 0x40000000u && high < 0xC0000000u) {
-            int m = clz32(~(low << 1));
-            const int mz = clz32(high << 1);
-            if (mz < m) m = mz;
-            if (m > 31) m = 31;
-            pending += (uint64_t)m;
-            low = (low << m) & 0x7FFFFFFFu;
-            high = (high << m) | 0x80000000u | ((1u << m) - 1u);
+            int m = clz32(~(low << 1)); const int mz = clz32(high << 1); if (mz < m) m = mz; if (m > 31) m = 31;
+            pending += (uint64_t)m; low = (low << m) & 0x7FFFFFFFu; high = (high << m) | 0x80000000u | ((1u << m) - 1u);
         }
     }
     ++pending;
     const uint32_t last = low < 0x40000000u ? 0u : 1u;
-    sink.put(last, 1);
-    sink.put_run(last ^ 1u, pending);
-    sink.flush();
+    sink.put(last, 1); sink.put_run(last ^ 1u, pending); sink.flush();
     return sink.len <= cap ? sink.len : -sink.len;
 }
-
 extern "C" int pcgc_rc_decode(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int64_t nbytes, int16_t* sym, int64_t n) {
-    BitSource src{in, nbytes};
-    uint32_t low = 0, high = 0xFFFFFFFFu;
-    uint32_t value = src.take(32);
+    std::vector<uint8_t> padded((size_t)nbytes + 64 + (size_t)n, 0);
+    std::memcpy(padded.data(), in, (size_t)nbytes);
+    Source src{padded.data()};
+    uint32_t low = 0, high = 0xFFFFFFFFu; uint32_t value = src.take(32);
     const int top_symbol = Lp - 2;
-    // search seed: for each channel and each high byte b of the 16-bit target, the largest m with row[m] <= (b << 8);
-    // the true symbol is found by walking forward from there (latent pmfs are peaked: usually 0-2 steps).
+    std::vector<uint32_t> rows((size_t)C * Lp);
+    for (int c = 0; c < C; ++c) { for (int j = 0; j < Lp - 1; ++j) rows[(size_t)c * Lp + j] = cdf[(size_t)c * Lp + j]; rows[(size_t)c * Lp + Lp - 1] = 0x10000u; }
     std::vector<int16_t> seed((size_t)C * 256);
-    for (int c = 0; c < C; ++c) {
-        const uint16_t* row = cdf + (size_t)c * Lp;
-        int m = 0;
-        for (int b = 0; b < 256; ++b) {
-            const uint32_t t = (uint32_t)b << 8;
-            while (m < top_symbol && row[m + 1] <= t) ++m;
-            seed[(size_t)c * 256 + b] = (int16_t)m;
-        }
-    }
+    for (int c = 0; c < C; ++c) { const uint32_t* row = rows.data() + (size_t)c * Lp; int m = 0; for (int b = 0; b < 256; ++b) { const uint32_t t = (uint32_t)b << 8; while (m < top_symbol && row[m + 1] <= t) ++m; seed[(size_t)c * 256 + b] = (int16_t)m; } }
     int ch = 0;
     for (int64_t i = 0; i < n; ++i) {
-        const uint16_t* row = cdf + (size_t)ch * Lp;
-        const int16_t* sd = seed.data() + (size_t)ch * 256;
+        const uint32_t* row = rows.data() + (size_t)ch * Lp; const int16_t* sd = seed.data() + (size_t)ch * 256;
         if (++ch == C) ch = 0;
         const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
         const uint32_t target = (uint16_t)((((uint64_t)value - (uint64_t)low + 1) * 0x10000ull - 1) / span);
-        int s = sd[target >> 8];                                             // row[s] <= target guaranteed
-        while (s < top_symbol && row[s + 1] <= target) ++s;                  // the wrapped entry row[Lp-1] is never read
+        int s = sd[target >> 8];
+        while (row[s + 1] <= target) ++s;              // row[top+1] = 0x10000 > target: no bound check needed
         sym[i] = (int16_t)s;
         if (i == n - 1) break;
-        const uint32_t c_lo = row[s];
-        const uint32_t c_hi = (s == top_symbol) ? 0x10000u : row[s + 1];
-        high = (low - 1) + (uint32_t)((span * c_hi) >> 16);
-        low = low + (uint32_t)((span * c_lo) >> 16);
+        high = (low - 1) + (uint32_t)((span * row[s + 1]) >> 16);
+        low = low + (uint32_t)((span * row[s]) >> 16);
         const int nshare = clz32(low ^ high);
-        if (nshare) {
-            if (nshare == 32) { low = 0; high = 0xFFFFFFFFu; value = src.take(32); }
-            else {
-                low <<= nshare; high = (high << nshare) | ((1u << nshare) - 1u);
-                value = (value << nshare) | src.take(nshare);
-            }
-        }
+        if (nshare) { low <<= nshare; high = (high << nshare) | ((1u << nshare) - 1u); value = (value << nshare) | src.take(nshare); }
         while (low >= 0x40000000u && high < 0xC0000000u) {
-            int m = clz32(~(low << 1));
-            const int mz = clz32(high << 1);
-            if (mz < m) m = mz;
-            if (m > 31) m = 31;
-            low = (low << m) & 0x7FFFFFFFu;
-            high = (high << m) | 0x80000000u | ((1u << m) - 1u);
-            value = ((value << m) | src.take(m)) ^ 0x80000000u;              // m steps of (v - 2^30) << 1 | bit
+            int m = clz32(~(low << 1)); const int mz = clz32(high << 1); if (mz < m) m = mz; if (m > 31) m = 31;
+            low = (low << m) & 0x7FFFFFFFu; high = (high << m) | 0x80000000u | ((1u << m) - 1u);
+            value = ((value << m) | src.take(m)) ^ 0x80000000u;
         }
     }
     return 0;
