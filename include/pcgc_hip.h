@@ -160,6 +160,12 @@ int64_t pcgc_oct_encode(const int32_t* xyz /*[host n,3]*/, int64_t n, uint8_t* o
 int64_t pcgc_oct_decode_count(const uint8_t* in, int64_t nbytes);                                   /* points or <0 */
 int pcgc_oct_decode(const uint8_t* in, int64_t nbytes, int32_t* xyz /*[host n,3]*/, int64_t n);
 
+/* ---- ASCII PLY geometry I/O (data_utils.py:19-48: read_ply_ascii_geo / write_ply_ascii_geo), HOST.
+ *      read: returns the number of data rows (call with xyz = NULL to size the buffer); same acceptance rule as the
+ *      reference (a line is data iff all its ' '-separated tokens parse as floats); columns 0:3 truncated to int. ---- */
+int64_t pcgc_ply_read_ascii_geo(const char* path, int32_t* xyz /*[host cap,3] or NULL*/, int64_t cap);
+int pcgc_ply_write_ascii_geo(const char* path, const int32_t* xyz /*[host n,3]*/, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,40 +8,27 @@ from .sparse import SparseTensor, sparse_collate, CoordMap
 
 
 def read_ply_ascii_geo(filedir):
-    """data_utils.py:19-34: every line whose tokens all parse as floats is a data row; keep columns 0:3 as int."""
-    with open(filedir, 'rb') as f:
-        raw = f.read()
-    end = raw.find(b'end_header')
-    if end >= 0:
-        body = raw[raw.find(b'\n', end) + 1:]
-        try:
-            first = body[:body.find(b'\n')].split()
-            ncol = len(first)
-            flat = np.array(body.split(), dtype=np.float64)
-            if ncol > 0 and flat.size % ncol == 0:
-                return flat.reshape(-1, ncol)[:, 0:3].astype('int')
-        except ValueError:
-            pass
-    data = []                                   # general (slow) path, same acceptance rule as the reference
-    for line in raw.decode('utf-8', 'replace').splitlines(keepends=True):
-        try:
-            vals = [float(v) for v in line.split(' ') if v != '\n']
-        except ValueError:
-            continue
-        data.append(vals)
-    return np.array(data)[:, 0:3].astype('int')
+    """data_utils.py:19-34: every line whose tokens all parse as floats is a data row; keep columns 0:3 as int.
+    Parsed natively (pcgc_ply_read_ascii_geo): the reference's per-line Python loop takes seconds at ~10^6 points."""
+    from ._lib import lib, PcgcError
+    path = os.fsencode(filedir)
+    n = int(lib().pcgc_ply_read_ascii_geo(path, None, 0))
+    if n == -1:
+        raise FileNotFoundError(filedir)
+    if n < 0:
+        raise PcgcError(f'{filedir}: malformed PLY data rows')
+    out = np.empty((n, 3), dtype=np.int32)
+    if int(lib().pcgc_ply_read_ascii_geo(path, out.ctypes.data, n)) != n:
+        raise PcgcError(f'{filedir}: file changed while reading')
+    return out.astype('int')
 
 
 def write_ply_ascii_geo(filedir, coords):
-    """data_utils.py:36-48: ASCII PLY, `property float x/y/z`, integer text."""
-    coords = np.asarray(coords).astype('int')
-    head = ('ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nend_header\n'
-            % coords.shape[0])
-    body = '\n'.join(' '.join(map(str, row)) for row in coords.tolist())
-    with open(filedir, 'w') as f:
-        f.write(head)
-        if body:
-            f.write(body + '\n')
+    """data_utils.py:36-48: ASCII PLY, `property float x/y/z`, integer text (native writer)."""
+    from ._lib import lib, PcgcError
+    coords = np.ascontiguousarray(np.asarray(coords).astype('int'), dtype=np.int32).reshape(-1, 3)
+    if int(lib().pcgc_ply_write_ascii_geo(os.fsencode(filedir), coords.ctypes.data, len(coords))) != 0:
+        raise PcgcError(f'cannot write {filedir}')
 
 
 def array2vector(array, step):

@@ -157,3 +157,39 @@ def test_oracle_roundtrip_small_shell():
     # latent symbols use a realistic alphabet with the synthetic gain
     hdr_min, hdr_max = np.frombuffer(enc['H'][9:17], np.float32)
     assert 4 <= hdr_max - hdr_min <= 200
+
+
+def test_native_ply_reader_matches_reference_rule(tmp_path):
+    """The native reader against the oracle's restatement of the reference loop on awkward inputs."""
+    from pcgcv2_amd.data_utils import read_ply_ascii_geo, write_ply_ascii_geo
+    rng = np.random.default_rng(11)
+    cases = {
+        'plain': 'ply\nformat ascii 1.0\nelement vertex 2\nproperty float x\nend_header\n1 2 3\n4 5 6\n',
+        'floats_colors': 'ply\nend_header\n1.9 2.1 -3.7 255 0 12\n1e2 2.5e1 3 1 1 1\n',
+        'no_header': '7 8 9\n10 11 12\n',
+        'crlf': 'ply\r\nend_header\r\n1 2 3\r\n4 5 6\r\n',
+        'trailing_space': 'end_header\n1 2 3 \n4 5 6\n',             # "3 " -> tokens [...,'3','\n'] : accepted
+        'double_space': 'end_header\n1  2 3\n4 5 6\n',              # empty token -> line rejected by the reference
+        'no_final_newline': 'end_header\n1 2 3\n4 5 6',
+        'text_line_inside': 'end_header\n1 2 3\ncomment here 5\n4 5 6\n',
+        'numeric_header_like': 'element vertex 2\n3 4\n1 2 3\n',    # a 2-number line makes the reference fail too
+    }
+    for name, text in cases.items():
+        p = tmp_path / (name + '.ply')
+        p.write_bytes(text.encode())
+        try:
+            want = orc.read_ply_ascii_geo(str(p))
+        except Exception:
+            want = None
+        if want is None:
+            with pytest.raises(Exception):
+                read_ply_ascii_geo(str(p))
+        else:
+            np.testing.assert_array_equal(read_ply_ascii_geo(str(p)), want, err_msg=name)
+    big = rng.integers(-5, 4096, size=(20000, 3))
+    p = tmp_path / 'big.ply'
+    write_ply_ascii_geo(str(p), big)
+    assert p.read_bytes() == orc.ply_ascii_bytes(big)
+    np.testing.assert_array_equal(read_ply_ascii_geo(str(p)), big)
+    with pytest.raises(FileNotFoundError):
+        read_ply_ascii_geo(str(tmp_path / 'missing.ply'))
