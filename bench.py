@@ -143,6 +143,10 @@ def main():
     else:
         total_points, total_out, total_bits = float(n_points), float(n_out), float(bits)
 
+    # quality of this rank's frame (outside the timed region, as coder.py:180-182): D1 on the GPU
+    from pcgcv2_amd.pc_error import d1_psnr_device
+    x_chk = SparseTensor(feats, coordinates=coords, tensor_stride=1, device=dev)
+    d1 = d1_psnr_device(x_chk.C, out.C, 1024)
     roof = ops.PROFILE.summary(HBM_PEAK_GBS, args.steps)
     if rank == 0:
         value = total_points * args.steps / elapsed / 1e6
@@ -155,7 +159,8 @@ def main():
                                    f'weights (seed 1234, gain 50), 1 frame per GPU per step, encode+decode incl. bitstream files',
                        'points_per_gpu': n_points, 'enc_ms': round(enc_t / args.steps * 1e3, 3),
                        'dec_ms': round(dec_t / args.steps * 1e3, 3), 'bpp': round(total_bits / total_points, 5),
-                       'points_out': int(total_out), 'coord_codec': 'native-octree (tmc3 absent)', 'step_ms_rank0': step_ms},
+                       'points_out': int(total_out), 'coord_codec': 'native-octree (tmc3 absent)', 'step_ms_rank0': step_ms,
+                       'd1_psnr_rank0_db': round(d1['mseF,PSNR (p2point)'], 4), 'd1_note': 'synthetic random weights: the value only shows the metric path runs'},
             'roofline': roof,
         }
         if roof is not None:

@@ -160,6 +160,12 @@ int64_t pcgc_oct_encode(const int32_t* xyz /*[host n,3]*/, int64_t n, uint8_t* o
 int64_t pcgc_oct_decode_count(const uint8_t* in, int64_t nbytes);                                   /* points or <0 */
 int pcgc_oct_decode(const uint8_t* in, int64_t nbytes, int32_t* xyz /*[host n,3]*/, int64_t n);
 
+/* ---- D1 point-to-point distortion (pc_error.py:27-74 -> mpeg-pcc-dmetric ‡): sum and max over A of the squared distance to
+ *      the nearest point of B, B given by its coordinate hash (stride 1).  offsets: int32 [n,4] = (dx,dy,dz,d2) sorted by d2. ---- */
+int pcgc_d1_nn(const int32_t* a /*[dev na,4]*/, int64_t na, const uint64_t* b_keys, const int32_t* b_vals, int64_t b_cap,
+               const int32_t* offsets /*[dev n_offsets,4]*/, int n_offsets, double* sum /*[dev 1]*/, uint64_t* max_d2 /*[dev 1]*/,
+               int32_t* unresolved /*[dev 1]*/, void* stream);
+
 /* ---- ASCII PLY geometry I/O (data_utils.py:19-48: read_ply_ascii_geo / write_ply_ascii_geo), HOST.
  *      read: returns the number of data rows (call with xyz = NULL to size the buffer); same acceptance rule as the
  *      reference (a line is data iff all its ' '-separated tokens parse as floats); columns 0:3 truncated to int. ---- */

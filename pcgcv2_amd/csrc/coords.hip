@@ -278,3 +278,53 @@ extern "C" int pcgc_compact_index(const uint8_t* mask, const int32_t* prefix, in
     PCGC_CHECK_LAUNCH("compact_index");
     return 0;
 }
+
+// ---- D1 (point-to-point) geometry distortion on device -------------------------------------------------------------
+// mpeg-pcc-dmetric's D1 (pc_error.py:27-74) is the mean squared distance from every point of A to its nearest neighbour in
+// B (and back).  On voxelised clouds the nearest neighbour is found exactly by probing B's coordinate hash at lattice
+// offsets visited in ASCENDING squared distance: the first occupied offset is the nearest neighbour.  `offsets` is that
+// table (dx,dy,dz,d2 as int4, sorted by d2, all offsets with max|d| <= R).  Squared distances are integers, so the
+// float64 sum is exact and independent of the reduction order.  Points with no neighbour inside the table are counted in
+// `unresolved` (the host finishes those with a KD-tree; it does not happen for codec outputs).
+__global__ void __launch_bounds__(256) k_d1_nn(const int4* __restrict__ a, int64_t na, const uint64_t* __restrict__ keys,
+                                               const int32_t* __restrict__ vals, uint64_t cap_mask,
+                                               const int4* __restrict__ offsets, int n_off, double* __restrict__ sum,
+                                               unsigned long long* __restrict__ max_d2, int32_t* __restrict__ unresolved) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double mine = 0.0; unsigned long long mymax = 0; int miss = 0;
+    if (i < na) {
+        const int4 c = a[i];
+        int found = -1;
+        for (int t = 0; t < n_off; ++t) {
+            const int4 o = offsets[t];
+            if (hash_lookup(keys, vals, cap_mask, 0, c.x, c.y + o.x, c.z + o.y, c.w + o.z) >= 0) { found = o.w; break; }
+        }
+        if (found >= 0) { mine = (double)found; mymax = (unsigned long long)found; } else miss = 1;
+    }
+    // wave reduction, then one atomic per wave
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        mine += __shfl_xor(mine, d, 64);
+        const unsigned long long om = __shfl_xor(mymax, d, 64); mymax = om > mymax ? om : mymax;
+        miss += __shfl_xor(miss, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (mine != 0.0) atomicAdd(sum, mine);
+        if (mymax) atomicMax(max_d2, mymax);
+        if (miss) atomicAdd(unresolved, miss);
+    }
+}
+extern "C" int pcgc_d1_nn(const int32_t* a, int64_t na, const uint64_t* b_keys, const int32_t* b_vals, int64_t b_cap,
+                          const int32_t* offsets, int n_offsets, double* sum, uint64_t* max_d2, int32_t* unresolved,
+                          void* stream) {
+    PCGC_REQUIRE(b_cap > 0 && (b_cap & (b_cap - 1)) == 0, "bad hash capacity");
+    hipError_t e = hipMemsetAsync(sum, 0, 8, S(stream));
+    if (e == hipSuccess) e = hipMemsetAsync(max_d2, 0, 8, S(stream));
+    if (e == hipSuccess) e = hipMemsetAsync(unresolved, 0, 4, S(stream));
+    if (e != hipSuccess) { pcgc_set_error("d1_nn: %s", hipGetErrorString(e)); return -1; }
+    if (na == 0) return 0;
+    hipLaunchKernelGGL(k_d1_nn, dim3(grid_for(na, 256)), dim3(256), 0, S(stream), (const int4*)a, na, b_keys, b_vals,
+                       (uint64_t)(b_cap - 1), (const int4*)offsets, n_offsets, sum, (unsigned long long*)max_d2, unresolved);
+    PCGC_CHECK_LAUNCH("d1_nn");
+    return 0;
+}

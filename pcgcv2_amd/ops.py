@@ -404,6 +404,37 @@ def cdf_table(params, C, min_v, max_v):
     return q, f
 
 
+# ------------------------------------------------------------------------------------------------ D1 metric
+_D1_OFFSETS = {}
+
+
+def _d1_offsets(device, radius=12):
+    """(dx,dy,dz,d2) for every lattice offset with max|d| <= radius, sorted by d2 (ties in a fixed order)."""
+    key = (str(device), radius)
+    if key not in _D1_OFFSETS:
+        r = np.arange(-radius, radius + 1)
+        g = np.stack(np.meshgrid(r, r, r, indexing='ij'), -1).reshape(-1, 3)
+        d2 = (g * g).sum(1)
+        order = np.lexsort((g[:, 0], g[:, 1], g[:, 2], d2))
+        tab = np.concatenate([g[order], d2[order, None]], 1).astype(np.int32)
+        # an offset at Chebyshev distance > radius could be closer than the corner offsets: keep only d2 <= radius^2
+        tab = tab[tab[:, 3] <= radius * radius]
+        _D1_OFFSETS[key] = torch.from_numpy(np.ascontiguousarray(tab)).to(device)
+    return _D1_OFFSETS[key]
+
+
+def d1_nn(a, b, radius=12):
+    """a, b: int32 [N,4] device coordinate tensors (stride 1).  -> (sum of squared NN distances a->b, max, unresolved count)."""
+    table = HashTable(_i32(b), 1)
+    off = _d1_offsets(a.device, radius)
+    s = torch.empty(1, dtype=torch.float64, device=a.device)
+    m = torch.empty(1, dtype=torch.int64, device=a.device)
+    u = torch.empty(1, dtype=torch.int32, device=a.device)
+    check(lib().pcgc_d1_nn(_p(_i32(a)), a.shape[0], _p(table.keys), _p(table.vals), table.cap, _p(off), off.shape[0], _p(s), _p(m),
+                           _p(u), _stream()), 'd1_nn')
+    return s, m, u
+
+
 # ------------------------------------------------------------------------------------------------ host codecs (numpy)
 def _np(a, dt):
     return np.ascontiguousarray(a, dtype=dt)

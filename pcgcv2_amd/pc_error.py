@@ -48,6 +48,33 @@ def d1_psnr(a, b, res):
             'h.        (p2point)': max(h1, h2), 'h.,PSNR   (p2point)': psnr(max(h1, h2))}
 
 
+def d1_psnr_device(a, b, res, radius=12):
+    """Same metrics as d1_psnr, computed on the GPU from two device coordinate tensors [N,4] (or sparse tensors' .C):
+    exact nearest neighbours by ascending-distance probes of the coordinate hash (pcgc_d1_nn).  Points farther than `radius`
+    voxels from the other cloud (never the case for codec outputs) are finished on the host."""
+    from . import ops
+    out = []
+    for p, q in ((a, b), (b, a)):
+        s, m, u = ops.d1_nn(p, q, radius)
+        s, m, u = float(s.item()), float(m.item()), int(u.item())
+        if u:                                               # rare: finish the far points exactly on the host
+            pc, qc = p[:, 1:].cpu().numpy(), q[:, 1:].cpu().numpy()
+            from scipy.spatial import cKDTree
+            d, _ = cKDTree(qc.astype(np.float64)).query(pc.astype(np.float64), workers=-1)
+            d2 = np.rint(d * d)
+            s, m = float(d2.sum()), float(d2.max())
+        out.append((s, m))
+    (s1, h1), (s2, h2) = out
+    mse1, mse2 = s1 / a.shape[0], s2 / b.shape[0]
+    peak = float(res - 1)
+    psnr = lambda v: float(10 * np.log10(3 * peak * peak / v)) if v > 0 else float('inf')
+    return {'mse1      (p2point)': mse1, 'mse1,PSNR (p2point)': psnr(mse1), 'h.       1(p2point)': h1, 'h.,PSNR  1(p2point)': psnr(h1),
+            'mse2      (p2point)': mse2, 'mse2,PSNR (p2point)': psnr(mse2), 'h.       2(p2point)': h2, 'h.,PSNR  2(p2point)': psnr(h2),
+            'mseF      (p2point)': max(mse1, mse2), 'mseF,PSNR (p2point)': psnr(max(mse1, mse2)),
+            'h.        (p2point)': max(h1, h2), 'h.,PSNR   (p2point)': psnr(max(h1, h2)),
+            'sse1': s1, 'sse2': s2}
+
+
 def pc_error(infile1, infile2, res, normal=False, show=False):
     exe = _exe()
     if exe is None:

@@ -101,7 +101,7 @@ def code_units(coder, units, rho=1.0, res=1024, with_d1=False):
     """Encode+decode this rank's share of `units` = list of (name, SparseTensor) and return (Stats, {name: decoded}).
     Each unit uses postfix '_<name>' so its four files never collide."""
     import os
-    from .pc_error import d1_sums
+    from .pc_error import d1_psnr_device
     stats = Stats(device=units[0][1].device if units else 'cpu')
     outs = {}
     for idx in shard_units(len(units)):
@@ -111,9 +111,9 @@ def code_units(coder, units, rho=1.0, res=1024, with_d1=False):
         out = coder.decode(rho=rho, postfix=post)
         bits = sum(os.path.getsize(coder.filename + post + s) * 8 for s in ('_C.bin', '_F.bin', '_H.bin', '_num_points.bin'))
         ab = ba = 0.0
-        if with_d1:
-            a, b = x.C[:, 1:].cpu().numpy(), out.C[:, 1:].cpu().numpy()
-            ab, ba = d1_sums(a, b)[0], d1_sums(b, a)[0]
+        if with_d1:                                       # exact nearest neighbours on the GPU (pcgc_d1_nn)
+            m = d1_psnr_device(x.C, out.C, res)
+            ab, ba = m['sse1'], m['sse2']
         stats.add(bits=bits, n_in=len(x), n_out=len(out), sse_ab=ab, sse_ba=ba)
         outs[name] = out
     return stats, outs

@@ -439,3 +439,18 @@ def test_rd_sweep_harness_and_cli(tmp_path):
     # CLI (coder.py:114-184)
     coder_mod.main(['--ckptdir', ckpts[1], '--filedir', str(ply), '--res', '256', '--outdir', str(tmp_path / 'cli')])
     assert (tmp_path / 'cli' / 'shell8_dec.ply').exists()
+
+
+def test_device_d1_metric_matches_pc_error_d_golden(golden_dir):
+    """GPU D1 (pcgc_d1_nn) against the stdout of the vendored mpeg-pcc-dmetric binary (golden G4) and the host KD-tree."""
+    from pcgcv2_amd.pc_error import d1_psnr_device, d1_psnr
+    g = np.load(os.path.join(golden_dir, 'd1_metric.npz'))
+    for i in range(int(g['n_cases'])):
+        a, b, res = g[f'p{i}_a'], g[f'p{i}_b'], int(g[f'p{i}_res'])
+        a4 = np.concatenate([np.zeros((len(a), 1), np.int32), a], 1); b4 = np.concatenate([np.zeros((len(b), 1), np.int32), b], 1)
+        m = d1_psnr_device(_t(a4), _t(b4), res, radius=3 if i == 0 else 12)         # radius 3 exercises the host finish path
+        assert m['mseF      (p2point)'] == pytest.approx(float(g[f'p{i}_mseF(p2point)']), rel=1e-5, abs=1e-9)
+        assert m['mse1      (p2point)'] == pytest.approx(float(g[f'p{i}_mse1(p2point)']), rel=1e-5, abs=1e-9)
+        assert m['h.        (p2point)'] == pytest.approx(float(g[f'p{i}_h.(p2point)']), rel=1e-5, abs=1e-9)
+        h = d1_psnr(a, b, res)
+        assert m['mse1      (p2point)'] == h['mse1      (p2point)'] and m['mse2      (p2point)'] == h['mse2      (p2point)']
