@@ -454,3 +454,36 @@ def test_device_d1_metric_matches_pc_error_d_golden(golden_dir):
         assert m['h.        (p2point)'] == pytest.approx(float(g[f'p{i}_h.(p2point)']), rel=1e-5, abs=1e-9)
         h = d1_psnr(a, b, res)
         assert m['mse1      (p2point)'] == h['mse1      (p2point)'] and m['mse2      (p2point)'] == h['mse2      (p2point)']
+
+
+@pytest.mark.parametrize('case', ['single', 'pair_far', 'tiny_cluster', 'duplicates', 'line'])
+def test_edge_case_clouds_match_oracle(case, sd, sd_np, tmp_path):
+    """Degenerate inputs through the full codec, bit-exact vs the oracle: 1 point, 2 far-apart points, a 10-point cluster, an
+    input with duplicated rows (ME.SparseTensor dedups, data_utils.py:108), a 1-voxel-thick line (ragged pyramid)."""
+    from pcgcv2_amd.coder import Coder
+    rng = np.random.default_rng(3)
+    if case == 'single':
+        c = np.array([[100, 200, 300]], np.int32)
+    elif case == 'pair_far':
+        c = np.array([[0, 0, 0], [1023, 1023, 1023]], np.int32)
+    elif case == 'tiny_cluster':
+        c = np.unique(rng.integers(500, 504, size=(10, 3)), axis=0).astype(np.int32)
+    elif case == 'duplicates':
+        base = np.unique(rng.integers(0, 40, size=(300, 3)), axis=0).astype(np.int32)
+        c = np.concatenate([base, base[::3], base[5:50]], 0)
+    else:
+        c = np.stack([np.arange(7, 300), np.full(293, 33), np.full(293, 70)], 1).astype(np.int32)
+    c4 = np.concatenate([np.zeros((len(c), 1), np.int32), c], 1)
+    x = SparseTensor(torch.ones((len(c4), 1)), coordinates=_t(c4), tensor_stride=1, device=DEV)
+    uniq = orc.unique_first(c4)
+    np.testing.assert_array_equal(x.C.cpu().numpy(), uniq)
+    m = _model(sd)
+    coder = Coder(m, str(tmp_path / case))
+    coder.encode(x)
+    ref = orc.encode(sd_np, uniq)
+    for k in ('F', 'H', 'num_points'):
+        assert (tmp_path / f'{case}_{k}.bin').read_bytes() == ref[k], k
+    for rho in (1.0, 0.5, 3.0):
+        out = coder.decode(rho=rho)
+        want = orc.decode(sd_np, ref['coords8'], ref['F'], ref['H'], ref['num_points'], rho=rho)
+        np.testing.assert_array_equal(out.C.cpu().numpy(), want)
