@@ -98,15 +98,6 @@ int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const float* in, 
 /* kernel selection for the gather conv: -1 auto (default), 0 = v0 direct-load kernel, 1 = v1 LDS-DMA kernel where eligible.
  * Both produce bit-identical results; the switch exists for A/B measurements and tests. */
 int pcgc_set_conv_impl(int impl);
-/* Tile-local maps: for every tile of 64 consecutive output rows, the distinct source rows it gathers (U [tiles,256] int32,
- * first ucount[t] valid) and, per (offset, lane), a uint8 index into them (L [tiles,27,64], 255 = absent).  Built once per
- * level from its k3 kernel map; lets the conv kernels fetch a tile's neighbourhood into LDS once instead of per offset.
- * Tiles with more than 255 distinct rows report ucount > 255 and are handled by the per-offset path. */
-int pcgc_tilemap_build(const int32_t* nbr /*[27,n]*/, int64_t n, int32_t* U, uint8_t* L, int32_t* ucount /*[tiles]*/, void* stream);
-/* k3 gather conv (Cin = 16) on a tile-local map; bit-identical to pcgc_conv_gather. */
-int pcgc_conv_gather_tl(const int32_t* nbr, const int32_t* U, const uint8_t* L, const int32_t* ucount, int64_t n_out,
-                        const float* in, int64_t n_in, int Cin, int in_ld, const float* W, const float* bias,
-                        const float* residual, int res_ld, int relu, float* out, int Cout, int out_ld, void* stream);
 /* Fused InceptionResNet block (autoencoder.py:7-57):  out = cat(conv0_1(relu(conv0_0 x)), conv1_2(relu(conv1_1(relu(conv1_0 x))))) + x
  * in two gather passes.  params[10] = {conv0_0.kernel, .bias, conv0_1.kernel, .bias, conv1_0.kernel, .bias, conv1_1.kernel,
  * .bias, conv1_2.kernel, .bias} (ME layouts).  t_scratch: [n, C/2] fp32 workspace.  Bit-identical to the five

@@ -33,8 +33,6 @@ SIGNATURES = {
     'pcgc_compact_index': (ci, [vp, vp, i64, vp, vp]),
     'pcgc_conv_gather': (ci, [vp, ci, i64, vp, i64, ci, ci, ci, vp, vp, vp, ci, ci, ci, vp, ci, ci, ci, vp]),
     'pcgc_set_conv_impl': (ci, [ci]),
-    'pcgc_tilemap_build': (ci, [vp, i64, vp, vp, vp, vp]),
-    'pcgc_conv_gather_tl': (ci, [vp, vp, vp, vp, i64, vp, i64, ci, ci, vp, vp, vp, ci, ci, vp, ci, ci, vp]),
     'pcgc_irn_block': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, ci, vp]),
     'pcgc_irn_pass': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, ci, ci, vp]),
     'pcgc_conv_up2': (ci, [i64, vp, ci, ci, vp, vp, ci, vp, ci, vp]),

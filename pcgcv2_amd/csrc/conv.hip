@@ -247,201 +247,6 @@ static bool dispatch_dma_cout(int Cout, const int32_t* nbr, int K, int64_t n_out
 
 
 // ----------------------------------------------------------------------------------------------------------------
-// Tile-local maps.  A 64-row tile touches 64 x ~18 neighbour rows but only ~150-250 DISTINCT ones (neighbouring sites
-// share neighbours; measured reuse 7x on the decoder's hierarchically ordered levels).  Per level we therefore build,
-// once, for every tile t:   U[t][0..ucount)  the distinct source rows,   L[t][k][lane]  uint8 index into U (255 = absent).
-// The conv kernels then fetch U's rows into LDS ONCE per 16-channel block and run all 27 offsets out of LDS, instead of
-// one latency-bound global gather per offset.  Tiles with more than 255 distinct rows keep ucount > 255 and take the
-// per-offset path inside the same kernel.
-// ----------------------------------------------------------------------------------------------------------------
-constexpr int TL_UMAX = 256;          // LDS rows per tile (16 KiB per 16-channel block); ids 0..254 usable, 255 = absent
-constexpr int TL_HASH = 2048;         // per-wave dedup table (>= 64*27 so it can never fill up)
-
-__global__ void __launch_bounds__(256) k_tilemap_build(const int32_t* __restrict__ nbr, int64_t n, int32_t* __restrict__ U,
-                                                       uint8_t* __restrict__ L, int32_t* __restrict__ ucount) {
-    __shared__ int32_t keys_s[4][TL_HASH];
-    __shared__ uint16_t ids_s[4][TL_HASH];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t row = tile * 64 + lane;
-    int32_t* keys = keys_s[wave];
-    uint16_t* ids = ids_s[wave];
-    for (int i = lane; i < TL_HASH; i += 64) keys[i] = -1;
-    __builtin_amdgcn_wave_barrier();
-    if (tile * 64 >= n) return;
-    int slot[27];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-        const int32_t r = row < n ? nbr[(int64_t)k * n + row] : -1;
-        int h = -1;
-        if (r >= 0) {
-            h = (int)(((uint32_t)r * 2654435761u) >> 21);                 // 11 bits
-            for (;;) {
-                const int32_t prev = atomicCAS(&keys[h], -1, r);
-                if (prev == -1 || prev == r) break;
-                h = (h + 1) & (TL_HASH - 1);
-            }
-        }
-        slot[k] = h;
-    }
-    __builtin_amdgcn_wave_barrier();
-    // number the occupied slots: each lane owns 32 consecutive slots
-    int cnt = 0;
-    const int base = lane * (TL_HASH / 64);
-#pragma unroll 8
-    for (int i = 0; i < TL_HASH / 64; ++i) cnt += keys[base + i] >= 0;
-    int incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-    const int total = __shfl(incl, 63, 64);
-    int id = incl - cnt;
-    for (int i = 0; i < TL_HASH / 64; ++i) {
-        const int32_t key = keys[base + i];
-        if (key >= 0) {
-            ids[base + i] = (uint16_t)id;
-            if (id < TL_UMAX) U[tile * TL_UMAX + id] = key;
-            ++id;
-        }
-    }
-    if (lane == 0) ucount[tile] = total;
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-        const int v = slot[k] >= 0 ? (int)ids[slot[k]] : 255;
-        L[(tile * 27 + k) * 64 + lane] = (uint8_t)(v > 255 ? 255 : v);    // meaningless (never read) when total > 255
-    }
-}
-
-extern "C" int pcgc_tilemap_build(const int32_t* nbr, int64_t n, int32_t* U, uint8_t* L, int32_t* ucount, void* stream) {
-    if (n == 0) return 0;
-    const int64_t tiles = (n + 63) / 64;
-    hipLaunchKernelGGL(k_tilemap_build, dim3(grid_for(tiles, 4)), dim3(256), 0, S(stream), nbr, n, U, L, ucount);
-    PCGC_CHECK_LAUNCH("tilemap_build");
-    return 0;
-}
-
-// Shared pieces of the tile-local kernels -------------------------------------------------------------------------
-// LDS layout per wave: rows [TL_UMAX][4] 16-byte slots (one 16-channel block of every distinct row), then the tile's
-// local index table [27][64] bytes.  Slot p of local row u holds chunk p ^ ((u>>2) & 3), so the 16-byte slot hit by a
-// reader depends on 4 bits of u and 64 arbitrary rows spread over all 16 slots of a bank row.
-constexpr int TL_WAVE_LDS = TL_UMAX * 64 + 27 * 64;
-
-// fetch the 16-channel block `cb` of every distinct row of the tile: ceil(ucnt/16) DMA instructions, all in flight
-__device__ static inline void tl_fetch_rows(const __amdgpu_buffer_rsrc_t& rs, float4* rows, const int32_t* __restrict__ Ut,
-                                            int ucnt, int in_ld, int col0, int lane) {
-    const int p = lane & 3;
-    for (int i = 0; i * 16 < ucnt; ++i) {
-        const int u = i * 16 + (lane >> 2);
-        const int rid = u < ucnt ? Ut[u] : -1;
-        const int chunk = p ^ ((u >> 2) & 3);
-        const unsigned voff = rid >= 0 ? (unsigned)(((int64_t)rid * in_ld + col0 + chunk * 4) * 4) : 0xFFFFFFF0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)(rows + i * 64), 16, (int)voff, 0, 0, 0);
-    }
-}
-__device__ static inline void tl_fetch_index(const __amdgpu_buffer_rsrc_t& rsL, uint8_t* lidx, int64_t tile, int lane) {
-    // 27*64 bytes = 432 dwords: 7 DMA instructions of 64 dwords (the last one partially out of range -> no fetch)
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const int d = i * 64 + lane;
-        const unsigned voff = d < 432 ? (unsigned)((tile * 432 + d) * 4) : 0xFFFFFFF0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, (lds_void_ptr)((uint32_t*)lidx + i * 64), 4, (int)voff, 0, 0, 0);
-    }
-}
-
-// VALU gather conv on tile-local maps (lane = output row).  Fallback for overflow tiles: the per-offset DMA path.
-template <int CIN, int CT>
-__global__ void __launch_bounds__(256)
-k_conv_tl(const int32_t* __restrict__ nbr, const int32_t* __restrict__ U, const uint8_t* __restrict__ L,
-          const int32_t* __restrict__ ucount, int64_t n_out, const float* __restrict__ in, int64_t n_in, int in_ld,
-          const float* __restrict__ W, int Cout, const float* __restrict__ bias, const float* __restrict__ res, int res_ld,
-          int relu, float* __restrict__ out, int out_ld) {
-    // One 16-channel block only: with several blocks, "fetch block, run 27 offsets" would reorder the canonical chain
-    // (k-major over ALL input channels).  Wider gathers keep the per-offset kernels until the chain order is revisited.
-    static_assert(CIN == 16, "tile-local fast path is defined for 16-channel gathers");
-    constexpr int NB = CIN / 16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned char* wbase = lds_raw + (size_t)wave * TL_WAVE_LDS;
-    float4* rows = (float4*)wbase;
-    uint8_t* lidx = wbase + TL_UMAX * 64;
-    const int64_t tile = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave;
-    const int64_t row0 = tile * 64;
-    if (row0 >= n_out) return;
-    const int co0 = blockIdx.y * CT;
-    const int64_t my_row = row0 + lane;
-    const bool valid = my_row < n_out;
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(n_in * in_ld * 4), 0x00020000);
-    const int64_t n_tiles = (n_out + 63) / 64;
-    const __amdgpu_buffer_rsrc_t rs_L = __builtin_amdgcn_make_buffer_rsrc((void*)L, 0, (int)(n_tiles * 27 * 64), 0x00020000);
-
-    __attribute__((aligned(8))) float acc[CT];
-#pragma unroll
-    for (int co = 0; co < CT; ++co) acc[co] = 0.0f;
-    const int ucnt = __builtin_amdgcn_readfirstlane(ucount[tile]);
-
-    if (ucnt <= 255) {
-        tl_fetch_index(rs_L, lidx, tile, lane);
-#pragma unroll 1
-        for (int cb = 0; cb < NB; ++cb) {
-            if (cb > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // previous block fully read
-            tl_fetch_rows(rs_in, rows, U + tile * TL_UMAX, ucnt, in_ld, cb * 16, lane);
-            wait_vmcnt<0>();
-#pragma unroll 1
-            for (int k = 0; k < 27; ++k) {
-                const int li = valid ? (int)lidx[k * 64 + lane] : 255;
-                if (li != 255) {
-                    const float4* src = rows + li * 4;
-                    const int sw = (li >> 2) & 3;
-                    const float* w = W + ((int64_t)k * CIN + cb * 16) * Cout + co0;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float4 x = src[c ^ sw];
-                        fma4<CT>(acc, x, w + (int64_t)(4 * c) * Cout, Cout);
-                    }
-                }
-            }
-        }
-    } else {
-        // overflow tile: per-offset gather (same arithmetic order: k ascending, then ci ascending within k ... see note)
-        float4* rowbuf = rows;
-        int idx_cur = valid ? nbr[my_row] : -1;
-        for (int k = 0; k < 27; ++k) {
-            int idx_nxt = -1;
-#pragma unroll 1
-            for (int cb = 0; cb < NB; ++cb) {
-                RowGather<4>::fetch(rs_in, rowbuf, idx_cur, in_ld, cb * 16, lane);
-                if (cb == NB - 1 && k + 1 < 27) {
-                    if (valid) idx_nxt = nbr[(int64_t)(k + 1) * n_out + my_row];
-                    asm volatile("" ::: "memory");
-                    wait_vmcnt<1>();
-                } else wait_vmcnt<0>();
-                float4 xv[4];
-                RowGather<4>::read(rowbuf, lane, xv);
-                if (idx_cur >= 0) {
-                    const float* w = W + ((int64_t)k * CIN + cb * 16) * Cout + co0;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) fma4<CT>(acc, xv[c], w + (int64_t)(4 * c) * Cout, Cout);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            idx_cur = idx_nxt;
-        }
-    }
-    if (!valid) return;
-    float* y = out + my_row * out_ld + co0;
-    const float* rr = res ? res + my_row * res_ld + co0 : nullptr;
-#pragma unroll
-    for (int co = 0; co < CT; ++co) {
-        float v = acc[co];
-        if (bias) v = v + bias[co0 + co];
-        if (rr) v = v + rr[co];
-        if (relu) v = fmaxf(v, 0.0f);
-        y[co] = v;
-    }
-}
-
-// ----------------------------------------------------------------------------------------------------------------
 // v2 kernel: LDS-DMA gather + fp32 MFMA channel GEMM, for Cin in {16,32,64} and Cout a multiple of 16.
 // One wave = 64 output rows (4 M-tiles of 16) x CT = 16*NT output channels.  Per sub-step (offset k, 16 input channels):
 //   * gather: 4 `buffer_load_dwordx4 ... lds` (4 adjacent lanes = one 64-byte row segment); lanes whose neighbour is
@@ -575,6 +380,121 @@ k_conv_gather_mfma(const int32_t* __restrict__ nbr, int K, int64_t n_out, const 
                 out[row * out_ld + col] = v;
             }
         }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// v2b: the same MFMA gather conv with the weight (B) tiles shared by the workgroup through LDS.
+// PMC on v2 (64->64, 150 k rows): 3.7 GB fetched per launch against 0.74 GB algorithmic — every wave streams its share of
+// the 442 KB weight set from L2, and with 16-column tiles (gridDim.y = 4) every row is gathered four times.  Here a
+// workgroup of 4 waves x (16*MT) rows computes ALL output columns: the 16 x COUT weight slice of a sub-step is staged once
+// per workgroup into a double-buffered LDS tile (one __syncthreads per sub-step; the slice for sub-step t+1 is fetched
+// while t is computed), and every wave reads its B fragments from LDS.
+// ----------------------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int MT>
+__global__ void __launch_bounds__(256)
+k_conv_gather_mfma_wlds(const int32_t* __restrict__ nbr, int K, int64_t n_out, const float* __restrict__ in, int64_t n_in,
+                        int in_ld, const float* __restrict__ W, const float* __restrict__ bias,
+                        const float* __restrict__ res, int res_ld, int relu, float* __restrict__ out, int out_ld) {
+    constexpr int NB = CIN / 16, NT = COUT / 16, ROWS = 16 * MT;
+    constexpr int WSLICE = 16 * COUT;                                  // floats per (k, cb) weight slice
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* wbuf = (float*)lds_raw;                                      // [2][16][COUT]
+    float4* rowbuf = (float4*)(lds_raw + 2 * WSLICE * 4) + (size_t)wave * (ROWS * 4);   // [ROWS][4] slots per wave
+    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * ROWS;
+    const bool wave_active = row0 < n_out;                              // idle waves still take part in staging + barriers
+    const int64_t my_row = row0 + lane;
+    const bool valid = wave_active && lane < ROWS && my_row < n_out;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(n_in * in_ld * 4), 0x00020000);
+    const int mi = lane & 15, mq = lane >> 4;
+    const int f_a = (0x78 >> (2 * (mi >> 2))) & 3;
+    const int dma_row_lo = lane >> 2, dma_p = lane & 3;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int T = K * NB;
+    // stage slice t (k = t / NB, cb = t % NB) into wbuf[t & 1]: WSLICE/4 float4, one or fewer per thread
+    auto stage_w = [&](int t) {
+        const int k = t / NB, cb = t % NB;
+        const float4* src = (const float4*)(W + ((int64_t)k * CIN + cb * 16) * COUT);
+        float4* dst = (float4*)(wbuf + (t & 1) * WSLICE);
+        for (int i = threadIdx.x; i < WSLICE / 4; i += 256) dst[i] = src[i];
+    };
+    stage_w(0);
+    int idx_cur = valid ? nbr[my_row] : -1;
+    for (int t = 0; t < T; ++t) {
+        const int k = t / NB, cb = t % NB;
+        __syncthreads();                                                // slice t staged; everyone done with sub-step t-1
+        if (t + 1 < T) stage_w(t + 1);
+        int idx_nxt = -1;
+        if (cb == NB - 1 && k + 1 < K && valid) idx_nxt = nbr[(int64_t)(k + 1) * n_out + my_row];
+        if (wave_active) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int r = i * 16 + dma_row_lo;
+                const int rid = __shfl(idx_cur, r, 64);
+                const int chunk = dma_p ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3);
+                const unsigned voff = rid >= 0 ? (unsigned)(((int64_t)rid * in_ld + cb * 16 + chunk * 4) * 4) : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_ptr)(rowbuf + i * 64), 16, (int)voff, 0, 0, 0);
+                if (rid < 0) lds_zero16(rowbuf + i * 64 + lane);
+            }
+            asm volatile("" ::: "memory");
+            wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float4 a[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                a[m] = rowbuf[(16 * m + mi) * 4 + (mq ^ f_a)];
+                lane_transpose4(a[m]);
+            }
+            const float* wb = wbuf + (t & 1) * WSLICE + mq * COUT + mi;     // B[j][n] = wb[(4j)*COUT + 16n]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float b[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) b[n] = wb[(4 * j) * COUT + 16 * n];
+                const float aj[4] = {0, 0, 0, 0};
+                (void)aj;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float av = j == 0 ? a[m].x : (j == 1 ? a[m].y : (j == 2 ? a[m].z : a[m].w));
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[n], acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+        if (cb == NB - 1) idx_cur = idx_nxt;
+    }
+    if (!wave_active) return;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 16 * m + 4 * mq + r;
+            if (row >= n_out) continue;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int col = 16 * n + mi;
+                float v = acc[m][n][r];
+                if (bias) v = v + bias[col];
+                if (res) v = v + res[row * res_ld + col];
+                if (relu) v = fmaxf(v, 0.0f);
+                out[row * out_ld + col] = v;
+            }
+        }
+}
+
+template <int CIN, int COUT, int MT>
+static void launch_mfma_wlds(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int in_ld, const float* W,
+                             const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld, hipStream_t s) {
+    constexpr size_t lds = 2 * 16 * COUT * 4 + 4 * (size_t)(16 * MT * 64);
+    hipLaunchKernelGGL((k_conv_gather_mfma_wlds<CIN, COUT, MT>), dim3(grid_for(n_out, 4 * 16 * MT)), dim3(256), lds, s, nbr, K,
+                       n_out, in, n_in, in_ld, W, bias, res, res_ld, relu, out, out_ld);
 }
 
 template <int CIN, int NT>
@@ -821,37 +741,8 @@ static int irn_launch(const int32_t* nbr, int64_t n, const float* x, int C, int 
     return 0;
 }
 
-extern "C" int pcgc_conv_gather_tl(const int32_t* nbr, const int32_t* U, const uint8_t* L, const int32_t* ucount, int64_t n_out,
-                                   const float* in, int64_t n_in, int Cin, int in_ld, const float* W, const float* bias,
-                                   const float* residual, int res_ld, int relu, float* out, int Cout, int out_ld, void* stream) {
-    PCGC_REQUIRE(Cin == 16, "tile-local gather conv: Cin must be 16");
-    PCGC_REQUIRE((in_ld & 3) == 0 && (((uintptr_t)in | (uintptr_t)W) & 15) == 0, "unaligned input");
-    PCGC_REQUIRE(n_in * (int64_t)in_ld * 4 < (int64_t)0xFFFFFFF0, "tensor too large for 32-bit buffer offsets");
-    if (n_out == 0) return 0;
-    const size_t lds = 4 * (size_t)TL_WAVE_LDS;
-    dim3 g(grid_for(n_out, 256), 1), b(256);
-#define PCGC_TL(CTILE)                                                                                                          \
-    {                                                                                                                           \
-        static bool once = false;                                                                                               \
-        if (!once) { (void)hipFuncSetAttribute((const void*)k_conv_tl<16, CTILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } \
-        g.y = Cout / CTILE;                                                                                                     \
-        hipLaunchKernelGGL((k_conv_tl<16, CTILE>), g, b, lds, S(stream), nbr, U, L, ucount, n_out, in, n_in, in_ld, W, Cout, bias,  \
-                           residual, res_ld, relu, out, out_ld);                                                               \
-    }
-    switch (Cout) {
-        case 1: PCGC_TL(1) break;
-        case 4: PCGC_TL(4) break;
-        case 8: PCGC_TL(8) break;
-        case 16: PCGC_TL(16) break;
-        case 32: PCGC_TL(16) break;
-        default: pcgc_set_error("conv_gather_tl: unsupported Cout %d", Cout); return -2;
-    }
-#undef PCGC_TL
-    PCGC_CHECK_LAUNCH("conv_gather_tl");
-    return 0;
-}
-
 static int g_conv_impl = -1;        // -1 auto, 0 force v0 (direct loads), 1 force v1 (LDS-DMA + VALU), 2 force v2 (LDS-DMA + MFMA)
+static int g_auto_wlds = 1;         // auto: LDS-shared-weight MFMA kernel for 64->64 (591 -> 403 us at 150 k rows; no gain for 32->32)
 static int g_auto_mfma = 1;         // auto mode uses the MFMA kernel for its eligible shapes once A/B says so
 extern "C" int pcgc_set_conv_impl(int impl) { g_conv_impl = impl; return 0; }
 
@@ -870,6 +761,20 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
     // on par (0.9-1.4x) on the FMA-bound ones; v0 only wins on tiny levels (< ~30k rows) where launch geometry dominates.
     const bool v1_eligible = nbr != nullptr && K <= 27 && aligned && small && (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64);
     const bool v1_wanted = g_conv_impl == 1 || (g_conv_impl < 0 && n_out >= 30000);
+    const bool wlds_shape = (Cin == 64 && Cout == 64) || (Cin == 32 && Cout == 32);
+    if (v1_eligible && wlds_shape && (((uintptr_t)W) & 15) == 0 && (g_conv_impl == 3 || (g_conv_impl < 0 && g_auto_wlds && Cin == 64 && n_out >= 30000))) {
+        const float* res0 = residual ? residual + res_coff : nullptr;
+        float* out0 = out + out_coff;
+        if (Cin == 64) {
+            if (n_out < 400000) launch_mfma_wlds<64, 64, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+            else launch_mfma_wlds<64, 64, 4>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        } else {
+            if (n_out < 400000) launch_mfma_wlds<32, 32, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+            else launch_mfma_wlds<32, 32, 4>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        }
+        PCGC_CHECK_LAUNCH("conv_gather_mfma_wlds");
+        return 0;
+    }
     const bool mfma_eligible = v1_eligible && (Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 16 || Cout == 32 || Cout == 64);
     if (mfma_eligible && (g_conv_impl == 2 || (g_conv_impl < 0 && g_auto_mfma && n_out >= 30000))) {
         const float* res0 = residual ? residual + res_coff : nullptr;

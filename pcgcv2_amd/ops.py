@@ -274,31 +274,6 @@ def conv_gather(nbr, x, W, bias, out=None, residual=None, relu=False, n_out=None
     return out
 
 
-class TileMap:
-    """Tile-local map of one level (built from its k3 kernel map): distinct source rows + uint8 local indices per tile."""
-
-    def __init__(self, nbr):
-        n = nbr.shape[1]
-        tiles = (n + 63) // 64
-        self.nbr = nbr
-        self.U = torch.empty((tiles, 256), dtype=torch.int32, device=nbr.device)
-        self.L = torch.empty((tiles, 27, 64), dtype=torch.uint8, device=nbr.device)
-        self.ucount = torch.empty(tiles, dtype=torch.int32, device=nbr.device)
-        check(lib().pcgc_tilemap_build(_p(nbr), n, _p(self.U), _p(self.L), _p(self.ucount), _stream()), 'tilemap_build')
-
-
-def conv_gather_tl(tm, x, W, bias, out=None, residual=None, relu=False):
-    _f32(x, 'x'); _f32(W, 'W')
-    K, Cin, Cout = W.shape
-    n_out = tm.nbr.shape[1]
-    if out is None:
-        out = torch.empty((n_out, Cout), dtype=torch.float32, device=x.device)
-    res_p, res_ld = (None, 0) if residual is None else (_p(_f32(residual)), _ld(residual))
-    check(lib().pcgc_conv_gather_tl(_p(tm.nbr), _p(tm.U), _p(tm.L), _p(tm.ucount), n_out, _p(x), x.shape[0], Cin, _ld(x), _p(W),
-                                    _p(bias), res_p, res_ld, int(relu), _p(out), Cout, _ld(out), _stream()), 'conv_gather_tl')
-    return out
-
-
 FUSE_IRN = True           # tests flip this to compare the fused block against its five-conv composition
 
 

@@ -23,7 +23,7 @@ for name, cin, cout in shapes:
     x = torch.randn((n, cin), generator=g).to(dev); W = (torch.randn((27, cin, cout), generator=g) / (27 * cin) ** .5).to(dev)
     b = torch.randn((1, cout), generator=g).to(dev)
     res = {}
-    for impl in (0, 1, 2):
+    for impl in (0, 1, 2, 3):
         ops.set_conv_impl(impl)
         for _ in range(2): y = ops.conv_gather(nbr, x, W, b)
         torch.cuda.synchronize()
@@ -34,7 +34,8 @@ for name, cin, cout in shapes:
         res[impl] = (e0.elapsed_time(e1) / 5 * 1e3, y.clone())
     assert torch.equal(res[0][1], res[1][1]), (name, cin, cout)
     assert torch.equal(res[0][1], res[2][1]), ('mfma', name, cin, cout)
+    assert torch.equal(res[0][1], res[3][1]), ('wlds', name, cin, cout)
     us = res[1][0]
     alg = P * cin * 4 + P * 8 + n * cout * 4
-    print(f'{name:>5} {n:8d} {cin:3d} {cout:4d} {res[0][0]:8.1f} {us:8.1f} {res[0][0] / us:7.2f}  {alg / us / 1e3:8.0f}  {2 * 27 * n * cin * cout / us / 1e6:6.1f}   mfma {res[2][0]:8.1f} us {2 * 27 * n * cin * cout / res[2][0] / 1e6:6.1f} TF')
+    print(f'{name:>5} {n:8d} {cin:3d} {cout:4d} {res[0][0]:8.1f} {us:8.1f} {res[0][0] / us:7.2f}  {alg / us / 1e3:8.0f}  {2 * 27 * n * cin * cout / us / 1e6:6.1f}   mfma {res[2][0]:8.1f} us {2 * 27 * n * cin * cout / res[2][0] / 1e6:6.1f} TF   wlds {res[3][0]:8.1f} us')
 ops.set_conv_impl(-1)
