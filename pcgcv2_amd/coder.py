@@ -1,91 +1,106 @@
-"""Codec API (reference coder.py:16-184): CoordinateCoder / FeatureCoder / Coder and the CLI, on the HIP operator set.
+"""Codec API of PCGCv2 on the MI355X operator set — drop-in for the reference's `coder.py` (classes CoordinateCoder,
+FeatureCoder, Coder at coder.py:16-112; CLI at coder.py:114-184): same constructor / method signatures, same four files.
 
-Same constructor / method signatures, same four files per coded cloud:
-   <prefix><postfix>_C.bin           coordinates of the stride-8 latent (tmc3 stream, or native "PCGO" stream)
-   <prefix><postfix>_F.bin           range-coded latent features (torchac-compatible stream)
-   <prefix><postfix>_H.bin           int32[2] shape | int8 len(min_v)=1 | float32 min_v | float32 max_v   (17 bytes)
-   <prefix><postfix>_num_points.bin  int32[3] = [N4, N2, N1]
+Bitstream of one coded cloud, `<prefix><postfix>` + :
+    _C.bin            coordinates of the stride-8 latent: a G-PCC stream if a `tmc3` binary is installed, else the native
+                      "PCGO" octree stream (gpcc.py)
+    _F.bin            range-coded latent features (torchac-compatible stream)
+    _H.bin            17 bytes, little endian:  int32 N8 | int32 C | int8 1 | float32 min_v | float32 max_v
+    _num_points.bin   int32[3] = [N4, N2, N1]   (the top-k budgets of the three decoder stages)
 """
 import os
+import struct
 import time
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 import torch
 
-from . import gpcc
-from .data_utils import (array2vector, istopk, sort_spare_tensor, load_sparse_tensor, scale_sparse_tensor,
+from . import gpcc, ops
+from .data_utils import (array2vector, istopk, sort_spare_tensor, load_sparse_tensor, scale_sparse_tensor,  # noqa: F401
                          write_ply_ascii_geo, read_ply_ascii_geo)
 from .pc_error import pc_error
 from .pcc_model import PCCModel
-from concurrent.futures import ThreadPoolExecutor
 from .sparse import SparseTensor, CoordMap, require_gpu
-from . import ops
-
-_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix='pcgc-coord')
 
 device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix='pcgc-coord')
+
+_HEADER = struct.Struct('<iibff')                 # (N8, C, len(min_v)=1, min_v, max_v) — coder.py:51-55
+_COUNTS = struct.Struct('<3i')                    # (N4, N2, N1)                       — coder.py:85-87
+STREAMS = ('_C.bin', '_F.bin', '_H.bin', '_num_points.bin')
+
+
+def _dump(path, payload):
+    with open(path, 'wb') as fh:
+        fh.write(payload)
+
+
+def _slurp(path):
+    with open(path, 'rb') as fh:
+        return fh.read()
+
+
+def stream_bits(prefix, postfix=''):
+    """bits of the four files of one coded cloud (coder.py:169-170)."""
+    return np.array([os.path.getsize(prefix + postfix + s) * 8 for s in STREAMS])
 
 
 class CoordinateCoder():
-    """coder.py:16-36.  Uses tmc3 when installed (identical temp-PLY + subprocess protocol), else the native codec."""
+    """Lossless coder of the stride-8 coordinates.  With tmc3 installed: the reference's temp-PLY + subprocess protocol
+    (coder.py:23-36); otherwise the in-process octree codec, no temp files."""
 
     def __init__(self, filename):
         self.filename = filename
         self.ply_filename = filename + '.ply'
 
+    def _path(self, postfix):
+        return self.filename + postfix + '_C.bin'
+
     def encode(self, coords, postfix=''):
-        coords = (coords.numpy() if isinstance(coords, torch.Tensor) else np.asarray(coords)).astype('int')
-        bin_path = self.filename + postfix + '_C.bin'
-        if gpcc.tmc3_path() is not None:
-            write_ply_ascii_geo(filedir=self.ply_filename, coords=coords)
-            gpcc.gpcc_encode(self.ply_filename, bin_path)
+        pts = coords.numpy() if isinstance(coords, torch.Tensor) else np.asarray(coords)
+        pts = pts.astype('int')
+        if gpcc.tmc3_path() is None:
+            gpcc.native_encode(pts, self._path(postfix))
+            return
+        write_ply_ascii_geo(filedir=self.ply_filename, coords=pts)
+        try:
+            gpcc.gpcc_encode(self.ply_filename, self._path(postfix))
+        finally:
             os.remove(self.ply_filename)
-        else:
-            gpcc.native_encode(coords, bin_path)
-        return
 
     def decode(self, postfix=''):
-        bin_path = self.filename + postfix + '_C.bin'
-        if gpcc.is_native_stream(bin_path):
-            return gpcc.native_decode(bin_path)
-        gpcc.gpcc_decode(bin_path, self.ply_filename)
-        coords = read_ply_ascii_geo(self.ply_filename)
-        os.remove(self.ply_filename)
-        return coords
+        if gpcc.is_native_stream(self._path(postfix)):
+            return gpcc.native_decode(self._path(postfix))
+        gpcc.gpcc_decode(self._path(postfix), self.ply_filename)
+        try:
+            return read_ply_ascii_geo(self.ply_filename)
+        finally:
+            os.remove(self.ply_filename)
 
 
 class FeatureCoder():
-    """coder.py:39-70."""
+    """Latent features <-> `_F.bin` + `_H.bin` through the factorized entropy bottleneck (coder.py:39-70)."""
 
     def __init__(self, filename, entropy_model):
         self.filename = filename
-        self.entropy_model = entropy_model.cpu()      # no-op here: the tables are evaluated on the GPU
+        self.entropy_model = entropy_model.cpu()      # the reference moves it to the CPU; ours stays on the GPU (no-op)
 
     def encode(self, feats, postfix=''):
-        strings, min_v, max_v = self.entropy_model.compress(feats)
-        shape = feats.shape
-        with open(self.filename + postfix + '_F.bin', 'wb') as fout:
-            fout.write(strings)
-        with open(self.filename + postfix + '_H.bin', 'wb') as fout:
-            fout.write(np.array(shape, dtype=np.int32).tobytes())
-            fout.write(np.array(len(min_v), dtype=np.int8).tobytes())
-            fout.write(np.array(min_v, dtype=np.float32).tobytes())
-            fout.write(np.array(max_v, dtype=np.float32).tobytes())
-        return
+        payload, min_v, max_v = self.entropy_model.compress(feats)
+        _dump(self.filename + postfix + '_F.bin', payload)
+        n, c = feats.shape
+        _dump(self.filename + postfix + '_H.bin', _HEADER.pack(n, c, len(min_v), float(min_v[0]), float(max_v[0])))
 
     def decode(self, postfix='', device=None):
-        with open(self.filename + postfix + '_F.bin', 'rb') as fin:
-            strings = fin.read()
-        with open(self.filename + postfix + '_H.bin', 'rb') as fin:
-            shape = np.frombuffer(fin.read(4 * 2), dtype=np.int32)
-            len_min_v = np.frombuffer(fin.read(1), dtype=np.int8)[0]
-            min_v = np.frombuffer(fin.read(4 * len_min_v), dtype=np.float32)[0]
-            max_v = np.frombuffer(fin.read(4 * len_min_v), dtype=np.float32)[0]
-        return self.entropy_model.decompress(strings, min_v, max_v, shape, channels=shape[-1], device=device)
+        n, c, n_minv, min_v, max_v = _HEADER.unpack(_slurp(self.filename + postfix + '_H.bin')[:_HEADER.size])
+        if n_minv != 1:
+            raise ValueError('unsupported _H.bin: expected one (min_v, max_v) pair')
+        payload = _slurp(self.filename + postfix + '_F.bin')
+        return self.entropy_model.decompress(payload, np.float32(min_v), np.float32(max_v), (n, c), channels=c, device=device)
 
 
 class Coder():
-    """coder.py:73-112."""
-
     def __init__(self, model, filename):
         self.model = model
         self.filename = filename
@@ -94,102 +109,106 @@ class Coder():
 
     @torch.no_grad()
     def encode(self, x, postfix=''):
-        """coder.py:80-91.  Same outputs, different schedule: the geometry pyramid (N1 -> N2 -> N4 -> N8) is built first, so
-        the stride-8 coordinates — all the coordinate coder needs — are on the host before the convolutions are even
-        enqueued, and the (sequential, host-side) coordinate coding overlaps the GPU's encoder pass."""
-        c8 = x.cmap
+        """coder.py:80-91: writes the four files, returns the sorted stride-8 latent.  Schedule: the geometry pyramid
+        (N1 -> N2 -> N4 -> N8) is built first, so the stride-8 coordinates — all the coordinate coder needs — reach the host
+        before the convolutions are even enqueued; the sequential host-side coordinate coding then overlaps the GPU's
+        encoder pass."""
+        lvl8 = x.cmap
         for _ in range(3):
-            c8 = c8.down()[0]                                   # cached on the levels: the encoder reuses these maps
-        perm = ops.sort_zyx(c8.C)
-        y_C = ops.gather_coords(c8.C, perm)
-        coords8 = y_C.cpu().numpy()[:, 1:] // c8.stride         # tiny D2H (N8 x 16 B)
-        y_list = self.model.encoder(x)                          # asynchronous: ~60 kernel launches
-        self.coordinate_coder.encode(coords8, postfix=postfix)  # runs on the host while the GPU computes
-        y = SparseTensor(ops.gather_feats(y_list[0].F, perm), coordinate_map=CoordMap(y_C, c8.stride, unique=True))
-        num_points = [len(ground_truth) for ground_truth in y_list[1:] + [x]]
-        with open(self.filename + postfix + '_num_points.bin', 'wb') as f:
-            f.write(np.array(num_points, dtype=np.int32).tobytes())
+            lvl8 = lvl8.down()[0]                               # cached on the levels: the encoder reuses these maps
+        order = ops.sort_zyx(lvl8.C)                            # (z, y, x, batch) order of sort_spare_tensor
+        y_C = ops.gather_coords(lvl8.C, order)
+        coords8 = y_C.cpu().numpy()[:, 1:] // lvl8.stride       # tiny D2H (N8 x 16 B)
+        y_list = self.model.encoder(x)                          # asynchronous: ~40 kernel launches
+        self.coordinate_coder.encode(coords8, postfix=postfix)  # host work, hidden behind the GPU
+        y = SparseTensor(ops.gather_feats(y_list[0].F, order), coordinate_map=CoordMap(y_C, lvl8.stride, unique=True))
+        budgets = [len(t) for t in (y_list[1], y_list[2], x)]
+        _dump(self.filename + postfix + '_num_points.bin', _COUNTS.pack(*budgets))
         self.feature_coder.encode(y.F, postfix=postfix)
         return y
 
     @torch.no_grad()
     def decode(self, rho=1, postfix=''):
+        """coder.py:93-112: reads the four files, returns the decoded stride-1 sparse tensor."""
         dev = require_gpu(next(self.model.decoder.parameters()).device)
-        # the two bitstreams are independent: decode the coordinates on a helper thread while this thread range-decodes
+        # the two bitstreams are independent: the coordinates are decoded on a helper thread while this thread range-decodes
         # the features (both are native calls that release the GIL)
-        fut_C = _POOL.submit(self.coordinate_coder.decode, postfix)
+        pending = _POOL.submit(self.coordinate_coder.decode, postfix)
         y_F = self.feature_coder.decode(postfix=postfix, device=dev)
-        y_C = fut_C.result()
-        # coder.py:96-99: prepend the batch column and sort with array2vector on the host; here the (tiny) list goes to the
-        # device in one copy and is sorted there (same (z,y,x,batch) order)
-        y_C4 = np.zeros((len(y_C), 4), dtype=np.int32)
-        y_C4[:, 1:] = np.asarray(y_C, dtype=np.int32) * 8
+        xyz8 = np.asarray(pending.result(), dtype=np.int32)
+        y_C4 = np.zeros((len(xyz8), 4), dtype=np.int32)          # batch column 0, coordinates back at tensor stride 8
+        y_C4[:, 1:] = xyz8 * 8
         y_C = torch.from_numpy(y_C4).to(dev)
-        y_C = ops.gather_coords(y_C, ops.sort_zyx(y_C))
+        y_C = ops.gather_coords(y_C, ops.sort_zyx(y_C))          # coder.py:97-99 (host argsort there, device sort here)
         y = SparseTensor(features=y_F, coordinates=y_C, tensor_stride=8, device=dev, assume_unique=True)
-        with open(self.filename + postfix + '_num_points.bin', 'rb') as fin:
-            num_points = np.frombuffer(fin.read(4 * 3), dtype=np.int32).tolist()
-            num_points[-1] = int(rho * num_points[-1])
-            num_points = [[num] for num in num_points]
-        _, out = self.model.decoder(y, nums_list=num_points, ground_truth_list=[None] * 3, training=False)
+        n4, n2, n1 = _COUNTS.unpack(_slurp(self.filename + postfix + '_num_points.bin')[:_COUNTS.size])
+        budgets = [[n4], [n2], [int(rho * n1)]]                  # coder.py:105-108
+        _, out = self.model.decoder(y, nums_list=budgets, ground_truth_list=[None] * 3, training=False)
         return out
 
 
-def main(argv=None):
+# ------------------------------------------------------------------------------------------------ CLI (coder.py:114-184)
+def _parse_cli(argv):
     import argparse
-    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    parser.add_argument("--ckptdir", default='ckpts/r3_0.10bpp.pth')
-    parser.add_argument("--filedir", default='../../../testdata/8iVFB/longdress_vox10_1300.ply')
-    parser.add_argument("--scaling_factor", type=float, default=1.0, help='scaling_factor')
-    parser.add_argument("--rho", type=float, default=1.0,
-                        help='the ratio of the number of output points to the number of input points')
-    parser.add_argument("--res", type=int, default=1024, help='resolution')
-    parser.add_argument("--outdir", default='./output')
-    args = parser.parse_args(argv)
-    filedir = args.filedir
+    p = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("--ckptdir", default='ckpts/r3_0.10bpp.pth')
+    p.add_argument("--filedir", default='../../../testdata/8iVFB/longdress_vox10_1300.ply')
+    p.add_argument("--scaling_factor", type=float, default=1.0, help='scaling_factor')
+    p.add_argument("--rho", type=float, default=1.0, help='the ratio of the number of output points to the number of input points')
+    p.add_argument("--res", type=int, default=1024, help='resolution')
+    p.add_argument("--outdir", default='./output')
+    return p.parse_args(argv)
 
-    start_time = time.time()
-    x = load_sparse_tensor(filedir, device)
-    print('Loading Time:\t', round(time.time() - start_time, 4), 's')
 
+class _Stopwatch:
+    def __init__(self, label, digits=3, sync=True):
+        self.label, self.digits, self.sync = label, digits, sync
+
+    def __enter__(self):
+        self.t0 = time.time()
+        return self
+
+    def __exit__(self, *exc):
+        if self.sync and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        print(f'{self.label}:\t', round(time.time() - self.t0, self.digits), 's')
+
+
+def main(argv=None):
+    args = _parse_cli(argv)
+    with _Stopwatch('Loading Time', 4, sync=False):
+        x = load_sparse_tensor(args.filedir, device)
     os.makedirs(args.outdir, exist_ok=True)
-    filename = os.path.join(args.outdir, os.path.split(filedir)[-1].split('.')[0])
-    print(filename)
+    prefix = os.path.join(args.outdir, os.path.split(args.filedir)[-1].split('.')[0])
+    print(prefix)
 
     print('=' * 10, 'Test', '=' * 10)
+    if not os.path.exists(args.ckptdir):
+        raise FileNotFoundError(args.ckptdir)
     model = PCCModel().to(device)
-    assert os.path.exists(args.ckptdir)
-    ckpt = torch.load(args.ckptdir, map_location=device)
-    model.load_state_dict(ckpt['model'])
+    model.load_state_dict(torch.load(args.ckptdir, map_location=device)['model'])
     print('load checkpoint from \t', args.ckptdir)
 
-    coder = Coder(model=model, filename=filename)
-    x_in = scale_sparse_tensor(x, factor=args.scaling_factor) if args.scaling_factor != 1 else x
-
-    torch.cuda.synchronize(); start_time = time.time()
-    _ = coder.encode(x_in)
-    torch.cuda.synchronize(); print('Enc Time:\t', round(time.time() - start_time, 3), 's')
-
-    start_time = time.time()
-    x_dec = coder.decode(rho=args.rho)
-    torch.cuda.synchronize(); print('Dec Time:\t', round(time.time() - start_time, 3), 's')
-
-    if args.scaling_factor != 1:
+    coder = Coder(model=model, filename=prefix)
+    scaled = args.scaling_factor != 1
+    x_in = scale_sparse_tensor(x, factor=args.scaling_factor) if scaled else x
+    with _Stopwatch('Enc Time'):
+        coder.encode(x_in)
+    with _Stopwatch('Dec Time'):
+        x_dec = coder.decode(rho=args.rho)
+    if scaled:
         x_dec = scale_sparse_tensor(x_dec, factor=1.0 / args.scaling_factor)
 
-    bits = np.array([os.path.getsize(filename + postfix) * 8 for postfix in ['_C.bin', '_F.bin', '_H.bin', '_num_points.bin']])
-    bpps = (bits / len(x)).round(3)
+    bits = stream_bits(prefix)
+    bpps = (bits / len(x)).round(3)                      # per-file rounding, then summed (coder.py:171-173)
     print('bits:\t', bits, '\nbpps:\t', bpps)
     print('bits:\t', sum(bits), '\nbpps:\t', sum(bpps).round(3))
 
-    start_time = time.time()
-    write_ply_ascii_geo(filename + '_dec.ply', x_dec.C.detach().cpu().numpy()[:, 1:])
-    print('Write PC Time:\t', round(time.time() - start_time, 3), 's')
-
-    start_time = time.time()
-    pc_error_metrics = pc_error(args.filedir, filename + '_dec.ply', res=args.res, show=False)
-    print('PC Error Metric Time:\t', round(time.time() - start_time, 3), 's')
-    print('D1 PSNR:\t', pc_error_metrics["mseF,PSNR (p2point)"][0])
+    with _Stopwatch('Write PC Time', sync=False):
+        write_ply_ascii_geo(prefix + '_dec.ply', x_dec.C.detach().cpu().numpy()[:, 1:])
+    with _Stopwatch('PC Error Metric Time', sync=False):
+        metrics = pc_error(args.filedir, prefix + '_dec.ply', res=args.res, show=False)
+    print('D1 PSNR:\t', metrics["mseF,PSNR (p2point)"][0])
 
 
 if __name__ == '__main__':

@@ -102,6 +102,7 @@ def code_units(coder, units, rho=1.0, res=1024, with_d1=False):
     Each unit uses postfix '_<name>' so its four files never collide."""
     import os
     from .pc_error import d1_psnr_device
+    from .coder import stream_bits
     stats = Stats(device=units[0][1].device if units else 'cpu')
     outs = {}
     for idx in shard_units(len(units)):
@@ -109,7 +110,7 @@ def code_units(coder, units, rho=1.0, res=1024, with_d1=False):
         post = '_' + str(name)
         coder.encode(x, postfix=post)
         out = coder.decode(rho=rho, postfix=post)
-        bits = sum(os.path.getsize(coder.filename + post + s) * 8 for s in ('_C.bin', '_F.bin', '_H.bin', '_num_points.bin'))
+        bits = int(stream_bits(coder.filename, post).sum())
         ab = ba = 0.0
         if with_d1:                                       # exact nearest neighbours on the GPU (pcgc_d1_nn)
             m = d1_psnr_device(x.C, out.C, res)
