@@ -39,6 +39,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', default='shell9', help='bounded sample of the same workload for the CPU oracle')
     ap.add_argument('--no-events', action='store_true', help='do not bracket the dominant kernel with HIP events')
+    ap.add_argument('--irn-rows', type=int, default=0, help='force the fused-IRN tile height (A/B); 0 = automatic')
     ap.add_argument('--detail', default='', help='optional path for a per-kernel-shape JSON breakdown')
     return ap.parse_args()
 
@@ -71,6 +72,8 @@ def main():
     from pcgcv2_amd import synthetic, ops
     from pcgcv2_amd.pcc_model import PCCModel
     from pcgcv2_amd.coder import Coder
+    if args.irn_rows:
+        ops.set_irn_rows(args.irn_rows)
     from pcgcv2_amd.sparse import SparseTensor
 
     # ---- inputs: one frame per rank (distinct clouds per rank, like the 8iVFB 4-sequence config) ----

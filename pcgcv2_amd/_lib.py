@@ -33,6 +33,7 @@ SIGNATURES = {
     'pcgc_compact_index': (ci, [vp, vp, i64, vp, vp]),
     'pcgc_conv_gather': (ci, [vp, ci, i64, vp, i64, ci, ci, ci, vp, vp, vp, ci, ci, ci, vp, ci, ci, ci, vp]),
     'pcgc_set_conv_impl': (ci, [ci]),
+    'pcgc_set_irn_rows': (ci, [ci]),
     'pcgc_irn_block': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, ci, vp]),
     'pcgc_irn_pass': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, ci, ci, vp]),
     'pcgc_conv_up2': (ci, [i64, vp, ci, ci, vp, vp, ci, vp, ci, vp]),

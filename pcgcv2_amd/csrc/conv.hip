@@ -100,16 +100,17 @@ __device__ static inline unsigned xcd_tile(unsigned b, unsigned nb) {
 template <int N>
 __device__ static inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int CH>
-struct RowGather {                                   // one wave, 64 rows, CH 16-byte chunks per row
-    static constexpr int RPI = 64 / CH;
+template <int CH, int ROWS = 64>
+struct RowGather {                                   // one wave, ROWS (64/32/16) rows, CH 16-byte chunks per row
+    static constexpr int RPI = 64 / CH;              // rows fetched by one DMA instruction
+    static constexpr int NI = (ROWS + RPI - 1) / RPI;
     static constexpr int SH = (CH == 2) ? 3 : (CH == 4 ? 2 : 1);
     __device__ static inline void fetch(const __amdgpu_buffer_rsrc_t& rs, float4* rowbuf, int idx_cur, int in_ld, int col0, int lane) {
         const int dma_row_lo = lane / CH, dma_p = lane % CH;
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int r = i * RPI + dma_row_lo;
-            const int rid = __shfl(idx_cur, r, 64);
+            const int rid = r < ROWS ? __shfl(idx_cur, r, 64) : -1;
             const int chunk = dma_p ^ ((r >> SH) & (CH - 1));
             const unsigned voff = rid >= 0 ? (unsigned)(((int64_t)rid * in_ld + col0 + chunk * 4) * 4) : 0xFFFFFFF0u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)(rowbuf + i * 64), 16, (int)voff, 0, 0, 0);
@@ -121,6 +122,7 @@ struct RowGather {                                   // one wave, 64 rows, CH 16
 #pragma unroll
         for (int c = 0; c < CH; ++c) x[c] = rowbuf[lane * CH + (c ^ swz)];
     }
+    static constexpr int SLOTS = NI * 64;             // float4 slots one gather occupies in LDS
 };
 
 // acc[0..NO) += x4 (4 consecutive input channels) * w[4][ldw] rows, channel order preserved.
@@ -527,12 +529,15 @@ static bool dispatch_mfma(int Cout, const int32_t* nbr, int K, int64_t n_out, co
 //       ONE gather of the 2Q-wide rows of t feeds both k3 convs (the unfused form gathers two Q-wide tensors).
 // 5 launches / 3 gathers / 2 pointwise passes become 2 launches / 2 gathers; every fmaf chain is unchanged.
 // ----------------------------------------------------------------------------------------------------------------
+static int g_irn_rows = 0;          // 0 = choose the tile height from the level size; 64/32/16 force (A/B tests)
+extern "C" int pcgc_set_irn_rows(int rows) { g_irn_rows = rows; return 0; }
+
 // kernel offsets gathered per wait (27 = 9 x 3): more gathers in flight per wave.  Pays only while the extra row buffers do
 // not cut occupancy: measured irn_b<16> 194 -> 167 us, but irn_b<32> 127 -> 160 us and irn_b<64> 196 -> 433 us with 3.
 template <int C> struct IrnKG { static constexpr int value = (C == 16) ? 3 : 1; };       // pass B
 template <int C> struct IrnKGA { static constexpr int value = 1; };                     // pass A: 227 vs 212 us with 3 at C=16
 
-template <int C>
+template <int C, int ROWS>
 __global__ void __launch_bounds__(256)
 k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x, int x_ld,
         const float* __restrict__ W00, const float* __restrict__ b00, const float* __restrict__ W10,
@@ -542,11 +547,12 @@ k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x,
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float4* rowbuf = (float4*)lds_raw + (size_t)wave * (IrnKGA<C>::value * 64 * CH);
-    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * 64;
+    using RG = RowGather<CH, ROWS>;
+    float4* rowbuf = (float4*)lds_raw + (size_t)wave * (IrnKGA<C>::value * RG::SLOTS);
+    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * ROWS;
     if (row0 >= n) return;
     const int64_t my_row = row0 + lane;
-    const bool valid = my_row < n;
+    const bool valid = lane < ROWS && my_row < n;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(n * x_ld * 4), 0x00020000);
     __attribute__((aligned(8))) float acc0[Q];
     __attribute__((aligned(8))) float acc1[Q];
@@ -559,7 +565,7 @@ k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x,
         for (int g = 0; g < KG; ++g) idx[g] = valid ? nbr[(int64_t)g * n + my_row] : -1;
         for (int k0 = 0; k0 < 27; k0 += KG) {
 #pragma unroll
-            for (int g = 0; g < KG; ++g) RowGather<CH>::fetch(rs, rowbuf + g * (64 * CH), idx[g], x_ld, 0, lane);
+            for (int g = 0; g < KG; ++g) RG::fetch(rs, rowbuf + g * RG::SLOTS, idx[g], x_ld, 0, lane);
             int idx_n[KG];
 #pragma unroll
             for (int g = 0; g < KG; ++g) idx_n[g] = (valid && k0 + KG + g < 27) ? nbr[(int64_t)(k0 + KG + g) * n + my_row] : -1;
@@ -568,7 +574,7 @@ k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x,
 #pragma unroll
             for (int g = 0; g < KG; ++g) {
                 float4 xv[CH];
-                RowGather<CH>::read(rowbuf + g * (64 * CH), lane, xv);
+                RG::read(rowbuf + g * RG::SLOTS, lane, xv);
                 if (idx[g] >= 0) {
                     const int k = k0 + g;
                     const float* w = W00 + (int64_t)k * C * Q;
@@ -590,14 +596,14 @@ k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x,
         int idx_nxt = -1;
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
-            RowGather<CH>::fetch(rs, rowbuf, idx_cur, x_ld, cb * CB, lane);
+            RG::fetch(rs, rowbuf, idx_cur, x_ld, cb * CB, lane);
             if (cb == NB - 1 && k + 1 < 27) {
                 if (valid) idx_nxt = nbr[(int64_t)(k + 1) * n + my_row];
                 asm volatile("" ::: "memory");
                 wait_vmcnt<1>();
             } else wait_vmcnt<0>();
             float4 xv[CH];
-            RowGather<CH>::read(rowbuf, lane, xv);
+            RG::read(rowbuf, lane, xv);
             if (idx_cur >= 0) {
                 const float* w = W00 + ((int64_t)k * C + cb * CB) * Q;
 #pragma unroll
@@ -621,7 +627,7 @@ k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x,
     for (int i = 0; i < Q; ++i) y[Q + i] = fmaxf(acc1[i] + b10[i], 0.0f);
 }
 
-template <int C>
+template <int C, int ROWS>
 __global__ void __launch_bounds__(256)
 k_irn_b(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ t /*[n, C/2]*/, const float* __restrict__ x,
         int x_ld, const float* __restrict__ W01, const float* __restrict__ b01, const float* __restrict__ W11,
@@ -634,11 +640,12 @@ k_irn_b(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ t 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float4* rowbuf = (float4*)lds_raw + (size_t)wave * (KG * 64 * CH);
-    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * 64;
+    using RG = RowGather<CH, ROWS>;
+    float4* rowbuf = (float4*)lds_raw + (size_t)wave * (KG * RG::SLOTS);
+    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * ROWS;
     if (row0 >= n) return;
     const int64_t my_row = row0 + lane;
-    const bool valid = my_row < n;
+    const bool valid = lane < ROWS && my_row < n;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)t, 0, (int)(n * H * 4), 0x00020000);
     __attribute__((aligned(8))) float acc0[H];
     __attribute__((aligned(8))) float acc1[Q];
@@ -652,7 +659,7 @@ k_irn_b(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ t 
     for (int g = 0; g < KG; ++g) idx[g] = valid ? nbr[(int64_t)g * n + my_row] : -1;
     for (int k0 = 0; k0 < 27; k0 += KG) {
 #pragma unroll
-        for (int g = 0; g < KG; ++g) RowGather<CH>::fetch(rs, rowbuf + g * (64 * CH), idx[g], H, 0, lane);
+        for (int g = 0; g < KG; ++g) RG::fetch(rs, rowbuf + g * RG::SLOTS, idx[g], H, 0, lane);
         int idx_n[KG];
 #pragma unroll
         for (int g = 0; g < KG; ++g) idx_n[g] = (valid && k0 + KG + g < 27) ? nbr[(int64_t)(k0 + KG + g) * n + my_row] : -1;
@@ -661,7 +668,7 @@ k_irn_b(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ t 
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
             float4 tv[CH];
-            RowGather<CH>::read(rowbuf + g * (64 * CH), lane, tv);
+            RG::read(rowbuf + g * RG::SLOTS, lane, tv);
             if (idx[g] >= 0) {
                 const int k = k0 + g;
                 const float* w0 = W01 + (int64_t)k * Q * H;          // [Q][H]
@@ -700,17 +707,31 @@ k_irn_b(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ t 
     }
 }
 
-// phase: 1 = pass A only, 2 = pass B only, 3 = both
-template <int C>
+// phase: 1 = pass A only, 2 = pass B only, 3 = both.  ROWS = rows per wave (64 by default; 32 / 16 exist for A/B tests: the
+// idea was to give small levels more waves per SIMD — a 71 k-row level is only 1.1 waves per SIMD with 64-row tiles).
+template <int C, int ROWS>
 static void launch_irn(const int32_t* nbr, int64_t n, const float* x, int x_ld, const float* const* P, float* t, float* out,
                        int out_ld, int phase, hipStream_t s) {
     constexpr int CBA = C < 32 ? C : 32;
-    const size_t lds_a = 4 * (size_t)(IrnKGA<C>::value * 64 * (CBA / 4) * 16), lds_b = 4 * (size_t)(IrnKG<C>::value * 64 * (C / 8) * 16);
+    const size_t lds_a = 4 * (size_t)(IrnKGA<C>::value * RowGather<CBA / 4, ROWS>::SLOTS * 16);
+    const size_t lds_b = 4 * (size_t)(IrnKG<C>::value * RowGather<C / 8, ROWS>::SLOTS * 16);
+    const dim3 grid(grid_for(n, 4 * ROWS));
     if (phase & 1)
-        hipLaunchKernelGGL((k_irn_a<C>), dim3(grid_for(n, 256)), dim3(256), lds_a, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
+        hipLaunchKernelGGL((k_irn_a<C, ROWS>), grid, dim3(256), lds_a, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
     if (phase & 2)
-        hipLaunchKernelGGL((k_irn_b<C>), dim3(grid_for(n, 256)), dim3(256), lds_b, s, nbr, n, t, x, x_ld, P[2], P[3], P[6], P[7],
-                           P[8], P[9], out, out_ld);
+        hipLaunchKernelGGL((k_irn_b<C, ROWS>), grid, dim3(256), lds_b, s, nbr, n, t, x, x_ld, P[2], P[3], P[6], P[7], P[8], P[9],
+                           out, out_ld);
+}
+template <int C>
+static void launch_irn_rows(const int32_t* nbr, int64_t n, const float* x, int x_ld, const float* const* P, float* t, float* out,
+                            int out_ld, int phase, hipStream_t s) {
+    // measured (bench.py --irn-rows): 64 everywhere 13.8 ms/frame; 32/16 on the small levels 14.9 ms; 32 everywhere 15.0 ms —
+    // shorter tiles lose more DMA efficiency than the extra waves gain, so the automatic choice is always 64.
+    (void)n;
+    const int rows = g_irn_rows > 0 ? g_irn_rows : 64;
+    if (rows == 64) launch_irn<C, 64>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
+    else if (rows == 32) launch_irn<C, 32>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
+    else launch_irn<C, 16>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
 }
 
 // params: {W00,b00, W01,b01, W10,b10, W11,b11, W12,b12} = conv0_0, conv0_1, conv1_0, conv1_1, conv1_2 (kernel, bias)
@@ -734,9 +755,9 @@ static int irn_launch(const int32_t* nbr, int64_t n, const float* x, int C, int 
     for (int i = 0; i < 10; ++i) PCGC_REQUIRE(params[i] != nullptr, "null parameter tensor");
     PCGC_REQUIRE((((uintptr_t)x | (uintptr_t)t_scratch | (uintptr_t)out) & 15) == 0, "buffers must be 16-byte aligned");
     if (n == 0) return 0;
-    if (C == 16) launch_irn<16>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
-    else if (C == 32) launch_irn<32>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
-    else launch_irn<64>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
+    if (C == 16) launch_irn_rows<16>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
+    else if (C == 32) launch_irn_rows<32>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
+    else launch_irn_rows<64>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
     PCGC_CHECK_LAUNCH("irn_block");
     return 0;
 }

@@ -274,6 +274,11 @@ def conv_gather(nbr, x, W, bias, out=None, residual=None, relu=False, n_out=None
     return out
 
 
+def set_irn_rows(rows):
+    """rows per wave of the fused InceptionResNet passes: 0 = by level size (default), or force 64 / 32 / 16."""
+    check(lib().pcgc_set_irn_rows(int(rows)), 'set_irn_rows')
+
+
 FUSE_IRN = True           # tests flip this to compare the fused block against its five-conv composition
 
 

@@ -148,8 +148,9 @@ def test_conv_gather_bit_exact(K, cin, cout, conv_impl):
     assert not buf[:, :cout].any()
 
 
+@pytest.mark.parametrize('rows', [64, 32, 16])
 @pytest.mark.parametrize('C', [16, 32, 64])
-def test_fused_inception_resnet_bit_exact(C):
+def test_fused_inception_resnet_bit_exact(C, rows):
     """pcgc_irn_block (2 gather passes) == the oracle's five-conv InceptionResNet == the unfused HIP composition."""
     from pcgcv2_amd.autoencoder import InceptionResNet
     rng = np.random.default_rng(C)
@@ -164,13 +165,15 @@ def test_fused_inception_resnet_bit_exact(C):
     sd = {'b.' + k: v.detach().cpu().numpy() for k, v in blk.state_dict().items()}
     want = orc.inception_resnet(sd, 'b', orc.Level(c4, 1), x)
     assert ops.irn_eligible(xs.F)
-    with torch.no_grad():
-        fused = blk(xs).F.cpu().numpy()
-        ops.FUSE_IRN = False
-        try:
+    ops.set_irn_rows(rows)
+    try:
+        with torch.no_grad():
+            fused = blk(xs).F.cpu().numpy()
+            ops.FUSE_IRN = False
             unfused = blk(xs).F.cpu().numpy()
-        finally:
-            ops.FUSE_IRN = True
+    finally:
+        ops.FUSE_IRN = True
+        ops.set_irn_rows(0)
     np.testing.assert_array_equal(unfused, want)
     np.testing.assert_array_equal(fused, want)
 
