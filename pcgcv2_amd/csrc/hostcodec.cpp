@@ -118,9 +118,8 @@ extern "C" int pcgc_rc_decode(const uint16_t* cdf, int C, int Lp, const uint8_t*
 
 // ------------------------------------------------------------------------------------------------ octree codec
 // Breadth-first occupancy octree over the Morton-sorted points; each node's 8-bit child occupancy is coded as 8 binary
-// decisions with an adaptive binary range coder (12-bit probabilities, carry-propagating 32-bit range, LZMA-style).
-// Context of child bit j = (level bucket, bits already coded in this node, number of occupied face-neighbours of the
-// PARENT among the 6 same-level neighbours) — neighbour occupancy is what G-PCC exploits too; here it is a 0..6 count.
+// decisions with an adaptive binary range coder (12-bit probabilities, carry-propagating 32-bit range, LZMA-style);
+// the contexts (struct OctCoder) are neighbour-occupancy based, which is also what G-PCC exploits.
 namespace {
 
 struct BinEnc {
@@ -176,41 +175,72 @@ inline void demorton3(uint64_t m, int32_t& x, int32_t& y, int32_t& z) {
     x = compact(m); y = compact(m >> 1); z = compact(m >> 2);
 }
 
-constexpr int kLevelBuckets = 4;       // root-side levels share statistics poorly; bucket by distance from the leaves
-constexpr int kNbrClasses = 7;         // 0..6 occupied face neighbours
-struct OctModel {
-    std::vector<uint16_t> p;
-    OctModel() : p((size_t)kLevelBuckets * kNbrClasses * 256, 2048) {}
-    inline uint16_t& at(int bucket, int nb, int node) { return p[((size_t)bucket * kNbrClasses + nb) * 256 + node]; }
-};
-
-// Occupancy of one octree level for the neighbour contexts: a Morton-indexed bitmap while the level has at most 2^24
-// cells (2 MiB), binary search in the sorted node list beyond that.
+// Occupancy of one octree level: a Morton-indexed bitmap while the level has at most 2^24 cells (2 MiB), binary search in
+// the sorted node list beyond that.  `grow` variant: the level under construction (children appended in Morton order).
 struct LevelOcc {
     const std::vector<uint64_t>* nodes = nullptr; int level_bits = 0; bool use_bitmap = false;
     std::vector<uint64_t> bits;
-    void build(const std::vector<uint64_t>& n, int lb) {
+    void begin(const std::vector<uint64_t>& n, int lb, bool prefill) {
         nodes = &n; level_bits = lb; use_bitmap = 3 * lb <= 24;
         if (use_bitmap) {
             bits.assign(((size_t)1 << (3 * lb)) / 64 + 1, 0);
-            for (uint64_t c : n) bits[c >> 6] |= 1ull << (c & 63);
+            if (prefill) for (uint64_t c : n) bits[c >> 6] |= 1ull << (c & 63);
         }
     }
+    inline void mark(uint64_t c) { if (use_bitmap) bits[c >> 6] |= 1ull << (c & 63); }
     inline bool has(uint64_t c) const {
         return use_bitmap ? ((bits[c >> 6] >> (c & 63)) & 1ull) != 0 : std::binary_search(nodes->begin(), nodes->end(), c);
     }
-    // number of occupied face neighbours (0..6) of node `code`
-    inline int face_neighbours(uint64_t code) const {
-        int32_t x, y, z; demorton3(code, x, y, z);
-        const int32_t lim = (level_bits >= 21) ? INT32_MAX : (1 << level_bits);
+    inline int lim() const { return level_bits >= 21 ? INT32_MAX : (1 << level_bits); }
+};
+
+// Context model shared by encoder and decoder.  For child j = (jx,jy,jz) of node P the context is
+//   * the level bucket (distance from the leaves, 0..3),
+//   * per axis, whether the child's OUTWARD neighbour is occupied: on the low side (j_axis = 0) that neighbour is a child of
+//     P - e_axis, which precedes P in Morton order and is therefore already coded (exact child-level knowledge); on the high
+//     side (j_axis = 1) it belongs to P + e_axis whose children are not known yet, so the parent-level occupancy is used,
+//   * the position in the node's byte: child index and how many of the earlier siblings are occupied,
+//   * the number of occupied face neighbours of P (0..6), coarsened to 0 / 1-2 / 3-4 / 5-6.
+// Surfaces are locally connected, so "is there something right next to this cell" is by far the strongest predictor.
+constexpr uint8_t kOctVersion = 2;
+struct OctCoder {
+    static constexpr int kBuckets = 4, kAxis = 8, kPos = 8 * 9, kNb = 4;
+    std::vector<uint16_t> prob;
+    LevelOcc parent, child;
+    OctCoder() : prob((size_t)kBuckets * kAxis * kPos * kNb, 2048) {}
+    int bucket = 0, nb_class = 0;
+    bool has_hi[3] = {false, false, false};          // parent-level neighbour on the +x / +y / +z side exists
+    bool lo_ok[3] = {false, false, false};           // parent has a neighbour slot on the -x / -y / -z side (inside the cube)
+    uint64_t lo_code[3] = {0, 0, 0};                 // Morton code of P - e_axis (its children are already coded)
+    void begin_level(const std::vector<uint64_t>& nodes, const std::vector<uint64_t>& next, int lvl, int depth) {
+        bucket = std::min(kBuckets - 1, depth - 1 - lvl);
+        parent.begin(nodes, lvl, true);
+        child.begin(next, lvl + 1, false);
+    }
+    void begin_node(uint64_t node) {
+        int px, py, pz; demorton3(node, px, py, pz);
+        const int lim = parent.lim();
+        const int p[3] = {px, py, pz};
         int cnt = 0;
-        if (x > 0) cnt += has(morton3(x - 1, y, z));
-        if (x + 1 < lim) cnt += has(morton3(x + 1, y, z));
-        if (y > 0) cnt += has(morton3(x, y - 1, z));
-        if (y + 1 < lim) cnt += has(morton3(x, y + 1, z));
-        if (z > 0) cnt += has(morton3(x, y, z - 1));
-        if (z + 1 < lim) cnt += has(morton3(x, y, z + 1));
-        return cnt;
+        for (int a = 0; a < 3; ++a) {
+            int q[3] = {px, py, pz};
+            lo_ok[a] = p[a] > 0;
+            if (lo_ok[a]) { q[a] = p[a] - 1; lo_code[a] = morton3(q[0], q[1], q[2]); cnt += parent.has(lo_code[a]); }
+            has_hi[a] = false;
+            if (p[a] + 1 < lim) { q[a] = p[a] + 1; has_hi[a] = parent.has(morton3(q[0], q[1], q[2])); cnt += has_hi[a]; }
+        }
+        nb_class = (cnt + 1) / 2;                                   // 0, 1-2, 3-4, 5-6
+    }
+    // outward neighbour of child j along axis a: high side -> parent-level knowledge; low side -> the child (j | bit_a) of
+    // P - e_a, looked up in the level under construction
+    inline bool outward(int j, int a) const {
+        const int bit = 1 << a;
+        if (j & bit) return has_hi[a];
+        return lo_ok[a] && child.has((lo_code[a] << 3) | (uint64_t)(j | bit));
+    }
+    inline uint16_t& ctx(int j, int occupied_before) {
+        const int axis = (int)outward(j, 0) | ((int)outward(j, 1) << 1) | ((int)outward(j, 2) << 2);
+        return prob[(((size_t)bucket * kAxis + axis) * kPos + (j * 9 + occupied_before)) * kNb + nb_class];
     }
 };
 
@@ -218,6 +248,7 @@ constexpr uint8_t kMagic[4] = {'P', 'C', 'G', 'O'};
 
 }  // namespace
 
+// stream: "PCGO" | version u8 | depth u8 | n u32 | range-coded occupancy bits
 extern "C" int64_t pcgc_oct_encode(const int32_t* xyz, int64_t n, uint8_t* out, int64_t cap) {
     uint32_t maxc = 0;
     for (int64_t i = 0; i < 3 * n; ++i) { if (xyz[i] < 0 || xyz[i] >= (1 << 21)) return INT64_MIN; maxc = std::max(maxc, (uint32_t)xyz[i]); }
@@ -228,68 +259,66 @@ extern "C" int64_t pcgc_oct_encode(const int32_t* xyz, int64_t n, uint8_t* out, 
     leaves.erase(std::unique(leaves.begin(), leaves.end()), leaves.end());
     const int64_t n_unique = (int64_t)leaves.size();
 
-    BinEnc enc; OctModel model; LevelOcc occ_map;
+    BinEnc enc; OctCoder oc;
     std::vector<uint64_t> level_nodes, next;
     if (n_unique > 0) level_nodes.push_back(0);
     for (int lvl = 0; lvl < depth && !level_nodes.empty(); ++lvl) {
         const int shift = 3 * (depth - 1 - lvl);                     // leaves >> shift = child code at level lvl+1
-        const int bucket = std::min(kLevelBuckets - 1, depth - 1 - lvl);
         next.clear();
-        occ_map.build(level_nodes, lvl);
+        next.reserve(level_nodes.size() * 2);
+        oc.begin_level(level_nodes, next, lvl, depth);
         size_t cursor = 0;
         for (uint64_t node : level_nodes) {
             unsigned occ = 0;
             while (cursor < leaves.size() && ((leaves[cursor] >> shift) >> 3) == node) { occ |= 1u << ((leaves[cursor] >> shift) & 7); ++cursor; }
-            const int nb = occ_map.face_neighbours(node);
-            int tree = 1;
+            oc.begin_node(node);
+            int before = 0;
             for (int j = 0; j < 8; ++j) {
-                int bit = (occ >> j) & 1;
-                enc.encode(model.at(bucket, nb, tree), bit);
-                tree = (tree << 1) | bit;
-                if (bit) next.push_back((node << 3) | (uint64_t)j);
+                const int bit = (occ >> j) & 1;
+                enc.encode(oc.ctx(j, before), bit);
+                if (bit) { const uint64_t c = (node << 3) | (uint64_t)j; next.push_back(c); oc.child.mark(c); ++before; }
             }
         }
         level_nodes.swap(next);
     }
     enc.finish();
-    const int64_t total = 4 + 1 + 4 + (int64_t)enc.out.size();
+    const int64_t total = 4 + 2 + 4 + (int64_t)enc.out.size();
     if (total > cap) return -total;
     std::memcpy(out, kMagic, 4);
-    out[4] = (uint8_t)depth;
-    uint32_t n32 = (uint32_t)n_unique; std::memcpy(out + 5, &n32, 4);
-    std::memcpy(out + 9, enc.out.data(), enc.out.size());
+    out[4] = kOctVersion; out[5] = (uint8_t)depth;
+    uint32_t n32 = (uint32_t)n_unique; std::memcpy(out + 6, &n32, 4);
+    std::memcpy(out + 10, enc.out.data(), enc.out.size());
     return total;
 }
 
 extern "C" int64_t pcgc_oct_decode_count(const uint8_t* in, int64_t nbytes) {
-    if (nbytes < 9 || std::memcmp(in, kMagic, 4) != 0) return -1;
-    uint32_t n32; std::memcpy(&n32, in + 5, 4);
+    if (nbytes < 10 || std::memcmp(in, kMagic, 4) != 0 || in[4] != kOctVersion) return -1;
+    uint32_t n32; std::memcpy(&n32, in + 6, 4);
     return (int64_t)n32;
 }
 
 extern "C" int pcgc_oct_decode(const uint8_t* in, int64_t nbytes, int32_t* xyz, int64_t n) {
     if (pcgc_oct_decode_count(in, nbytes) != n) return -1;
-    const int depth = in[4];
+    const int depth = in[5];
     if (depth < 1 || depth > 21) return -1;
-    BinDec dec{in + 9, nbytes - 9}; dec.init();
-    OctModel model; LevelOcc occ_map;
+    BinDec dec{in + 10, nbytes - 10}; dec.init();
+    OctCoder oc;
     std::vector<uint64_t> level_nodes, next;
     if (n > 0) level_nodes.push_back(0);
     for (int lvl = 0; lvl < depth && !level_nodes.empty(); ++lvl) {
-        const int bucket = std::min(kLevelBuckets - 1, depth - 1 - lvl);
         next.clear();
-        occ_map.build(level_nodes, lvl);
+        next.reserve(level_nodes.size() * 2);
+        oc.begin_level(level_nodes, next, lvl, depth);
         for (uint64_t node : level_nodes) {
-            const int nb = occ_map.face_neighbours(node);
-            int tree = 1;
+            oc.begin_node(node);
+            int before = 0;
             for (int j = 0; j < 8; ++j) {
-                int bit = dec.decode(model.at(bucket, nb, tree));
-                tree = (tree << 1) | bit;
-                if (bit) next.push_back((node << 3) | (uint64_t)j);
+                const int bit = dec.decode(oc.ctx(j, before));
+                if (bit) { const uint64_t c = (node << 3) | (uint64_t)j; next.push_back(c); oc.child.mark(c); ++before; }
             }
+            if ((int64_t)next.size() > n) return -2;                  // corrupt stream
         }
         level_nodes.swap(next);
-        if ((int64_t)level_nodes.size() > n) return -2;              // corrupt stream
     }
     if ((int64_t)level_nodes.size() != n) return -2;
     for (int64_t i = 0; i < n; ++i) demorton3(level_nodes[(size_t)i], xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);

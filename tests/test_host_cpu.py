@@ -61,7 +61,7 @@ def test_octree_codec_roundtrip(case):
     elif case == 'big_coords':
         pts = np.unique(rng.integers(0, 1 << 20, size=(500, 3)), axis=0).astype(np.int32)
     else:
-        pts = np.unique(synthetic.shell('shell8').numpy() // 8, axis=0).astype(np.int32)
+        pts = np.unique(synthetic.shell('shell9').numpy() // 8, axis=0).astype(np.int32)          # 4576 stride-8 voxels
     rng.shuffle(pts)
     data = ops.oct_encode(pts)
     back = ops.oct_decode(data)
@@ -70,7 +70,7 @@ def test_octree_codec_roundtrip(case):
     np.testing.assert_array_equal(key(back), key(pts))
     if case == 'shell':
         bits_per_point = 8 * len(data) / len(pts)
-        assert bits_per_point < 4.0, bits_per_point
+        assert bits_per_point < 2.1, bits_per_point              # neighbour-context model: 1.88 bit/pt here, 1.47 on the vox10 frame
 
 
 def test_octree_rejects_foreign_stream():
