@@ -106,6 +106,14 @@ int pcgc_set_irn_rows(int rows);
  * pcgc_conv_gather calls it replaces. */
 int pcgc_irn_block(const int32_t* nbr /*[27,n]*/, int64_t n, const float* x /*[n,C], ld x_ld*/, int C, int x_ld,
                    const float* const* params, float* t_scratch, float* out, int out_ld, void* stream);
+/* Block-sparse k3 gather conv on the fp32 MFMA kernel with workgroup-shared weights (shapes 64->32 and 32->48, the two
+ * passes of the C=64 InceptionResNet with fused weights).  W [27,Cin,Cout] dense (zeros where sparse); tile_mask [27*Cin/16]
+ * uint32: bit n set = column tile n (16 columns) of that 16-row weight slice is non-zero; NULL = all tiles active. */
+int pcgc_conv_gather_masked(const int32_t* nbr, int64_t n_out, const float* in, int64_t n_in, int Cin, int in_ld, const float* W,
+                            int Cout, const uint32_t* tile_mask, const float* bias, int relu, float* out, int out_ld, void* stream);
+/* pointwise tail of the fused C=64 InceptionResNet: out = [u[:, :32] + x[:, :32] | relu(u[:, 32:48]) @ W12 + b12 + x[:, 32:]] */
+int pcgc_irn_tail(const float* u /*[n,48]*/, const float* x, int C, int x_ld, const float* W12 /*[16,32]*/, const float* b12,
+                  float* out, int out_ld, int64_t n, void* stream);
 /* the two gather passes of pcgc_irn_block separately (pass 1 = A: x -> t_scratch, pass 2 = B: t_scratch, x -> out);
  * same arguments; used to time the passes individually. */
 int pcgc_irn_pass(const int32_t* nbr, int64_t n, const float* x, int C, int x_ld, const float* const* params,

@@ -35,6 +35,8 @@ SIGNATURES = {
     'pcgc_set_conv_impl': (ci, [ci]),
     'pcgc_set_irn_rows': (ci, [ci]),
     'pcgc_irn_block': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, ci, vp]),
+    'pcgc_conv_gather_masked': (ci, [vp, i64, vp, i64, ci, ci, vp, ci, vp, vp, ci, vp, ci, vp]),
+    'pcgc_irn_tail': (ci, [vp, vp, ci, ci, vp, vp, vp, ci, i64, vp]),
     'pcgc_irn_pass': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, ci, ci, vp]),
     'pcgc_conv_up2': (ci, [i64, vp, ci, ci, vp, vp, ci, vp, ci, vp]),
     'pcgc_topk_workspace_bytes': (sz, [i64]),

@@ -25,8 +25,14 @@ class InceptionResNet(torch.nn.Module):
 
     def forward(self, x):
         c = x.F.shape[1]
-        if ops.irn_eligible(x.F):                           # two fused gather passes (pcgc_irn_block)
+        if ops.irn_eligible(x.F):                           # two fused gather passes
             params = [p for m in (self.conv0_0, self.conv0_1, self.conv1_0, self.conv1_1, self.conv1_2) for p in (m.kernel, m.bias)]
+            if c == 64 and ops.MFMA_IRN and x.F.shape[0] >= 30000:
+                # block-sparse MFMA path; the fused weights are rebuilt whenever a parameter tensor was replaced or modified
+                stamp = tuple((p.data_ptr(), p._version) for p in params)
+                if getattr(self, '_fused_stamp', None) != stamp:
+                    self._fused, self._fused_stamp = ops.fuse_irn64(params), stamp
+                return SparseTensor(ops.irn_block_mfma64(x.cmap.k3, x.F, self._fused), coordinate_map=x.cmap)
             return SparseTensor(ops.irn_block(x.cmap.k3, x.F, params), coordinate_map=x.cmap)
         out = torch.empty_like(x.F)
         a = self.conv0_0(x, relu=True)

@@ -395,7 +395,8 @@ k_conv_gather_mfma(const int32_t* __restrict__ nbr, int K, int64_t n_out, const 
 template <int CIN, int COUT, int MT>
 __global__ void __launch_bounds__(256)
 k_conv_gather_mfma_wlds(const int32_t* __restrict__ nbr, int K, int64_t n_out, const float* __restrict__ in, int64_t n_in,
-                        int in_ld, const float* __restrict__ W, const float* __restrict__ bias,
+                        int in_ld, const float* __restrict__ W, const uint32_t* __restrict__ tile_mask,
+                        const float* __restrict__ bias,
                         const float* __restrict__ res, int res_ld, int relu, float* __restrict__ out, int out_ld) {
     constexpr int NB = CIN / 16, NT = COUT / 16, ROWS = 16 * MT;
     constexpr int WSLICE = 16 * COUT;                                  // floats per (k, cb) weight slice
@@ -455,18 +456,23 @@ k_conv_gather_mfma_wlds(const int32_t* __restrict__ nbr, int K, int64_t n_out, c
                 lane_transpose4(a[m]);
             }
             const float* wb = wbuf + (t & 1) * WSLICE + mq * COUT + mi;     // B[j][n] = wb[(4j)*COUT + 16n]
+            // block-sparse weights: bit n of tile_mask[t] = "column tile n has a non-zero weight in slice t"; an all-zero tile
+            // would only add fma(x, 0, acc) = acc, so it is skipped (wave-uniform branch)
+            const uint32_t tmask = tile_mask ? __builtin_amdgcn_readfirstlane(tile_mask[t]) : 0xFFFFFFFFu;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float b[NT];
 #pragma unroll
                 for (int n = 0; n < NT; ++n) b[n] = wb[(4 * j) * COUT + 16 * n];
-                const float aj[4] = {0, 0, 0, 0};
-                (void)aj;
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const float av = j == 0 ? a[m].x : (j == 1 ? a[m].y : (j == 2 ? a[m].z : a[m].w));
+                for (int n = 0; n < NT; ++n) {
+                    if (tmask & (1u << n)) {
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[n], acc[m][n], 0, 0, 0);
+                        for (int m = 0; m < MT; ++m) {
+                            const float av = j == 0 ? a[m].x : (j == 1 ? a[m].y : (j == 2 ? a[m].z : a[m].w));
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[n], acc[m][n], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
@@ -493,10 +499,63 @@ k_conv_gather_mfma_wlds(const int32_t* __restrict__ nbr, int K, int64_t n_out, c
 
 template <int CIN, int COUT, int MT>
 static void launch_mfma_wlds(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int in_ld, const float* W,
-                             const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld, hipStream_t s) {
+                             const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld, hipStream_t s,
+                             const uint32_t* tile_mask = nullptr) {
     constexpr size_t lds = 2 * 16 * COUT * 4 + 4 * (size_t)(16 * MT * 64);
     hipLaunchKernelGGL((k_conv_gather_mfma_wlds<CIN, COUT, MT>), dim3(grid_for(n_out, 4 * 16 * MT)), dim3(256), lds, s, nbr, K,
-                       n_out, in, n_in, in_ld, W, bias, res, res_ld, relu, out, out_ld);
+                       n_out, in, n_in, in_ld, W, tile_mask, bias, res, res_ld, relu, out, out_ld);
+}
+
+// Block-sparse k3 gather conv on the LDS-shared-weight MFMA kernel (used by the fused C=64 InceptionResNet passes).
+extern "C" int pcgc_conv_gather_masked(const int32_t* nbr, int64_t n_out, const float* in, int64_t n_in, int Cin, int in_ld,
+                                       const float* W, int Cout, const uint32_t* tile_mask, const float* bias, int relu,
+                                       float* out, int out_ld, void* stream) {
+    PCGC_REQUIRE(nbr && in && W && out, "null argument");
+    PCGC_REQUIRE((in_ld & 3) == 0 && (((uintptr_t)in | (uintptr_t)W) & 15) == 0, "unaligned input");
+    PCGC_REQUIRE(n_in * (int64_t)in_ld * 4 < (int64_t)0xFFFFFFF0, "tensor too large for 32-bit buffer offsets");
+    if (n_out == 0) return 0;
+    hipStream_t s = S(stream);
+    if (Cin == 64 && Cout == 32) launch_mfma_wlds<64, 32, 2>(nbr, 27, n_out, in, n_in, in_ld, W, bias, nullptr, 0, relu, out, out_ld, s, tile_mask);
+    else if (Cin == 32 && Cout == 48) launch_mfma_wlds<32, 48, 2>(nbr, 27, n_out, in, n_in, in_ld, W, bias, nullptr, 0, relu, out, out_ld, s, tile_mask);
+    else { pcgc_set_error("conv_gather_masked: unsupported shape %d -> %d (64->32, 32->48)", Cin, Cout); return -2; }
+    PCGC_CHECK_LAUNCH("conv_gather_masked");
+    return 0;
+}
+
+// Tail of the fused C=64 InceptionResNet: u = [conv0_1 + b01 (2Q) | conv1_1 + b11 (Q)] ->
+//   out[:, 0:2Q] = u[:, 0:2Q] + x[:, 0:2Q] ;  out[:, 2Q:4Q] = (relu(u[:, 2Q:3Q]) @ W12 + b12) + x[:, 2Q:4Q]      (Q = C/4)
+template <int C>
+__global__ void __launch_bounds__(256) k_irn_tail(const float* __restrict__ u, const float* __restrict__ x, int x_ld,
+                                                  const float* __restrict__ W12, const float* __restrict__ b12,
+                                                  float* __restrict__ out, int out_ld, int64_t n) {
+    constexpr int Q = C / 4, H = C / 2, UW = 3 * Q;
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const float* ur = u + row * UW;
+    const float* xr = x + row * x_ld;
+    float* y = out + row * out_ld;
+    float acc[H];
+#pragma unroll
+    for (int i = 0; i < H; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int ci = 0; ci < Q; ++ci) {
+        const float v = fmaxf(ur[H + ci], 0.0f);
+#pragma unroll
+        for (int co = 0; co < H; ++co) acc[co] = fmaf(v, W12[ci * H + co], acc[co]);
+    }
+#pragma unroll
+    for (int co = 0; co < H; ++co) {
+        y[co] = ur[co] + xr[co];
+        y[H + co] = (acc[co] + b12[co]) + xr[H + co];
+    }
+}
+extern "C" int pcgc_irn_tail(const float* u, const float* x, int C, int x_ld, const float* W12, const float* b12, float* out,
+                             int out_ld, int64_t n, void* stream) {
+    PCGC_REQUIRE(C == 64, "irn_tail: only C = 64 is built");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL((k_irn_tail<64>), dim3(grid_for(n, 256)), dim3(256), 0, S(stream), u, x, x_ld, W12, b12, out, out_ld, n);
+    PCGC_CHECK_LAUNCH("irn_tail");
+    return 0;
 }
 
 template <int CIN, int NT>

@@ -307,6 +307,57 @@ def irn_block(nbr, x, params):
     return out
 
 
+MFMA_IRN = True           # C = 64 blocks run on the block-sparse MFMA kernel (A/B switch)
+
+
+def fuse_irn64(params):
+    """Fused weights of a C=64 InceptionResNet for the block-sparse MFMA path.  params as in irn_block.
+    pass A: Wa [27,64,32] = [conv0_0 | conv1_0 embedded at the centre offset, zero elsewhere], mask: tile 1 only at k = 13
+    pass B: Wb [27,32,48] = block diagonal [conv0_1 on channels 0:16 -> cols 0:32 | conv1_1 on channels 16:32 -> cols 32:48]."""
+    W00, b00, W01, b01, W10, b10, W11, b11, W12, b12 = [p.detach() for p in params]
+    dev = W00.device
+    Wa = torch.zeros((27, 64, 32), dtype=torch.float32, device=dev)
+    Wa[:, :, :16] = W00
+    Wa[13, :, 16:] = W10
+    ba = torch.cat([b00.reshape(-1), b10.reshape(-1)]).contiguous()
+    mask_a = torch.tensor([(1 | (2 if k == 13 else 0)) for k in range(27) for _ in range(4)], dtype=torch.int32, device=dev)
+    Wb = torch.zeros((27, 32, 48), dtype=torch.float32, device=dev)
+    Wb[:, :16, :32] = W01
+    Wb[:, 16:, 32:] = W11
+    bb = torch.cat([b01.reshape(-1), b11.reshape(-1)]).contiguous()
+    mask_b = torch.tensor([3, 4] * 27, dtype=torch.int32, device=dev)
+    return {'Wa': Wa, 'ba': ba, 'mask_a': mask_a, 'Wb': Wb, 'bb': bb, 'mask_b': mask_b,
+            'W12': W12.contiguous(), 'b12': b12.reshape(-1).contiguous()}
+
+
+def irn_block_mfma64(nbr, x, f):
+    """C = 64 InceptionResNet: two block-sparse MFMA gather convs + a pointwise tail; bit-identical to irn_block."""
+    _f32(x, 'x')
+    n = x.shape[0]
+    t = torch.empty((n, 32), dtype=torch.float32, device=x.device)
+    u = torch.empty((n, 48), dtype=torch.float32, device=x.device)
+    out = torch.empty((n, 64), dtype=torch.float32, device=x.device)
+    if PROFILE.counting:
+        PROFILE.count(nbr)
+    Q, C = 16, 64
+    steps = (
+        ('MFMA pass A k_conv_gather_mfma_wlds<64,32>', lambda P: (P * C * 4 + P * 8 + n * Q * 4) + n * (C + Q) * 4, lambda P: 2 * P * C * Q + 2 * n * C * Q,
+         lambda: lib().pcgc_conv_gather_masked(_p(nbr), n, _p(x), n, 64, _ld(x), _p(f['Wa']), 32, _p(f['mask_a']), _p(f['ba']), 1, _p(t), 32, _stream())),
+        ('MFMA pass B k_conv_gather_mfma_wlds<32,48>', lambda P: (P * Q * 4 + P * 8 + n * 2 * Q * 4) + (P * Q * 4 + P * 8 + n * Q * 4) + n * 3 * Q * 4,
+         lambda P: 2 * P * Q * 2 * Q + 2 * P * Q * Q + 2 * n * Q * 2 * Q,
+         lambda: lib().pcgc_conv_gather_masked(_p(nbr), n, _p(t), n, 32, 32, _p(f['Wb']), 48, _p(f['mask_b']), _p(f['bb']), 0, _p(u), 48, _stream())),
+    )
+    for name, bf, ff, call in steps:
+        if PROFILE.enabled:
+            e0, e1 = PROFILE.bracket((name, n), name, n, bf, ff)
+            e0.record()
+        check(call(), 'conv_gather_masked')
+        if PROFILE.enabled:
+            e1.record()
+    check(lib().pcgc_irn_tail(_p(u), _p(x), 64, _ld(x), _p(f['W12']), _p(f['b12']), _p(out), 64, n, _stream()), 'irn_tail')
+    return out
+
+
 def irn_eligible(x):
     return FUSE_IRN and x.shape[1] in (16, 32, 64) and x.shape[0] * x.shape[1] * 4 < 0xFFFFFFF0
 

@@ -176,6 +176,13 @@ def test_fused_inception_resnet_bit_exact(C, rows):
         ops.set_irn_rows(0)
     np.testing.assert_array_equal(unfused, want)
     np.testing.assert_array_equal(fused, want)
+    if C == 64 and rows == 64:                               # VALU-fused form too (the default for C = 64 is the MFMA form)
+        ops.MFMA_IRN = False
+        try:
+            with torch.no_grad():
+                np.testing.assert_array_equal(blk(xs).F.cpu().numpy(), want)
+        finally:
+            ops.MFMA_IRN = True
 
 
 @pytest.mark.parametrize('cin,cout', [(8, 64), (64, 32), (32, 16)])
