@@ -195,7 +195,8 @@ def attach_pmc_traffic(roof):
     except ValueError:
         return
     for e in table.get('kernels', []):
-        if e['kernel'] in roof['kernel'] and abs(e.get('grid_rows', roof['n_out']) - roof['n_out']) < 256:
+        rows = e.get('grid_rows', roof['n_out'])
+        if e['kernel'] == roof['kernel'] and (abs(rows - roof['n_out']) < 256 or abs(rows - 4 * ((roof['n_out'] + 127) // 128) * 64) < 512):
             roof['traffic'] = e['hbm_bytes_per_launch']
             roof['traffic_detail'] = {k: e[k] for k in ('fetch_bytes_raw', 'fetch_bytes_corrected', 'write_bytes', 'source') if k in e}
             return

@@ -528,32 +528,38 @@ template <int C>
 __global__ void __launch_bounds__(256) k_irn_tail(const float* __restrict__ u, const float* __restrict__ x, int x_ld,
                                                   const float* __restrict__ W12, const float* __restrict__ b12,
                                                   float* __restrict__ out, int out_ld, int64_t n) {
-    constexpr int Q = C / 4, H = C / 2, UW = 3 * Q;
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // one thread per (row, 4 output columns): consecutive lanes touch consecutive 16-byte chunks (coalesced loads/stores)
+    constexpr int Q = C / 4, H = C / 2, UW = 3 * Q, CHUNKS = C / 4;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = t / CHUNKS;
+    const int c = (int)(t % CHUNKS);
     if (row >= n) return;
     const float* ur = u + row * UW;
-    const float* xr = x + row * x_ld;
-    float* y = out + row * out_ld;
-    float acc[H];
+    const float4 xr = *(const float4*)(x + row * x_ld + 4 * c);
+    float4 y;
+    if (c < H / 4) {                                              // cat slot 0: conv0_1 (+bias, already in u) + residual
+        const float4 uv = *(const float4*)(ur + 4 * c);
+        y = make_float4(uv.x + xr.x, uv.y + xr.y, uv.z + xr.z, uv.w + xr.w);
+    } else {                                                      // cat slot 1: conv1_2(relu(conv1_1)) + bias + residual
+        const int co = 4 * (c - H / 4);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-    for (int i = 0; i < H; ++i) acc[i] = 0.0f;
-#pragma unroll
-    for (int ci = 0; ci < Q; ++ci) {
-        const float v = fmaxf(ur[H + ci], 0.0f);
-#pragma unroll
-        for (int co = 0; co < H; ++co) acc[co] = fmaf(v, W12[ci * H + co], acc[co]);
+        for (int ci = 0; ci < Q; ++ci) {
+            const float v = fmaxf(ur[H + ci], 0.0f);
+            const float4 w = *(const float4*)(W12 + ci * H + co);
+            a0 = fmaf(v, w.x, a0); a1 = fmaf(v, w.y, a1); a2 = fmaf(v, w.z, a2); a3 = fmaf(v, w.w, a3);
+        }
+        const float4 bb = *(const float4*)(b12 + co);
+        y = make_float4((a0 + bb.x) + xr.x, (a1 + bb.y) + xr.y, (a2 + bb.z) + xr.z, (a3 + bb.w) + xr.w);
     }
-#pragma unroll
-    for (int co = 0; co < H; ++co) {
-        y[co] = ur[co] + xr[co];
-        y[H + co] = (acc[co] + b12[co]) + xr[H + co];
-    }
+    *(float4*)(out + row * out_ld + 4 * c) = y;
 }
 extern "C" int pcgc_irn_tail(const float* u, const float* x, int C, int x_ld, const float* W12, const float* b12, float* out,
                              int out_ld, int64_t n, void* stream) {
     PCGC_REQUIRE(C == 64, "irn_tail: only C = 64 is built");
     if (n == 0) return 0;
-    hipLaunchKernelGGL((k_irn_tail<64>), dim3(grid_for(n, 256)), dim3(256), 0, S(stream), u, x, x_ld, W12, b12, out, out_ld, n);
+    PCGC_REQUIRE((x_ld & 3) == 0 && (out_ld & 3) == 0, "leading dimensions must be multiples of 4");
+    hipLaunchKernelGGL((k_irn_tail<64>), dim3(grid_for(n * 16, 256)), dim3(256), 0, S(stream), u, x, x_ld, W12, b12, out, out_ld, n);
     PCGC_CHECK_LAUNCH("irn_tail");
     return 0;
 }

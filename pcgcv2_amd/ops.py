@@ -296,8 +296,8 @@ def irn_block(nbr, x, params):
         check(lib().pcgc_irn_block(_p(nbr), n, _p(x), C, _ld(x), arr, _p(t), _p(out), C, _stream()), 'irn_block')
         return out
     Q = C // 4
-    passes = ((1, f'k_irn_a<{C}>', lambda P, n=n: (P * C * 4 + P * 8 + n * Q * 4) + n * (C + Q) * 4, lambda P, n=n: 2 * P * C * Q + 2 * n * C * Q),
-              (2, f'k_irn_b<{C}>', lambda P, n=n: (P * Q * 4 + P * 8 + n * 2 * Q * 4) + (P * Q * 4 + P * 8 + n * Q * 4) + n * 3 * Q * 4,
+    passes = ((1, f'k_irn_a<{C}, 64>', lambda P, n=n: (P * C * 4 + P * 8 + n * Q * 4) + n * (C + Q) * 4, lambda P, n=n: 2 * P * C * Q + 2 * n * C * Q),
+              (2, f'k_irn_b<{C}, 64>', lambda P, n=n: (P * Q * 4 + P * 8 + n * 2 * Q * 4) + (P * Q * 4 + P * 8 + n * Q * 4) + n * 3 * Q * 4,
                lambda P, n=n: 2 * P * Q * 2 * Q + 2 * P * Q * Q + 2 * n * Q * 2 * Q))
     for ps, name, bf, ff in passes:
         e0, e1 = PROFILE.bracket((name, n), name, n, bf, ff)
@@ -341,9 +341,9 @@ def irn_block_mfma64(nbr, x, f):
         PROFILE.count(nbr)
     Q, C = 16, 64
     steps = (
-        ('MFMA pass A k_conv_gather_mfma_wlds<64,32>', lambda P: (P * C * 4 + P * 8 + n * Q * 4) + n * (C + Q) * 4, lambda P: 2 * P * C * Q + 2 * n * C * Q,
+        ('k_conv_gather_mfma_wlds<64, 32, 2>', lambda P: (P * C * 4 + P * 8 + n * Q * 4) + n * (C + Q) * 4, lambda P: 2 * P * C * Q + 2 * n * C * Q,
          lambda: lib().pcgc_conv_gather_masked(_p(nbr), n, _p(x), n, 64, _ld(x), _p(f['Wa']), 32, _p(f['mask_a']), _p(f['ba']), 1, _p(t), 32, _stream())),
-        ('MFMA pass B k_conv_gather_mfma_wlds<32,48>', lambda P: (P * Q * 4 + P * 8 + n * 2 * Q * 4) + (P * Q * 4 + P * 8 + n * Q * 4) + n * 3 * Q * 4,
+        ('k_conv_gather_mfma_wlds<32, 48, 2>', lambda P: (P * Q * 4 + P * 8 + n * 2 * Q * 4) + (P * Q * 4 + P * 8 + n * Q * 4) + n * 3 * Q * 4,
          lambda P: 2 * P * Q * 2 * Q + 2 * P * Q * Q + 2 * n * Q * 2 * Q,
          lambda: lib().pcgc_conv_gather_masked(_p(nbr), n, _p(t), n, 32, 32, _p(f['Wb']), 48, _p(f['mask_b']), _p(f['bb']), 0, _p(u), 48, _stream())),
     )
