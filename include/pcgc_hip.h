@@ -149,6 +149,13 @@ int pcgc_desymbolize(const int16_t* sym, int64_t count, float min_v, float* feat
 int pcgc_cdf_table(const float* params /*[dev 352]*/, int C, float min_v, float max_v, uint16_t* cdf_u16 /*[dev]*/,
                    float* cdf_f32 /*[dev] or NULL*/, void* stream);
 
+/* The whole tail of EntropyBottleneck.compress (entropy_model.py:151-176) enqueued without a host round trip:
+ * minmax[2] <- symbol range, sym <- int16 symbols, cdf_u16/cdf_f32 <- [C, L+1] tables packed for the actual L,
+ * info[0] <- L (0 if L > max_L: use the two-phase calls).  All outputs are device buffers; fetch them with one copy. */
+int pcgc_compress_prepare(const float* feats, int64_t count, const float* params, int C, int max_L, float* minmax /*[dev 2]*/,
+                          int16_t* sym /*[dev count]*/, uint16_t* cdf_u16 /*[dev C*(max_L+1)]*/, float* cdf_f32 /*[dev C*(max_L+1)]*/,
+                          int32_t* info /*[dev 1]*/, void* stream);
+
 /* ---- range coder, bit-compatible with torchac 0.9.3 ‡ encode_float_cdf / decode_float_cdf
  *      (entropy_model.py:174,192).  HOST functions; symbols row-major [point, channel], one CDF row per channel. ---- */
 int64_t pcgc_rc_encode(const uint16_t* cdf /*[host C,Lp]*/, int C, int Lp, const int16_t* sym /*[host n]*/, int64_t n,

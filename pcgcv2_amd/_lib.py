@@ -48,6 +48,7 @@ SIGNATURES = {
     'pcgc_round_minmax': (ci, [vp, i64, vp, vp]),
     'pcgc_symbolize': (ci, [vp, i64, f32, vp, vp]),
     'pcgc_desymbolize': (ci, [vp, i64, f32, vp, vp]),
+    'pcgc_compress_prepare': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, vp, vp, vp]),
     'pcgc_cdf_table': (ci, [vp, ci, f32, f32, vp, vp, vp]),
     'pcgc_d1_nn': (ci, [vp, i64, vp, vp, i64, vp, ci, vp, vp, vp, vp]),
     'pcgc_rc_encode': (i64, [vp, ci, ci, vp, i64, vp, i64]),

@@ -70,12 +70,14 @@ class EntropyBottleneck(nn.Module):
         """entropy_model.py:151-176 -> (bytes, min_v ndarray[1], max_v ndarray[1])."""
         if inputs.dim() != 2 or inputs.shape[1] != self._channels:
             raise PcgcError(f'compress expects [N, {self._channels}] features')
-        mm = ops.round_minmax(inputs).cpu().numpy()                  # sync #1: symbol range sizes the table
-        min_v, max_v = np.float32(mm[0]), np.float32(mm[1])
-        sym = ops.symbolize(inputs, min_v)
-        table, _ = self.cdf_table(min_v, max_v, inputs.device)
-        sym_h = sym.cpu().numpy()                                    # D2H: int16 symbols
-        table_h = table.cpu().numpy().view(np.uint16)
+        prep = ops.compress_prepare(inputs, self.packed_params(inputs.device), self._channels)     # one D2H + sync
+        if prep is not None:
+            min_v, max_v, sym_h, table_h = prep
+        else:                                                        # alphabet larger than the staged table: two-phase path
+            mm = ops.round_minmax(inputs).cpu().numpy()
+            min_v, max_v = np.float32(mm[0]), np.float32(mm[1])
+            sym_h = ops.symbolize(inputs, min_v).cpu().numpy()
+            table_h = self.cdf_table(min_v, max_v, inputs.device)[0].cpu().numpy().view(np.uint16)
         strings = ops.rc_encode(table_h, sym_h)
         return strings, np.array([min_v], np.float32), np.array([max_v], np.float32)
 

@@ -426,6 +426,29 @@ def desymbolize(sym, min_v):
     return out
 
 
+def compress_prepare(feats, params, C, max_L=1024):
+    """Device-side tail of compress(): -> (min_v, max_v, sym int16 ndarray, cdf uint16 ndarray [C, L+1]) with ONE
+    synchronising device->host transfer, or None if the alphabet exceeds max_L."""
+    feats = _f32(feats).contiguous()
+    n = feats.numel()
+    # one pinned-size staging buffer: [minmax f32 x2 | info i32 | pad | table u16 C*(max_L+1) | sym i16 n]
+    tab_elems = C * (max_L + 1)
+    head = torch.empty(4, dtype=torch.float32, device=feats.device)          # minmax (2 floats) + info (1 int32 viewed) + pad
+    table = torch.empty(tab_elems, dtype=torch.int16, device=feats.device)
+    scratch = torch.empty(tab_elems, dtype=torch.float32, device=feats.device)
+    sym = torch.empty(feats.shape, dtype=torch.int16, device=feats.device)
+    info = head[2:3].view(torch.int32)
+    check(lib().pcgc_compress_prepare(_p(feats), n, _p(_f32(params, 'params')), C, max_L, _p(head), _p(sym), _p(table), _p(scratch),
+                                      _p(info), _stream()), 'compress_prepare')
+    packed = torch.cat([head.view(torch.int16), table, sym.reshape(-1)]).cpu().numpy()        # single D2H + sync
+    min_v, max_v = packed[:4].view(np.float32)[:2]
+    L = int(packed[4:6].view(np.int32)[0])
+    if L == 0:
+        return None
+    tab = packed[8:8 + C * (L + 1)].view(np.uint16).reshape(C, L + 1)
+    return np.float32(min_v), np.float32(max_v), packed[8 + tab_elems:].reshape(feats.shape), tab
+
+
 def cdf_table(params, C, min_v, max_v):
     """-> (cdf_u16 as int16-typed tensor [C, L+1] holding the uint16 bit patterns, cdf_f32 [C, L+1])."""
     L = int(max_v - min_v) + 1
