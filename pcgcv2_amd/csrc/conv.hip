@@ -827,7 +827,11 @@ static int irn_launch(const int32_t* nbr, int64_t n, const float* x, int C, int 
     return 0;
 }
 
-static int g_conv_impl = -1;        // -1 auto, 0 force v0 (direct loads), 1 force v1 (LDS-DMA + VALU), 2 force v2 (LDS-DMA + MFMA)
+// kernel selection for pcgc_conv_gather (all variants are bit-identical; tests run every one of them):
+//   -1 auto | 0 v0 direct loads + VALU | 1 v1 LDS-DMA + VALU | 2 v2 LDS-DMA + MFMA | 3 v2b MFMA with LDS-shared weights
+// auto policy (measured per shape, tools/conv_ab.py): >= 30 k rows: 64->64 -> v2b; Cin in {16,32,64} & Cout in {16,32,64} -> v2;
+// other gathered shapes with Cin in {8,16,32,64} -> v1; everything else (Cin 1/4, k1 convs, tiny levels) -> v0.
+static int g_conv_impl = -1;
 static int g_auto_wlds = 1;         // auto: LDS-shared-weight MFMA kernel for 64->64 (591 -> 403 us at 150 k rows; no gain for 32->32)
 static int g_auto_mfma = 1;         // auto mode uses the MFMA kernel for its eligible shapes once A/B says so
 extern "C" int pcgc_set_conv_impl(int impl) { g_conv_impl = impl; return 0; }
@@ -843,8 +847,6 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
     const float* in0 = in + in_coff;
     const bool aligned = (((uintptr_t)in0 | (uintptr_t)W) & 15) == 0 && (in_ld & 3) == 0;
     const bool small = n_in * in_ld * 4 < (int64_t)0xFFFFFFF0 && (int64_t)K * n_out * 4 < (int64_t)0xFFFFFFF0;
-    // auto: measured per shape on MI355X (tools/conv_ab.py): v1 is 2-6x faster on the gather-bound shapes (Cout <= 8) and
-    // on par (0.9-1.4x) on the FMA-bound ones; v0 only wins on tiny levels (< ~30k rows) where launch geometry dominates.
     const bool v1_eligible = nbr != nullptr && K <= 27 && aligned && small && (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64);
     const bool v1_wanted = g_conv_impl == 1 || (g_conv_impl < 0 && n_out >= 30000);
     const bool wlds_shape = (Cin == 64 && Cout == 64) || (Cin == 32 && Cout == 32);
