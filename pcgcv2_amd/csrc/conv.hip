@@ -635,7 +635,8 @@ k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x,
 #pragma unroll
             for (int g = 0; g < KG; ++g) idx_n[g] = (valid && k0 + KG + g < 27) ? nbr[(int64_t)(k0 + KG + g) * n + my_row] : -1;
             asm volatile("" ::: "memory");
-            wait_vmcnt<KG>();
+            static_assert(27 % KG == 0, "offset groups must tile the 27 offsets");
+            if (k0 + KG < 27) wait_vmcnt<KG>(); else wait_vmcnt<0>();       // last group: no prefetches, all DMAs must land
 #pragma unroll
             for (int g = 0; g < KG; ++g) {
                 float4 xv[CH];
@@ -729,7 +730,10 @@ k_irn_b(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ t 
 #pragma unroll
         for (int g = 0; g < KG; ++g) idx_n[g] = (valid && k0 + KG + g < 27) ? nbr[(int64_t)(k0 + KG + g) * n + my_row] : -1;
         asm volatile("" ::: "memory");
-        wait_vmcnt<KG>();                                        // the KG map prefetches may stay in flight
+        // counted wait: only the map prefetches issued AFTER the DMAs may stay in flight.  27 % KG == 0, so a group issues
+        // either all KG prefetches or (the last group) none — in which case every outstanding VMEM op is a DMA: wait for all.
+        static_assert(27 % KG == 0, "offset groups must tile the 27 offsets");
+        if (k0 + KG < 27) wait_vmcnt<KG>(); else wait_vmcnt<0>();
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
             float4 tv[CH];
