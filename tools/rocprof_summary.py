@@ -1,15 +1,26 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 --kernel-trace result (rocpd sqlite .db) into per-kernel statistics, the same columns as
-`--stats` (calls, total, average, min, max, %).  Usage: rocprof_summary.py results.db [--skip-substr at::native]"""
+"""Summarise a rocprofv3 --kernel-trace --stats result into per-kernel statistics (calls, total, average, min, max, %).
+Input: the rocpd sqlite .db, or the *_kernel_stats.csv written with --output-format csv.
+Usage: rocprof_summary.py results.db|kernel_stats.csv [substring-to-skip ...]"""
+import csv
 import sqlite3
 import sys
 
 
-def main():
-    db = sqlite3.connect(sys.argv[1])
-    skip = [a for a in sys.argv[2:] if not a.startswith('--')]
-    rows = list(db.execute('select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) '
+def load(path):
+    if path.endswith('.csv'):
+        rows = []
+        for r in csv.DictReader(open(path)):
+            rows.append((r['Name'], int(r['Calls']), float(r['TotalDurationNs']), float(r['AverageNs']), float(r['MinNs']), float(r['MaxNs'])))
+        return sorted(rows, key=lambda r: -r[2])
+    db = sqlite3.connect(path)
+    return list(db.execute('select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) '
                            'from kernels group by name order by 3 desc'))
+
+
+def main():
+    skip = [a for a in sys.argv[2:] if not a.startswith('--')]
+    rows = load(sys.argv[1])
     rows = [r for r in rows if not any(s in r[0] for s in skip)]
     total = sum(r[2] for r in rows) or 1
     print(f'{"calls":>7} {"total_ms":>10} {"avg_us":>10} {"min_us":>10} {"max_us":>10} {"pct":>6}  kernel')
