@@ -161,6 +161,9 @@ int pcgc_compress_prepare(const float* feats, int64_t count, const float* params
 int64_t pcgc_rc_encode(const uint16_t* cdf /*[host C,Lp]*/, int C, int Lp, const int16_t* sym /*[host n]*/, int64_t n,
                        uint8_t* out /*[host cap]*/, int64_t cap);          /* returns bytes, or -needed if cap too small */
 int pcgc_rc_decode(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int64_t nbytes, int16_t* sym, int64_t n);
+/* decoder selection for A/B tests: 0 automatic (AVX-512 boundary count when the host CPU has it and Lp <= 64, else the
+ * portable scalar search), 1 portable scalar.  Both are bit-identical. */
+int pcgc_set_rc_impl(int impl);
 
 /* ---- native lossless coordinate codec for _C.bin when the external tmc3 binary (gpcc.py:6-41) is absent.
  *      Occupancy-octree + adaptive range coder.  NOT interoperable with G-PCC; flagged by its magic "PCGO". HOST. ---- */

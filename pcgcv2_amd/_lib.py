@@ -53,6 +53,7 @@ SIGNATURES = {
     'pcgc_d1_nn': (ci, [vp, i64, vp, vp, i64, vp, ci, vp, vp, vp, vp]),
     'pcgc_rc_encode': (i64, [vp, ci, ci, vp, i64, vp, i64]),
     'pcgc_rc_decode': (ci, [vp, ci, ci, vp, i64, vp, i64]),
+    'pcgc_set_rc_impl': (ci, [ci]),
     'pcgc_oct_encode': (i64, [vp, i64, vp, i64]),
     'pcgc_oct_decode_count': (i64, [vp, i64]),
     'pcgc_oct_decode': (ci, [vp, i64, vp, i64]),

@@ -8,31 +8,31 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+#include <immintrin.h>
 #include "../../include/pcgc_hip.h"
 
 // ------------------------------------------------------------------------------------------------ torchac-compatible
 namespace {
 inline int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
-// MSB-first bit writer: bits are staged in a 64-bit word and flushed 32 at a time with one byte-swapped store (the
-// reference appends one bit at a time).
+// MSB-first bit writer: bits are staged in a 64-bit word; a whole 32-bit word is stored speculatively on every call and
+// only kept (len advanced) when it is complete — no data-dependent branch (the reference appends one bit at a time).
 struct Sink {
     uint8_t* out; int64_t cap; int64_t len = 0; uint64_t acc = 0; int nbits = 0;   // nbits < 32 between calls
-    inline void put(uint32_t v, int n) {            // n <= 32
-        acc = (acc << n) | (uint64_t)(n == 32 ? v : (v & ((1u << n) - 1u)));
+    inline void put(uint32_t v, int n) {            // n <= 32, v < 2^n
+        acc = (acc << n) | (uint64_t)v;
         nbits += n;
-        if (nbits >= 32) {
-            nbits -= 32;
-            const uint32_t w = __builtin_bswap32((uint32_t)(acc >> nbits));
-            if (len + 4 <= cap) std::memcpy(out + len, &w, 4);
-            len += 4;
-        }
+        const int full = nbits >= 32;
+        const int keep = nbits - (full << 5);
+        const uint32_t w = __builtin_bswap32((uint32_t)(acc >> keep));
+        if (len + 4 <= cap) std::memcpy(out + len, &w, 4);
+        len += full << 2;
+        nbits = keep;
     }
-    inline void put_run(uint32_t bit, uint64_t count) { const uint32_t word = bit ? 0xFFFFFFFFu : 0u; while (count >= 32) { put(word, 32); count -= 32; } put(word, (int)count); }
+    inline void put_run(uint32_t bit, uint64_t count) { const uint32_t word = bit ? 0xFFFFFFFFu : 0u; while (count >= 32) { put(word, 32); count -= 32; } put(count ? (word >> (32 - count)) : 0u, (int)count); }
     inline void flush() { while (nbits > 0) { int take = nbits >= 8 ? 8 : nbits; uint8_t b = (uint8_t)((nbits >= 8 ? (acc >> (nbits - 8)) : (acc << (8 - nbits))) & 0xff); if (len < cap) out[len] = b; ++len; nbits -= take; } }
 };
-// MSB-first bit reader over a zero-padded copy of the stream (past the end the reference's reader yields zeros too);
-// refills 32 bits at a time.
-struct Source {
+// MSB-first bit readers over a zero-padded copy of the stream (past the end the reference's reader yields zeros too).
+struct Source {                                      // refills 32 bits at a time
     const uint8_t* in; int64_t pos = 0; uint64_t acc = 0; int nbits = 0;
     inline uint32_t take(int n) {
         if (nbits < n) { uint32_t w; std::memcpy(&w, in + pos, 4); pos += 4; acc = (acc << 32) | __builtin_bswap32(w); nbits += 32; }
@@ -40,21 +40,35 @@ struct Source {
         return n == 0 ? 0u : (uint32_t)((acc >> nbits) & ((n == 32) ? 0xFFFFFFFFull : ((1ull << n) - 1ull)));
     }
 };
+struct SourceBF {                                    // branch-free: refill() leaves >= 56 valid bits at the top of acc
+    const uint8_t* in; int64_t pos = 0; uint64_t acc = 0; int nbits = 0;
+    inline void refill() { uint64_t w; std::memcpy(&w, in + pos, 8); acc |= __builtin_bswap64(w) >> nbits; pos += (63 - nbits) >> 3; nbits |= 56; }
+    inline uint32_t take(int n) { const uint32_t v = (uint32_t)((acc >> 1) >> (63 - n)); acc <<= n; nbits -= n; return v; }   // n <= 32
+};
+// One 16-bit CDF row per channel, widened to 32 bits with the last boundary pinned to 2^16 (torchac hard-codes
+// c_high = 0x10000 for the top symbol): removes the per-symbol special case.
+std::vector<uint32_t> widen_rows(const uint16_t* cdf, int C, int Lp) {
+    std::vector<uint32_t> rows((size_t)C * Lp);
+    for (int c = 0; c < C; ++c) { for (int j = 0; j < Lp - 1; ++j) rows[(size_t)c * Lp + j] = cdf[(size_t)c * Lp + j]; rows[(size_t)c * Lp + Lp - 1] = 0x10000u; }
+    return rows;
 }
-// Renormalisation in runs instead of single bits.  After coding a symbol:
-//   (1) low and high share n = clz(low ^ high) leading bits -> emit them (the first one releases the pending
-//       opposite bits), shift both by n;
-//   (2) then low = 01.., high = 10..: the E3 "near convergence" case repeats m = min(leading ones of low<<1,
-//       leading zeros of high<<1) times -> pending += m, low/high shifted by m with their MSBs pinned to 0 / 1.
-// After (2) neither case applies again, exactly as in the bit-serial loop of torchac ‡.  The CDF rows are widened to
-// 32 bits with the last boundary pinned to 2^16 (torchac hard-codes c_high = 0x10000 for the top symbol), which removes
-// the per-symbol special case; the decoder seeds its symbol search from the target's high byte.
+int g_rc_impl = 0;                                   // 0 automatic, 1 portable scalar decoder (A/B and tests)
+}
+extern "C" int pcgc_set_rc_impl(int impl) { if (impl < 0 || impl > 1) return -1; g_rc_impl = impl; return 0; }
+
+// Renormalisation in runs instead of single bits, without data-dependent branches.  After coding a symbol:
+//   (1) low and high share n = clz(low ^ high) leading bits -> they are emitted; the first one, b, resolves the pending
+//       E3 bits: "b followed by `pending` copies of !b" is the number (2^pending - 1) + b in pending+1 bits, so it goes out
+//       as ONE field whatever b and pending are (pending = 0 included); low/high shift by n;
+//   (2) then low = 0.., high = 1..: the E3 "near convergence" case repeats m = clz(((~low | high) << 1) | 1) times
+//       (leading ones of low and zeros of high below the MSB) -> pending += m, low/high shift by m with their MSBs pinned
+//       to 0 / 1 (a no-op for m = 0).
+// After (2) neither case applies again, exactly as in the bit-serial loop of torchac ‡.
 extern "C" int64_t pcgc_rc_encode(const uint16_t* cdf, int C, int Lp, const int16_t* sym, int64_t n, uint8_t* out, int64_t cap) {
     Sink sink{out, cap};
     uint32_t low = 0, high = 0xFFFFFFFFu; uint64_t pending = 0;
     const int top_symbol = Lp - 2;
-    std::vector<uint32_t> rows((size_t)C * Lp);
-    for (int c = 0; c < C; ++c) { for (int j = 0; j < Lp - 1; ++j) rows[(size_t)c * Lp + j] = cdf[(size_t)c * Lp + j]; rows[(size_t)c * Lp + Lp - 1] = 0x10000u; }
+    const std::vector<uint32_t> rows = widen_rows(cdf, C, Lp);
     int ch = 0;
     for (int64_t i = 0; i < n; ++i) {
         const uint32_t* row = rows.data() + (size_t)ch * Lp;
@@ -65,32 +79,34 @@ extern "C" int64_t pcgc_rc_encode(const uint16_t* cdf, int C, int Lp, const int1
         high = (low - 1) + (uint32_t)((span * row[s + 1]) >> 16);
         low = low + (uint32_t)((span * row[s]) >> 16);
         const int nshare = clz32(low ^ high);
-        if (nshare) {
-            const uint32_t bits = low >> (32 - nshare);
-            if (pending) {
-                const uint32_t first = (bits >> (nshare - 1)) & 1u;
-                sink.put(first, 1); sink.put_run(first ^ 1u, pending); pending = 0; sink.put(bits, nshare - 1);
-            } else sink.put(bits, nshare);
-            low <<= nshare; high = (high << nshare) | ((1u << nshare) - 1u);
+        if (nshare) {                                           // (almost always taken: > 1 bit per symbol)
+            const uint32_t bits = (uint32_t)(((uint64_t)low << nshare) >> 32);
+            const uint32_t first = bits >> (nshare - 1);
+            if (pending > 31) { sink.put(first, 1); sink.put_run(first ^ 1u, pending); }
+            else sink.put(((1u << pending) - 1u) + first, (int)pending + 1);
+            sink.put(bits & ((1u << (nshare - 1)) - 1u), nshare - 1);
+            pending = 0;
+            low = (uint32_t)((uint64_t)low << nshare); high = (uint32_t)((((uint64_t)high + 1) << nshare) - 1);
         }
-        while (low >= 0x40000000u && high < 0xC0000000u) {
-            int m = clz32(~(low << 1)); const int mz = clz32(high << 1); if (mz < m) m = mz; if (m > 31) m = 31;
-            pending += (uint64_t)m; low = (low << m) & 0x7FFFFFFFu; high = (high << m) | 0x80000000u | ((1u << m) - 1u);
-        }
+        const int m = __builtin_clz((((~low) | high) << 1) | 1u);
+        low = (low << m) & 0x7FFFFFFFu; high = (high << m) | 0x80000000u | ((1u << m) - 1u);
+        pending += (uint64_t)m;
     }
     ++pending;
     const uint32_t last = low < 0x40000000u ? 0u : 1u;
     sink.put(last, 1); sink.put_run(last ^ 1u, pending); sink.flush();
     return sink.len <= cap ? sink.len : -sink.len;
 }
-extern "C" int pcgc_rc_decode(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int64_t nbytes, int16_t* sym, int64_t n) {
+
+// Portable decoder: torchac's target = ((value - low + 1) * 2^16 - 1) / span, symbol search seeded from the target's high
+// byte.
+static int rc_decode_scalar(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int64_t nbytes, int16_t* sym, int64_t n) {
     std::vector<uint8_t> padded((size_t)nbytes + 64 + (size_t)n, 0);
     std::memcpy(padded.data(), in, (size_t)nbytes);
     Source src{padded.data()};
     uint32_t low = 0, high = 0xFFFFFFFFu; uint32_t value = src.take(32);
     const int top_symbol = Lp - 2;
-    std::vector<uint32_t> rows((size_t)C * Lp);
-    for (int c = 0; c < C; ++c) { for (int j = 0; j < Lp - 1; ++j) rows[(size_t)c * Lp + j] = cdf[(size_t)c * Lp + j]; rows[(size_t)c * Lp + Lp - 1] = 0x10000u; }
+    const std::vector<uint32_t> rows = widen_rows(cdf, C, Lp);
     std::vector<int16_t> seed((size_t)C * 256);
     for (int c = 0; c < C; ++c) { const uint32_t* row = rows.data() + (size_t)c * Lp; int m = 0; for (int b = 0; b < 256; ++b) { const uint32_t t = (uint32_t)b << 8; while (m < top_symbol && row[m + 1] <= t) ++m; seed[(size_t)c * 256 + b] = (int16_t)m; } }
     int ch = 0;
@@ -114,6 +130,61 @@ extern "C" int pcgc_rc_decode(const uint16_t* cdf, int C, int Lp, const uint8_t*
         }
     }
     return 0;
+}
+
+// AVX-512 decoder for alphabets of up to 63 symbols (the PCGCv2 latents use ~20): no division and no search loop.
+// torchac picks the largest s with cdf[s] <= target; since  cdf[j] <= floor(((off + 1) * 2^16 - 1) / span)  <=>
+// (span * cdf[j]) >> 16 <= off  (off = value - low), s + 1 is the number of boundaries whose scaled position
+// cum(j) = (span * cdf[j]) >> 16 is <= off.  All cum(j) of the row are evaluated at once in 64-bit lanes
+// (vpmuludq on span - 1 <= 2^32 - 1, plus cdf[j], keeps the product exact for span = 2^32) and counted with a mask
+// popcount; lanes past the row are padded with 2^16 (cum = span > off).  Renormalisation as in the encoder, one
+// branch-free bit fetch of nshare + m <= 56 bits per symbol (a symbol has probability >= 2^-16: at most 18 shifts).
+__attribute__((target("avx512f,avx512bw,avx512dq,popcnt")))
+static int rc_decode_avx512(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int64_t nbytes, int16_t* sym, int64_t n) {
+    std::vector<uint8_t> padded((size_t)nbytes + 64 + (size_t)n * 3, 0);
+    std::memcpy(padded.data(), in, (size_t)nbytes);
+    SourceBF src{padded.data()};
+    src.refill();
+    uint32_t low = 0, high = 0xFFFFFFFFu; uint32_t value = src.take(32);
+    const int top_symbol = Lp - 2;
+    const int nvec = (Lp + 7) / 8, W = nvec * 8;
+    const std::vector<uint32_t> rows = widen_rows(cdf, C, Lp);
+    std::vector<uint64_t> wide_store((size_t)C * W + 8);
+    uint64_t* wide = (uint64_t*)(((uintptr_t)wide_store.data() + 63) & ~(uintptr_t)63);
+    for (int c = 0; c < C; ++c) for (int j = 0; j < W; ++j) wide[(size_t)c * W + j] = j < Lp ? rows[(size_t)c * Lp + j] : 0x10000u;
+    int ch = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t* row = rows.data() + (size_t)ch * Lp; const uint64_t* wr = wide + (size_t)ch * W;
+        if (++ch == C) ch = 0;
+        src.refill();
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+        const __m512i vs = _mm512_set1_epi64((long long)(span - 1)), voff = _mm512_set1_epi64((long long)(uint64_t)(uint32_t)(value - low));
+        int cnt = 0;
+        for (int v = 0; v < nvec; ++v) {
+            const __m512i r = _mm512_load_si512((const void*)(wr + 8 * v));
+            const __m512i cum = _mm512_srli_epi64(_mm512_add_epi64(_mm512_mul_epu32(vs, r), r), 16);
+            cnt += __builtin_popcount((unsigned)_mm512_cmple_epu64_mask(cum, voff));
+        }
+        int s = cnt - 1; if (s > top_symbol) s = top_symbol; if (s < 0) s = 0;        // (only a corrupt stream can clamp)
+        sym[i] = (int16_t)s;
+        high = (low - 1) + (uint32_t)((span * row[s + 1]) >> 16);
+        low = low + (uint32_t)((span * row[s]) >> 16);
+        const int nshare = clz32(low ^ high);
+        low = (uint32_t)((uint64_t)low << nshare); high = (uint32_t)((((uint64_t)high + 1) << nshare) - 1);
+        const int m = __builtin_clz((((~low) | high) << 1) | 1u);
+        low = (low << m) & 0x7FFFFFFFu; high = (high << m) | 0x80000000u | ((1u << m) - 1u);
+        const int t = nshare + m;
+        if (t > 48) return -2;                                                   // impossible for a valid table
+        value = ((uint32_t)((uint64_t)value << t) | src.take(t)) ^ ((uint32_t)(m != 0) << 31);
+    }
+    return 0;
+}
+
+extern "C" int pcgc_rc_decode(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int64_t nbytes, int16_t* sym, int64_t n) {
+    if (n <= 0) return 0;
+    if (g_rc_impl == 0 && Lp <= 64 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq"))
+        return rc_decode_avx512(cdf, C, Lp, in, nbytes, sym, n);
+    return rc_decode_scalar(cdf, C, Lp, in, nbytes, sym, n);
 }
 
 // ------------------------------------------------------------------------------------------------ octree codec

@@ -494,6 +494,11 @@ def _np(a, dt):
     return np.ascontiguousarray(a, dtype=dt)
 
 
+def set_rc_impl(impl):
+    """0 automatic, 1 portable scalar range decoder (bit-identical; for A/B tests)."""
+    check(lib().pcgc_set_rc_impl(int(impl)), 'set_rc_impl')
+
+
 def rc_encode(cdf_u16, sym):
     cdf = _np(cdf_u16, np.uint16)
     sym = _np(sym, np.int16).ravel()

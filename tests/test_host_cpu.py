@@ -24,7 +24,14 @@ def test_library_exports_every_declared_symbol():
     assert l.pcgc_version() >= 1
 
 
-def test_range_coder_matches_oracle_bit_for_bit(golden_dir):
+@pytest.fixture(params=[0, 1], ids=['rc-auto', 'rc-scalar'])
+def rc_impl(request):
+    ops.set_rc_impl(request.param)
+    yield request.param
+    ops.set_rc_impl(0)
+
+
+def test_range_coder_matches_oracle_bit_for_bit(golden_dir, rc_impl):
     rng = np.random.default_rng(1)
     g = np.load(os.path.join(golden_dir, 'entropy_tables.npz'))
     for case, (lo, hi) in [('c1', (-20, 20)), ('c0', (-8, 9)), ('c3', (0, 0)), ('c2', (-3, 2))]:
@@ -38,6 +45,46 @@ def test_range_coder_matches_oracle_bit_for_bit(golden_dir):
             assert a == b
             np.testing.assert_array_equal(ops.rc_decode(table, a, sym.size), sym.ravel())
             np.testing.assert_array_equal(orc.rc_decode(table, a, sym.size), sym.ravel())
+
+
+def _table_from_pmf(pmf):
+    """[C, L] probabilities -> torchac-normalised uint16 table [C, L+1] through the oracle's quantiser."""
+    cdf = np.concatenate([np.zeros((len(pmf), 1)), np.cumsum(pmf / pmf.sum(1, keepdims=True), 1)], 1).clip(0, 1)
+    return orc.cdf_u16(cdf.astype(np.float32))
+
+
+@pytest.mark.parametrize('shape', ['two_symbols_skewed', 'half_half', 'uniform21', 'tails63', 'wide100', 'wide300', 'spike_mid'])
+def test_range_coder_adversarial_tables(shape, rc_impl):
+    """Tables that stress each renormalisation case against the bit-serial oracle: near-certain symbols (no shared bits
+    for many symbols), p = 1/2 around the interval midpoint (long E3 pending chains), minimum-probability symbols
+    (17-bit shifts), alphabets on both sides of the 64-boundary SIMD limit."""
+    rng = np.random.default_rng(11)
+    C = 8
+    if shape == 'two_symbols_skewed':
+        pmf = np.tile([0.999, 0.001], (C, 1)); draw = lambda n: (rng.random((n, C)) < 0.002).astype(np.int16)
+    elif shape == 'half_half':
+        pmf = np.tile([0.5, 0.5], (C, 1)); draw = lambda n: np.tile(np.array([0, 1, 1, 0, 1, 0, 0, 1], np.int16), (n, 1)) ^ (rng.random((n, C)) < 0.02)
+    elif shape == 'uniform21':
+        pmf = np.ones((C, 21)); draw = lambda n: rng.integers(0, 21, (n, C)).astype(np.int16)
+    elif shape == 'tails63':
+        x = np.arange(63) - 31; pmf = np.tile(np.exp(-0.5 * (x / 1.5) ** 2) + 1e-12, (C, 1)); draw = lambda n: rng.integers(0, 63, (n, C)).astype(np.int16)
+    elif shape == 'wide100':
+        x = np.arange(100) - 50; pmf = np.tile(np.exp(-np.abs(x) / 9.0), (C, 1)); draw = lambda n: np.clip(np.rint(rng.laplace(50, 9, (n, C))), 0, 99).astype(np.int16)
+    elif shape == 'wide300':
+        x = np.arange(300) - 150; pmf = np.tile(np.exp(-0.5 * (x / 40.0) ** 2) + 1e-9, (C, 1)); draw = lambda n: np.clip(np.rint(rng.normal(150, 40, (n, C))), 0, 299).astype(np.int16)
+    else:
+        pmf = np.tile([1e-6, 0.25, 0.5 - 2e-6, 0.25, 1e-6], (C, 1)); draw = lambda n: rng.choice(5, (n, C), p=[0.02, 0.24, 0.48, 0.24, 0.02]).astype(np.int16)
+    table = _table_from_pmf(np.asarray(pmf, np.float64))
+    for n in (1, 2, 9, 1000, 20000):
+        sym = np.ascontiguousarray(draw(n).astype(np.int16))
+        a = ops.rc_encode(table, sym)
+        if n <= 1000:
+            assert a == orc.rc_encode(table, sym)
+            np.testing.assert_array_equal(orc.rc_decode(table, a, sym.size), sym.ravel())
+        np.testing.assert_array_equal(ops.rc_decode(table, a, sym.size), sym.ravel())
+    # a truncated / corrupt stream must not crash either decoder
+    ops.rc_decode(table, a[:len(a) // 2], sym.size)
+    ops.rc_decode(table, bytes(rng.integers(0, 256, 64, dtype=np.uint8)), 4096)
 
 
 def test_range_coder_rejects_out_of_table_symbol():
