@@ -127,20 +127,28 @@ class Coder():
         self.feature_coder.encode(y.F, postfix=postfix)
         return y
 
+    def _decode_geometry(self, postfix, dev):
+        """`_C.bin` -> sorted stride-8 coordinate level on `dev` (coder.py:94-99: host argsort there, device sort here)."""
+        torch.cuda.set_device(dev)                               # the current device is per thread
+        xyz8 = np.asarray(self.coordinate_coder.decode(postfix), dtype=np.int32)
+        y_C4 = np.zeros((len(xyz8), 4), dtype=np.int32)          # batch column 0, coordinates back at tensor stride 8
+        y_C4[:, 1:] = xyz8 * 8
+        y_C = torch.from_numpy(y_C4).to(dev)
+        lvl8 = CoordMap(ops.gather_coords(y_C, ops.sort_zyx(y_C)), 8, unique=True)
+        if len(lvl8):
+            lvl8.prepare_up()
+        return lvl8
+
     @torch.no_grad()
     def decode(self, rho=1, postfix=''):
         """coder.py:93-112: reads the four files, returns the decoded stride-1 sparse tensor."""
         dev = require_gpu(next(self.model.decoder.parameters()).device)
-        # the two bitstreams are independent: the coordinates are decoded on a helper thread while this thread range-decodes
-        # the features (both are native calls that release the GIL)
-        pending = _POOL.submit(self.coordinate_coder.decode, postfix)
+        # the two bitstreams are independent: a helper thread decodes the coordinates, uploads and sorts them and prebuilds
+        # the coordinate-only part of the first decoder stage (children level + kernel maps) while this thread range-decodes
+        # the features (native calls that release the GIL; both threads enqueue on the device's default stream)
+        pending = _POOL.submit(self._decode_geometry, postfix, dev)
         y_F = self.feature_coder.decode(postfix=postfix, device=dev)
-        xyz8 = np.asarray(pending.result(), dtype=np.int32)
-        y_C4 = np.zeros((len(xyz8), 4), dtype=np.int32)          # batch column 0, coordinates back at tensor stride 8
-        y_C4[:, 1:] = xyz8 * 8
-        y_C = torch.from_numpy(y_C4).to(dev)
-        y_C = ops.gather_coords(y_C, ops.sort_zyx(y_C))          # coder.py:97-99 (host argsort there, device sort here)
-        y = SparseTensor(features=y_F, coordinates=y_C, tensor_stride=8, device=dev, assume_unique=True)
+        y = SparseTensor(features=y_F, coordinate_map=pending.result())
         n4, n2, n1 = _COUNTS.unpack(_slurp(self.filename + postfix + '_num_points.bin')[:_COUNTS.size])
         budgets = [[n4], [n2], [int(rho * n1)]]                  # coder.py:105-108
         _, out = self.model.decoder(y, nums_list=budgets, ground_truth_list=[None] * 3, training=False)

@@ -56,17 +56,22 @@ int g_rc_impl = 0;                                   // 0 automatic, 1 portable 
 }
 extern "C" int pcgc_set_rc_impl(int impl) { if (impl < 0 || impl > 1) return -1; g_rc_impl = impl; return 0; }
 
-// Renormalisation in runs instead of single bits, without data-dependent branches.  After coding a symbol:
-//   (1) low and high share n = clz(low ^ high) leading bits -> they are emitted; the first one, b, resolves the pending
+// Renormalisation in runs instead of single bits, without data-dependent branches.  The coder state is kept as
+// (low, span = high - low + 1): every E1/E2/E3 step of torchac ‡ doubles the span, so after t steps span' = span << t and
+// `high` never has to be formed.  After narrowing to [lo, hi] for a symbol:
+//   (1) lo and hi share n = clz(lo ^ hi) leading bits -> they are emitted; the first one, b, resolves the pending
 //       E3 bits: "b followed by `pending` copies of !b" is the number (2^pending - 1) + b in pending+1 bits, so it goes out
-//       as ONE field whatever b and pending are (pending = 0 included); low/high shift by n;
-//   (2) then low = 0.., high = 1..: the E3 "near convergence" case repeats m = clz(((~low | high) << 1) | 1) times
-//       (leading ones of low and zeros of high below the MSB) -> pending += m, low/high shift by m with their MSBs pinned
-//       to 0 / 1 (a no-op for m = 0).
-// After (2) neither case applies again, exactly as in the bit-serial loop of torchac ‡.
-extern "C" int64_t pcgc_rc_encode(const uint16_t* cdf, int C, int Lp, const int16_t* sym, int64_t n, uint8_t* out, int64_t cap) {
+//       as ONE field whatever b and pending are (pending = 0 included);
+//   (2) below the first differing bit (lo 0, hi 1) the E3 "near convergence" case repeats for every further position
+//       where lo has a 1 and hi a 0: with y = lo & ~hi, the run ends at the first zero of y below bit 31 - n, i.e.
+//       t = n + m = clz(~y & (0x7FFFFFFF >> n)) - 1 (an all-ones tail gives clz = 32: the run reaches bit 0);
+//   (3) low' = (lo << t) with the MSB cleared (E3 pins it to 0; after E1/E2 alone it already is 0), pending += m.
+// After that neither case applies again, exactly as in the bit-serial loop of torchac.
+namespace {
+template <class LZ>
+__attribute__((always_inline)) inline int64_t rc_encode_body(const uint16_t* cdf, int C, int Lp, const int16_t* sym, int64_t n, uint8_t* out, int64_t cap, LZ lz) {
     Sink sink{out, cap};
-    uint32_t low = 0, high = 0xFFFFFFFFu; uint64_t pending = 0;
+    uint32_t low = 0; uint64_t span = 1ull << 32; uint64_t pending = 0;
     const int top_symbol = Lp - 2;
     const std::vector<uint32_t> rows = widen_rows(cdf, C, Lp);
     int ch = 0;
@@ -75,27 +80,38 @@ extern "C" int64_t pcgc_rc_encode(const uint16_t* cdf, int C, int Lp, const int1
         if (++ch == C) ch = 0;
         const int s = sym[i];
         if ((unsigned)s > (unsigned)top_symbol) return INT64_MIN;
-        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
-        high = (low - 1) + (uint32_t)((span * row[s + 1]) >> 16);
-        low = low + (uint32_t)((span * row[s]) >> 16);
-        const int nshare = clz32(low ^ high);
+        const uint32_t c_lo = (uint32_t)((span * row[s]) >> 16), c_hi = (uint32_t)((span * row[s + 1]) >> 16);
+        const uint32_t lo = low + c_lo, hi = low + c_hi - 1;
+        const int nshare = lz(lo ^ hi);
+        const int t = lz(~(lo & ~hi) & (uint32_t)(0x7FFFFFFFull >> nshare)) - 1;
         if (nshare) {                                           // (almost always taken: > 1 bit per symbol)
-            const uint32_t bits = (uint32_t)(((uint64_t)low << nshare) >> 32);
+            const uint32_t bits = (uint32_t)(((uint64_t)lo << nshare) >> 32);
             const uint32_t first = bits >> (nshare - 1);
             if (pending > 31) { sink.put(first, 1); sink.put_run(first ^ 1u, pending); }
             else sink.put(((1u << pending) - 1u) + first, (int)pending + 1);
             sink.put(bits & ((1u << (nshare - 1)) - 1u), nshare - 1);
             pending = 0;
-            low = (uint32_t)((uint64_t)low << nshare); high = (uint32_t)((((uint64_t)high + 1) << nshare) - 1);
         }
-        const int m = __builtin_clz((((~low) | high) << 1) | 1u);
-        low = (low << m) & 0x7FFFFFFFu; high = (high << m) | 0x80000000u | ((1u << m) - 1u);
-        pending += (uint64_t)m;
+        pending += (uint64_t)(t - nshare);
+        low = (uint32_t)((uint64_t)lo << t) & 0x7FFFFFFFu;
+        span = (uint64_t)(c_hi - c_lo) << t;
     }
     ++pending;
     const uint32_t last = low < 0x40000000u ? 0u : 1u;
     sink.put(last, 1); sink.put_run(last ^ 1u, pending); sink.flush();
     return sink.len <= cap ? sink.len : -sink.len;
+}
+__attribute__((target("lzcnt,bmi,bmi2")))
+int64_t rc_encode_bmi(const uint16_t* cdf, int C, int Lp, const int16_t* sym, int64_t n, uint8_t* out, int64_t cap) {
+    return rc_encode_body(cdf, C, Lp, sym, n, out, cap, [](uint32_t v) __attribute__((target("lzcnt"))) { return (int)_lzcnt_u32(v); });
+}
+int64_t rc_encode_generic(const uint16_t* cdf, int C, int Lp, const int16_t* sym, int64_t n, uint8_t* out, int64_t cap) {
+    return rc_encode_body(cdf, C, Lp, sym, n, out, cap, [](uint32_t v) { return clz32(v); });
+}
+}
+extern "C" int64_t pcgc_rc_encode(const uint16_t* cdf, int C, int Lp, const int16_t* sym, int64_t n, uint8_t* out, int64_t cap) {
+    if (g_rc_impl == 0 && __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("lzcnt")) return rc_encode_bmi(cdf, C, Lp, sym, n, out, cap);
+    return rc_encode_generic(cdf, C, Lp, sym, n, out, cap);
 }
 
 // Portable decoder: torchac's target = ((value - low + 1) * 2^16 - 1) / span, symbol search seeded from the target's high
@@ -137,52 +153,52 @@ static int rc_decode_scalar(const uint16_t* cdf, int C, int Lp, const uint8_t* i
 // (span * cdf[j]) >> 16 <= off  (off = value - low), s + 1 is the number of boundaries whose scaled position
 // cum(j) = (span * cdf[j]) >> 16 is <= off.  All cum(j) of the row are evaluated at once in 64-bit lanes
 // (vpmuludq on span - 1 <= 2^32 - 1, plus cdf[j], keeps the product exact for span = 2^32) and counted with a mask
-// popcount; lanes past the row are padded with 2^16 (cum = span > off).  Renormalisation as in the encoder, one
-// branch-free bit fetch of nshare + m <= 56 bits per symbol (a symbol has probability >= 2^-16: at most 18 shifts).
-__attribute__((target("avx512f,avx512bw,avx512dq,popcnt")))
+// popcount; lanes past the row are padded with 2^16 (cum = span > off).  The state is (low, span, off): E1/E2/E3 shift
+// value and low alike, so off' = ((off - cum_lo) << t) | next t bits, and neither `value` nor `high` is ever formed.
+// One branch-free bit fetch of t = nshare + m bits per symbol (a symbol has probability >= 2^-16: t <= 18).
+// The 32-bit rows carry one guard entry in front and guards behind, so any boundary count 0..W (only a corrupt stream
+// produces the extremes) indexes inside the row.
+__attribute__((target("avx512f,avx512bw,avx512dq,popcnt,lzcnt,bmi,bmi2")))
 static int rc_decode_avx512(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int64_t nbytes, int16_t* sym, int64_t n) {
-    std::vector<uint8_t> padded((size_t)nbytes + 64 + (size_t)n * 3, 0);
+    std::vector<uint8_t> padded((size_t)nbytes + 64 + (size_t)n * 4, 0);
     std::memcpy(padded.data(), in, (size_t)nbytes);
     SourceBF src{padded.data()};
     src.refill();
-    uint32_t low = 0, high = 0xFFFFFFFFu; uint32_t value = src.take(32);
-    const int top_symbol = Lp - 2;
-    const int nvec = (Lp + 7) / 8, W = nvec * 8;
-    const std::vector<uint32_t> rows = widen_rows(cdf, C, Lp);
+    uint32_t low = 0; uint64_t span = 1ull << 32; uint32_t off = src.take(32);
+    const int nvec = (Lp + 7) / 8, W = nvec * 8, RS = W + 8;
+    std::vector<uint32_t> rows((size_t)C * RS, 0x10000u);
+    for (int c = 0; c < C; ++c) { uint32_t* r = rows.data() + (size_t)c * RS; r[0] = 0; for (int j = 0; j < Lp - 1; ++j) r[1 + j] = cdf[(size_t)c * Lp + j]; }
     std::vector<uint64_t> wide_store((size_t)C * W + 8);
     uint64_t* wide = (uint64_t*)(((uintptr_t)wide_store.data() + 63) & ~(uintptr_t)63);
-    for (int c = 0; c < C; ++c) for (int j = 0; j < W; ++j) wide[(size_t)c * W + j] = j < Lp ? rows[(size_t)c * Lp + j] : 0x10000u;
+    for (int c = 0; c < C; ++c) for (int j = 0; j < W; ++j) wide[(size_t)c * W + j] = j < Lp - 1 ? cdf[(size_t)c * Lp + j] : 0x10000u;
     int ch = 0;
     for (int64_t i = 0; i < n; ++i) {
-        const uint32_t* row = rows.data() + (size_t)ch * Lp; const uint64_t* wr = wide + (size_t)ch * W;
+        const uint32_t* row = rows.data() + (size_t)ch * RS; const uint64_t* wr = wide + (size_t)ch * W;
         if (++ch == C) ch = 0;
         src.refill();
-        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
-        const __m512i vs = _mm512_set1_epi64((long long)(span - 1)), voff = _mm512_set1_epi64((long long)(uint64_t)(uint32_t)(value - low));
-        int cnt = 0;
+        const __m512i vs = _mm512_set1_epi64((long long)(span - 1)), voff = _mm512_set1_epi64((long long)(uint64_t)off);
+        unsigned cnt = 0;                                                          // = s + 1
         for (int v = 0; v < nvec; ++v) {
             const __m512i r = _mm512_load_si512((const void*)(wr + 8 * v));
             const __m512i cum = _mm512_srli_epi64(_mm512_add_epi64(_mm512_mul_epu32(vs, r), r), 16);
-            cnt += __builtin_popcount((unsigned)_mm512_cmple_epu64_mask(cum, voff));
+            cnt += (unsigned)__builtin_popcount((unsigned)_mm512_cmple_epu64_mask(cum, voff));
         }
-        int s = cnt - 1; if (s > top_symbol) s = top_symbol; if (s < 0) s = 0;        // (only a corrupt stream can clamp)
-        sym[i] = (int16_t)s;
-        high = (low - 1) + (uint32_t)((span * row[s + 1]) >> 16);
-        low = low + (uint32_t)((span * row[s]) >> 16);
-        const int nshare = clz32(low ^ high);
-        low = (uint32_t)((uint64_t)low << nshare); high = (uint32_t)((((uint64_t)high + 1) << nshare) - 1);
-        const int m = __builtin_clz((((~low) | high) << 1) | 1u);
-        low = (low << m) & 0x7FFFFFFFu; high = (high << m) | 0x80000000u | ((1u << m) - 1u);
-        const int t = nshare + m;
-        if (t > 48) return -2;                                                   // impossible for a valid table
-        value = ((uint32_t)((uint64_t)value << t) | src.take(t)) ^ ((uint32_t)(m != 0) << 31);
+        sym[i] = (int16_t)((int)cnt - 1);
+        const uint32_t c_lo = (uint32_t)((span * row[cnt]) >> 16), c_hi = (uint32_t)((span * row[cnt + 1]) >> 16);   // cdf[s], cdf[s + 1]
+        const uint32_t lo = low + c_lo, hi = low + c_hi - 1;
+        const int nshare = (int)_lzcnt_u32(lo ^ hi);
+        const int t = (int)_lzcnt_u32(~(lo & ~hi) & (uint32_t)(0x7FFFFFFFull >> nshare)) - 1;
+        low = (uint32_t)((uint64_t)lo << t) & 0x7FFFFFFFu;
+        span = (uint64_t)(c_hi - c_lo) << t;
+        off = (uint32_t)((uint64_t)(off - c_lo) << t) | src.take(t);
     }
     return 0;
 }
 
 extern "C" int pcgc_rc_decode(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int64_t nbytes, int16_t* sym, int64_t n) {
     if (n <= 0) return 0;
-    if (g_rc_impl == 0 && Lp <= 64 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq"))
+    if (g_rc_impl == 0 && Lp <= 64 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq") &&
+        __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("lzcnt"))
         return rc_decode_avx512(cdf, C, Lp, in, nbytes, sym, n);
     return rc_decode_scalar(cdf, C, Lp, in, nbytes, sym, n);
 }

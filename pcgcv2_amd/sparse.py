@@ -38,6 +38,7 @@ class CoordMap:
         self._down = None
         self._parent_of = None
         self._unique = unique
+        self._prepared_up = None
 
     def __len__(self):
         return self.C.shape[0]
@@ -84,11 +85,22 @@ class CoordMap:
     def up(self):
         """-> children CoordMap at stride/2, rows 8*i+k: MinkowskiGenerativeConvolutionTranspose(k=2, stride=2).
         Not cached on the parent: the child keeps a strong reference to its parent (to derive its kernel map), and a
-        back-reference would form a cycle that keeps hundreds of MB of maps alive until Python's cyclic GC runs."""
+        back-reference would form a cycle that keeps hundreds of MB of maps alive until Python's cyclic GC runs.
+        (`prepare_up()` parks one prebuilt child here; it is handed out — and the reference dropped — by the next up().)"""
+        if self._prepared_up is not None:
+            child, self._prepared_up = self._prepared_up, None
+            return child
         return CoordMap(ops.coords_children(self.C, self.stride), self.stride // 2, unique=True, origin=('children', self))
 
+    def prepare_up(self):
+        """Build the children level and its k3 kernel map ahead of time (the decoder's first stage needs both); used to
+        overlap this coordinate-only work with host-side entropy decoding."""
+        child = self.up()
+        child.k3
+        self._prepared_up = child
+
     def drop_caches(self):
-        self._table = self._k3 = self._down = self._parent_of = None
+        self._table = self._k3 = self._down = self._parent_of = self._prepared_up = None
 
 
 def dedup(coords, feats, stride):
@@ -112,6 +124,8 @@ class SparseTensor:
             self.cmap = coordinate_map
             dev = coordinate_map.C.device
             self.F = features if features.device == dev else features.to(dev)
+            if self.F.shape[0] != len(coordinate_map):
+                raise PcgcError('coordinates / features length mismatch')
         else:
             dev = require_gpu(device if device is not None else coordinates.device)
             coords = coordinates.to(device=dev, dtype=torch.int32).contiguous()
