@@ -24,6 +24,19 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* OpenMP thread count of the row-parallel loops (bench.py's cpu_baseline reports an all-cores and a 1-thread figure). */
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n; return 1;
+#endif
+}
 
 /* ------------------------------------------------------------------------------------------------
  * coordinate keys.  coords are int32 [N,4] = (batch, x, y, z) as ME.SparseTensor.C

@@ -42,6 +42,8 @@ def _load():
     lib.orc_rc_decode.argtypes = [vp, C.c_int, C.c_int, vp, i64, vp, i64]
     lib.orc_nn_sqdist_sum.restype = C.c_double
     lib.orc_nn_sqdist_sum.argtypes = [vp, i64, vp, i64, vp]
+    lib.orc_set_threads.restype = C.c_int
+    lib.orc_set_threads.argtypes = [C.c_int]
     return lib
 
 
@@ -53,6 +55,11 @@ def lib():
     if _lib is None:
         _lib = _load()
     return _lib
+
+
+def set_threads(n):
+    """OpenMP threads of the row-parallel oracle loops; returns the count now in effect."""
+    return int(lib().orc_set_threads(int(n)))
 
 
 def _p(a):

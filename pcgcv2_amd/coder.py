@@ -111,20 +111,21 @@ class Coder():
     def encode(self, x, postfix=''):
         """coder.py:80-91: writes the four files, returns the sorted stride-8 latent.  Schedule: the geometry pyramid
         (N1 -> N2 -> N4 -> N8) is built first, so the stride-8 coordinates — all the coordinate coder needs — reach the host
-        before the convolutions are even enqueued; the sequential host-side coordinate coding then overlaps the GPU's
-        encoder pass."""
+        before the convolutions are even enqueued; the sequential host-side coordinate coding then runs on a helper thread
+        while this thread enqueues the encoder and the GPU executes it."""
         lvl8 = x.cmap
         for _ in range(3):
             lvl8 = lvl8.down()[0]                               # cached on the levels: the encoder reuses these maps
         order = ops.sort_zyx(lvl8.C)                            # (z, y, x, batch) order of sort_spare_tensor
         y_C = ops.gather_coords(lvl8.C, order)
         coords8 = y_C.cpu().numpy()[:, 1:] // lvl8.stride       # tiny D2H (N8 x 16 B)
-        y_list = self.model.encoder(x)                          # asynchronous: ~40 kernel launches
-        self.coordinate_coder.encode(coords8, postfix=postfix)  # host work, hidden behind the GPU
+        coded = _POOL.submit(self.coordinate_coder.encode, coords8, postfix)    # host work on the helper thread (GIL released)
+        y_list = self.model.encoder(x)                          # ~40 kernel launches, enqueued while the octree is coded
         y = SparseTensor(ops.gather_feats(y_list[0].F, order), coordinate_map=CoordMap(y_C, lvl8.stride, unique=True))
         budgets = [len(t) for t in (y_list[1], y_list[2], x)]
         _dump(self.filename + postfix + '_num_points.bin', _COUNTS.pack(*budgets))
         self.feature_coder.encode(y.F, postfix=postfix)
+        coded.result()                                          # (re-raises a coordinate-coder failure)
         return y
 
     def _decode_geometry(self, postfix, dev):

@@ -55,11 +55,24 @@ class _Profile:
     def __init__(self):
         self.reset(False)
 
-    def reset(self, enabled=False):
+    def reset(self, enabled=False, only=None):
         self.enabled = enabled
+        self.only = only           # bracket just this (kernel, shape) key: keeps the event overhead out of a timed region
         self.counting = False
         self.records = {}          # key -> dict(kernel, n, bytes(P), flops(P), events=[(e0,e1)])
         self.pairs = {}            # n_out -> P of the level's k3 map
+
+    def want(self, key):
+        return self.enabled and (self.only is None or self.only == key)
+
+    def dominant_key(self):
+        """key of the (kernel, shape) with the largest total bracketed time so far."""
+        best, best_ms = None, -1.0
+        for key, r in self.records.items():
+            ms = sum(e0.elapsed_time(e1) for e0, e1 in r['events'])
+            if ms > best_ms:
+                best, best_ms = key, ms
+        return best
 
     def bracket(self, key, kernel, n, bytes_fn, flops_fn):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -259,7 +272,7 @@ def conv_gather(nbr, x, W, bias, out=None, residual=None, relu=False, n_out=None
     if out is None:
         out = torch.empty((n_out, Cout), dtype=torch.float32, device=x.device)
     res_p, res_ld = (None, 0) if residual is None else (_p(_f32(residual)), _ld(residual))
-    prof = PROFILE.enabled and K == 27
+    prof = K == 27 and PROFILE.want(('conv', Cin, Cout, n_out))
     if prof:
         e0, e1 = PROFILE.bracket(('conv', Cin, Cout, n_out), f'k3 gather conv Cin={Cin} Cout={Cout} (k_conv_gather_mfma/dma)', n_out,
                                  lambda P, a=Cin, b=Cout, n=n_out: P * a * 4 + P * 8 + n * b * 4,
@@ -292,7 +305,7 @@ def irn_block(nbr, x, params):
     arr = (ctypes.c_void_p * 10)(*[p.data_ptr() for p in params])
     if PROFILE.counting:
         PROFILE.count(nbr)
-    if not PROFILE.enabled:
+    if not (PROFILE.want((f'k_irn_a<{C}, 64>', n)) or PROFILE.want((f'k_irn_b<{C}, 64>', n))):
         check(lib().pcgc_irn_block(_p(nbr), n, _p(x), C, _ld(x), arr, _p(t), _p(out), C, _stream()), 'irn_block')
         return out
     Q = C // 4
@@ -300,10 +313,13 @@ def irn_block(nbr, x, params):
               (2, f'k_irn_b<{C}, 64>', lambda P, n=n: (P * Q * 4 + P * 8 + n * 2 * Q * 4) + (P * Q * 4 + P * 8 + n * Q * 4) + n * 3 * Q * 4,
                lambda P, n=n: 2 * P * Q * 2 * Q + 2 * P * Q * Q + 2 * n * Q * 2 * Q))
     for ps, name, bf, ff in passes:
-        e0, e1 = PROFILE.bracket((name, n), name, n, bf, ff)
-        e0.record()
+        prof = PROFILE.want((name, n))
+        if prof:
+            e0, e1 = PROFILE.bracket((name, n), name, n, bf, ff)
+            e0.record()
         check(lib().pcgc_irn_pass(_p(nbr), n, _p(x), C, _ld(x), arr, _p(t), _p(out), C, ps, _stream()), 'irn_pass')
-        e1.record()
+        if prof:
+            e1.record()
     return out
 
 
@@ -348,11 +364,12 @@ def irn_block_mfma64(nbr, x, f):
          lambda: lib().pcgc_conv_gather_masked(_p(nbr), n, _p(t), n, 32, 32, _p(f['Wb']), 48, _p(f['mask_b']), _p(f['bb']), 0, _p(u), 48, _stream())),
     )
     for name, bf, ff, call in steps:
-        if PROFILE.enabled:
+        prof = PROFILE.want((name, n))
+        if prof:
             e0, e1 = PROFILE.bracket((name, n), name, n, bf, ff)
             e0.record()
         check(call(), 'conv_gather_masked')
-        if PROFILE.enabled:
+        if prof:
             e1.record()
     check(lib().pcgc_irn_tail(_p(u), _p(x), 64, _ld(x), _p(f['W12']), _p(f['b12']), _p(out), 64, n, _stream()), 'irn_tail')
     return out
