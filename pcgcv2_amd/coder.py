@@ -118,8 +118,10 @@ class Coder():
             lvl8 = lvl8.down()[0]                               # cached on the levels: the encoder reuses these maps
         order = ops.sort_zyx(lvl8.C)                            # (z, y, x, batch) order of sort_spare_tensor
         y_C = ops.gather_coords(lvl8.C, order)
-        coords8 = y_C.cpu().numpy()[:, 1:] // lvl8.stride       # tiny D2H (N8 x 16 B)
-        coded = _POOL.submit(self.coordinate_coder.encode, coords8, postfix)    # host work on the helper thread (GIL released)
+        # the stride-8 coordinates leave on a side stream into pinned memory (N8 x 16 B); the helper thread waits for that
+        # copy and runs the host coordinate coder, while this thread goes straight on to enqueue the encoder
+        arrived, host_C = self._stage_to_host(y_C)
+        coded = _POOL.submit(self._encode_geometry, arrived, host_C, lvl8.stride, postfix)
         y_list = self.model.encoder(x)                          # ~40 kernel launches, enqueued while the octree is coded
         y = SparseTensor(ops.gather_feats(y_list[0].F, order), coordinate_map=CoordMap(y_C, lvl8.stride, unique=True))
         budgets = [len(t) for t in (y_list[1], y_list[2], x)]
@@ -127,6 +129,30 @@ class Coder():
         self.feature_coder.encode(y.F, postfix=postfix)
         coded.result()                                          # (re-raises a coordinate-coder failure)
         return y
+
+    def _stage_to_host(self, t):
+        """Asynchronous device->host copy of a small tensor on a side stream; -> (event to wait for, pinned host view)."""
+        dev = t.device
+        if getattr(self, '_side', None) is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+            self._pinned = None
+        if self._pinned is None or self._pinned.numel() < t.numel() or self._pinned.dtype != t.dtype:
+            self._pinned = torch.empty(max(t.numel(), 1 << 16), dtype=t.dtype, pin_memory=True)
+        host = self._pinned[:t.numel()].view(t.shape)
+        ready = torch.cuda.Event()
+        ready.record()                                           # on the current stream: t is complete after this
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            host.copy_(t, non_blocking=True)
+            arrived = torch.cuda.Event()
+            arrived.record(self._side)
+        t.record_stream(self._side)
+        return arrived, host
+
+    def _encode_geometry(self, arrived, host_C, stride, postfix):
+        torch.cuda.set_device(self._side.device)                 # the current device is per thread
+        arrived.synchronize()
+        self.coordinate_coder.encode(host_C.numpy()[:, 1:] // stride, postfix=postfix)
 
     def _decode_geometry(self, postfix, dev):
         """`_C.bin` -> sorted stride-8 coordinate level on `dev` (coder.py:94-99: host argsort there, device sort here)."""

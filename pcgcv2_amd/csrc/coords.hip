@@ -32,14 +32,20 @@ __global__ void k_hash_insert(const int4* __restrict__ coords, int64_t n, int sh
     if (!coord_in_range(c.x, c.y, c.z, c.w)) return;  // out-of-range rows are never found again; host validates
     uint64_t key = coord_key(c.x, c.y, c.z, c.w);
     uint64_t h = hash_slot(c.x, c.y, c.z, c.w, sh, cap_mask);
+    // Quantised coordinates arrive up to 8 times each.  Test before the atomics: a slot only ever goes EMPTY -> key and its
+    // row value only ever decreases, so a plain (possibly stale) load that already shows this key / a smaller row lets the
+    // thread skip the CAS / the atomicMin; a stale load merely falls through to the atomic path.
     for (;;) {
-        unsigned long long prev = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)PCGC_EMPTY_KEY,
-                                            (unsigned long long)key);
-        if (prev == PCGC_EMPTY_KEY || prev == key) { atomicMin(&vals[h], (int32_t)i); return; }
+        unsigned long long prev = __builtin_nontemporal_load((const unsigned long long*)&keys[h]);
+        if (prev == PCGC_EMPTY_KEY)                     // (a slot holding another key keeps it for good: just probe on)
+            prev = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)PCGC_EMPTY_KEY, (unsigned long long)key);
+        if (prev == PCGC_EMPTY_KEY || prev == key) {
+            if (__builtin_nontemporal_load(&vals[h]) > (int32_t)i) atomicMin(&vals[h], (int32_t)i);
+            return;
+        }
         h = (h + 1) & cap_mask;
     }
 }
-
 __global__ void k_hash_first_mask(const int4* __restrict__ coords, int64_t n, int sh, const uint64_t* __restrict__ keys,
                                   const int32_t* __restrict__ vals, uint64_t cap_mask, uint8_t* keep, int32_t* first_row) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
