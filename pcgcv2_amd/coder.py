@@ -24,7 +24,7 @@ from .pcc_model import PCCModel
 from .sparse import SparseTensor, CoordMap, require_gpu
 
 device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
-_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix='pcgc-coord')
+_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix='pcgc-coord')      # helpers of up to 4 frames in flight
 
 _HEADER = struct.Struct('<iibff')                 # (N8, C, len(min_v)=1, min_v, max_v) — coder.py:51-55
 _COUNTS = struct.Struct('<3i')                    # (N4, N2, N1)                       — coder.py:85-87
@@ -154,16 +154,18 @@ class Coder():
         arrived.synchronize()
         self.coordinate_coder.encode(host_C.numpy()[:, 1:] // stride, postfix=postfix)
 
-    def _decode_geometry(self, postfix, dev):
-        """`_C.bin` -> sorted stride-8 coordinate level on `dev` (coder.py:94-99: host argsort there, device sort here)."""
-        torch.cuda.set_device(dev)                               # the current device is per thread
+    def _decode_geometry(self, postfix, dev, stream):
+        """`_C.bin` -> sorted stride-8 coordinate level on `dev` (coder.py:94-99: host argsort there, device sort here).
+        Runs on the helper thread but enqueues on the CALLER's stream (current device and stream are per thread)."""
+        torch.cuda.set_device(dev)
         xyz8 = np.asarray(self.coordinate_coder.decode(postfix), dtype=np.int32)
         y_C4 = np.zeros((len(xyz8), 4), dtype=np.int32)          # batch column 0, coordinates back at tensor stride 8
         y_C4[:, 1:] = xyz8 * 8
-        y_C = torch.from_numpy(y_C4).to(dev)
-        lvl8 = CoordMap(ops.gather_coords(y_C, ops.sort_zyx(y_C)), 8, unique=True)
-        if len(lvl8):
-            lvl8.prepare_up()
+        with torch.cuda.stream(stream):
+            y_C = torch.from_numpy(y_C4).to(dev)
+            lvl8 = CoordMap(ops.gather_coords(y_C, ops.sort_zyx(y_C)), 8, unique=True)
+            if len(lvl8):
+                lvl8.prepare_up()
         return lvl8
 
     @torch.no_grad()
@@ -173,7 +175,7 @@ class Coder():
         # the two bitstreams are independent: a helper thread decodes the coordinates, uploads and sorts them and prebuilds
         # the coordinate-only part of the first decoder stage (children level + kernel maps) while this thread range-decodes
         # the features (native calls that release the GIL; both threads enqueue on the device's default stream)
-        pending = _POOL.submit(self._decode_geometry, postfix, dev)
+        pending = _POOL.submit(self._decode_geometry, postfix, dev, torch.cuda.current_stream(dev))
         y_F = self.feature_coder.decode(postfix=postfix, device=dev)
         y = SparseTensor(features=y_F, coordinate_map=pending.result())
         n4, n2, n1 = _COUNTS.unpack(_slurp(self.filename + postfix + '_num_points.bin')[:_COUNTS.size])

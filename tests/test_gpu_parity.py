@@ -339,6 +339,36 @@ def test_full_size_frame_properties(sd, tmp_path):
     np.testing.assert_array_equal(yF.cpu().numpy(), np.rint(y.F.cpu().numpy()) + np.float32(0))
 
 
+@pytest.mark.parametrize('in_flight', [2, 4])
+def test_frames_in_flight_identical_to_sequential(in_flight, sd, sd_np, tmp_path):
+    """Serving mode (shard.code_units(in_flight=F)): F host threads with their own Coder + HIP stream code different frames
+    concurrently.  Bitstreams and decoded clouds must equal the sequential run byte for byte; one small frame is also
+    checked against the oracle.  Repeated to give stream-ordering races a chance to show."""
+    from pcgcv2_amd.coder import Coder, STREAMS
+    from pcgcv2_amd import shard
+    m = _model(sd)
+    names = ['shell8', 'shell9', 'shell7', 'shell9_b' if 'shell9_b' in synthetic.SHELLS else 'shell8', 'shell6', 'shell9']
+    units = []
+    for i, nm in enumerate(names):
+        c4 = _coords(nm)
+        units.append((f'u{i}', SparseTensor(torch.ones((len(c4), 1)), coordinates=_t(c4), tensor_stride=1, device=DEV)))
+    seq_dir, par_dir = tmp_path / 'seq', tmp_path / 'par'
+    seq_dir.mkdir(); par_dir.mkdir()
+    st_seq, out_seq = shard.code_units(Coder(m, str(seq_dir / 'f')), units)
+    for rep in range(3):
+        st_par, out_par = shard.code_units(Coder(m, str(par_dir / 'f')), units, in_flight=in_flight)
+        torch.cuda.synchronize()
+        assert st_par.v.tolist() == st_seq.v.tolist()
+        for name, _ in units:
+            for suffix in STREAMS:
+                assert (par_dir / f'f_{name}{suffix}').read_bytes() == (seq_dir / f'f_{name}{suffix}').read_bytes(), (name, suffix)
+            assert torch.equal(out_par[name].C, out_seq[name].C), name
+    ref = orc.encode(sd_np, _coords('shell7'))
+    assert (par_dir / 'f_u2_F.bin').read_bytes() == ref['F']
+    want = orc.decode(sd_np, ref['coords8'], ref['F'], ref['H'], ref['num_points'])
+    np.testing.assert_array_equal(out_par['u2'].C.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize('name,n_expect', [('shell11', None)])
 def test_vox11_frame_roundtrip_properties(name, n_expect, sd, tmp_path):
     """BASELINE config 4 shape (dancer vox11, res 2048, ~2.6 M points): the stand-in shell11 through encode/decode."""
