@@ -92,12 +92,13 @@ class FeatureCoder():
         n, c = feats.shape
         _dump(self.filename + postfix + '_H.bin', _HEADER.pack(n, c, len(min_v), float(min_v[0]), float(max_v[0])))
 
-    def decode(self, postfix='', device=None):
+    def decode(self, postfix='', device=None, on_table_launched=None):
         n, c, n_minv, min_v, max_v = _HEADER.unpack(_slurp(self.filename + postfix + '_H.bin')[:_HEADER.size])
         if n_minv != 1:
             raise ValueError('unsupported _H.bin: expected one (min_v, max_v) pair')
         payload = _slurp(self.filename + postfix + '_F.bin')
-        return self.entropy_model.decompress(payload, np.float32(min_v), np.float32(max_v), (n, c), channels=c, device=device)
+        return self.entropy_model.decompress(payload, np.float32(min_v), np.float32(max_v), (n, c), channels=c, device=device,
+                                             on_table_launched=on_table_launched)
 
 
 class Coder():
@@ -174,10 +175,14 @@ class Coder():
         dev = require_gpu(next(self.model.decoder.parameters()).device)
         # the two bitstreams are independent: a helper thread decodes the coordinates, uploads and sorts them and prebuilds
         # the coordinate-only part of the first decoder stage (children level + kernel maps) while this thread range-decodes
-        # the features (native calls that release the GIL; both threads enqueue on the device's default stream)
-        pending = _POOL.submit(self._decode_geometry, postfix, dev, torch.cuda.current_stream(dev))
-        y_F = self.feature_coder.decode(postfix=postfix, device=dev)
-        y = SparseTensor(features=y_F, coordinate_map=pending.result())
+        # the features (native calls that release the GIL; both threads enqueue on this thread's stream).  The helper is
+        # started once this thread has read its files and enqueued the CDF-table kernel, so its Python prologue runs while
+        # this thread waits for the table instead of competing for the interpreter lock.
+        stream = torch.cuda.current_stream(dev)
+        pending = []
+        y_F = self.feature_coder.decode(postfix=postfix, device=dev,
+                                        on_table_launched=lambda: pending.append(_POOL.submit(self._decode_geometry, postfix, dev, stream)))
+        y = SparseTensor(features=y_F, coordinate_map=pending[0].result())
         n4, n2, n1 = _COUNTS.unpack(_slurp(self.filename + postfix + '_num_points.bin')[:_COUNTS.size])
         budgets = [[n4], [n2], [int(rho * n1)]]                  # coder.py:105-108
         _, out = self.model.decoder(y, nums_list=budgets, ground_truth_list=[None] * 3, training=False)

@@ -82,11 +82,14 @@ class EntropyBottleneck(nn.Module):
         return strings, np.array([min_v], np.float32), np.array([max_v], np.float32)
 
     @torch.no_grad()
-    def decompress(self, strings, min_v, max_v, shape, channels, device=None):
-        """entropy_model.py:178-196 -> fp32 [shape[0], channels] on `device`."""
+    def decompress(self, strings, min_v, max_v, shape, channels, device=None, on_table_launched=None):
+        """entropy_model.py:178-196 -> fp32 [shape[0], channels] on `device`.  `on_table_launched` (optional) is called once
+        the CDF-table kernel is enqueued, before this thread blocks on its result: the place to start concurrent host work."""
         device = torch.device('cuda') if device is None else device
         min_v, max_v = np.float32(np.asarray(min_v).reshape(-1)[0]), np.float32(np.asarray(max_v).reshape(-1)[0])
         table, _ = self.cdf_table(min_v, max_v, device)
+        if on_table_launched is not None:
+            on_table_launched()
         n = int(shape[0]) * int(channels)
         sym_h = ops.rc_decode(table.cpu().numpy().view(np.uint16), strings, n)
         sym = torch.from_numpy(sym_h.reshape(int(shape[0]), int(channels))).to(device)
