@@ -84,6 +84,9 @@ __attribute__((always_inline)) inline int64_t rc_encode_body(const uint16_t* cdf
         const uint32_t lo = low + c_lo, hi = low + c_hi - 1;
         const int nshare = lz(lo ^ hi);
         const int t = lz(~(lo & ~hi) & (uint32_t)(0x7FFFFFFFull >> nshare)) - 1;
+        // the coder state first: this is the loop-carried dependency chain; the bit emission below hangs off it
+        low = (uint32_t)((uint64_t)lo << t) & 0x7FFFFFFFu;
+        span = (uint64_t)(c_hi - c_lo) << t;
         if (nshare) {                                           // (almost always taken: > 1 bit per symbol)
             const uint32_t bits = (uint32_t)(((uint64_t)lo << nshare) >> 32);
             const uint32_t first = bits >> (nshare - 1);
@@ -93,8 +96,6 @@ __attribute__((always_inline)) inline int64_t rc_encode_body(const uint16_t* cdf
             pending = 0;
         }
         pending += (uint64_t)(t - nshare);
-        low = (uint32_t)((uint64_t)lo << t) & 0x7FFFFFFFu;
-        span = (uint64_t)(c_hi - c_lo) << t;
     }
     ++pending;
     const uint32_t last = low < 0x40000000u ? 0u : 1u;
