@@ -794,10 +794,10 @@ static void launch_irn(const int32_t* nbr, int64_t n, const float* x, int x_ld, 
 template <int C>
 static void launch_irn_rows(const int32_t* nbr, int64_t n, const float* x, int x_ld, const float* const* P, float* t, float* out,
                             int out_ld, int phase, hipStream_t s) {
-    // measured (bench.py --irn-rows): 64 everywhere 13.8 ms/frame; 32/16 on the small levels 14.9 ms; 32 everywhere 15.0 ms —
-    // shorter tiles lose more DMA efficiency than the extra waves gain, so the automatic choice is always 64.
-    (void)n;
-    const int rows = g_irn_rows > 0 ? g_irn_rows : 64;
+    // measured per level (bench.py --irn-rows, us for pass A / pass B at C = 32): 18.7 k rows: 64 -> 62.7 / 45.8, 32 -> 51.8 / 38.0,
+    // 16 -> 43.7 / 32.8 (a level that small is 73 tiles of 64 rows: the extra waves win); 256 k rows: 68.5 / 54.3, 93.1 / 66.3,
+    // 141.7 / 100.4 and likewise above (shorter tiles lose more DMA efficiency than the extra waves gain).
+    const int rows = g_irn_rows > 0 ? g_irn_rows : (n < 40000 ? 16 : 64);
     if (rows == 64) launch_irn<C, 64>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
     else if (rows == 32) launch_irn<C, 32>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
     else launch_irn<C, 16>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
@@ -868,7 +868,7 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
         return 0;
     }
     const bool mfma_eligible = v1_eligible && (Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 16 || Cout == 32 || Cout == 64);
-    if (mfma_eligible && (g_conv_impl == 2 || (g_conv_impl < 0 && g_auto_mfma && n_out >= 30000))) {
+    if (mfma_eligible && (g_conv_impl == 2 || (g_conv_impl < 0 && g_auto_mfma && n_out >= 8192))) {      // (down2 64->32 at 18.7 k rows: 58 -> 38 us)
         const float* res0 = residual ? residual + res_coff : nullptr;
         float* out0 = out + out_coff;
         bool ok = false;

@@ -287,9 +287,19 @@ def conv_gather(nbr, x, W, bias, out=None, residual=None, relu=False, n_out=None
     return out
 
 
+_IRN_ROWS = 0
+
+
 def set_irn_rows(rows):
     """rows per wave of the fused InceptionResNet passes: 0 = by level size (default), or force 64 / 32 / 16."""
+    global _IRN_ROWS
     check(lib().pcgc_set_irn_rows(int(rows)), 'set_irn_rows')
+    _IRN_ROWS = int(rows)
+
+
+def _irn_rows(n):
+    """the tile height pcgc_irn_block picks (conv.hip launch_irn_rows): exact kernel names for the profile records"""
+    return _IRN_ROWS if _IRN_ROWS > 0 else (16 if n < 40000 else 64)
 
 
 FUSE_IRN = True           # tests flip this to compare the fused block against its five-conv composition
@@ -305,12 +315,13 @@ def irn_block(nbr, x, params):
     arr = (ctypes.c_void_p * 10)(*[p.data_ptr() for p in params])
     if PROFILE.counting:
         PROFILE.count(nbr)
-    if not (PROFILE.want((f'k_irn_a<{C}, 64>', n)) or PROFILE.want((f'k_irn_b<{C}, 64>', n))):
+    R = _irn_rows(n)
+    if not (PROFILE.want((f'k_irn_a<{C}, {R}>', n)) or PROFILE.want((f'k_irn_b<{C}, {R}>', n))):
         check(lib().pcgc_irn_block(_p(nbr), n, _p(x), C, _ld(x), arr, _p(t), _p(out), C, _stream()), 'irn_block')
         return out
     Q = C // 4
-    passes = ((1, f'k_irn_a<{C}, 64>', lambda P, n=n: (P * C * 4 + P * 8 + n * Q * 4) + n * (C + Q) * 4, lambda P, n=n: 2 * P * C * Q + 2 * n * C * Q),
-              (2, f'k_irn_b<{C}, 64>', lambda P, n=n: (P * Q * 4 + P * 8 + n * 2 * Q * 4) + (P * Q * 4 + P * 8 + n * Q * 4) + n * 3 * Q * 4,
+    passes = ((1, f'k_irn_a<{C}, {R}>', lambda P, n=n: (P * C * 4 + P * 8 + n * Q * 4) + n * (C + Q) * 4, lambda P, n=n: 2 * P * C * Q + 2 * n * C * Q),
+              (2, f'k_irn_b<{C}, {R}>', lambda P, n=n: (P * Q * 4 + P * 8 + n * 2 * Q * 4) + (P * Q * 4 + P * 8 + n * Q * 4) + n * 3 * Q * 4,
                lambda P, n=n: 2 * P * Q * 2 * Q + 2 * P * Q * Q + 2 * n * Q * 2 * Q))
     for ps, name, bf, ff in passes:
         prof = PROFILE.want((name, n))
