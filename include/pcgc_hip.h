@@ -85,6 +85,14 @@ int pcgc_kmap_k3_from_coarse(const int32_t* fine /*[n_fine,4]*/, int64_t n_fine,
 /* parent_of[c] = prefix[first_row[c]]; down[slot(c)][parent_of[c]] = c — the k2s2 kernel map without hash probes */
 int pcgc_down_maps(const int32_t* fine, const int32_t* first_row, const int32_t* prefix, int64_t n_fine, int32_t stride_fine,
                    int64_t n_coarse, int32_t* parent_of /*[dev n_fine]*/, int32_t* down /*[dev 8,n_coarse]*/, void* stream);
+/* One strided pyramid level = pcgc_coords_quantize + hash clear/insert/first_mask + pcgc_mask_scan (prepare), then — after
+ * the host has read *total = n_coarse — pcgc_compact_coords + pcgc_down_maps (finish).  Same kernels, two calls. */
+int pcgc_down_prepare(const int32_t* fine /*[dev n,4]*/, int64_t n, int32_t stride_fine, int32_t* q /*[dev n,4] quantised*/,
+                      uint64_t* keys, int32_t* vals, int64_t cap, uint8_t* keep /*[dev n]*/, int32_t* first_row /*[dev n]*/,
+                      int32_t* prefix /*[dev n]*/, int32_t* total /*[dev 1]*/, void* scan_ws, size_t scan_ws_bytes, void* stream);
+int pcgc_down_finish(const int32_t* fine, const int32_t* q, const uint8_t* keep, const int32_t* first_row, const int32_t* prefix,
+                     int64_t n, int32_t stride_fine, int64_t n_coarse, int32_t* coarse /*[dev n_coarse,4]*/,
+                     int32_t* parent_of /*[dev n]*/, int32_t* down /*[dev 8,n_coarse]*/, void* stream);
 /* orig[prefix[i]] = i for set mask bytes (row indices that survive a compaction) */
 int pcgc_compact_index(const uint8_t* mask, const int32_t* prefix, int64_t n, int32_t* orig /*[dev total]*/, void* stream);
 

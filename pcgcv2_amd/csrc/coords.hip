@@ -278,6 +278,26 @@ extern "C" int pcgc_down_maps(const int32_t* fine, const int32_t* first_row, con
     PCGC_CHECK_LAUNCH("down_maps");
     return 0;
 }
+// One strided level of the encoder pyramid (MinkowskiConvolution k=2 s=2 coordinate side) as two calls around the single
+// host read-back of the coarse count: the host-side launch glue between the seven small dependent kernels of a level was
+// as long as the kernels themselves (this phase starts behind a synchronisation, so the host cannot run ahead).
+extern "C" int pcgc_down_prepare(const int32_t* fine, int64_t n, int32_t stride_fine, int32_t* q, uint64_t* keys, int32_t* vals,
+                                 int64_t cap, uint8_t* keep, int32_t* first_row, int32_t* prefix, int32_t* total, void* scan_ws,
+                                 size_t scan_ws_bytes, void* stream) {
+    int rc;
+    if ((rc = pcgc_coords_quantize(fine, n, 2 * stride_fine, q, stream))) return rc;
+    if ((rc = pcgc_hash_clear(keys, vals, cap, stream))) return rc;
+    if ((rc = pcgc_hash_insert(q, n, 2 * stride_fine, keys, vals, cap, stream))) return rc;
+    if ((rc = pcgc_hash_first_mask(q, n, 2 * stride_fine, keys, vals, cap, keep, first_row, stream))) return rc;
+    return pcgc_mask_scan(keep, n, prefix, total, scan_ws, scan_ws_bytes, stream);
+}
+extern "C" int pcgc_down_finish(const int32_t* fine, const int32_t* q, const uint8_t* keep, const int32_t* first_row,
+                                const int32_t* prefix, int64_t n, int32_t stride_fine, int64_t n_coarse, int32_t* coarse,
+                                int32_t* parent_of, int32_t* down, void* stream) {
+    int rc;
+    if ((rc = pcgc_compact_coords(q, keep, prefix, n, coarse, stream))) return rc;
+    return pcgc_down_maps(fine, first_row, prefix, n, stride_fine, n_coarse, parent_of, down, stream);
+}
 extern "C" int pcgc_compact_index(const uint8_t* mask, const int32_t* prefix, int64_t n, int32_t* orig, void* stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_compact_index, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), mask, prefix, n, orig);

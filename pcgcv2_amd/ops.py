@@ -156,6 +156,32 @@ def down_maps(fine, first_row, prefix, stride_fine, n_coarse):
     return parent_of, down
 
 
+def down_level(fine, stride_fine):
+    """One strided pyramid level (MinkowskiConvolution k=2 s=2, coordinate side) in two library calls around the one
+    host read-back of the coarse count -> (coarse int32 [n_coarse,4], parent_of int32 [n], down int32 [8,n_coarse]).
+    Canonical order: coarse rows in first-occurrence order of the quantised fine rows."""
+    fine = _i32(fine)
+    n, dev = fine.shape[0], fine.device
+    cap = int(lib().pcgc_hash_capacity(n))
+    q = torch.empty_like(fine)
+    keys = torch.empty(cap, dtype=torch.int64, device=dev)
+    i32buf = torch.empty(cap + 2 * n + 1, dtype=torch.int32, device=dev)          # vals | first_row | prefix | total
+    vals, first_row, prefix, total = i32buf[:cap], i32buf[cap:cap + n], i32buf[cap + n:cap + 2 * n], i32buf[cap + 2 * n:]
+    keep = torch.empty(n, dtype=torch.uint8, device=dev)
+    ws_bytes = int(lib().pcgc_scan_workspace_bytes(n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    s = _stream()
+    check(lib().pcgc_down_prepare(_p(fine), n, int(stride_fine), _p(q), _p(keys), _p(vals), cap, _p(keep), _p(first_row), _p(prefix),
+                                  _p(total), _p(ws), ws_bytes, s), 'down_prepare')
+    n_coarse = int(total.item())                               # host sync: sizes the coarse level
+    coarse = torch.empty((n_coarse, 4), dtype=torch.int32, device=dev)
+    parent_of = torch.empty(n, dtype=torch.int32, device=dev)
+    down = torch.empty((8, n_coarse), dtype=torch.int32, device=dev)
+    check(lib().pcgc_down_finish(_p(fine), _p(q), _p(keep), _p(first_row), _p(prefix), n, int(stride_fine), n_coarse, _p(coarse),
+                                 _p(parent_of), _p(down), s), 'down_finish')
+    return coarse, parent_of, down
+
+
 def compact_index(mask, prefix, n_out):
     orig = torch.empty(n_out, dtype=torch.int32, device=mask.device)
     check(lib().pcgc_compact_index(_p(mask), _p(prefix), mask.shape[0], _p(orig), _stream()), 'compact_index')

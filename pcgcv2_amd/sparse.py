@@ -72,14 +72,8 @@ class CoordMap:
         """-> (coarse CoordMap at 2*stride, [8, N_coarse] kernel map): MinkowskiConvolution(kernel_size=2, stride=2).
         One hash insert + one probe per fine row (the dedup of the quantised coordinates); the map itself is a scatter."""
         if self._down is None:
-            q = ops.coords_quantize(self.C, 2 * self.stride)
-            qt = ops.HashTable(q, 2 * self.stride)
-            keep, first_row = ops.first_occurrence_mask(q, qt, want_rows=True)
-            prefix, total = ops.mask_scan(keep)
-            n_coarse = int(total.item())                       # host sync: sizes the coarse level
-            coarse = CoordMap(ops.compact_coords(q, keep, prefix, n_coarse), 2 * self.stride, unique=True)
-            self._parent_of, down = ops.down_maps(self.C, first_row, prefix, self.stride, n_coarse)
-            self._down = (coarse, down)
+            coarse_C, self._parent_of, down = ops.down_level(self.C, self.stride)
+            self._down = (CoordMap(coarse_C, 2 * self.stride, unique=True), down)
         return self._down
 
     def up(self):
