@@ -61,6 +61,8 @@ class MinkowskiPruning(torch.nn.Module):
         prefix, total = ops.mask_scan(mask)
         n = int(total.item()) if n_keep is None else int(n_keep)
         coords = ops.compact_coords(x.C, mask, prefix, n)
-        feats = ops.compact_feats(x.F, mask, prefix, n)
+        # the surviving feature rows are compacted on first use: the last decoder stage only hands on coordinates
+        src = x.F
+        feats = lambda: ops.compact_feats(src, mask, prefix, n)
         return SparseTensor(feats, coordinate_map=CoordMap(coords, x.cmap.stride, unique=True,
                                                            origin=('pruned', x.cmap, mask, prefix)))

@@ -114,9 +114,13 @@ class SparseTensor:
     def __init__(self, features, coordinates=None, tensor_stride=1, device=None, coordinate_map=None, assume_unique=False):
         if isinstance(tensor_stride, (list, tuple)):
             tensor_stride = tensor_stride[0]
+        self._F_thunk = None
         if coordinate_map is not None:
             self.cmap = coordinate_map
             dev = coordinate_map.C.device
+            if callable(features):                     # deferred features: produced on first access of .F (MinkowskiPruning)
+                self._F, self._F_thunk = None, features
+                return
             self.F = features if features.device == dev else features.to(dev)
             if self.F.shape[0] != len(coordinate_map):
                 raise PcgcError('coordinates / features length mismatch')
@@ -132,6 +136,16 @@ class SparseTensor:
                 coords, feats = dedup(coords, feats, int(tensor_stride))
             self.cmap = CoordMap(coords, int(tensor_stride), unique=True)
             self.F = feats
+
+    @property
+    def F(self):
+        if self._F is None and self._F_thunk is not None:
+            self._F, self._F_thunk = self._F_thunk(), None
+        return self._F
+
+    @F.setter
+    def F(self, value):
+        self._F, self._F_thunk = value, None
 
     @property
     def C(self):
