@@ -106,6 +106,9 @@ int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const float* in, 
 /* kernel selection for the gather conv: -1 auto (default), 0 = v0 direct-load kernel, 1 = v1 LDS-DMA kernel where eligible.
  * Both produce bit-identical results; the switch exists for A/B measurements and tests. */
 int pcgc_set_conv_impl(int impl);
+/* the LDS-shared-weight MFMA kernels come in two schedules (v2b: 16-channel sub-steps; v2c: 32-channel steps with the next
+ * step's loads in flight): -1 choose by level size (default), 0 always v2b, 1 always v2c.  Bit-identical. */
+int pcgc_set_mfma_pipe(int mode);
 /* rows per wave of the fused InceptionResNet passes: 0 = by level size (default), or force 64 / 32 / 16 (A/B tests). */
 int pcgc_set_irn_rows(int rows);
 /* Fused InceptionResNet block (autoencoder.py:7-57):  out = cat(conv0_1(relu(conv0_0 x)), conv1_2(relu(conv1_1(relu(conv1_0 x))))) + x

@@ -5,6 +5,7 @@
 //   acc = +0 ; for k ascending, for ci ascending: acc = fmaf(in[nbr[k][o]][ci], W[k][ci][co], acc)
 //   out = acc + bias ; out += residual ; out = relu(out)
 // Output-stationary => deterministic, no atomics, and the k-ascending order survives any tiling.
+#include <cstdlib>
 #include "pcgc_common.h"
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -251,8 +252,10 @@ static bool dispatch_dma_cout(int Cout, const int32_t* nbr, int K, int64_t n_out
 // ----------------------------------------------------------------------------------------------------------------
 // v2 kernel: LDS-DMA gather + fp32 MFMA channel GEMM, for Cin in {16,32,64} and Cout a multiple of 16.
 // One wave = 64 output rows (4 M-tiles of 16) x CT = 16*NT output channels.  Per sub-step (offset k, 16 input channels):
-//   * gather: 4 `buffer_load_dwordx4 ... lds` (4 adjacent lanes = one 64-byte row segment); lanes whose neighbour is
-//     absent write a zero slot themselves (MFMA cannot mask rows; fma(0, w, acc) == acc keeps the chain exact);
+//   * gather: 4 `buffer_load_dwordx4 ... lds` (4 adjacent lanes = one 64-byte row segment); a lane whose neighbour is
+//     absent uses an out-of-range buffer offset, for which the LDS-DMA writes ZEROS into the lane's slot (the bounds-checked
+//     load returns 0 and that is what lands in LDS — observed when such lanes overwrote live data, and relied on since:
+//     every parity test runs through it).  MFMA cannot mask rows; fma(0, w, acc) == acc keeps the chain exact;
 //   * A fragments: `v_mfma_f32_16x16x4_f32` wants A[row = lane&15][k = lane>>4].  Lane (i,q) reads the 16-byte chunk q of
 //     row 16m+i with ONE ds_read_b128 — slot q ^ f(i>>2) of the source-swizzled image, f = (0,2,3,1), which puts the
 //     four hardware lane groups of a b128 read on 16 distinct 16-byte slots (conflict-free) — and the 4x4 (lane-quarter x
@@ -263,15 +266,6 @@ static bool dispatch_dma_cout(int Cout, const int32_t* nbr, int K, int64_t n_out
 //     latency vs 32-cycle issue); per accumulator the channel order stays ascending => bitwise the canonical fmaf chain.
 // ----------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// 16-byte zero store to LDS that the compiler does not see as an LDS access: a plain store would make hipcc wait
-// `vmcnt(0)` for the in-flight LDS-DMA (possible alias) and serialise the four gathers of a sub-step.  The slot belongs
-// to this lane only (its DMA element is out of range and is not written), and the reader waits lgkmcnt(0) first.
-__device__ static inline void lds_zero16(float4* p) {
-    const unsigned addr = (unsigned)(uintptr_t)(lds_void_ptr)p;
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(z) : "memory");
-}
 
 __device__ static inline void lane_transpose4(float4& v) {
     // in: lane-quarter q holds components (c = 0..3) = element [q][c]; out: component c of quarter q = element [c][q]
@@ -325,7 +319,6 @@ k_conv_gather_mfma(const int32_t* __restrict__ nbr, int K, int64_t n_out, const 
                 const int chunk = dma_p ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3);
                 const unsigned voff = rid >= 0 ? (unsigned)(((int64_t)rid * in_ld + cb * 16 + chunk * 4) * 4) : 0xFFFFFFF0u;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_ptr)(rowbuf + i * 64), 16, (int)voff, 0, 0, 0);
-                if (rid < 0) lds_zero16(rowbuf + i * 64 + lane);       // inline asm: must not be ordered against the DMA
             }
             // ---- B fragments for this (k, cb): [j][n]
             float b[4][NT];
@@ -336,7 +329,6 @@ k_conv_gather_mfma(const int32_t* __restrict__ nbr, int K, int64_t n_out, const 
                 for (int n = 0; n < NT; ++n) b[j][n] = wk[(int64_t)(4 * j) * Cout + 16 * n];
             asm volatile("" ::: "memory");
             wait_vmcnt<0>();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // zero-slot writes landed
             // ---- A fragments
             float4 a[4];
 #pragma unroll
@@ -399,11 +391,15 @@ k_conv_gather_mfma_wlds(const int32_t* __restrict__ nbr, int K, int64_t n_out, c
                         const float* __restrict__ bias,
                         const float* __restrict__ res, int res_ld, int relu, float* __restrict__ out, int out_ld) {
     constexpr int NB = CIN / 16, NT = COUT / 16, ROWS = 16 * MT;
-    constexpr int WSLICE = 16 * COUT;                                  // floats per (k, cb) weight slice
+    // weight rows are padded to WLD floats in LDS: lane quarter q reads row 4j+q, so the row stride decides the banks of the
+    // four quarters — 32 floats puts two of them on the same 16 banks and 64 all four (PMC: 25 % of the LDS cycles of
+    // wlds<64,32,2> were bank conflicts, none in <32,48,2>); 48 / 80 keep the quarters apart
+    constexpr int WLD = (COUT % 32 == 0) ? COUT + 16 : COUT;
+    constexpr int WSLICE = 16 * WLD;                                   // floats per (k, cb) weight slice in LDS
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* wbuf = (float*)lds_raw;                                      // [2][16][COUT]
+    float* wbuf = (float*)lds_raw;                                      // [2][16][WLD]
     float4* rowbuf = (float4*)(lds_raw + 2 * WSLICE * 4) + (size_t)wave * (ROWS * 4);   // [ROWS][4] slots per wave
     const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * ROWS;
     const bool wave_active = row0 < n_out;                              // idle waves still take part in staging + barriers
@@ -426,7 +422,7 @@ k_conv_gather_mfma_wlds(const int32_t* __restrict__ nbr, int K, int64_t n_out, c
         const int k = t / NB, cb = t % NB;
         const float4* src = (const float4*)(W + ((int64_t)k * CIN + cb * 16) * COUT);
         float4* dst = (float4*)(wbuf + (t & 1) * WSLICE);
-        for (int i = threadIdx.x; i < WSLICE / 4; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < 16 * COUT / 4; i += 256) dst[(i / (COUT / 4)) * (WLD / 4) + i % (COUT / 4)] = src[i];
     };
     stage_w(0);
     int idx_cur = valid ? nbr[my_row] : -1;
@@ -444,7 +440,6 @@ k_conv_gather_mfma_wlds(const int32_t* __restrict__ nbr, int K, int64_t n_out, c
                 const int chunk = dma_p ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3);
                 const unsigned voff = rid >= 0 ? (unsigned)(((int64_t)rid * in_ld + cb * 16 + chunk * 4) * 4) : 0xFFFFFFF0u;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_ptr)(rowbuf + i * 64), 16, (int)voff, 0, 0, 0);
-                if (rid < 0) lds_zero16(rowbuf + i * 64 + lane);
             }
             asm volatile("" ::: "memory");
             wait_vmcnt<0>();
@@ -455,7 +450,7 @@ k_conv_gather_mfma_wlds(const int32_t* __restrict__ nbr, int K, int64_t n_out, c
                 a[m] = rowbuf[(16 * m + mi) * 4 + (mq ^ f_a)];
                 lane_transpose4(a[m]);
             }
-            const float* wb = wbuf + (t & 1) * WSLICE + mq * COUT + mi;     // B[j][n] = wb[(4j)*COUT + 16n]
+            const float* wb = wbuf + (t & 1) * WSLICE + mq * WLD + mi;      // B[j][n] = wb[(4j)*WLD + 16n]
             // block-sparse weights: bit n of tile_mask[t] = "column tile n has a non-zero weight in slice t"; an all-zero tile
             // would only add fma(x, 0, acc) = acc, so it is skipped (wave-uniform branch)
             const uint32_t tmask = tile_mask ? __builtin_amdgcn_readfirstlane(tile_mask[t]) : 0xFFFFFFFFu;
@@ -463,7 +458,7 @@ k_conv_gather_mfma_wlds(const int32_t* __restrict__ nbr, int K, int64_t n_out, c
             for (int j = 0; j < 4; ++j) {
                 float b[NT];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) b[n] = wb[(4 * j) * COUT + 16 * n];
+                for (int n = 0; n < NT; ++n) b[n] = wb[(4 * j) * WLD + 16 * n];
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     if (tmask & (1u << n)) {
@@ -501,12 +496,210 @@ template <int CIN, int COUT, int MT>
 static void launch_mfma_wlds(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int in_ld, const float* W,
                              const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld, hipStream_t s,
                              const uint32_t* tile_mask = nullptr) {
-    constexpr size_t lds = 2 * 16 * COUT * 4 + 4 * (size_t)(16 * MT * 64);
+    constexpr size_t lds = 2 * 16 * ((COUT % 32 == 0) ? COUT + 16 : COUT) * 4 + 4 * (size_t)(16 * MT * 64);
     hipLaunchKernelGGL((k_conv_gather_mfma_wlds<CIN, COUT, MT>), dim3(grid_for(n_out, 4 * 16 * MT)), dim3(256), lds, s, nbr, K,
                        n_out, in, n_in, in_ld, W, tile_mask, bias, res, res_ld, relu, out, out_ld);
 }
 
-// Block-sparse k3 gather conv on the LDS-shared-weight MFMA kernel (used by the fused C=64 InceptionResNet passes).
+// ----------------------------------------------------------------------------------------------------------------
+// v2c: v2b with 32-channel steps and the next step's loads in flight during the current step's MFMAs.
+// On the C = 64 levels (71 k / 150 k rows) there are only 2-5 row tiles per SIMD and v2b runs each tile as 108 dependent
+// sub-steps of "stage weights (global -> VGPR -> LDS) -> barrier -> gather -> wait -> 8..16 MFMAs": ~1.7 us per sub-step of
+// which ~0.15 us is MFMA work (wlds<64,32,2> on 150 k rows: 186 us = 108 x 1.7 us; the MFMA pipe is 28 % busy).  Here
+//   * a step is one kernel offset x 32 input channels (54 / 27 steps for Cin = 64 / 32): twice the MFMA work per barrier;
+//   * both operand streams are double-buffered in LDS and filled by LDS-DMA: the gathered rows ([ROWS][8] 16-byte slots per
+//     wave, 8 adjacent lanes per 128-byte row segment) and the 32 x COUT weight slice (thread i copies float4 i; no VGPR
+//     round trip, so nothing waits at issue).  Order per step: wait for step s -> s_barrier (slice s visible to all waves,
+//     everyone done with s-1) -> issue step s+1 into the other buffers -> MFMAs of step s;
+//   * the LDS reads of a step are hidden from the compiler (lds_ld*_raw): a visible read of a DMA destination makes hipcc
+//     wait vmcnt(0) first, which would serialise the prefetch again.
+// LDS image of the rows: slot (r, u) holds 16-byte chunk u ^ ((r >> 1) & 7) of row r (source-side swizzle): a b128 read of
+// one chunk index over 16 consecutive rows then touches 16 distinct bank groups.  MFMA operand layouts, lane transposes,
+// tile masks and the accumulation order are those of v2b: bit-identical results.
+// ----------------------------------------------------------------------------------------------------------------
+__device__ static inline f32x4 lds_ld128_raw(const float4* p) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)(lds_void_ptr)p) : "memory");
+    return v;
+}
+template <int BYTE_OFF>
+__device__ static inline float lds_ld32_raw(const float* p) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(uintptr_t)(lds_void_ptr)p), "n"(BYTE_OFF) : "memory");
+    return v;
+}
+__device__ static inline void lds_tie(f32x4& v) { asm volatile("" : "+v"(v)); }
+__device__ static inline void lds_tie(float& v) { asm volatile("" : "+v"(v)); }
+// b[j][n] = wb[(4j) * COUT + 16n] for one 16-channel block, compile-time LDS offsets
+template <int COUT, int NT, int J = 0, int N = 0>
+__device__ static inline void pipe_load_b(const float* wb, float (&b)[4][NT]) {
+    if constexpr (J < 4) {
+        b[J][N] = lds_ld32_raw<((4 * J) * COUT + 16 * N) * 4>(wb);
+        if constexpr (N + 1 < NT) pipe_load_b<COUT, NT, J, N + 1>(wb, b);
+        else pipe_load_b<COUT, NT, J + 1, 0>(wb, b);
+    }
+}
+
+template <int CIN, int COUT, int MT>
+__global__ void __launch_bounds__(256)
+k_conv_gather_mfma_pipe(const int32_t* __restrict__ nbr, int K, int64_t n_out, const float* __restrict__ in, int64_t n_in,
+                        int in_ld, const float* __restrict__ W, const uint32_t* __restrict__ tile_mask,
+                        const float* __restrict__ bias,
+                        const float* __restrict__ res, int res_ld, int relu, float* __restrict__ out, int out_ld) {
+    constexpr int NB2 = CIN / 32, NB = CIN / 16, NT = COUT / 16, ROWS = 16 * MT;
+    constexpr int WLD = (COUT == 32) ? 48 : COUT;                      // padded LDS row of the weight slice (see v2b: bank spread); 64 stays
+                                                                       // unpadded: 80 would cost a third DMA per step and the third block per CU
+    constexpr int WSLICE = 32 * WLD;                                   // floats per (k, 32-channel block) weight slice in LDS
+    constexpr int WI = (WSLICE / 4 + 255) / 256;                       // weight DMA instructions per wave and step
+    constexpr int WBUF = WI * 256 * 4;                                 // floats per weight buffer: whole DMA instructions (an out-of-range
+                                                                       // lane still owns its 16-byte LDS slot, which must not be live data)
+    constexpr int ASLOTS = ROWS * 8;                                   // float4 slots of one row tile (32 channels)
+    constexpr int AI = ROWS / 8;                                       // row DMA instructions per wave and step
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* wring = (float*)lds_raw;                                                              // [2][32][COUT]
+    float4* aring = (float4*)(lds_raw + (size_t)2 * WBUF * 4) + (size_t)wave * (2 * ASLOTS);       // [2][ROWS][8] per wave
+    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * ROWS;
+    const bool wave_active = row0 < n_out;                              // idle waves still copy weights and take the barriers
+    const int64_t my_row = row0 + lane;
+    const bool valid = wave_active && lane < ROWS && my_row < n_out;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(n_in * in_ld * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)((int64_t)K * CIN * COUT * 4), 0x00020000);
+    const int mi = lane & 15, mq = lane >> 4;
+    const int dma_row_lo = lane >> 3, dma_p = lane & 7;                 // 8 lanes per 128-byte row segment, 8 rows per instruction
+    const int S = K * NB2;
+
+    // step u = (k, c2): rows of offset k (map entries `idx`, one per lane = tile row), channels [32 c2, 32 c2 + 32)
+    auto issue = [&](int u, int idx) {
+        const int k = u / NB2, c2 = u % NB2, buf = u & 1;
+        float4* abase = aring + buf * ASLOTS;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int r = i * 8 + dma_row_lo;
+            const int rid = __shfl(idx, r, 64);
+            const int chunk = dma_p ^ ((r >> 1) & 7);
+            const unsigned voff = rid >= 0 ? (unsigned)(((int64_t)rid * in_ld + c2 * 32 + chunk * 4) * 4) : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_ptr)(abase + i * 64), 16, (int)voff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int e = i * 256 + threadIdx.x;                       // float4 slot of the LDS image: row e / (WLD/4), column e % (WLD/4)
+            const int wr = e / (WLD / 4), wc = e % (WLD / 4);
+            const unsigned woff = (wr < 32 && wc < COUT / 4) ? (unsigned)((((int64_t)k * CIN + c2 * 32 + wr) * COUT + wc * 4) * 4) : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_ptr)((float4*)(wring + buf * WBUF) + i * 256 + wave * 64), 16,
+                                                     (int)woff, 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int idx_cur = valid ? nbr[my_row] : -1;                             // offset of the step being issued next
+    int idx_nxt = (valid && K > 1) ? nbr[n_out + my_row] : -1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // after issuing step u: if it was the last 32-channel block of its offset, the next step gathers the next offset's rows
+    auto advance = [&](int u) {
+        if (u % NB2 == NB2 - 1) {
+            const int kn = u / NB2 + 2;
+            idx_cur = idx_nxt;
+            idx_nxt = (valid && kn < K) ? nbr[(int64_t)kn * n_out + my_row] : -1;
+        }
+    };
+    issue(0, idx_cur);
+    advance(0);
+    for (int s = 0; s < S; ++s) {
+        wait_vmcnt<0>();                                                // step s has landed (and the map entry fetched below)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // own LDS reads of step s-1 retired
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 1 < S) {
+            issue(s + 1, idx_cur);
+            advance(s + 1);
+        }
+        if (wave_active) {
+            const int buf = s & 1;
+            const float4* abase = aring + buf * ASLOTS;
+            const float* wsl = wring + buf * WBUF;
+#pragma unroll
+            for (int cq = 0; cq < 2; ++cq) {                            // the two 16-channel blocks of the step
+                f32x4 araw[MT];
+                float b[4][NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int r = 16 * m + mi;
+                    araw[m] = lds_ld128_raw(abase + r * 8 + ((cq * 4 + mq) ^ ((r >> 1) & 7)));
+                }
+                pipe_load_b<WLD, NT>(wsl + (cq * 16 + mq) * WLD + mi, b);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int m = 0; m < MT; ++m) lds_tie(araw[m]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) lds_tie(b[j][n]);
+                float4 a[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    a[m] = make_float4(araw[m][0], araw[m][1], araw[m][2], araw[m][3]);
+                    lane_transpose4(a[m]);
+                }
+                const int t16 = (s / NB2) * NB + (s % NB2) * 2 + cq;    // (k, 16-channel block) index of the tile mask
+                const uint32_t tmask = tile_mask ? __builtin_amdgcn_readfirstlane(tile_mask[t16]) : 0xFFFFFFFFu;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        if (tmask & (1u << n)) {
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+                                const float av = j == 0 ? a[m].x : (j == 1 ? a[m].y : (j == 2 ? a[m].z : a[m].w));
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j][n], acc[m][n], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!wave_active) return;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 16 * m + 4 * mq + r;
+            if (row >= n_out) continue;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int col = 16 * n + mi;
+                float v = acc[m][n][r];
+                if (bias) v = v + bias[col];
+                if (res) v = v + res[row * res_ld + col];
+                if (relu) v = fmaxf(v, 0.0f);
+                out[row * out_ld + col] = v;
+            }
+        }
+}
+
+template <int CIN, int COUT, int MT>
+static void launch_mfma_pipe(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int in_ld, const float* W,
+                             const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld, hipStream_t s,
+                             const uint32_t* tile_mask = nullptr) {
+    constexpr int wld = (COUT == 32) ? 48 : COUT;
+    constexpr size_t lds = (size_t)2 * (((32 * wld / 4 + 255) / 256) * 256 * 16) + 4 * (size_t)(2 * 16 * MT * 8 * 16);
+    static_assert(lds <= 64 * 1024, "stays under the default dynamic LDS limit");
+    hipLaunchKernelGGL((k_conv_gather_mfma_pipe<CIN, COUT, MT>), dim3(grid_for(n_out, 4 * 16 * MT)), dim3(256), lds, s, nbr, K,
+                       n_out, in, n_in, in_ld, W, tile_mask, bias, res, res_ld, relu, out, out_ld);
+}
+
+static int g_mfma_pipe = -1;        // v2c (32-channel steps, double-buffered): -1 by level size, 0 never, 1 always (A/B tests)
+extern "C" int pcgc_set_mfma_pipe(int mode) { g_mfma_pipe = mode; return 0; }
+
+// Block-sparse k3 gather conv on the LDS-shared-weight MFMA kernels (used by the fused C=64 InceptionResNet passes).
 extern "C" int pcgc_conv_gather_masked(const int32_t* nbr, int64_t n_out, const float* in, int64_t n_in, int Cin, int in_ld,
                                        const float* W, int Cout, const uint32_t* tile_mask, const float* bias, int relu,
                                        float* out, int out_ld, void* stream) {
@@ -515,7 +708,11 @@ extern "C" int pcgc_conv_gather_masked(const int32_t* nbr, int64_t n_out, const 
     PCGC_REQUIRE(n_in * (int64_t)in_ld * 4 < (int64_t)0xFFFFFFF0, "tensor too large for 32-bit buffer offsets");
     if (n_out == 0) return 0;
     hipStream_t s = S(stream);
-    if (Cin == 64 && Cout == 32) launch_mfma_wlds<64, 32, 2>(nbr, 27, n_out, in, n_in, in_ld, W, bias, nullptr, 0, relu, out, out_ld, s, tile_mask);
+    // v2c below ~110 k rows (measured us, v2b -> v2c: 64->32 at 71 k rows 140 -> 103, at 150 k 175 -> 180; 32->48 86 -> 70 / 114 -> 124)
+    const bool pipe = g_mfma_pipe > 0 || (g_mfma_pipe < 0 && n_out < 110000);
+    if (pipe && Cin == 64 && Cout == 32) launch_mfma_pipe<64, 32, 2>(nbr, 27, n_out, in, n_in, in_ld, W, bias, nullptr, 0, relu, out, out_ld, s, tile_mask);
+    else if (pipe && Cin == 32 && Cout == 48) launch_mfma_pipe<32, 48, 2>(nbr, 27, n_out, in, n_in, in_ld, W, bias, nullptr, 0, relu, out, out_ld, s, tile_mask);
+    else if (Cin == 64 && Cout == 32) launch_mfma_wlds<64, 32, 2>(nbr, 27, n_out, in, n_in, in_ld, W, bias, nullptr, 0, relu, out, out_ld, s, tile_mask);
     else if (Cin == 32 && Cout == 48) launch_mfma_wlds<32, 48, 2>(nbr, 27, n_out, in, n_in, in_ld, W, bias, nullptr, 0, relu, out, out_ld, s, tile_mask);
     else { pcgc_set_error("conv_gather_masked: unsupported shape %d -> %d (64->32, 32->48)", Cin, Cout); return -2; }
     PCGC_CHECK_LAUNCH("conv_gather_masked");
@@ -857,7 +1054,9 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
     if (v1_eligible && wlds_shape && (((uintptr_t)W) & 15) == 0 && (g_conv_impl == 3 || (g_conv_impl < 0 && g_auto_wlds && Cin == 64 && n_out >= 30000))) {
         const float* res0 = residual ? residual + res_coff : nullptr;
         float* out0 = out + out_coff;
-        if (Cin == 64) {
+        const bool pipe = g_mfma_pipe > 0 || (g_mfma_pipe < 0 && n_out < 110000);        // 64->64: 248 -> 220 us at 71 k rows, 381 -> 395 at 150 k
+        if (Cin == 64 && pipe) launch_mfma_pipe<64, 64, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        else if (Cin == 64) {
             if (n_out < 400000) launch_mfma_wlds<64, 64, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
             else launch_mfma_wlds<64, 64, 4>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         } else {

@@ -112,11 +112,13 @@ CONV_SHAPES = [(27, 1, 16), (27, 16, 16), (27, 32, 8), (27, 8, 16), (27, 8, 8), 
                (8, 16, 32), (8, 32, 64), (8, 64, 32), (1, 32, 8), (1, 8, 16), (1, 64, 16), (1, 16, 32), (1, 16, 4), (1, 4, 8)]
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=['v0_direct', 'v1_ldsdma', 'v2_mfma', 'v2b_mfma_wlds'])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=['v0_direct', 'v1_ldsdma', 'v2_mfma', 'v2b_mfma_wlds', 'v2c_mfma_pipe'])
 def conv_impl(request):
-    ops.set_conv_impl(request.param)
+    ops.set_conv_impl(min(request.param, 3))
+    ops.set_mfma_pipe(1 if request.param == 4 else 0)
     yield request.param
     ops.set_conv_impl(-1)
+    ops.set_mfma_pipe(-1)
 
 
 @pytest.mark.parametrize('K,cin,cout', CONV_SHAPES)
@@ -176,6 +178,14 @@ def test_fused_inception_resnet_bit_exact(C, rows):
         ops.set_irn_rows(0)
     np.testing.assert_array_equal(unfused, want)
     np.testing.assert_array_equal(fused, want)
+    if C == 64:                                              # both schedules of the block-sparse MFMA kernels
+        for mode in (0, 1):
+            ops.set_mfma_pipe(mode)
+            try:
+                with torch.no_grad():
+                    np.testing.assert_array_equal(blk(xs).F.cpu().numpy(), want)
+            finally:
+                ops.set_mfma_pipe(-1)
     if C == 64 and rows == 64:                               # VALU-fused form too (the default for C = 64 is the MFMA form)
         ops.MFMA_IRN = False
         try:
