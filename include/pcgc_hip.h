@@ -109,6 +109,8 @@ int pcgc_set_conv_impl(int impl);
 /* the LDS-shared-weight MFMA kernels come in two schedules (v2b: 16-channel sub-steps; v2c: 32-channel steps with the next
  * step's loads in flight): -1 choose by level size (default), 0 always v2b, 1 always v2c.  Bit-identical. */
 int pcgc_set_mfma_pipe(int mode);
+/* generative transpose 64->32 / 32->16: 1 fp32-MFMA kernel (default), 0 VALU kernel.  Bit-identical. */
+int pcgc_set_up2_impl(int mfma);
 /* rows per wave of the fused InceptionResNet passes: 0 = by level size (default), or force 64 / 32 / 16 (A/B tests). */
 int pcgc_set_irn_rows(int rows);
 /* Fused InceptionResNet block (autoencoder.py:7-57):  out = cat(conv0_1(relu(conv0_0 x)), conv1_2(relu(conv1_1(relu(conv1_0 x))))) + x

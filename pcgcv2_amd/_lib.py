@@ -36,6 +36,7 @@ SIGNATURES = {
     'pcgc_conv_gather': (ci, [vp, ci, i64, vp, i64, ci, ci, ci, vp, vp, vp, ci, ci, ci, vp, ci, ci, ci, vp]),
     'pcgc_set_conv_impl': (ci, [ci]),
     'pcgc_set_mfma_pipe': (ci, [ci]),
+    'pcgc_set_up2_impl': (ci, [ci]),
     'pcgc_set_irn_rows': (ci, [ci]),
     'pcgc_irn_block': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, ci, vp]),
     'pcgc_conv_gather_masked': (ci, [vp, i64, vp, i64, ci, ci, vp, ci, vp, vp, ci, vp, ci, vp]),

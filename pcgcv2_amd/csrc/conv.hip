@@ -1168,12 +1168,91 @@ static int launch_up2_rows(int64_t n_in, const float* in, int in_ld, const float
     return 0;
 }
 
+// fp32 MFMA form for the two large up-convs (64->32 on 8*N4', 32->16 on 8*N2'): out[8p + k] = in[p] @ W[k] is eight
+// [N x Cin] @ [Cin x Cout] GEMMs that share the A operand.  One wave = 64 parent rows: the A fragments (lane (i,q) loads the
+// 16-byte chunk q of row 16m+i of each 16-channel block and gets "channel 4j+q" by the 4x4 lane transpose, as in the gather
+// kernels) are loaded ONCE and stay in registers for all eight k; B fragments W[k][16cb + 4j + q][16n + i] come from L1/L2.
+// Channel order per accumulator: cb, j, q ascending = 0..Cin-1: bitwise the canonical chain.  The VALU form above issues
+// Cin*4 dependent FMAs per 16-byte store and was compute-, not write-bound (123 us for 131 MB at 32->16).
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256)
+k_conv_up2_mfma(int64_t n_in, const float* __restrict__ in, int in_ld, const float* __restrict__ W,
+                const float* __restrict__ bias, int relu, float* __restrict__ out) {
+    constexpr int NB = CIN / 16, NT = COUT / 16, MT = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * MT);
+    if (p0 >= n_in) return;
+    const int mi = lane & 15, mq = lane >> 4;
+    float4 a[MT][NB];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int64_t p = p0 + 16 * m + mi;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            a[m][cb] = p < n_in ? *(const float4*)(in + p * in_ld + 16 * cb + 4 * mq) : make_float4(0.f, 0.f, 0.f, 0.f);
+            lane_transpose4(a[m][cb]);
+        }
+    }
+    for (int k = 0; k < 8; ++k) {
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* wk = W + ((int64_t)k * CIN + mq) * COUT + mi;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            float b[4][NT];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) b[j][n] = wk[(16 * cb + 4 * j) * COUT + 16 * n];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const float av = j == 0 ? a[m][cb].x : (j == 1 ? a[m][cb].y : (j == 2 ? a[m][cb].z : a[m][cb].w));
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j][n], acc[m][n], 0, 0, 0);
+                    }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t p = p0 + 16 * m + 4 * mq + r;
+                if (p >= n_in) continue;
+                float* y = out + (8 * p + k) * COUT;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int col = 16 * n + mi;
+                    float v = acc[m][n][r];
+                    if (bias) v = v + bias[col];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    y[col] = v;
+                }
+            }
+    }
+}
+template <int CIN, int COUT>
+static int launch_up2_mfma(int64_t n_in, const float* in, int in_ld, const float* W, const float* bias, int relu, float* out,
+                           hipStream_t s) {
+    hipLaunchKernelGGL((k_conv_up2_mfma<CIN, COUT>), dim3(grid_for(n_in, 256)), dim3(256), 0, s, n_in, in, in_ld, W, bias, relu, out);
+    return 0;
+}
+static int g_up2_mfma = 1;          // 0 = VALU form (A/B tests)
+extern "C" int pcgc_set_up2_impl(int mfma) { g_up2_mfma = mfma; return 0; }
+
 extern "C" int pcgc_conv_up2(int64_t n_in, const float* in, int Cin, int in_ld, const float* W, const float* bias, int relu,
                              float* out, int Cout, void* stream) {
     if (n_in == 0) return 0;
     if ((in_ld & 3) == 0 && (((uintptr_t)in | (uintptr_t)W | (uintptr_t)out | (uintptr_t)bias) & 15) == 0) {
         bool done = true;
         if (Cin == 8 && Cout == 64) launch_up2_rows<8, 64>(n_in, in, in_ld, W, bias, relu, out, S(stream));
+        else if (g_up2_mfma && Cin == 64 && Cout == 32) launch_up2_mfma<64, 32>(n_in, in, in_ld, W, bias, relu, out, S(stream));
+        else if (g_up2_mfma && Cin == 32 && Cout == 16) launch_up2_mfma<32, 16>(n_in, in, in_ld, W, bias, relu, out, S(stream));
         else if (Cin == 64 && Cout == 32) launch_up2_rows<64, 32>(n_in, in, in_ld, W, bias, relu, out, S(stream));
         else if (Cin == 32 && Cout == 16) launch_up2_rows<32, 16>(n_in, in, in_ld, W, bias, relu, out, S(stream));
         else done = false;

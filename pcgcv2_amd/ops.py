@@ -313,6 +313,11 @@ def conv_gather(nbr, x, W, bias, out=None, residual=None, relu=False, n_out=None
     return out
 
 
+def set_up2_impl(mfma):
+    """generative transpose conv kernel for 64->32 / 32->16: 1 fp32 MFMA (default), 0 VALU."""
+    check(lib().pcgc_set_up2_impl(int(mfma)), 'set_up2_impl')
+
+
 def set_mfma_pipe(mode):
     """schedule of the LDS-shared-weight MFMA kernels: -1 by level size, 0 v2b (16-channel sub-steps), 1 v2c (pipelined 32-channel steps)."""
     check(lib().pcgc_set_mfma_pipe(int(mode)), 'set_mfma_pipe')

@@ -195,8 +195,17 @@ def test_fused_inception_resnet_bit_exact(C, rows):
             ops.MFMA_IRN = True
 
 
+@pytest.mark.parametrize('impl', [1, 0], ids=['mfma', 'valu'])
 @pytest.mark.parametrize('cin,cout', [(8, 64), (64, 32), (32, 16)])
-def test_conv_up2_bit_exact(cin, cout):
+def test_conv_up2_bit_exact(cin, cout, impl):
+    ops.set_up2_impl(impl)
+    try:
+        _conv_up2_case(cin, cout)
+    finally:
+        ops.set_up2_impl(1)
+
+
+def _conv_up2_case(cin, cout):
     rng = np.random.default_rng(cin + cout)
     x = rng.standard_normal((3001, cin)).astype(np.float32)
     W = (rng.standard_normal((8, cin, cout)) / np.sqrt(8 * cin)).astype(np.float32)
