@@ -1169,16 +1169,16 @@ static int launch_up2_rows(int64_t n_in, const float* in, int in_ld, const float
 }
 
 // fp32 MFMA form for the two large up-convs (64->32 on 8*N4', 32->16 on 8*N2'): out[8p + k] = in[p] @ W[k] is eight
-// [N x Cin] @ [Cin x Cout] GEMMs that share the A operand.  One wave = 64 parent rows: the A fragments (lane (i,q) loads the
+// [N x Cin] @ [Cin x Cout] GEMMs that share the A operand.  One wave = 16*MT parent rows: the A fragments (lane (i,q) loads the
 // 16-byte chunk q of row 16m+i of each 16-channel block and gets "channel 4j+q" by the 4x4 lane transpose, as in the gather
 // kernels) are loaded ONCE and stay in registers for all eight k; B fragments W[k][16cb + 4j + q][16n + i] come from L1/L2.
 // Channel order per accumulator: cb, j, q ascending = 0..Cin-1: bitwise the canonical chain.  The VALU form above issues
 // Cin*4 dependent FMAs per 16-byte store and was compute-, not write-bound (123 us for 131 MB at 32->16).
-template <int CIN, int COUT>
+template <int CIN, int COUT, int MT>
 __global__ void __launch_bounds__(256)
 k_conv_up2_mfma(int64_t n_in, const float* __restrict__ in, int in_ld, const float* __restrict__ W,
                 const float* __restrict__ bias, int relu, float* __restrict__ out) {
-    constexpr int NB = CIN / 16, NT = COUT / 16, MT = 4;
+    constexpr int NB = CIN / 16, NT = COUT / 16;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * MT);
@@ -1239,7 +1239,9 @@ k_conv_up2_mfma(int64_t n_in, const float* __restrict__ in, int in_ld, const flo
 template <int CIN, int COUT>
 static int launch_up2_mfma(int64_t n_in, const float* in, int in_ld, const float* W, const float* bias, int relu, float* out,
                            hipStream_t s) {
-    hipLaunchKernelGGL((k_conv_up2_mfma<CIN, COUT>), dim3(grid_for(n_in, 256)), dim3(256), 0, s, n_in, in, in_ld, W, bias, relu, out);
+    // 16 parent rows per wave: these levels are small (71 k / 256 k parents) and a wave runs its eight k serially, so more, shorter
+    // waves win (measured us for 64->32 / 32->16: 16 rows 58 / 58, 32 rows 70 / 59, 64 rows 99 / 68; VALU form 97 / 123)
+    hipLaunchKernelGGL((k_conv_up2_mfma<CIN, COUT, 1>), dim3(grid_for(n_in, 64)), dim3(256), 0, s, n_in, in, in_ld, W, bias, relu, out);
     return 0;
 }
 static int g_up2_mfma = 1;          // 0 = VALU form (A/B tests)
