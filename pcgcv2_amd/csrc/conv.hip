@@ -1030,10 +1030,11 @@ static int irn_launch(const int32_t* nbr, int64_t n, const float* x, int C, int 
 
 // kernel selection for pcgc_conv_gather (all variants are bit-identical; tests run every one of them):
 //   -1 auto | 0 v0 direct loads + VALU | 1 v1 LDS-DMA + VALU | 2 v2 LDS-DMA + MFMA | 3 v2b MFMA with LDS-shared weights
-// auto policy (measured per shape, tools/conv_ab.py): >= 30 k rows: 64->64 -> v2b; Cin in {16,32,64} & Cout in {16,32,64} -> v2;
+// auto policy (measured per shape, tools/conv_ab.py, tools/conv32_ab.py): >= 30 k rows: 64->64 and 32->32 -> v2b (v2c below 110 k rows for 64->64); Cin in {16,32,64} & Cout in {16,32,64} -> v2;
 // other gathered shapes with Cin in {8,16,32,64} -> v1; everything else (Cin 1/4, k1 convs, tiny levels) -> v0.
 static int g_conv_impl = -1;
-static int g_auto_wlds = 1;         // auto: LDS-shared-weight MFMA kernel for 64->64 (591 -> 403 us at 150 k rows; no gain for 32->32)
+static int g_auto_wlds = 1;         // auto: LDS-shared-weight MFMA kernel for 64->64 (591 -> 403 us at 150 k rows) and, since the weight rows are
+                                    // bank-conflict free, 32->32 (181 -> 168 us at 256 k rows, 400 -> 374 at 570 k)
 static int g_auto_mfma = 1;         // auto mode uses the MFMA kernel for its eligible shapes once A/B says so
 extern "C" int pcgc_set_conv_impl(int impl) { g_conv_impl = impl; return 0; }
 
@@ -1051,7 +1052,7 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
     const bool v1_eligible = nbr != nullptr && K <= 27 && aligned && small && (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64);
     const bool v1_wanted = g_conv_impl == 1 || (g_conv_impl < 0 && n_out >= 30000);
     const bool wlds_shape = (Cin == 64 && Cout == 64) || (Cin == 32 && Cout == 32);
-    if (v1_eligible && wlds_shape && (((uintptr_t)W) & 15) == 0 && (g_conv_impl == 3 || (g_conv_impl < 0 && g_auto_wlds && Cin == 64 && n_out >= 30000))) {
+    if (v1_eligible && wlds_shape && (((uintptr_t)W) & 15) == 0 && (g_conv_impl == 3 || (g_conv_impl < 0 && g_auto_wlds && n_out >= 30000))) {
         const float* res0 = residual ? residual + res_coff : nullptr;
         float* out0 = out + out_coff;
         const bool pipe = g_mfma_pipe > 0 || (g_mfma_pipe < 0 && n_out < 110000);        // 64->64: 248 -> 220 us at 71 k rows, 381 -> 395 at 150 k
@@ -1059,6 +1060,8 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
         else if (Cin == 64) {
             if (n_out < 400000) launch_mfma_wlds<64, 64, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
             else launch_mfma_wlds<64, 64, 4>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        } else if (g_mfma_pipe > 0) {
+            launch_mfma_pipe<32, 32, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         } else {
             if (n_out < 400000) launch_mfma_wlds<32, 32, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
             else launch_mfma_wlds<32, 32, 4>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
