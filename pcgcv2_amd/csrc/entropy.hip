@@ -58,33 +58,62 @@ extern "C" int pcgc_desymbolize(const int16_t* sym, int64_t count, float min_v, 
 // tensors feeding a discontinuity (likelihood, clamp, running cumsum).
 __device__ static inline double eb_softplus(double x) { return x > 0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 __device__ static inline double eb_sigmoid(double x) { return x >= 0 ? 1.0 / (1.0 + exp(-x)) : exp(x) / (1.0 + exp(x)); }
-__device__ static double eb_logits(const float* __restrict__ P, int C, int c, double v) {
+// The parameter-only factors of the 4-layer chain — softplus(matrix) (24 per channel) and tanh(factor) (10 per channel) —
+// are evaluated once per block into LDS; a table entry then costs 2 x 10 tanh + 2 sigmoid instead of 2 x 68 fp64
+// transcendentals (the two table kernels sit on the critical path of encode and decode: 42 -> ~12 us each).  Same values,
+// same operation order as evaluating them in place.
+constexpr int EB_MAX_C = 16;
+struct EbShared { double sp[EB_MAX_C * 24]; double tf[EB_MAX_C * 10]; };
+__device__ static void eb_prepare(const float* __restrict__ P, int C, EbShared& sh) {
+    const float* M = P; const float* Fa = P + 24 * C + 10 * C;
     const int F[5] = {1, 3, 3, 3, 1};
-    const float* M = P; const float* B = P + 24 * C; const float* Fa = B + 10 * C;
+    for (int e = threadIdx.x; e < C * 34; e += blockDim.x) {
+        const int c = e / 34, r = e % 34;
+        if (r < 24) {                                   // matrix entry: local index -> (layer i, position inside the layer)
+            int i = r < 3 ? 0 : (r < 12 ? 1 : (r < 21 ? 2 : 3));
+            const int loff = i == 0 ? 0 : (i == 1 ? 3 : (i == 2 ? 12 : 21));
+            int moff = 0;
+            for (int j = 0; j < i; ++j) moff += C * F[j + 1] * F[j];
+            sh.sp[c * 24 + r] = eb_softplus((double)M[moff + c * F[i + 1] * F[i] + (r - loff)]);
+        } else {
+            const int q = r - 24;                       // factor entry 0..9: layers of 3, 3, 3, 1
+            const int i = q < 3 ? 0 : (q < 6 ? 1 : (q < 9 ? 2 : 3));
+            const int boff = C * 3 * i;
+            sh.tf[c * 10 + q] = tanh((double)Fa[boff + c * F[i + 1] + (q - 3 * i)]);
+        }
+    }
+}
+__device__ static double eb_logits(const float* __restrict__ P, int C, int c, double v, const EbShared& sh) {
+    const int F[5] = {1, 3, 3, 3, 1};
+    const float* B = P + 24 * C;
+    const double* sp = sh.sp + c * 24; const double* tf = sh.tf + c * 10;
     double h[3] = {v, 0, 0}, t[3];
-    int moff = 0, boff = 0;
+    int loff = 0, boff = 0, foff = 0;
     for (int i = 0; i < 4; ++i) {
         int fi = F[i], fo = F[i + 1];
-        const float* m = M + moff + c * fo * fi; const float* b = B + boff + c * fo; const float* f = Fa + boff + c * fo;
+        const float* b = B + boff + c * fo;
         for (int r = 0; r < fo; ++r) {
             double s = 0;
-            for (int q = 0; q < fi; ++q) s += eb_softplus((double)m[r * fi + q]) * h[q];
+            for (int q = 0; q < fi; ++q) s += sp[loff + r * fi + q] * h[q];
             s += (double)b[r];
-            s += tanh((double)f[r]) * tanh(s);
+            s += tf[foff + r] * tanh(s);
             t[r] = s;
         }
         for (int r = 0; r < fo; ++r) h[r] = t[r];
-        moff += C * fo * fi; boff += C * fo;
+        loff += fo * fi; boff += C * fo; foff += fo;
     }
     return h[0];
 }
 // phase 1: likelihood(c, s) -> cdf_f32[c][s+1] (temporarily holds the clamped pmf)
 __global__ void k_cdf_likelihood(const float* __restrict__ P, int C, int L, float min_v, float* __restrict__ cdf_f32) {
+    __shared__ EbShared sh;
+    eb_prepare(P, C, sh);
+    __syncthreads();
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= C * L) return;
     int c = t / L, s = t % L;
     double v = (double)min_v + s;
-    double lo = eb_logits(P, C, c, v - 0.5), up = eb_logits(P, C, c, v + 0.5);
+    double lo = eb_logits(P, C, c, v - 0.5, sh), up = eb_logits(P, C, c, v + 0.5, sh);
     double sum = lo + up, sign = sum > 0 ? -1.0 : (sum < 0 ? 1.0 : 0.0);
     float p = (float)fabs(eb_sigmoid(sign * up) - eb_sigmoid(sign * lo));
     cdf_f32[c * (L + 1) + s + 1] = p < 1e-9f ? 1e-9f : p;
@@ -111,7 +140,8 @@ extern "C" int pcgc_cdf_table(const float* params, int C, float min_v, float max
     PCGC_REQUIRE(cdf_f32 != nullptr, "cdf_f32 scratch/output buffer is required");
     int L = (int)(max_v - min_v) + 1;
     PCGC_REQUIRE(L >= 1 && L < 32768, "symbol alphabet out of int16 range");
-    hipLaunchKernelGGL(k_cdf_likelihood, dim3(grid_for((int64_t)C * L, 64)), dim3(64), 0, S(stream), params, C, L, min_v, cdf_f32);
+    PCGC_REQUIRE(C >= 1 && C <= EB_MAX_C, "entropy bottleneck: at most 16 channels");
+    hipLaunchKernelGGL(k_cdf_likelihood, dim3(grid_for((int64_t)C * L, 256)), dim3(256), 0, S(stream), params, C, L, min_v, cdf_f32);
     hipLaunchKernelGGL(k_cdf_finish, dim3(1), dim3(64), 0, S(stream), C, L, cdf_f32, cdf_u16);
     PCGC_CHECK_LAUNCH("cdf_table");
     return 0;
@@ -126,15 +156,19 @@ __global__ void k_symbolize_dev(const float* __restrict__ f, int64_t count, cons
 }
 __global__ void k_cdf_likelihood_dev(const float* __restrict__ P, int C, const float* __restrict__ minmax, int max_L,
                                      float* __restrict__ cdf_f32, int32_t* __restrict__ info) {
+    __shared__ EbShared sh;
     const float min_v = minmax[0];
     const int L = (int)(minmax[1] - min_v) + 1;
     if (blockIdx.x == 0 && threadIdx.x == 0) info[0] = (L >= 1 && L <= max_L) ? L : 0;
     if (L < 1 || L > max_L) return;
+    if ((int)(blockIdx.x * blockDim.x) >= C * L) return;          // whole block beyond the table (block-uniform)
+    eb_prepare(P, C, sh);
+    __syncthreads();
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= C * L) return;
     int c = t / L, s = t % L;
     double v = (double)min_v + s;
-    double lo = eb_logits(P, C, c, v - 0.5), up = eb_logits(P, C, c, v + 0.5);
+    double lo = eb_logits(P, C, c, v - 0.5, sh), up = eb_logits(P, C, c, v + 0.5, sh);
     double sum = lo + up, sign = sum > 0 ? -1.0 : (sum < 0 ? 1.0 : 0.0);
     float p = (float)fabs(eb_sigmoid(sign * up) - eb_sigmoid(sign * lo));
     cdf_f32[c * (L + 1) + s + 1] = p < 1e-9f ? 1e-9f : p;
@@ -158,9 +192,10 @@ __global__ void k_cdf_finish_dev(int C, const int32_t* __restrict__ info, float*
 extern "C" int pcgc_compress_prepare(const float* feats, int64_t count, const float* params, int C, int max_L, float* minmax,
                                      int16_t* sym, uint16_t* cdf_u16, float* cdf_f32, int32_t* info, void* stream) {
     PCGC_REQUIRE(count > 0 && max_L >= 1, "empty latent");
+    PCGC_REQUIRE(C >= 1 && C <= EB_MAX_C, "entropy bottleneck: at most 16 channels");
     hipLaunchKernelGGL(k_round_minmax, dim3(1), dim3(1024), 0, S(stream), feats, count, minmax);
     hipLaunchKernelGGL(k_symbolize_dev, dim3(grid_for(count, 256)), dim3(256), 0, S(stream), feats, count, minmax, sym);
-    hipLaunchKernelGGL(k_cdf_likelihood_dev, dim3(grid_for((int64_t)C * max_L, 64)), dim3(64), 0, S(stream), params, C, minmax,
+    hipLaunchKernelGGL(k_cdf_likelihood_dev, dim3(grid_for((int64_t)C * max_L, 256)), dim3(256), 0, S(stream), params, C, minmax,
                        max_L, cdf_f32, info);
     hipLaunchKernelGGL(k_cdf_finish_dev, dim3(1), dim3(64), 0, S(stream), C, info, cdf_f32, cdf_u16);
     PCGC_CHECK_LAUNCH("compress_prepare");
