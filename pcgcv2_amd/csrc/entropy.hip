@@ -11,10 +11,14 @@ __device__ static inline float ord2f(int32_t o) { return __int_as_float(o >= 0 ?
 __global__ void __launch_bounds__(1024) k_round_minmax(const float* __restrict__ f, int64_t count, float* minmax) {
     __shared__ int32_t smin[16], smax[16];
     int32_t lo = 0x7fffffff, hi = (int32_t)0x80000000;
-    for (int64_t i = threadIdx.x; i < count; i += 1024) {
-        int32_t o = f2ord(rintf(f[i]) + 0.0f);
-        lo = min(lo, o); hi = max(hi, o);
+    auto take = [&](float x) { const int32_t o = f2ord(rintf(x) + 0.0f); lo = min(lo, o); hi = max(hi, o); };
+    const bool vec = (((uintptr_t)f) & 15) == 0;          // 16-byte loads: a quarter of the dependent iterations of this one block
+    const int64_t n4 = vec ? count / 4 : 0;
+    for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+        const float4 v = ((const float4*)f)[i];
+        take(v.x); take(v.y); take(v.z); take(v.w);
     }
+    for (int64_t i = 4 * n4 + threadIdx.x; i < count; i += 1024) take(f[i]);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { lo = min(lo, __shfl_xor(lo, d, 64)); hi = max(hi, __shfl_xor(hi, d, 64)); }
     if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
