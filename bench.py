@@ -180,14 +180,16 @@ def main():
             return us
         shard.code_units(coder, fresh(units[:args.serving_in_flight]), in_flight=args.serving_in_flight)       # warm the worker path
         torch.cuda.synchronize()
-        fresh(units)
-        t_s = time.perf_counter()
-        shard.code_units(coder, units, in_flight=args.serving_in_flight)
-        torch.cuda.synchronize()
-        dt_s = time.perf_counter() - t_s
         n_s = sum(len(u) for _, u in units)
+        dt_s = float('inf')
+        for _ in range(2):                           # best of two passes: the figure is auxiliary and worker start-up (threads,
+            fresh(units)                             # streams, pinned staging buffers) occasionally lands inside a pass
+            t_s = time.perf_counter()
+            shard.code_units(coder, units, in_flight=args.serving_in_flight)
+            torch.cuda.synchronize()
+            dt_s = min(dt_s, time.perf_counter() - t_s)
         serving = {'frames_in_flight': args.serving_in_flight, 'frames': len(units), 'value': round(n_s / dt_s / 1e6, 3), 'unit': 'Mpoints/s',
-                   'note': 'throughput over independent vox10 frames coded concurrently on one GPU (own thread + HIP stream each); '
+                   'note': 'throughput over independent vox10 frames coded concurrently on one GPU (own thread + HIP stream each), best of 2 passes; '
                            'the headline `value` is the single-frame-at-a-time rate'}
     # the coordinate-coder stage on its own (report with and without it).  Inside a step it runs on a helper
     # thread concurrently with the GPU, so it adds nothing to ms_per_step unless it outlasts the work it hides behind.
