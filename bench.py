@@ -260,6 +260,10 @@ def attach_pmc_traffic(roof):
         rows = e.get('grid_rows', roof['n_out'])
         if e['kernel'] == roof['kernel'] and (abs(rows - roof['n_out']) < 256 or abs(rows - 4 * ((roof['n_out'] + 127) // 128) * 64) < 512):
             roof['traffic'] = e['hbm_bytes_per_launch']
+            # what actually crossed to HBM per launch / the measured launch time: the algorithmic rate above can exceed the HBM peak
+            # because the L2 / Infinity Cache serve the ~18x row re-use of a gather
+            roof['traffic_rate'] = {'GBps': round(e['hbm_bytes_per_launch'] / (roof['avg_launch_us'] * 1e-6) / 1e9, 1),
+                                    'frac_of_peak': round(e['hbm_bytes_per_launch'] / (roof['avg_launch_us'] * 1e-6) / 1e9 / roof['peak'], 4)}
             roof['traffic_detail'] = {k: e[k] for k in ('fetch_bytes_raw', 'fetch_bytes_corrected', 'write_bytes', 'source') if k in e}
             return
 
