@@ -9,9 +9,10 @@ from pcgcv2_amd.sparse import CoordMap
 dev = torch.device('cuda:0')
 pts = synthetic.shell('shell10', device=dev)
 c = torch.cat([torch.zeros((len(pts), 1), dtype=torch.int32, device=dev), pts], 1).contiguous()
-l2 = CoordMap(c, 1, unique=True).down()[0]
-lvl = l2.up(); nbr = lvl.k3; n = len(lvl)
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+l2 = CoordMap(c, 1, unique=True).down()[0]
+lvl = l2.up() if C == 16 else l2.down()[0].up()       # the level the decoder runs this width on: 8*N2 (C = 16), 8*N4 (C = 32)
+nbr = lvl.k3; n = len(lvl)
 Q = C // 4
 g = torch.Generator(device='cpu').manual_seed(0)
 mk = lambda *s: (torch.randn(s, generator=g) / 30).to(dev)
