@@ -113,6 +113,9 @@ int pcgc_set_mfma_pipe(int mode);
 int pcgc_set_up2_impl(int mfma);
 /* rows per wave of the fused InceptionResNet passes: 0 = by level size (default), or force 64 / 32 / 16 (A/B tests). */
 int pcgc_set_irn_rows(int rows);
+/* C = 32 pass A gathers 16 instead of 32 channels per sub-step on levels of at least `min_rows` rows (default 400 000; 0 =
+ * always, negative = default).  Bit-identical; a speed/occupancy trade measured per level size. */
+int pcgc_set_irn_cb16_rows(int64_t min_rows);
 /* Fused InceptionResNet block (autoencoder.py:7-57):  out = cat(conv0_1(relu(conv0_0 x)), conv1_2(relu(conv1_1(relu(conv1_0 x))))) + x
  * in two gather passes.  params[10] = {conv0_0.kernel, .bias, conv0_1.kernel, .bias, conv1_0.kernel, .bias, conv1_1.kernel,
  * .bias, conv1_2.kernel, .bias} (ME layouts).  t_scratch: [n, C/2] fp32 workspace.  Bit-identical to the five

@@ -792,6 +792,8 @@ static bool dispatch_mfma(int Cout, const int32_t* nbr, int K, int64_t n_out, co
 // 5 launches / 3 gathers / 2 pointwise passes become 2 launches / 2 gathers; every fmaf chain is unchanged.
 // ----------------------------------------------------------------------------------------------------------------
 static int g_irn_rows = 0;          // 0 = choose the tile height from the level size; 64/32/16 force (A/B tests)
+static int64_t g_irn_cb16_rows = 400000;   // C = 32 pass A: 16-channel sub-steps from this many rows on (0 = always, for tests)
+extern "C" int pcgc_set_irn_cb16_rows(int64_t min_rows) { g_irn_cb16_rows = min_rows < 0 ? 400000 : min_rows; return 0; }
 extern "C" int pcgc_set_irn_rows(int rows) { g_irn_rows = rows; return 0; }
 
 // kernel offsets gathered per wait (27 = 9 x 3): more gathers in flight per wave.  Pays only while the extra row buffers do
@@ -799,13 +801,16 @@ extern "C" int pcgc_set_irn_rows(int rows) { g_irn_rows = rows; return 0; }
 template <int C> struct IrnKG { static constexpr int value = (C == 16) ? 3 : 1; };       // pass B
 template <int C> struct IrnKGA { static constexpr int value = 1; };                     // pass A: 227 vs 212 us with 3 at C=16
 
-template <int C, int ROWS>
+// CBMAX = channels gathered per sub-step (32, or 16): at C = 32 the 32-channel form holds 117 VGPRs (4 waves/SIMD); 16-channel
+// sub-steps double the gather/wait steps but run 6 waves/SIMD — faster on the big level (570 k rows: 206 -> 175 us), slower on
+// the small ones (256 k: 68 -> 74 us), so launch_irn picks by level size.
+template <int C, int ROWS, int CBMAX = 32>
 __global__ void __launch_bounds__(256)
 k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x, int x_ld,
         const float* __restrict__ W00, const float* __restrict__ b00, const float* __restrict__ W10,
         const float* __restrict__ b10, float* __restrict__ t /*[n, C/2]*/) {
     constexpr int Q = C / 4;
-    constexpr int CB = C < 32 ? C : 32, NB = C / CB, CH = CB / 4;
+    constexpr int CB = C < CBMAX ? C : CBMAX, NB = C / CB, CH = CB / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -982,7 +987,10 @@ static void launch_irn(const int32_t* nbr, int64_t n, const float* x, int x_ld, 
     const size_t lds_a = 4 * (size_t)(IrnKGA<C>::value * RowGather<CBA / 4, ROWS>::SLOTS * 16);
     const size_t lds_b = 4 * (size_t)(IrnKG<C>::value * RowGather<C / 8, ROWS>::SLOTS * 16);
     const dim3 grid(grid_for(n, 4 * ROWS));
-    if (phase & 1)
+    if ((phase & 1) && C == 32 && ROWS == 64 && n >= g_irn_cb16_rows) {
+        const size_t lds16 = 4 * (size_t)(IrnKGA<C>::value * RowGather<4, ROWS>::SLOTS * 16);
+        hipLaunchKernelGGL((k_irn_a<C, ROWS, 16>), grid, dim3(256), lds16, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
+    } else if (phase & 1)
         hipLaunchKernelGGL((k_irn_a<C, ROWS>), grid, dim3(256), lds_a, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
     if (phase & 2)
         hipLaunchKernelGGL((k_irn_b<C, ROWS>), grid, dim3(256), lds_b, s, nbr, n, t, x, x_ld, P[2], P[3], P[6], P[7], P[8], P[9],

@@ -333,6 +333,11 @@ def set_irn_rows(rows):
     _IRN_ROWS = int(rows)
 
 
+def set_irn_cb16_rows(min_rows):
+    """C = 32 pass A uses 16-channel sub-steps on levels of at least `min_rows` rows (negative = default 400 000, 0 = always)."""
+    check(lib().pcgc_set_irn_cb16_rows(int(min_rows)), 'set_irn_cb16_rows')
+
+
 def _irn_rows(n):
     """the tile height pcgc_irn_block picks (conv.hip launch_irn_rows): exact kernel names for the profile records"""
     return _IRN_ROWS if _IRN_ROWS > 0 else (16 if n < 40000 else 64)

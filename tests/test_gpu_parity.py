@@ -178,6 +178,13 @@ def test_fused_inception_resnet_bit_exact(C, rows):
         ops.set_irn_rows(0)
     np.testing.assert_array_equal(unfused, want)
     np.testing.assert_array_equal(fused, want)
+    if C == 32 and rows == 64:                               # 16-channel sub-step form of pass A (the default above 400 k rows)
+        ops.set_irn_cb16_rows(0)
+        try:
+            with torch.no_grad():
+                np.testing.assert_array_equal(blk(xs).F.cpu().numpy(), want)
+        finally:
+            ops.set_irn_cb16_rows(-1)
     if C == 64:                                              # both schedules of the block-sparse MFMA kernels
         for mode in (0, 1):
             ops.set_mfma_pipe(mode)
