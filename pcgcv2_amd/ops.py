@@ -333,9 +333,19 @@ def set_irn_rows(rows):
     _IRN_ROWS = int(rows)
 
 
+_IRN_CB16_ROWS = 400000
+
+
 def set_irn_cb16_rows(min_rows):
     """C = 32 pass A uses 16-channel sub-steps on levels of at least `min_rows` rows (negative = default 400 000, 0 = always)."""
+    global _IRN_CB16_ROWS
     check(lib().pcgc_set_irn_cb16_rows(int(min_rows)), 'set_irn_cb16_rows')
+    _IRN_CB16_ROWS = 400000 if min_rows < 0 else int(min_rows)
+
+
+def _irn_a_cb(C, R, n):
+    """channels per sub-step of the pass-A kernel launch_irn picks (conv.hip): exact kernel names for the profile records"""
+    return 16 if (C == 32 and R == 64 and n >= _IRN_CB16_ROWS) else 32
 
 
 def _irn_rows(n):
@@ -357,11 +367,12 @@ def irn_block(nbr, x, params):
     if PROFILE.counting:
         PROFILE.count(nbr)
     R = _irn_rows(n)
-    if not (PROFILE.want((f'k_irn_a<{C}, {R}>', n)) or PROFILE.want((f'k_irn_b<{C}, {R}>', n))):
+    name_a = f'k_irn_a<{C}, {R}, {_irn_a_cb(C, R, n)}>'
+    if not (PROFILE.want((name_a, n)) or PROFILE.want((f'k_irn_b<{C}, {R}>', n))):
         check(lib().pcgc_irn_block(_p(nbr), n, _p(x), C, _ld(x), arr, _p(t), _p(out), C, _stream()), 'irn_block')
         return out
     Q = C // 4
-    passes = ((1, f'k_irn_a<{C}, {R}>', lambda P, n=n: (P * C * 4 + P * 8 + n * Q * 4) + n * (C + Q) * 4, lambda P, n=n: 2 * P * C * Q + 2 * n * C * Q),
+    passes = ((1, name_a, lambda P, n=n: (P * C * 4 + P * 8 + n * Q * 4) + n * (C + Q) * 4, lambda P, n=n: 2 * P * C * Q + 2 * n * C * Q),
               (2, f'k_irn_b<{C}, {R}>', lambda P, n=n: (P * Q * 4 + P * 8 + n * 2 * Q * 4) + (P * Q * 4 + P * 8 + n * Q * 4) + n * 3 * Q * 4,
                lambda P, n=n: 2 * P * Q * 2 * Q + 2 * P * Q * Q + 2 * n * Q * 2 * Q))
     for ps, name, bf, ff in passes:
