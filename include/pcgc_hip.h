@@ -44,6 +44,11 @@ int pcgc_hash_first_mask(const int32_t* coords, int64_t n, int32_t stride, const
                          int64_t cap, uint8_t* keep /*[dev n]*/, int32_t* first_row /*[dev n] or NULL*/, void* stream);
                          /* keep[i] = row i is the first occurrence of its coordinate; first_row[i] = that first row */
 
+/* *bad <- number of rows outside the representable range (negative, >= 2^20, batch >= 16).  ME accepts any int32
+ * coordinate; this library does not, so the host layer validates caller-supplied coordinates (SparseTensor ctor,
+ * scale_sparse_tensor) and raises instead of silently dropping rows. */
+int pcgc_coords_check(const int32_t* coords /*[dev n,4]*/, int64_t n, int32_t* bad /*[dev 1]*/, void* stream);
+
 /* ---- coordinate transforms ---- */
 /* output coords of MinkowskiConvolution(kernel_size=2, stride=2): floor(c / stride_out) * stride_out per row
  * (autoencoder.py:78-84,97-103,116-122); dedup with the hash calls above. */
@@ -159,6 +164,10 @@ int pcgc_round_minmax(const float* feats, int64_t count, float* minmax /*[dev 2]
 int pcgc_symbolize(const float* feats, int64_t count, float min_v, int16_t* sym /*[dev count]*/, void* stream);
 /* feats = float(sym) + min_v  (entropy_model.py:193-194). */
 int pcgc_desymbolize(const int16_t* sym, int64_t count, float min_v, float* feats, void* stream);
+/* the two calls above with the symbol range kept on the device: minmax[2] <- (min, max), sym <- int16(round(feats) - min).
+ * The host fetches both with one copy and evaluates the CDF table itself (reference arithmetic, see
+ * pcgcv2_amd/entropy_model.py:reference_table). */
+int pcgc_quantize_symbols(const float* feats, int64_t count, float* minmax /*[dev 2]*/, int16_t* sym /*[dev count]*/, void* stream);
 /* fused CDF table: _likelihood -> clamp(1e-9) -> cumsum -> clamp(1) -> torchac 16-bit normalisation
  * (entropy_model.py:112-149,165-170 + torchac ‡).  params: 352 fp32 packed matrices|biases|factors.
  * cdf_u16 [C, L+1], L = max_v-min_v+1.  cdf_f32 (optional, may be NULL) receives the fp32 cdf [C, L+1]. */

@@ -4,7 +4,8 @@ TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and ben
 never by the product package (pcgcv2_amd/).  Every function cites the reference lines it restates.
 
 Parity status (see also pcgc_oracle.c header and DESIGN.md):
-  pinned     entropy tables (G1), ordering/top-k (G2), PLY text (G3), D1 metric (G4), state-dict keys (G5)
+  pinned     entropy tables (G1: cdf_float_ref32 bit-exact on 15 cases; the fp64 C evaluation within fp32 round-off),
+             ordering/top-k (G2), PLY text (G3), D1 metric (G4), state-dict keys (G5)
   unpinned   MinkowskiEngine conv/map/prune semantics, torchac range coder  (un-vendored third-party; restated)
 """
 import ctypes as C
@@ -276,6 +277,53 @@ def cdf_float(params, min_v, max_v):
     return out
 
 
+def _eb_unpack(params, C=8):
+    """packed 352 floats -> (matrices, biases, factors) as lists of torch CPU tensors with the reference's shapes"""
+    import torch
+    params = _c(params, np.float32)
+    out, off = [], 0
+    for shp in EB_SHAPES:
+        n = int(np.prod(shp))
+        out.append(torch.from_numpy(params[off:off + n].reshape(shp).copy()))
+        off += n
+    return out[0:4], out[4:8], out[8:12]
+
+
+def cdf_float_ref32(params, min_v, max_v):
+    """The reference's own fp32 arithmetic for the CDF table (entropy_model.py:82-101, 112-130, 142-149, 163-172): the
+    reference runs these lines with torch on the CPU, and torch's CPU kernels choose vectorised / scalar-tail / BLAS code by
+    tensor shape, so the restatement uses the same torch operators on tensors of the same shape and layout.  Pinned to
+    golden G1 with exact equality (tests/test_oracle_golden.py).  -> fp32 ndarray [C, L+1]."""
+    import torch
+    import torch.nn.functional as tnf
+    M, B, Fa = _eb_unpack(params)
+    with torch.no_grad():
+        symbols = torch.arange(float(min_v), float(max_v) + 1).reshape(-1, 1).repeat(1, 8)      # [L, 8]
+        x = symbols.permute(1, 0).contiguous()
+        shape = x.size()
+        x = x.view(shape[0], 1, -1)
+
+        def logits_cumulative(h):                                   # entropy_model.py:93-99
+            for i in range(4):
+                h = torch.matmul(tnf.softplus(M[i]), h)
+                h += B[i]
+                h += torch.tanh(Fa[i]) * torch.tanh(h)
+            return h
+        lower = logits_cumulative(x - 0.5)
+        upper = logits_cumulative(x + 0.5)
+        sign = -torch.sign(torch.add(lower, upper))
+        like = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower)).view(shape).permute(1, 0)
+        pmf = torch.clamp(like, min=1e-9).permute(1, 0)
+        cdf = pmf.cumsum(dim=-1)
+        cdf = torch.cat([torch.zeros(pmf.shape[:-1] + (1,), dtype=pmf.dtype), cdf], dim=-1).clamp(max=1.)
+    return cdf.contiguous().numpy()
+
+
+def cdf_table_ref32(params, min_v, max_v):
+    """uint16 table [C, L+1]: cdf_float_ref32 + torchac's 16-bit normalisation (orc_cdf_u16)."""
+    return cdf_u16(cdf_float_ref32(params, min_v, max_v))
+
+
 def cdf_u16(cdf):
     cdf = _c(cdf, np.float32)
     out = np.empty(cdf.shape, np.uint16)
@@ -306,13 +354,13 @@ def eb_compress(params, feats):
     values = np.rint(np.asarray(feats, np.float32))              # torch.round == half-to-even
     min_v, max_v = np.float32(values.min() + 0.0), np.float32(values.max() + 0.0)
     sym = (values - min_v).astype(np.int16)
-    table = cdf_u16(cdf_float(params, min_v, max_v))
+    table = cdf_table_ref32(params, min_v, max_v)
     return rc_encode(table, sym), min_v, max_v
 
 
 def eb_decompress(params, data, min_v, max_v, shape):
     """entropy_model.py:178-196."""
-    table = cdf_u16(cdf_float(params, min_v, max_v))
+    table = cdf_table_ref32(params, min_v, max_v)
     n = int(shape[0]) * int(shape[1])
     return rc_decode(table, data, n).reshape(int(shape[0]), int(shape[1])).astype(np.float32) + np.float32(min_v)
 

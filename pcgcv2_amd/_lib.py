@@ -17,6 +17,7 @@ SIGNATURES = {
     'pcgc_hash_clear': (ci, [vp, vp, i64, vp]),
     'pcgc_hash_insert': (ci, [vp, i64, i32, vp, vp, i64, vp]),
     'pcgc_hash_first_mask': (ci, [vp, i64, i32, vp, vp, i64, vp, vp, vp]),
+    'pcgc_coords_check': (ci, [vp, i64, vp, vp]),
     'pcgc_coords_quantize': (ci, [vp, i64, i32, vp, vp]),
     'pcgc_coords_children': (ci, [vp, i64, i32, vp, vp]),
     'pcgc_coords_scale': (ci, [vp, i64, f32, vp, vp]),
@@ -53,6 +54,7 @@ SIGNATURES = {
     'pcgc_round_minmax': (ci, [vp, i64, vp, vp]),
     'pcgc_symbolize': (ci, [vp, i64, f32, vp, vp]),
     'pcgc_desymbolize': (ci, [vp, i64, f32, vp, vp]),
+    'pcgc_quantize_symbols': (ci, [vp, i64, vp, vp, vp]),
     'pcgc_compress_prepare': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, vp, vp, vp]),
     'pcgc_cdf_table': (ci, [vp, ci, f32, f32, vp, vp, vp]),
     'pcgc_d1_nn': (ci, [vp, i64, vp, vp, i64, vp, ci, vp, vp, vp, vp]),

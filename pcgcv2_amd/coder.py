@@ -52,10 +52,20 @@ class CoordinateCoder():
 
     def __init__(self, filename):
         self.filename = filename
-        self.ply_filename = filename + '.ply'
+        self.ply_filename = filename + '.ply'             # the reference's fixed temp name (coder.py:21); kept as an attribute only
 
     def _path(self, postfix):
         return self.filename + postfix + '_C.bin'
+
+    def _temp_ply(self, postfix):
+        """A temp PLY of this call alone.  The reference reuses `<filename>.ply` for every call, which is only safe because it
+        codes sequentially; here frames are coded concurrently (shard.code_units(in_flight>1), one Coder per worker with the
+        same prefix), so every call gets its own file next to the bitstream."""
+        import tempfile
+        head, tail = os.path.split(self.filename + postfix)
+        fd, path = tempfile.mkstemp(prefix=tail + '_C_', suffix='.ply', dir=head or '.')
+        os.close(fd)
+        return path
 
     def encode(self, coords, postfix=''):
         pts = coords.numpy() if isinstance(coords, torch.Tensor) else np.asarray(coords)
@@ -63,20 +73,22 @@ class CoordinateCoder():
         if gpcc.tmc3_path() is None:
             gpcc.native_encode(pts, self._path(postfix))
             return
-        write_ply_ascii_geo(filedir=self.ply_filename, coords=pts)
+        ply = self._temp_ply(postfix)
         try:
-            gpcc.gpcc_encode(self.ply_filename, self._path(postfix))
+            write_ply_ascii_geo(filedir=ply, coords=pts)
+            gpcc.gpcc_encode(ply, self._path(postfix))
         finally:
-            os.remove(self.ply_filename)
+            os.remove(ply)
 
     def decode(self, postfix=''):
         if gpcc.is_native_stream(self._path(postfix)):
             return gpcc.native_decode(self._path(postfix))
-        gpcc.gpcc_decode(self._path(postfix), self.ply_filename)
+        ply = self._temp_ply(postfix)
         try:
-            return read_ply_ascii_geo(self.ply_filename)
+            gpcc.gpcc_decode(self._path(postfix), ply)
+            return read_ply_ascii_geo(ply)
         finally:
-            os.remove(self.ply_filename)
+            os.remove(ply)
 
 
 class FeatureCoder():
@@ -114,6 +126,10 @@ class Coder():
         (N1 -> N2 -> N4 -> N8) is built first, so the stride-8 coordinates — all the coordinate coder needs — reach the host
         before the convolutions are even enqueued; the sequential host-side coordinate coding then runs on a helper thread
         while this thread enqueues the encoder and the GPU executes it."""
+        with torch.cuda.device(x.device):                       # current device = the tensors' device (kernels, events, streams)
+            return self._encode(x, postfix)
+
+    def _encode(self, x, postfix):
         lvl8 = x.cmap
         for _ in range(3):
             lvl8 = lvl8.down()[0]                               # cached on the levels: the encoder reuses these maps
@@ -141,7 +157,7 @@ class Coder():
             self._pinned = torch.empty(max(t.numel(), 1 << 16), dtype=t.dtype, pin_memory=True)
         host = self._pinned[:t.numel()].view(t.shape)
         ready = torch.cuda.Event()
-        ready.record()                                           # on the current stream: t is complete after this
+        ready.record(torch.cuda.current_stream(dev))             # on t's device's current stream: t is complete after this
         with torch.cuda.stream(self._side):
             self._side.wait_event(ready)
             host.copy_(t, non_blocking=True)
@@ -173,6 +189,10 @@ class Coder():
     def decode(self, rho=1, postfix=''):
         """coder.py:93-112: reads the four files, returns the decoded stride-1 sparse tensor."""
         dev = require_gpu(next(self.model.decoder.parameters()).device)
+        with torch.cuda.device(dev):
+            return self._decode(rho, postfix, dev)
+
+    def _decode(self, rho, postfix, dev):
         # the two bitstreams are independent: a helper thread decodes the coordinates, uploads and sorts them and prebuilds
         # the coordinate-only part of the first decoder stage (children level + kernel maps) while this thread range-decodes
         # the features (native calls that release the GIL; both threads enqueue on this thread's stream).  The helper is

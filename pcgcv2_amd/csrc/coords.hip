@@ -29,7 +29,7 @@ __global__ void k_hash_insert(const int4* __restrict__ coords, int64_t n, int sh
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int4 c = coords[i];                               // (b, x, y, z)
-    if (!coord_in_range(c.x, c.y, c.z, c.w)) return;  // out-of-range rows are never found again; host validates
+    if (!coord_in_range(c.x, c.y, c.z, c.w)) return;  // never found again; the host rejects such input up front (pcgc_coords_check)
     uint64_t key = coord_key(c.x, c.y, c.z, c.w);
     uint64_t h = hash_slot(c.x, c.y, c.z, c.w, sh, cap_mask);
     // Quantised coordinates arrive up to 8 times each.  Test before the atomics: a slot only ever goes EMPTY -> key and its
@@ -54,6 +54,22 @@ __global__ void k_hash_first_mask(const int4* __restrict__ coords, int64_t n, in
     int32_t f = hash_lookup(keys, vals, cap_mask, sh, c.x, c.y, c.z, c.w);
     keep[i] = f == (int32_t)i;
     if (first_row) first_row[i] = f;
+}
+
+// rows whose coordinates the 4+20+20+20-bit key cannot hold (negative, >= 2^20, batch >= 16): the hash kernels skip such rows,
+// so the host validates every externally supplied coordinate tensor with this before building a level on it
+__global__ void k_coords_check(const int4* __restrict__ coords, int64_t n, int32_t* __restrict__ bad) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool oob = i < n && !coord_in_range(coords[i].x, coords[i].y, coords[i].z, coords[i].w);
+    const unsigned long long b = __ballot(oob);
+    if (b && (threadIdx.x & 63) == 0) atomicAdd(bad, (int32_t)__popcll(b));
+}
+extern "C" int pcgc_coords_check(const int32_t* coords, int64_t n, int32_t* bad, void* stream) {
+    PCGC_REQUIRE(bad != nullptr, "null counter");
+    hipMemsetAsync(bad, 0, sizeof(int32_t), S(stream));
+    if (n > 0) hipLaunchKernelGGL(k_coords_check, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n, bad);
+    PCGC_CHECK_LAUNCH("coords_check");
+    return 0;
 }
 
 extern "C" int pcgc_hash_clear(uint64_t* keys, int32_t* vals, int64_t cap, void* stream) {

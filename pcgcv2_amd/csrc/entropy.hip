@@ -158,6 +158,14 @@ __global__ void k_symbolize_dev(const float* __restrict__ f, int64_t count, cons
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) sym[i] = (int16_t)(rintf(f[i]) - minmax[0]);
 }
+// symbol range + symbols in one enqueue (the host-table path of compress(): the CDF table is evaluated on the host)
+extern "C" int pcgc_quantize_symbols(const float* feats, int64_t count, float* minmax, int16_t* sym, void* stream) {
+    PCGC_REQUIRE(count > 0, "empty latent");
+    hipLaunchKernelGGL(k_round_minmax, dim3(1), dim3(1024), 0, S(stream), feats, count, minmax);
+    hipLaunchKernelGGL(k_symbolize_dev, dim3(grid_for(count, 256)), dim3(256), 0, S(stream), feats, count, minmax, sym);
+    PCGC_CHECK_LAUNCH("quantize_symbols");
+    return 0;
+}
 __global__ void k_cdf_likelihood_dev(const float* __restrict__ P, int C, const float* __restrict__ minmax, int max_L,
                                      float* __restrict__ cdf_f32, int32_t* __restrict__ info) {
     __shared__ EbShared sh;

@@ -4,10 +4,20 @@ Same parameter names as the reference — `_matrices.{0..3}`, `_biases.{0..3}`, 
 `matrix` / `bias` / `factor` that the reference creates by assigning `self.matrix = Parameter(...)` inside its
 constructor loop (entropy_model.py:68-80) — so a strict load_state_dict of a reference checkpoint succeeds.
 
-compress/decompress: quantisation, symbol range and the CDF table run on the GPU (pcgc_round_minmax, pcgc_symbolize,
-pcgc_cdf_table); only int16 symbols and the 8 x (L+1) 16-bit table cross to the host, where the sequential range coder
-(pcgc_rc_encode / pcgc_rc_decode, torchac-compatible) runs.  The reference's [N8, 8, L+1] fp32 CDF expansion
-(entropy_model.py:173) never exists.
+compress/decompress: quantisation, symbol range and symbolisation run on the GPU (pcgc_round_minmax, pcgc_symbolize);
+only int16 symbols cross to the host, where the sequential range coder (pcgc_rc_encode / pcgc_rc_decode,
+torchac-compatible) runs.  The reference's [N8, 8, L+1] fp32 CDF expansion (entropy_model.py:173) never exists.
+
+The 8 x (L+1) CDF table decides every bit of `_F.bin`, so encoder and decoder — here or in the reference — must derive
+the same uint16 values.  `table_mode`:
+  'reference' (default)  the table is evaluated on the host with the reference's own arithmetic: the same torch-CPU fp32
+                         operator sequence on tensors of the same shape and layout as entropy_model.py:82-101,112-130,
+                         142-149, then torchac's published 16-bit normalisation.  Pinned bit for bit to golden tables
+                         generated from the reference (tests/golden/entropy_tables.npz): a stream written here decodes
+                         in the reference on the same host and vice versa.  The table is consumed by the host range
+                         coder anyway, so nothing extra crosses PCIe.
+  'device'               the fused HIP kernel pcgc_cdf_table (fp64 evaluation rounded to fp32): self-consistent between
+                         this encoder and decoder, within 1 count of the reference table, NOT interoperable with it.
 """
 import numpy as np
 import torch
@@ -37,60 +47,132 @@ class EntropyBottleneck(nn.Module):
             self._matrices.append(m); self._biases.append(b); self._factors.append(f)
         # the reference's accidental aliases of the LAST layer's tensors (same Parameter objects)
         self.matrix, self.bias, self.factor = self._matrices[-1], self._biases[-1], self._factors[-1]
-        self._packed = None
+        self.table_mode = 'reference'
+        self._packed = self._packed_stamp = None
+        self._host = self._host_stamp = None
 
     def cpu(self):
         """coder.py:44 calls `entropy_model.cpu()`; the tables are evaluated on the GPU here, so the module stays put."""
         return self
 
-    def _apply(self, fn, *a, **k):
-        self._packed = None
-        return super()._apply(fn, *a, **k)
-
-    def load_state_dict(self, *a, **k):
-        self._packed = None
-        return super().load_state_dict(*a, **k)
+    def _stamp(self):
+        """identity + version of the 12 parameter tensors: any in-place update, re-assignment, .to() or load_state_dict —
+        through this module or any parent container — changes it, so derived copies can never go stale."""
+        return tuple((p.data_ptr(), p._version, p.device) for lst in (self._matrices, self._biases, self._factors)
+                     for p in lst._parameters.values())
 
     def packed_params(self, device):
         """352 fp32: matrices 0..3 | biases 0..3 | factors 0..3 — the layout pcgc_cdf_table expects."""
-        if self._packed is None or self._packed.device != device:
+        stamp = (self._stamp(), device)
+        if self._packed is None or self._packed_stamp != stamp:
             parts = [p.detach().reshape(-1).float() for lst in (self._matrices, self._biases, self._factors) for p in lst]
-            self._packed = torch.cat(parts).to(device).contiguous()
+            self._packed, self._packed_stamp = torch.cat(parts).to(device).contiguous(), stamp
         return self._packed
 
     def invalidate(self):
-        self._packed = None
+        self._packed = self._host = None
+
+    def _host_params(self):
+        """fp32 CPU copies of (matrices, biases, factors), refreshed when the parameters change."""
+        stamp = self._stamp()
+        if self._host is None or self._host_stamp != stamp:
+            mats, biases, factors = ([p.detach().to('cpu', torch.float32) for p in lst]
+                                     for lst in (self._matrices, self._biases, self._factors))
+            # the parameter-only terms of _logits_cumulative — softplus(matrix) (entropy_model.py:94) and tanh(factor) (:97) —
+            # are the same tensors in every call: evaluated once per parameter set with the same operators
+            self._host = ([torch.nn.functional.softplus(m) for m in mats], biases, [torch.tanh(f) for f in factors])
+            self._host_stamp = stamp
+        return self._host
+
+    @torch.no_grad()
+    def reference_table(self, min_v, max_v):
+        """The CDF table exactly as the reference derives it on the CPU -> (cdf fp32 [C, L+1], table uint16 ndarray [C, L+1]).
+
+        Same torch-CPU fp32 operators, in the same order, on tensors of the same shape and memory layout as
+        entropy_model.py:163-172 / 181-189 (symbols -> _likelihood :112-130 -> _logits_cumulative :82-101 -> clamp ->
+        _pmf_to_cdf :142-149): operator order, in-place forms and layouts are part of the contract, because torch's CPU
+        kernels pick vectorised / scalar-tail / BLAS paths by shape.  The last step is torchac 0.9.3's published
+        `_convert_to_int_and_normalize` (scale by 2^16 - (Lp - 1), round, int16, + arange(Lp))."""
+        sp_mats, biases, th_factors = self._host_params()
+        C = self._channels
+        sym = torch.arange(float(min_v), float(max_v) + 1)                    # float32, like arange(min_v, max_v + 1) there
+        pts = sym.reshape(-1, 1).repeat(1, C)                                 # [L, C]
+        grid = pts.permute(1, 0).contiguous()
+        shape = grid.size()
+        grid = grid.view(shape[0], 1, -1)                                     # [C, 1, L]
+        ends = []
+        for half in (-0.5, 0.5):                                              # lower = f(v - 0.5), upper = f(v + 0.5)
+            z = grid + half
+            for m, b, f in zip(sp_mats, biases, th_factors):
+                z = torch.matmul(m, z)
+                z += b
+                z += f * torch.tanh(z)
+            ends.append(z)
+        lower, upper = ends
+        sign = -torch.sign(torch.add(lower, upper))
+        lik = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
+        lik = lik.view(shape).permute(1, 0)                                   # [L, C] view, as _likelihood returns it
+        pmf = torch.clamp(lik, min=self._likelihood_bound).permute(1, 0)      # [C, L]
+        cdf = pmf.cumsum(dim=-1)
+        cdf = torch.cat([torch.zeros(pmf.shape[:-1] + (1,), dtype=pmf.dtype), cdf], dim=-1).clamp(max=1.)
+        # torchac: cdf_float.mul(2^16 - (Lp - 1)).round().to(int16).add_(arange(Lp, int16))
+        Lp = cdf.shape[-1]
+        top = torch.tensor(2, dtype=torch.float32).pow_(16) - (Lp - 1)
+        q = cdf.mul(top).round().to(dtype=torch.int16)
+        q.add_(torch.arange(Lp, dtype=torch.int16))
+        return cdf, q.contiguous().numpy().view(np.uint16)
 
     def cdf_table(self, min_v, max_v, device):
+        """device-kernel table (table_mode 'device'): (uint16 bit patterns as int16 tensor [C, L+1], fp32 cdf)."""
         q, f = ops.cdf_table(self.packed_params(device), self._channels, float(min_v), float(max_v))
         return q, f
+
+    def host_table(self, min_v, max_v, device):
+        """uint16 ndarray [C, L+1] on the host, by the configured table_mode."""
+        if self.table_mode == 'reference':
+            return self.reference_table(min_v, max_v)[1]
+        if self.table_mode != 'device':
+            raise PcgcError(f"table_mode must be 'reference' or 'device', got {self.table_mode!r}")
+        return self.cdf_table(min_v, max_v, device)[0].cpu().numpy().view(np.uint16)
 
     @torch.no_grad()
     def compress(self, inputs):
         """entropy_model.py:151-176 -> (bytes, min_v ndarray[1], max_v ndarray[1])."""
         if inputs.dim() != 2 or inputs.shape[1] != self._channels:
             raise PcgcError(f'compress expects [N, {self._channels}] features')
-        prep = ops.compress_prepare(inputs, self.packed_params(inputs.device), self._channels)     # one D2H + sync
-        if prep is not None:
-            min_v, max_v, sym_h, table_h = prep
-        else:                                                        # alphabet larger than the staged table: two-phase path
-            mm = ops.round_minmax(inputs).cpu().numpy()
-            min_v, max_v = np.float32(mm[0]), np.float32(mm[1])
-            sym_h = ops.symbolize(inputs, min_v).cpu().numpy()
-            table_h = self.cdf_table(min_v, max_v, inputs.device)[0].cpu().numpy().view(np.uint16)
+        if self.table_mode == 'device':
+            prep = ops.compress_prepare(inputs, self.packed_params(inputs.device), self._channels)     # one D2H + sync
+            if prep is not None:
+                min_v, max_v, sym_h, table_h = prep
+            else:                                                    # alphabet larger than the staged table: two-phase path
+                mm = ops.round_minmax(inputs).cpu().numpy()
+                min_v, max_v = np.float32(mm[0]), np.float32(mm[1])
+                sym_h = ops.symbolize(inputs, min_v).cpu().numpy()
+                table_h = self.host_table(min_v, max_v, inputs.device)
+        else:
+            # symbol range + symbols in one enqueue and ONE synchronising copy; the table is then evaluated on the host
+            # (reference arithmetic) where the range coder consumes it
+            min_v, max_v, sym_h = ops.quantize_symbols(inputs)
+            table_h = self.host_table(min_v, max_v, inputs.device)
         strings = ops.rc_encode(table_h, sym_h)
         return strings, np.array([min_v], np.float32), np.array([max_v], np.float32)
 
     @torch.no_grad()
     def decompress(self, strings, min_v, max_v, shape, channels, device=None, on_table_launched=None):
-        """entropy_model.py:178-196 -> fp32 [shape[0], channels] on `device`.  `on_table_launched` (optional) is called once
-        the CDF-table kernel is enqueued, before this thread blocks on its result: the place to start concurrent host work."""
+        """entropy_model.py:178-196 -> fp32 [shape[0], channels] on `device`.  `on_table_launched` (optional) is called
+        before this thread starts on the table: the place to start concurrent host work."""
         device = torch.device('cuda') if device is None else device
         min_v, max_v = np.float32(np.asarray(min_v).reshape(-1)[0]), np.float32(np.asarray(max_v).reshape(-1)[0])
-        table, _ = self.cdf_table(min_v, max_v, device)
-        if on_table_launched is not None:
-            on_table_launched()
+        if self.table_mode == 'device':
+            table, _ = self.cdf_table(min_v, max_v, device)
+            if on_table_launched is not None:
+                on_table_launched()
+            table_h = table.cpu().numpy().view(np.uint16)
+        else:
+            if on_table_launched is not None:
+                on_table_launched()
+            table_h = self.host_table(min_v, max_v, device)
         n = int(shape[0]) * int(channels)
-        sym_h = ops.rc_decode(table.cpu().numpy().view(np.uint16), strings, n)
+        sym_h = ops.rc_decode(table_h, strings, n)
         sym = torch.from_numpy(sym_h.reshape(int(shape[0]), int(channels))).to(device)
         return ops.desymbolize(sym, min_v)

@@ -9,8 +9,12 @@ import torch
 from ._lib import lib, check, PcgcError
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+def _stream(t=None):
+    """HIP stream the call is enqueued on: the current stream of the OPERAND's device (not of the current device — they differ
+    in a single-process multi-GPU program that never calls set_device)."""
+    if t is None:
+        return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream(t.device).cuda_stream
 
 
 def _p(t):
@@ -131,9 +135,19 @@ class HashTable:
         self.stride = int(stride)
         self.keys = torch.empty(self.cap, dtype=torch.int64, device=coords.device)
         self.vals = torch.empty(self.cap, dtype=torch.int32, device=coords.device)
-        check(lib().pcgc_hash_clear(_p(self.keys), _p(self.vals), self.cap, _stream()), 'hash_clear')
-        check(lib().pcgc_hash_insert(_p(_i32(coords)), n, self.stride, _p(self.keys), _p(self.vals), self.cap, _stream()),
+        check(lib().pcgc_hash_clear(_p(self.keys), _p(self.vals), self.cap, _stream(self.keys)), 'hash_clear')
+        check(lib().pcgc_hash_insert(_p(_i32(coords)), n, self.stride, _p(self.keys), _p(self.vals), self.cap, _stream(coords)),
               'hash_insert')
+
+
+def check_coords(coords, what='coordinates'):
+    """Raise PcgcError if any row is outside the range the coordinate key can hold (the hash kernels would skip it)."""
+    bad = torch.empty(1, dtype=torch.int32, device=coords.device)
+    check(lib().pcgc_coords_check(_p(_i32(coords)), coords.shape[0], _p(bad), _stream(coords)), 'coords_check')
+    n_bad = int(bad.item())
+    if n_bad:
+        raise PcgcError(f'{what}: {n_bad} of {coords.shape[0]} rows are outside the supported range '
+                        '(0 <= x, y, z < 2^20, 0 <= batch < 16)')
 
 
 def first_occurrence_mask(coords, table, want_rows=False):
@@ -142,7 +156,7 @@ def first_occurrence_mask(coords, table, want_rows=False):
     keep = torch.empty(n, dtype=torch.uint8, device=coords.device)
     first = torch.empty(n, dtype=torch.int32, device=coords.device) if want_rows else None
     check(lib().pcgc_hash_first_mask(_p(_i32(coords)), n, table.stride, _p(table.keys), _p(table.vals), table.cap, _p(keep),
-                                     _p(first), _stream()), 'hash_first_mask')
+                                     _p(first), _stream(coords)), 'hash_first_mask')
     return (keep, first) if want_rows else keep
 
 
@@ -152,7 +166,7 @@ def down_maps(fine, first_row, prefix, stride_fine, n_coarse):
     parent_of = torch.empty(n, dtype=torch.int32, device=fine.device)
     down = torch.empty((8, n_coarse), dtype=torch.int32, device=fine.device)
     check(lib().pcgc_down_maps(_p(_i32(fine)), _p(first_row), _p(prefix), n, int(stride_fine), n_coarse, _p(parent_of), _p(down),
-                               _stream()), 'down_maps')
+                               _stream(fine)), 'down_maps')
     return parent_of, down
 
 
@@ -170,7 +184,7 @@ def down_level(fine, stride_fine):
     keep = torch.empty(n, dtype=torch.uint8, device=dev)
     ws_bytes = int(lib().pcgc_scan_workspace_bytes(n))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    s = _stream()
+    s = _stream(fine)
     check(lib().pcgc_down_prepare(_p(fine), n, int(stride_fine), _p(q), _p(keys), _p(vals), cap, _p(keep), _p(first_row), _p(prefix),
                                   _p(total), _p(ws), ws_bytes, s), 'down_prepare')
     n_coarse = int(total.item())                               # host sync: sizes the coarse level
@@ -184,21 +198,21 @@ def down_level(fine, stride_fine):
 
 def compact_index(mask, prefix, n_out):
     orig = torch.empty(n_out, dtype=torch.int32, device=mask.device)
-    check(lib().pcgc_compact_index(_p(mask), _p(prefix), mask.shape[0], _p(orig), _stream()), 'compact_index')
+    check(lib().pcgc_compact_index(_p(mask), _p(prefix), mask.shape[0], _p(orig), _stream(mask)), 'compact_index')
     return orig
 
 
 def kmap_k3_children(parent_nbr):
     n_parent = parent_nbr.shape[1]
     nbr = torch.empty((27, 8 * n_parent), dtype=torch.int32, device=parent_nbr.device)
-    check(lib().pcgc_kmap_k3_children(_p(parent_nbr), n_parent, _p(nbr), _stream()), 'kmap_k3_children')
+    check(lib().pcgc_kmap_k3_children(_p(parent_nbr), n_parent, _p(nbr), _stream(parent_nbr)), 'kmap_k3_children')
     return nbr
 
 
 def kmap_k3_prune(cand_nbr, mask, prefix, orig):
     n_out = orig.shape[0]
     nbr = torch.empty((27, n_out), dtype=torch.int32, device=cand_nbr.device)
-    check(lib().pcgc_kmap_k3_prune(_p(cand_nbr), cand_nbr.shape[1], _p(mask), _p(prefix), _p(orig), n_out, _p(nbr), _stream()),
+    check(lib().pcgc_kmap_k3_prune(_p(cand_nbr), cand_nbr.shape[1], _p(mask), _p(prefix), _p(orig), n_out, _p(nbr), _stream(cand_nbr)),
           'kmap_k3_prune')
     return nbr
 
@@ -207,7 +221,7 @@ def kmap_k3_from_coarse(fine, stride_fine, parent_of, coarse_nbr, down):
     n = fine.shape[0]
     nbr = torch.empty((27, n), dtype=torch.int32, device=fine.device)
     check(lib().pcgc_kmap_k3_from_coarse(_p(_i32(fine)), n, int(stride_fine), _p(parent_of), _p(coarse_nbr), _p(down),
-                                         coarse_nbr.shape[1], _p(nbr), _stream()), 'kmap_k3_from_coarse')
+                                         coarse_nbr.shape[1], _p(nbr), _stream(fine)), 'kmap_k3_from_coarse')
     return nbr
 
 
@@ -218,14 +232,14 @@ def mask_scan(mask):
     total = torch.empty(1, dtype=torch.int32, device=mask.device)
     ws_bytes = int(lib().pcgc_scan_workspace_bytes(n))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mask.device)
-    check(lib().pcgc_mask_scan(_p(_dev(mask, torch.uint8, 'mask')), n, _p(prefix), _p(total), _p(ws), ws_bytes, _stream()),
+    check(lib().pcgc_mask_scan(_p(_dev(mask, torch.uint8, 'mask')), n, _p(prefix), _p(total), _p(ws), ws_bytes, _stream(mask)),
           'mask_scan')
     return prefix, total
 
 
 def compact_coords(coords, mask, prefix, n_out):
     out = torch.empty((n_out, 4), dtype=torch.int32, device=coords.device)
-    check(lib().pcgc_compact_coords(_p(_i32(coords)), _p(mask), _p(prefix), coords.shape[0], _p(out), _stream()),
+    check(lib().pcgc_compact_coords(_p(_i32(coords)), _p(mask), _p(prefix), coords.shape[0], _p(out), _stream(coords)),
           'compact_coords')
     return out
 
@@ -234,26 +248,26 @@ def compact_feats(feats, mask, prefix, n_out):
     _f32(feats)
     C = feats.shape[1]
     out = torch.empty((n_out, C), dtype=torch.float32, device=feats.device)
-    check(lib().pcgc_compact_feats(_p(feats), C, _ld(feats), _p(mask), _p(prefix), feats.shape[0], _p(out), _stream()),
+    check(lib().pcgc_compact_feats(_p(feats), C, _ld(feats), _p(mask), _p(prefix), feats.shape[0], _p(out), _stream(feats)),
           'compact_feats')
     return out
 
 
 def coords_quantize(coords, stride_out):
     out = torch.empty_like(coords)
-    check(lib().pcgc_coords_quantize(_p(_i32(coords)), coords.shape[0], int(stride_out), _p(out), _stream()), 'coords_quantize')
+    check(lib().pcgc_coords_quantize(_p(_i32(coords)), coords.shape[0], int(stride_out), _p(out), _stream(coords)), 'coords_quantize')
     return out
 
 
 def coords_children(coords, stride_in):
     out = torch.empty((8 * coords.shape[0], 4), dtype=torch.int32, device=coords.device)
-    check(lib().pcgc_coords_children(_p(_i32(coords)), coords.shape[0], int(stride_in), _p(out), _stream()), 'coords_children')
+    check(lib().pcgc_coords_children(_p(_i32(coords)), coords.shape[0], int(stride_in), _p(out), _stream(coords)), 'coords_children')
     return out
 
 
 def coords_scale(coords, factor):
     out = torch.empty_like(coords)
-    check(lib().pcgc_coords_scale(_p(_i32(coords)), coords.shape[0], float(np.float32(factor)), _p(out), _stream()),
+    check(lib().pcgc_coords_scale(_p(_i32(coords)), coords.shape[0], float(np.float32(factor)), _p(out), _stream(coords)),
           'coords_scale')
     return out
 
@@ -261,7 +275,7 @@ def coords_scale(coords, factor):
 def kmap_k3(coords, stride, table):
     n = coords.shape[0]
     nbr = torch.empty((27, n), dtype=torch.int32, device=coords.device)
-    check(lib().pcgc_kmap_k3(_p(_i32(coords)), n, int(stride), _p(table.keys), _p(table.vals), table.cap, _p(nbr), _stream()),
+    check(lib().pcgc_kmap_k3(_p(_i32(coords)), n, int(stride), _p(table.keys), _p(table.vals), table.cap, _p(nbr), _stream(coords)),
           'kmap_k3')
     return nbr
 
@@ -270,7 +284,7 @@ def kmap_down(coarse, stride_fine, fine_table):
     n = coarse.shape[0]
     nbr = torch.empty((8, n), dtype=torch.int32, device=coarse.device)
     check(lib().pcgc_kmap_down(_p(_i32(coarse)), n, int(stride_fine), _p(fine_table.keys), _p(fine_table.vals), fine_table.cap,
-                               _p(nbr), _stream()), 'kmap_down')
+                               _p(nbr), _stream(coarse)), 'kmap_down')
     return nbr
 
 
@@ -305,7 +319,7 @@ def conv_gather(nbr, x, W, bias, out=None, residual=None, relu=False, n_out=None
                                  lambda P, a=Cin, b=Cout: 2 * P * a * b)
         e0.record()
     check(lib().pcgc_conv_gather(_p(nbr), K, n_out, _p(x), x.shape[0], Cin, _ld(x), 0, _p(W), _p(bias), res_p, res_ld, 0, int(relu),
-                                 _p(out), Cout, _ld(out), 0, _stream()), 'conv_gather')
+                                 _p(out), Cout, _ld(out), 0, _stream(nbr)), 'conv_gather')
     if prof:
         e1.record()
     elif PROFILE.counting and K == 27:
@@ -369,7 +383,7 @@ def irn_block(nbr, x, params):
     R = _irn_rows(n)
     name_a = f'k_irn_a<{C}, {R}, {_irn_a_cb(C, R, n)}>'
     if not (PROFILE.want((name_a, n)) or PROFILE.want((f'k_irn_b<{C}, {R}>', n))):
-        check(lib().pcgc_irn_block(_p(nbr), n, _p(x), C, _ld(x), arr, _p(t), _p(out), C, _stream()), 'irn_block')
+        check(lib().pcgc_irn_block(_p(nbr), n, _p(x), C, _ld(x), arr, _p(t), _p(out), C, _stream(nbr)), 'irn_block')
         return out
     Q = C // 4
     passes = ((1, name_a, lambda P, n=n: (P * C * 4 + P * 8 + n * Q * 4) + n * (C + Q) * 4, lambda P, n=n: 2 * P * C * Q + 2 * n * C * Q),
@@ -380,7 +394,7 @@ def irn_block(nbr, x, params):
         if prof:
             e0, e1 = PROFILE.bracket((name, n), name, n, bf, ff)
             e0.record()
-        check(lib().pcgc_irn_pass(_p(nbr), n, _p(x), C, _ld(x), arr, _p(t), _p(out), C, ps, _stream()), 'irn_pass')
+        check(lib().pcgc_irn_pass(_p(nbr), n, _p(x), C, _ld(x), arr, _p(t), _p(out), C, ps, _stream(nbr)), 'irn_pass')
         if prof:
             e1.record()
     return out
@@ -421,10 +435,10 @@ def irn_block_mfma64(nbr, x, f):
     Q, C = 16, 64
     steps = (
         ('k_conv_gather_mfma_wlds<64, 32, 2>', lambda P: (P * C * 4 + P * 8 + n * Q * 4) + n * (C + Q) * 4, lambda P: 2 * P * C * Q + 2 * n * C * Q,
-         lambda: lib().pcgc_conv_gather_masked(_p(nbr), n, _p(x), n, 64, _ld(x), _p(f['Wa']), 32, _p(f['mask_a']), _p(f['ba']), 1, _p(t), 32, _stream())),
+         lambda: lib().pcgc_conv_gather_masked(_p(nbr), n, _p(x), n, 64, _ld(x), _p(f['Wa']), 32, _p(f['mask_a']), _p(f['ba']), 1, _p(t), 32, _stream(nbr))),
         ('k_conv_gather_mfma_wlds<32, 48, 2>', lambda P: (P * Q * 4 + P * 8 + n * 2 * Q * 4) + (P * Q * 4 + P * 8 + n * Q * 4) + n * 3 * Q * 4,
          lambda P: 2 * P * Q * 2 * Q + 2 * P * Q * Q + 2 * n * Q * 2 * Q,
-         lambda: lib().pcgc_conv_gather_masked(_p(nbr), n, _p(t), n, 32, 32, _p(f['Wb']), 48, _p(f['mask_b']), _p(f['bb']), 0, _p(u), 48, _stream())),
+         lambda: lib().pcgc_conv_gather_masked(_p(nbr), n, _p(t), n, 32, 32, _p(f['Wb']), 48, _p(f['mask_b']), _p(f['bb']), 0, _p(u), 48, _stream(nbr))),
     )
     for name, bf, ff, call in steps:
         prof = PROFILE.want((name, n))
@@ -434,7 +448,7 @@ def irn_block_mfma64(nbr, x, f):
         check(call(), 'conv_gather_masked')
         if prof:
             e1.record()
-    check(lib().pcgc_irn_tail(_p(u), _p(x), 64, _ld(x), _p(f['W12']), _p(f['b12']), _p(out), 64, n, _stream()), 'irn_tail')
+    check(lib().pcgc_irn_tail(_p(u), _p(x), 64, _ld(x), _p(f['W12']), _p(f['b12']), _p(out), 64, n, _stream(u)), 'irn_tail')
     return out
 
 
@@ -446,7 +460,7 @@ def conv_up2(x, W, bias, relu=False):
     _f32(x, 'x'); _f32(W, 'W')
     K, Cin, Cout = W.shape
     out = torch.empty((8 * x.shape[0], Cout), dtype=torch.float32, device=x.device)
-    check(lib().pcgc_conv_up2(x.shape[0], _p(x), Cin, _ld(x), _p(W), _p(bias), int(relu), _p(out), Cout, _stream()), 'conv_up2')
+    check(lib().pcgc_conv_up2(x.shape[0], _p(x), Cin, _ld(x), _p(W), _p(bias), int(relu), _p(out), Cout, _stream(x)), 'conv_up2')
     return out
 
 
@@ -459,7 +473,7 @@ def topk_mask(logits, k):
     mask = torch.empty(n, dtype=torch.uint8, device=logits.device)
     ws_bytes = int(lib().pcgc_topk_workspace_bytes(n))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=logits.device)
-    check(lib().pcgc_topk_mask(_p(logits), ld, n, int(k), _p(mask), _p(ws), ws_bytes, _stream()), 'topk_mask')
+    check(lib().pcgc_topk_mask(_p(logits), ld, n, int(k), _p(mask), _p(ws), ws_bytes, _stream(logits)), 'topk_mask')
     return mask
 
 
@@ -468,20 +482,20 @@ def sort_zyx(coords):
     perm = torch.empty(n, dtype=torch.int32, device=coords.device)
     ws_bytes = int(lib().pcgc_sort_workspace_bytes(n))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=coords.device)
-    check(lib().pcgc_sort_zyx(_p(_i32(coords)), n, _p(perm), _p(ws), ws_bytes, _stream()), 'sort_zyx')
+    check(lib().pcgc_sort_zyx(_p(_i32(coords)), n, _p(perm), _p(ws), ws_bytes, _stream(coords)), 'sort_zyx')
     return perm
 
 
 def gather_coords(coords, perm):
     out = torch.empty_like(coords)
-    check(lib().pcgc_gather_rows_i32x4(_p(_i32(coords)), _p(perm), coords.shape[0], _p(out), _stream()), 'gather_rows_i32x4')
+    check(lib().pcgc_gather_rows_i32x4(_p(_i32(coords)), _p(perm), coords.shape[0], _p(out), _stream(coords)), 'gather_rows_i32x4')
     return out
 
 
 def gather_feats(feats, perm):
     feats = _f32(feats).contiguous()
     out = torch.empty_like(feats)
-    check(lib().pcgc_gather_rows_f32(_p(feats), feats.shape[1], _p(perm), feats.shape[0], _p(out), _stream()), 'gather_rows_f32')
+    check(lib().pcgc_gather_rows_f32(_p(feats), feats.shape[1], _p(perm), feats.shape[0], _p(out), _stream(feats)), 'gather_rows_f32')
     return out
 
 
@@ -489,21 +503,33 @@ def gather_feats(feats, perm):
 def round_minmax(feats):
     feats = _f32(feats).contiguous()
     mm = torch.empty(2, dtype=torch.float32, device=feats.device)
-    check(lib().pcgc_round_minmax(_p(feats), feats.numel(), _p(mm), _stream()), 'round_minmax')
+    check(lib().pcgc_round_minmax(_p(feats), feats.numel(), _p(mm), _stream(feats)), 'round_minmax')
     return mm
 
 
 def symbolize(feats, min_v):
     feats = _f32(feats).contiguous()
     sym = torch.empty(feats.shape, dtype=torch.int16, device=feats.device)
-    check(lib().pcgc_symbolize(_p(feats), feats.numel(), float(min_v), _p(sym), _stream()), 'symbolize')
+    check(lib().pcgc_symbolize(_p(feats), feats.numel(), float(min_v), _p(sym), _stream(feats)), 'symbolize')
     return sym
 
 
 def desymbolize(sym, min_v):
     out = torch.empty(sym.shape, dtype=torch.float32, device=sym.device)
-    check(lib().pcgc_desymbolize(_p(_dev(sym, torch.int16, 'sym')), sym.numel(), float(min_v), _p(out), _stream()), 'desymbolize')
+    check(lib().pcgc_desymbolize(_p(_dev(sym, torch.int16, 'sym')), sym.numel(), float(min_v), _p(out), _stream(sym)), 'desymbolize')
     return out
+
+
+def quantize_symbols(feats):
+    """-> (min_v, max_v as np.float32, sym int16 ndarray of feats.shape): round + symbol range + symbolise on the device,
+    ONE synchronising device->host copy of [min | max | symbols]."""
+    feats = _f32(feats).contiguous()
+    n = feats.numel()
+    buf = torch.empty(4 + n, dtype=torch.int16, device=feats.device)          # [minmax as 2 fp32 = 4 int16 | sym]
+    check(lib().pcgc_quantize_symbols(_p(feats), n, _p(buf), buf.data_ptr() + 8, _stream(feats)), 'quantize_symbols')
+    host = buf.cpu().numpy()
+    mm = host[:4].view(np.float32)
+    return np.float32(mm[0]), np.float32(mm[1]), host[4:].reshape(feats.shape)
 
 
 def compress_prepare(feats, params, C, max_L=1024):
@@ -519,7 +545,7 @@ def compress_prepare(feats, params, C, max_L=1024):
     sym = torch.empty(feats.shape, dtype=torch.int16, device=feats.device)
     info = head[2:3].view(torch.int32)
     check(lib().pcgc_compress_prepare(_p(feats), n, _p(_f32(params, 'params')), C, max_L, _p(head), _p(sym), _p(table), _p(scratch),
-                                      _p(info), _stream()), 'compress_prepare')
+                                      _p(info), _stream(feats)), 'compress_prepare')
     packed = torch.cat([head.view(torch.int16), table, sym.reshape(-1)]).cpu().numpy()        # single D2H + sync
     min_v, max_v = packed[:4].view(np.float32)[:2]
     L = int(packed[4:6].view(np.int32)[0])
@@ -534,7 +560,7 @@ def cdf_table(params, C, min_v, max_v):
     L = int(max_v - min_v) + 1
     q = torch.empty((C, L + 1), dtype=torch.int16, device=params.device)
     f = torch.empty((C, L + 1), dtype=torch.float32, device=params.device)
-    check(lib().pcgc_cdf_table(_p(_f32(params, 'params')), C, float(min_v), float(max_v), _p(q), _p(f), _stream()), 'cdf_table')
+    check(lib().pcgc_cdf_table(_p(_f32(params, 'params')), C, float(min_v), float(max_v), _p(q), _p(f), _stream(params)), 'cdf_table')
     return q, f
 
 
@@ -565,7 +591,7 @@ def d1_nn(a, b, radius=12):
     m = torch.empty(1, dtype=torch.int64, device=a.device)
     u = torch.empty(1, dtype=torch.int32, device=a.device)
     check(lib().pcgc_d1_nn(_p(_i32(a)), a.shape[0], _p(table.keys), _p(table.vals), table.cap, _p(off), off.shape[0], _p(s), _p(m),
-                           _p(u), _stream()), 'd1_nn')
+                           _p(u), _stream(a)), 'd1_nn')
     return s, m, u
 
 

@@ -136,7 +136,7 @@ def code_units(coder, units, rho=1.0, res=1024, with_d1=False, in_flight=1):
         todo.put(u)
     done, errors, lock = [], [], threading.Lock()
     ready = torch.cuda.Event()
-    ready.record()                                        # the units' tensors were produced on the caller's stream
+    ready.record(torch.cuda.current_stream(dev))          # the units' tensors were produced on the caller's stream (of their device)
 
     def worker():
         try:

@@ -132,6 +132,8 @@ class SparseTensor:
                 raise PcgcError('coordinates must be [N,4] (batch, x, y, z)')
             if coords.shape[0] != feats.shape[0]:
                 raise PcgcError('coordinates / features length mismatch')
+            if coords.shape[0] > 0:
+                ops.check_coords(coords)                   # caller-supplied coordinates: reject what the hash cannot key
             if not assume_unique and coords.shape[0] > 0:
                 coords, feats = dedup(coords, feats, int(tensor_stride))
             self.cmap = CoordMap(coords, int(tensor_stride), unique=True)

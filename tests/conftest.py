@@ -26,3 +26,12 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _oracle_threads():
+    """The oracle's OpenMP loops use the CPUs this container may really use (cgroup quota), not every advertised core."""
+    import pcgcv2_amd
+    from oracle import pcgc_oracle
+    pcgc_oracle.set_threads(pcgcv2_amd.effective_cpus())
+    yield

@@ -39,8 +39,13 @@ def pack_params(eb):
 
 def g1():
     cases = {}
-    for ci, (seed, perturb, lo, hi) in enumerate([(1234, False, -8, 9), (7, True, -20, 20), (99, True, -3, 2),
-                                                  (5, True, 0, 0), (11, True, -40, 37)]):
+    # (seed, perturb, lo, hi): alphabets from 1 to 300 symbols — torch's CPU bmm switches implementation with the size
+    # (a plain loop below ~44 symbols, the BLAS batched GEMM above), and vectorised / scalar-tail transcendental paths
+    # alternate with the element count, so the cases cover small, medium and large L with odd and even lengths
+    G1_CASES = [(1234, False, -8, 9), (7, True, -20, 20), (99, True, -3, 2), (5, True, 0, 0), (11, True, -40, 37),
+                (21, True, -75, 74), (22, True, -150, 149), (23, True, -128, 127), (24, True, -17, 25), (25, True, -21, 22),
+                (26, True, -22, 22), (27, True, -31, 32), (28, True, -100, 56), (29, False, -60, 61), (30, True, -7, 7)]
+    for ci, (seed, perturb, lo, hi) in enumerate(G1_CASES):
         np.random.seed(seed); torch.manual_seed(seed)
         eb = ref_em.EntropyBottleneck(8)
         if perturb:
@@ -64,7 +69,9 @@ def g1():
             with open(os.path.join(OUT, 'state_dict_keys.txt'), 'w') as f:
                 for k, v in eb.state_dict().items():
                     f.write(f'{k} {list(v.shape)}\n')
-    cases['n_cases'] = np.array(5)
+    cases['n_cases'] = np.array(len(G1_CASES))
+    cases['cpu_capability'] = np.array(torch.backends.cpu.get_cpu_capability())
+    cases['torch_version'] = np.array(torch.__version__)
     np.savez_compressed(os.path.join(OUT, 'entropy_tables.npz'), **cases)
 
 
@@ -141,5 +148,7 @@ def g4():
 
 
 if __name__ == '__main__':
-    g1(); g2(); g3(); g4()
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4']
+    for name in which:
+        {'g1': g1, 'g2': g2, 'g3': g3, 'g4': g4}[name]()
     print('golden fixtures written to', OUT)

@@ -240,3 +240,89 @@ def test_native_ply_reader_matches_reference_rule(tmp_path):
     np.testing.assert_array_equal(read_ply_ascii_geo(str(p)), big)
     with pytest.raises(FileNotFoundError):
         read_ply_ascii_geo(str(tmp_path / 'missing.ply'))
+
+
+# ------------------------------------------------------------------------------------------------ tmc3 subprocess protocol
+_TMC3_STUB = r'''#!/usr/bin/env python3
+"""Stand-in for the MPEG tmc3 binary in tests: same command line (gpcc.py:11-21,30-36), `--mode=0` stores the PLY text behind a
+magic, `--mode=1` writes it back.  It exercises the subprocess protocol + temp-PLY handling, not G-PCC itself."""
+import sys
+args = dict(a[2:].split('=', 1) for a in sys.argv[1:] if a.startswith('--') and '=' in a)
+with open(args['compressedStreamPath'] + '.argv', 'a') as log:
+    log.write(' '.join(sys.argv[1:]) + '\n')
+if args['mode'] == '0':
+    ply = open(args['uncompressedDataPath'], 'rb').read()
+    assert ply.startswith(b'ply\nformat ascii 1.0\n'), 'encoder input must be the ASCII PLY the reference writes'
+    open(args['compressedStreamPath'], 'wb').write(b'STUBGPCC' + ply)
+elif args['mode'] == '1':
+    blob = open(args['compressedStreamPath'], 'rb').read()
+    assert blob[:8] == b'STUBGPCC'
+    assert args.get('outputBinaryPly') == '0'
+    open(args['reconstructedDataPath'], 'wb').write(blob[8:])
+else:
+    sys.exit(3)
+'''
+
+
+@pytest.fixture
+def tmc3_stub(tmp_path, monkeypatch):
+    exe = tmp_path / 'tmc3'
+    exe.write_text(_TMC3_STUB)
+    exe.chmod(0o755)
+    monkeypatch.setenv('PCGC_TMC3', str(exe))
+    return exe
+
+
+def test_coordinate_coder_runs_the_tmc3_protocol(tmc3_stub, tmp_path):
+    """CoordinateCoder with an installed `tmc3` (coder.py:16-36 + gpcc.py:6-41): temp ASCII PLY -> subprocess with the
+    reference's flags -> `_C.bin`; decode: subprocess -> temp PLY -> read_ply_ascii_geo; temp files removed."""
+    from pcgcv2_amd.coder import CoordinateCoder
+    from pcgcv2_amd import gpcc
+    assert gpcc.tmc3_path() == str(tmc3_stub)
+    rng = np.random.default_rng(0)
+    pts = np.unique(rng.integers(0, 128, size=(500, 3)), axis=0).astype(np.int32)
+    out = tmp_path / 'out'
+    out.mkdir()
+    cc = CoordinateCoder(str(out / 'frame'))
+    cc.encode(torch.from_numpy(pts), postfix='_r3')                 # the reference passes a CPU torch tensor (coder.py:89)
+    assert (out / 'frame_r3_C.bin').read_bytes()[:8] == b'STUBGPCC'
+    assert not gpcc.is_native_stream(str(out / 'frame_r3_C.bin'))
+    back = cc.decode(postfix='_r3')
+    np.testing.assert_array_equal(back, pts)
+    assert back.dtype.kind == 'i'
+    calls = (out / 'frame_r3_C.bin.argv').read_text().splitlines()
+    assert len(calls) == 2
+    for flag in ('--mode=0', '--positionQuantizationScale=1', '--trisoupNodeSizeLog2=0', '--neighbourAvailBoundaryLog2=8',
+                 '--intra_pred_max_node_size_log2=6', '--inferredDirectCodingMode=0', '--maxNumQtBtBeforeOt=4'):
+        assert flag in calls[0].split(), flag                        # gpcc.py:11-19
+    assert '--mode=1' in calls[1].split() and '--outputBinaryPly=0' in calls[1].split()      # gpcc.py:30-35
+    assert sorted(p.name for p in out.iterdir()) == ['frame_r3_C.bin', 'frame_r3_C.bin.argv']   # no temp PLY left behind
+
+
+def test_coordinate_coder_tmc3_concurrent_calls_do_not_share_temp_files(tmc3_stub, tmp_path):
+    """Several frames coded concurrently with the same prefix (serving mode): each call owns its temp PLY."""
+    from concurrent.futures import ThreadPoolExecutor
+    from pcgcv2_amd.coder import CoordinateCoder
+    rng = np.random.default_rng(1)
+    clouds = [np.unique(rng.integers(0, 64, size=(300 + 50 * i, 3)), axis=0).astype(np.int32) for i in range(8)]
+
+    def one(i):
+        cc = CoordinateCoder(str(tmp_path / 'f'))                    # same prefix for every worker, as shard.code_units does
+        for _ in range(3):
+            cc.encode(clouds[i], postfix=f'_u{i}')
+            np.testing.assert_array_equal(cc.decode(postfix=f'_u{i}'), clouds[i])
+        return True
+    with ThreadPoolExecutor(8) as ex:
+        assert all(ex.map(one, range(8)))
+    assert not [p for p in tmp_path.iterdir() if p.suffix == '.ply']
+
+
+def test_tmc3_failure_is_reported(tmp_path, monkeypatch):
+    exe = tmp_path / 'tmc3'
+    exe.write_text('#!/bin/sh\necho boom >&2\nexit 7\n')
+    exe.chmod(0o755)
+    monkeypatch.setenv('PCGC_TMC3', str(exe))
+    from pcgcv2_amd.coder import CoordinateCoder
+    with pytest.raises(RuntimeError, match='tmc3 encode failed'):
+        CoordinateCoder(str(tmp_path / 'x')).encode(np.zeros((3, 3), np.int32))
+    assert not [p for p in tmp_path.iterdir() if p.suffix == '.ply']
