@@ -143,6 +143,16 @@ int pcgc_irn_pass(const int32_t* nbr, int64_t n, const float* x, int C, int x_ld
 int pcgc_conv_up2(int64_t n_in, const float* in, int Cin, int in_ld, const float* W /*[8,Cin,Cout]*/, const float* bias,
                   int relu, float* out /*[dev 8n,Cout]*/, int Cout, void* stream);
 
+/* ---- k3 convolution on a CHILDREN level (the output level of a generative transpose: row 8p+j = child j of parent p) through
+ *      the PARENT level's kernel map: each neighbour row is gathered once per 16-parent tile and feeds every child that
+ *      reaches it (csrc/child.hip).  Replaces MinkowskiConvolution(k=3) at the decoder call sites autoencoder.py:162-168,
+ *      189-195,216-222 (conv0/1/2 after up0/1/2).  `table` = the layer's `kernel` re-laid-out as MFMA B fragments
+ *      [k][Cout/16][Cin/16][lane 64][4] (pcgcv2_amd/ops.py:child_conv_table).  Same canonical arithmetic. ---- */
+int pcgc_conv_child(const int32_t* parent_nbr /*[dev 27,n_parent]*/, int64_t n_parent, const float* in /*[dev 8 n_parent rows]*/,
+                    int Cin, int in_ld, const float* table /*[dev]*/, int64_t table_bytes,
+                    const float* bias, const float* residual, int res_ld, int relu, float* out, int Cout, int out_ld, void* stream);
+int pcgc_set_child_tuning(int waves_per_group, int ring_depth);       /* A/B switches; 0 = defaults */
+
 /* ---- top-k pruning mask: istopk (data_utils.py:77-89).  mask[i]=1 for the k largest logits;
  *      ties -> lower row index; -0.0 == +0.0. ---- */
 size_t pcgc_topk_workspace_bytes(int64_t n);

@@ -7,6 +7,7 @@
 // Output-stationary => deterministic, no atomics, and the k-ascending order survives any tiling.
 #include <cstdlib>
 #include "pcgc_common.h"
+#include "mfma_util.h"
 
 // ----------------------------------------------------------------------------------------------------------------
 // v0 generic kernel: one thread per output row, COUT accumulators in VGPRs, weights through wave-uniform (scalar)
@@ -88,19 +89,6 @@ static void launch_valu(const int32_t* nbr, int K, int64_t n_out, const float* i
 //     (measured: the double-buffered variant with staged maps needed 15-23 KiB per wave and was DMA-latency bound).
 // Numerics: identical fmaf chain (k ascending, ci ascending) — only the data path differs.
 // ----------------------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_void_ptr;
-
-// XCD-aware tile order: workgroup b is observed to run on XCD b % 8 (each XCD has its own 4 MiB L2).  Remap so every XCD
-// walks a contiguous slab of tiles: neighbouring tiles gather overlapping rows, which then hit the same L2.  Bijective
-// for any grid size; placement only affects speed, never results.
-__device__ static inline unsigned xcd_tile(unsigned b, unsigned nb) {
-    const unsigned q = nb >> 3, r = nb & 7, x = b & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-}
-
-template <int N>
-__device__ static inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
 template <int CH, int ROWS = 64>
 struct RowGather {                                   // one wave, ROWS (64/32/16) rows, CH 16-byte chunks per row
     static constexpr int RPI = 64 / CH;              // rows fetched by one DMA instruction
@@ -265,18 +253,6 @@ static bool dispatch_dma_cout(int Cout, const int32_t* nbr, int K, int64_t n_out
 //   * 16*NT MFMAs per sub-step, j outermost so consecutive MFMAs hit different accumulators (40-cycle dependent
 //     latency vs 32-cycle issue); per accumulator the channel order stays ascending => bitwise the canonical fmaf chain.
 // ----------------------------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ static inline void lane_transpose4(float4& v) {
-    // in: lane-quarter q holds components (c = 0..3) = element [q][c]; out: component c of quarter q = element [c][q]
-    unsigned x = __float_as_uint(v.x), y = __float_as_uint(v.y), z = __float_as_uint(v.z), w = __float_as_uint(v.w);
-    auto r0 = __builtin_amdgcn_permlane32_swap(x, z, false, false); x = r0[0]; z = r0[1];   // quarter bit 1 <-> component bit 1
-    auto r1 = __builtin_amdgcn_permlane32_swap(y, w, false, false); y = r1[0]; w = r1[1];
-    auto r2 = __builtin_amdgcn_permlane16_swap(x, y, false, false); x = r2[0]; y = r2[1];   // quarter bit 0 <-> component bit 0
-    auto r3 = __builtin_amdgcn_permlane16_swap(z, w, false, false); z = r3[0]; w = r3[1];
-    v = make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w));
-}
-
 template <int CIN, int NT>
 __global__ void __launch_bounds__(256)
 k_conv_gather_mfma(const int32_t* __restrict__ nbr, int K, int64_t n_out, const float* __restrict__ in, int64_t n_in,
@@ -517,19 +493,6 @@ static void launch_mfma_wlds(const int32_t* nbr, int K, int64_t n_out, const flo
 // one chunk index over 16 consecutive rows then touches 16 distinct bank groups.  MFMA operand layouts, lane transposes,
 // tile masks and the accumulation order are those of v2b: bit-identical results.
 // ----------------------------------------------------------------------------------------------------------------
-__device__ static inline f32x4 lds_ld128_raw(const float4* p) {
-    f32x4 v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)(lds_void_ptr)p) : "memory");
-    return v;
-}
-template <int BYTE_OFF>
-__device__ static inline float lds_ld32_raw(const float* p) {
-    float v;
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(uintptr_t)(lds_void_ptr)p), "n"(BYTE_OFF) : "memory");
-    return v;
-}
-__device__ static inline void lds_tie(f32x4& v) { asm volatile("" : "+v"(v)); }
-__device__ static inline void lds_tie(float& v) { asm volatile("" : "+v"(v)); }
 // b[j][n] = wb[(4j) * COUT + 16n] for one 16-channel block, compile-time LDS offsets
 template <int COUT, int NT, int J = 0, int N = 0>
 __device__ static inline void pipe_load_b(const float* wb, float (&b)[4][NT]) {

@@ -33,7 +33,15 @@ class MinkowskiConvolution(_ConvBase):
 
     def forward(self, x, relu=False, out=None, residual=None):
         k, s = self.kernel_size, self.stride
-        if k == 3 and s == 1:
+        if k == 3 and s == 1 and ops.child_conv_eligible(x, self.in_channels, self.out_channels):
+            # children level (output of a generative transpose): gather through the PARENT level's map, csrc/child.hip
+            stamp = (self.kernel.data_ptr(), self.kernel._version)
+            if getattr(self, '_child_stamp', None) != stamp:
+                self._child_table, self._child_stamp = ops.child_conv_table(self.kernel), stamp
+            y = ops.conv_child(x.cmap.origin[1].k3, x.F, self._child_table, self.bias, self.out_channels, out=out,
+                               residual=residual, relu=relu)
+            return SparseTensor(y, coordinate_map=x.cmap)
+        elif k == 3 and s == 1:
             cmap, nbr = x.cmap, x.cmap.k3
         elif k == 1 and s == 1:
             cmap, nbr = x.cmap, None

@@ -456,6 +456,67 @@ def irn_eligible(x):
     return FUSE_IRN and x.shape[1] in (16, 32, 64) and x.shape[0] * x.shape[1] * 4 < 0xFFFFFFF0
 
 
+# ------------------------------------------------------------------------------------------------ children-level convs
+CHILD_MFMA = True         # k3 convs on children levels go through the parent map (csrc/child.hip); A/B switch for tests
+
+
+def set_child_tuning(waves=0, depth=0):
+    check(lib().pcgc_set_child_tuning(int(waves), int(depth)), 'set_child_tuning')
+
+
+def child_conv_eligible(x, cin, cout):
+    """k3 conv of a SparseTensor living on a children level, in a shape the parent-map MFMA kernels are built for."""
+    org = x.cmap.origin
+    return (CHILD_MFMA and org is not None and org[0] == 'children' and (cin, cout) in ((16, 16), (32, 32))
+            and x.F.shape[0] >= 8192 and x.F.shape[0] * x.F.stride(0) * 4 < 0xFFFFFFF0)
+
+
+def _halo_cells():
+    """The 64 cells of a parent's 4x4x4 halo in ascending (cz, cy, cx) order -> list of (kp, j', reach) where kp = index of the
+    neighbour parent in the PARENT level's k3 map, j' = which of its children the cell is, and reach = [(j, k)]: the children j
+    of the centre parent whose 3x3x3 window contains the cell, with the kernel offset k they see it through."""
+    P1 = (0, 1, 1, 2)                  # floor(c / 2) + 1 for c = -1, 0, 1, 2
+    B = (1, 0, 1, 0)                   # c & 1
+    cells = []
+    for cz in range(4):
+        for cy in range(4):
+            for cx in range(4):
+                kp = P1[cz] * 9 + P1[cy] * 3 + P1[cx]
+                jc = B[cx] + 2 * B[cy] + 4 * B[cz]
+                reach = []
+                for j in range(8):
+                    kx, ky, kz = cx - (j & 1), cy - ((j >> 1) & 1), cz - (j >> 2)          # = (c - j) + 1 per axis
+                    if 0 <= kx <= 2 and 0 <= ky <= 2 and 0 <= kz <= 2:
+                        reach.append((j, kz * 9 + ky * 3 + kx))
+                cells.append((kp, jc, reach))
+    assert sum(len(r) for _, _, r in cells) == 216
+    return cells
+
+
+def child_conv_table(W):
+    """B-fragment table of pcgc_conv_child for a plain k3 conv `kernel` [27, Cin, Cout]:
+    table[k][n][cb][lane][jj] = W[k][16 cb + 4 jj + (lane >> 4)][16 n + (lane & 15)]   (one lane-linear 1 KB fragment per
+    (offset, column tile, 16-channel block): a lane's four K-step values are contiguous -> one conflict-free ds_read_b128)."""
+    K, Cin, Cout = W.shape
+    NB, NT = Cin // 16, Cout // 16
+    return W.detach().reshape(27, NB, 4, 4, NT, 16).permute(0, 4, 1, 3, 5, 2).contiguous().reshape(-1)      # [k][n][cb][mq][mi][jj]
+
+
+def conv_child(parent_nbr, x, table, bias, Cout, out=None, residual=None, relu=False):
+    """k3 conv on the children level of `parent_nbr`'s level: x has 8 * n_parent rows."""
+    _f32(x, 'x')
+    n_p = parent_nbr.shape[1]
+    if x.shape[0] != 8 * n_p:
+        raise PcgcError('conv_child: feature rows must be 8 x the parent level')
+    Cin = x.shape[1]
+    if out is None:
+        out = torch.empty((8 * n_p, Cout), dtype=torch.float32, device=x.device)
+    res_p, res_ld = (None, 0) if residual is None else (_p(_f32(residual)), _ld(residual))
+    check(lib().pcgc_conv_child(_p(parent_nbr), n_p, _p(x), Cin, _ld(x), _p(table), table.numel() * 4, _p(bias), res_p, res_ld,
+                                int(relu), _p(out), Cout, _ld(out), _stream(x)), 'conv_child')
+    return out
+
+
 def conv_up2(x, W, bias, relu=False):
     _f32(x, 'x'); _f32(W, 'W')
     K, Cin, Cout = W.shape

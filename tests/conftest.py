@@ -35,3 +35,17 @@ def _oracle_threads():
     from oracle import pcgc_oracle
     pcgc_oracle.set_threads(pcgcv2_amd.effective_cpus())
     yield
+
+
+def same_cpu_kind_as_golden(g):
+    """Golden G1 holds what the reference (torch on the CPU) computed on the authoring host.  torch-CPU is not bit-reproducible
+    across CPU kinds — its BLAS picks code paths by vendor / ISA level and the results of a K=3 dot product then differ in the
+    last bit (measured: on the GPU box's EPYC 9575F, 7 of 10 840 uint16 table entries differ from the Xeon-generated golden; the
+    reference itself would produce those other tables there).  Bit-equality with the golden is therefore asserted on hosts of
+    the golden's kind; elsewhere the tests assert equality with the oracle restatement and <= 1 count from the golden."""
+    import torch
+    try:
+        vendor = [l.split(':')[1].strip() for l in open('/proc/cpuinfo') if l.startswith('vendor_id')][0]
+    except (OSError, IndexError):
+        vendor = '?'
+    return str(g['cpu_capability']) == torch.backends.cpu.get_cpu_capability() and str(g['cpu_vendor']) == vendor

@@ -72,6 +72,7 @@ def g1():
     cases['n_cases'] = np.array(len(G1_CASES))
     cases['cpu_capability'] = np.array(torch.backends.cpu.get_cpu_capability())
     cases['torch_version'] = np.array(torch.__version__)
+    cases['cpu_vendor'] = np.array([l.split(':')[1].strip() for l in open('/proc/cpuinfo') if l.startswith('vendor_id')][0])
     np.savez_compressed(os.path.join(OUT, 'entropy_tables.npz'), **cases)
 
 

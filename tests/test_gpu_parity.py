@@ -279,9 +279,9 @@ def test_codec_table_equals_reference_golden(golden_dir):
     """The table the codec actually codes with (EntropyBottleneck.host_table, default mode) on a model living on the GPU:
     uint16-exact against the reference's own tables (golden G1) — zero mismatching entries."""
     from pcgcv2_amd.entropy_model import EntropyBottleneck
+    from conftest import same_cpu_kind_as_golden
     g = np.load(os.path.join(golden_dir, 'entropy_tables.npz'))
-    if str(g['cpu_capability']) != torch.backends.cpu.get_cpu_capability():
-        pytest.skip('host CPU capability differs from the golden host: torch-CPU picks other kernels, as it would for the reference')
+    exact = same_cpu_kind_as_golden(g)            # see conftest: torch-CPU itself is host-kind dependent in the last bit
     eb = EntropyBottleneck(8).to(DEV)
     assert eb.table_mode == 'reference'
     mismatches = entries = 0
@@ -294,7 +294,15 @@ def test_codec_table_equals_reference_golden(golden_dir):
         q = eb.host_table(lo, hi, DEV)
         want = orc.cdf_u16(g[f'c{ci}_cdf'])
         mismatches += int((q != want).sum()); entries += q.size
-    assert entries > 8000 and mismatches == 0
+        np.testing.assert_array_equal(q, orc.cdf_table_ref32(g[f'c{ci}_params'], lo, hi))       # oracle restatement, this host
+        d = (q.astype(np.int64) - want.astype(np.int64)) % 65536
+        assert np.all((d <= 1) | (d >= 65535))
+    assert entries > 8000
+    if exact:
+        assert mismatches == 0
+    else:
+        print(f'host kind differs from the golden host: {mismatches} of {entries} uint16 entries differ (all by one count)')
+        assert mismatches < entries // 500
 
 
 def test_table_modes_round_trip_and_differ_only_in_table():
@@ -634,3 +642,45 @@ def test_coder_through_tmc3_subprocess_protocol(sd, sd_np, tmp_path, monkeypatch
     out = coder.decode()
     np.testing.assert_array_equal(out.C.cpu().numpy(), orc.decode(sd_np, ref['coords8'], ref['F'], ref['H'], ref['num_points']))
     assert not [p for p in out_dir.iterdir() if p.suffix == '.ply']
+
+
+# ------------------------------------------------------------------------------------------------ children-level kernels
+def _children_level(name, prune=None):
+    """(parent CoordMap, children CoordMap, children coords ndarray) with the parent = stride-2 level of a synthetic cloud,
+    optionally pruned first (the decoder's parents are pruned levels: arbitrary subsets in arbitrary order of gaps)."""
+    c4 = _coords(name)
+    lvl = CoordMap(_t(c4), 1, unique=True).down()[0]
+    if prune is not None:
+        rng = np.random.default_rng(prune)
+        m = (rng.random(len(lvl)) < 0.6).astype(np.uint8)
+        mask = _t(m)
+        prefix, _ = ops.mask_scan(mask)
+        lvl = CoordMap(ops.compact_coords(lvl.C, mask, prefix, int(m.sum())), 2, unique=True, origin=('pruned', lvl, mask, prefix))
+    kids = lvl.up()
+    return lvl, kids, kids.C.cpu().numpy()
+
+
+@pytest.mark.parametrize('tuning', [(0, 0), (0, 2), (4, 0), (16, 1)], ids=['default', 'ring2', 'waves4', 'waves16_ring1'])
+@pytest.mark.parametrize('cin,cout', [(16, 16), (32, 32)])
+@pytest.mark.parametrize('name,prune', [('shell7', None), ('shell8', 7), ('shell6', 1)])
+def test_conv_child_bit_exact(name, prune, cin, cout, tuning):
+    """pcgc_conv_child (parent-map halo gather + fp32 MFMA) == the oracle's per-row gather conv on the children level's own map."""
+    parent, kids, kc = _children_level(name, prune)
+    n = len(kc)
+    rng = np.random.default_rng(cin + n)
+    x = rng.standard_normal((n, cin)).astype(np.float32)
+    W = (rng.standard_normal((27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    b = rng.standard_normal((1, cout)).astype(np.float32)
+    want = orc.conv_gather(orc.kmap_k3(kc, 1), x, W, b)
+    Wt = _t(W)
+    ops.set_child_tuning(*tuning)
+    try:
+        got = ops.conv_child(parent.k3, _t(x), ops.child_conv_table(Wt), _t(b), cout)
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        res = rng.standard_normal((n, 2 * cout)).astype(np.float32)
+        buf = torch.zeros((n, 2 * cout), device=DEV)
+        ops.conv_child(parent.k3, _t(x), ops.child_conv_table(Wt), _t(b), cout, out=buf[:, cout:], residual=_t(res)[:, cout:], relu=True)
+        np.testing.assert_array_equal(buf[:, cout:].cpu().numpy(), np.maximum(want + res[:, cout:], np.float32(0)))
+        assert not buf[:, :cout].any()
+    finally:
+        ops.set_child_tuning(0, 0)

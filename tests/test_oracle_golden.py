@@ -9,12 +9,7 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name))
 
 
-def _same_cpu_kind(g):
-    """Golden G1 holds what torch-CPU computed on the authoring host.  torch picks its CPU kernels (SLEEF vector width, BLAS
-    code path) by ISA level, so bit-equality with the golden is only promised on a host of the same capability level; on
-    another level the reference itself would produce different tables there."""
-    import torch
-    return str(g['cpu_capability']) == torch.backends.cpu.get_cpu_capability()
+from conftest import same_cpu_kind_as_golden as _same_cpu_kind
 
 
 def test_g1_entropy_tables_bit_exact(golden_dir):
