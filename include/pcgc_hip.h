@@ -82,6 +82,10 @@ int pcgc_kmap_k3_children(const int32_t* parent_nbr, int64_t n_parent, int32_t* 
 /* pruned level: surviving rows orig[r] of a candidate level, neighbours renumbered through mask/prefix */
 int pcgc_kmap_k3_prune(const int32_t* cand_nbr /*[27,n_cand]*/, int64_t n_cand, const uint8_t* mask, const int32_t* prefix,
                        const int32_t* orig /*[n_out]*/, int64_t n_out, int32_t* nbr /*[dev 27,n_out]*/, void* stream);
+/* the same pruned-level map derived straight from the PARENT level's map when the candidate level is a children level
+ * (mask / prefix / orig index candidate rows 8 i + j): the candidates' own [27][8 n_parent] map is never materialised. */
+int pcgc_kmap_k3_prune_parent(const int32_t* parent_nbr /*[dev 27,n_parent]*/, int64_t n_parent, const uint8_t* mask,
+                              const int32_t* prefix, const int32_t* orig, int64_t n_out, int32_t* nbr /*[dev 27,n_out]*/, void* stream);
 /* strided pyramid (encoder): fine level from the coarse level's map + the down map + each fine row's parent row */
 int pcgc_kmap_k3_from_coarse(const int32_t* fine /*[n_fine,4]*/, int64_t n_fine, int32_t stride_fine,
                              const int32_t* parent_of /*[n_fine]*/, const int32_t* coarse_nbr /*[27,n_coarse]*/,
@@ -151,7 +155,16 @@ int pcgc_conv_up2(int64_t n_in, const float* in, int Cin, int in_ld, const float
 int pcgc_conv_child(const int32_t* parent_nbr /*[dev 27,n_parent]*/, int64_t n_parent, const float* in /*[dev 8 n_parent rows]*/,
                     int Cin, int in_ld, const float* table /*[dev]*/, int64_t table_bytes,
                     const float* bias, const float* residual, int res_ld, int relu, float* out, int Cout, int out_ld, void* stream);
+/* Cout == 1 (the classification heads conv0/1/2_cls, autoencoder.py:169-175,196-202,223-229) is served by the same entry with a
+ * 64-fragment table (ops.child_cls_table): the 8 children are the 8 used columns of one accumulator tile. */
 int pcgc_set_child_tuning(int waves_per_group, int ring_depth);       /* A/B switches; 0 = defaults */
+/* Fused InceptionResNet (autoencoder.py:52-57) on a children level, C = 16 or 32, as two parent-map passes:
+ *   pass 1 (A): in = x [8 n_parent, C]      -> out = t [8 n_parent, C/2] = [relu(conv0_0 x + b0) | relu(conv1_0 x + b1)]
+ *   pass 2 (B): in = t [8 n_parent, C/2]    -> out [.., C] = [conv0_1(t[:, :Q]) + b0 | conv1_2(relu(conv1_1(t[:, Q:]) + b1)) + b2] + x
+ * The narrow layers pack (child, output channel) pairs into the MFMA N dimension; tables: ops.child_irn_tables. */
+int pcgc_irn_child_pass(const int32_t* parent_nbr, int64_t n_parent, int C, int pass, const float* in, int in_ld,
+                        const float* table, int64_t table_bytes, const float* b0, const float* b1, const float* b2,
+                        const float* x, int x_ld, float* out, int out_ld, void* stream);
 
 /* ---- top-k pruning mask: istopk (data_utils.py:77-89).  mask[i]=1 for the k largest logits;
  *      ties -> lower row index; -0.0 == +0.0. ---- */

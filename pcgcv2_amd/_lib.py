@@ -29,6 +29,7 @@ SIGNATURES = {
     'pcgc_kmap_down': (ci, [vp, i64, i32, vp, vp, i64, vp, vp]),
     'pcgc_kmap_k3_children': (ci, [vp, i64, vp, vp]),
     'pcgc_kmap_k3_prune': (ci, [vp, i64, vp, vp, vp, i64, vp, vp]),
+    'pcgc_kmap_k3_prune_parent': (ci, [vp, i64, vp, vp, vp, i64, vp, vp]),
     'pcgc_kmap_k3_from_coarse': (ci, [vp, i64, i32, vp, vp, vp, i64, vp, vp]),
     'pcgc_down_maps': (ci, [vp, vp, vp, i64, i32, i64, vp, vp, vp]),
     'pcgc_down_prepare': (ci, [vp, i64, i32, vp, vp, vp, i64, vp, vp, vp, vp, vp, sz, vp]),
@@ -46,6 +47,7 @@ SIGNATURES = {
     'pcgc_irn_pass': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, ci, ci, vp]),
     'pcgc_conv_child': (ci, [vp, i64, vp, ci, ci, vp, i64, vp, vp, ci, ci, vp, ci, ci, vp]),
     'pcgc_set_child_tuning': (ci, [ci, ci]),
+    'pcgc_irn_child_pass': (ci, [vp, i64, ci, ci, vp, ci, vp, i64, vp, vp, vp, vp, ci, vp, ci, vp]),
     'pcgc_conv_up2': (ci, [i64, vp, ci, ci, vp, vp, ci, vp, ci, vp]),
     'pcgc_topk_workspace_bytes': (sz, [i64]),
     'pcgc_topk_mask': (ci, [vp, ci, i64, i64, vp, vp, sz, vp]),

@@ -27,6 +27,12 @@ class InceptionResNet(torch.nn.Module):
         c = x.F.shape[1]
         if ops.irn_eligible(x.F):                           # two fused gather passes
             params = [p for m in (self.conv0_0, self.conv0_1, self.conv1_0, self.conv1_1, self.conv1_2) for p in (m.kernel, m.bias)]
+            if ops.irn_child_eligible(x):
+                # children level (decoder): both passes through the PARENT level's map, packed-N fp32 MFMA (csrc/child_kernels.h)
+                stamp = tuple((p.data_ptr(), p._version) for p in params)
+                if getattr(self, '_child_stamp', None) != stamp:
+                    self._child_tables, self._child_stamp = ops.child_irn_tables(params), stamp
+                return SparseTensor(ops.irn_block_child(x.cmap.origin[1].k3, x.F, params, self._child_tables), coordinate_map=x.cmap)
             if c == 64 and ops.MFMA_IRN and x.F.shape[0] >= 30000:
                 # block-sparse MFMA path; the fused weights are rebuilt whenever a parameter tensor was replaced or modified
                 stamp = tuple((p.data_ptr(), p._version) for p in params)

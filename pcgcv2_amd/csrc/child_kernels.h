@@ -1,0 +1,614 @@
+// Sparse k3 convolutions on CHILDREN levels (the decoder's levels: every row 8p+j is child j of parent p, produced by
+// MinkowskiGenerativeConvolutionTranspose, autoencoder.py:155-161,182-188,209-215) as fp32-MFMA kernels that gather each
+// input row ONCE per parent tile instead of once per output row.
+//
+// Geometry.  The 8 children of a parent occupy a 2x2x2 block; their 3x3x3 neighbourhoods together cover the 4x4x4 "halo" of
+// cells c = (cx,cy,cz), c* in {-1,0,1,2} (child units, relative to the parent's origin).  Cell c belongs to the neighbour
+// parent at offset P = floor(c/2) in {-1,0,0,1} per axis and is its child j' = c & 1 per axis.  Child j reaches cell c iff
+// |c - j| <= 1 on every axis, through kernel offset k = (c-j+1) (x fastest).  So per parent: 64 gathered rows feed
+// 216 = 8 x 27 (row, offset) pairs — 3.4x fewer gathered rows than the per-output-row gather kernels of conv.hip — and the
+// kernel map needed is the PARENT level's [27][n_p] (8x smaller than the children level's own map, which these kernels never
+// read).
+//
+// One wave = 16 parents (one MFMA M-tile; 128 output rows).  For each cell, in ascending (cz,cy,cx) order:
+//   A operand  = rows 8*pnbr[kp(c)][p] + j'(c) of the 16 parents, fetched by one `buffer_load_dwordx4 ... lds` per 16-channel
+//                block (4 adjacent lanes per 64-byte row segment; absent neighbours use an out-of-range offset and land as
+//                zeros) into a per-wave ring of D cells, so D-1 cells of gather are in flight behind the MFMAs;
+//   B operands = one lane-linear 1 KB fragment per (cell, accumulator tile), read from an LDS-resident table with one
+//                conflict-free ds_read_b128 per lane (4 K-steps at once);
+//   MFMA       = v_mfma_f32_16x16x4_f32 into the accumulator tiles the cell reaches.
+// The 64 cells are unrolled at compile time (which tiles a cell feeds is static geometry: no branches around the MFMAs);
+// WHERE a (cell, tile) pair's B fragment sits in the table is data (the "plan": one row of byte offsets per cell, read by
+// scalar loads), so one kernel serves every layer shape: plain convs (tile = (child j, 16 output columns), fragment = the
+// offset's weight slice) and the narrow layers whose N dimension packs (child, output channel) pairs with zero columns
+// where a child does not reach the cell (host-built tables, pcgcv2_amd/ops.py).
+//
+// Numerics: per output element the products arrive in ascending cell order = ascending kernel offset k, and inside a cell in
+// ascending input channel (16-channel block, K-step, K index) — the canonical fmaf chain of DESIGN.md §3.  A zero B column
+// or an absent (zero) row adds fma(x, 0, acc) = acc.  Bit-identical to the per-row kernels and the oracle (tests).
+#pragma once
+#include "pcgc_common.h"
+#include "mfma_util.h"
+#include <type_traits>
+
+#ifdef PCGC_CHILD_TIMING
+// per-phase shader-clock cycles summed over waves: [0] tile prologue (neighbour-parent loads + drain), [1] gather/MFMA loop,
+// [3] tiles, [4] whole tile iterations (prologue + loop + epilogue); experiments only (tools/child_timing.py)
+static __device__ unsigned long long g_child_dbg[8];
+#define CHILD_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define CHILD_TADD(slot, a, b) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_child_dbg[slot], (b) - (a)); } while (0)
+#else
+#define CHILD_T(var)
+#define CHILD_TADD(slot, a, b)
+#endif
+
+namespace {
+
+struct ChildEpi {
+    const float* bias;      // [cols]
+    const float* res;       // residual rows (children level) or nullptr
+    int res_ld;
+    int relu;
+    float* out;             // children-level rows [8 n_p][out_ld]
+    int out_ld;
+    int nt;                 // EPI 0: column tiles per child
+};
+
+// ---- static halo geometry (cell index c = (cz'*4 + cy')*4 + cx', c' = c + 1 in 0..3) -------------------------------------
+constexpr int halo_p1(int c) { return c == 0 ? 0 : (c == 3 ? 2 : 1); }           // neighbour-parent offset + 1
+constexpr int halo_bit(int c) { return (c == 0 || c == 2) ? 1 : 0; }              // which child of that parent (per axis)
+constexpr int cell_kp(int c) { return halo_p1(c >> 4) * 9 + halo_p1((c >> 2) & 3) * 3 + halo_p1(c & 3); }
+constexpr int cell_child(int c) { return halo_bit(c & 3) + 2 * halo_bit((c >> 2) & 3) + 4 * halo_bit(c >> 4); }
+constexpr bool axis_reach(int c, int jb) { return c - jb >= 0 && c - jb <= 2; }
+constexpr unsigned cell_reach(int c) {                                             // bit j = child j's window contains the cell
+    unsigned m = 0;
+    for (int j = 0; j < 8; ++j)
+        if (axis_reach(c & 3, j & 1) && axis_reach((c >> 2) & 3, (j >> 1) & 1) && axis_reach(c >> 4, j >> 2)) m |= 1u << j;
+    return m;
+}
+constexpr int cell_k(int c, int j) {                                               // kernel offset through which child j sees cell c
+    return ((c >> 4) - (j >> 2)) * 9 + (((c >> 2) & 3) - ((j >> 1) & 1)) * 3 + ((c & 3) - (j & 1));
+}
+constexpr int cz_of(int c) { return c >> 4; }
+constexpr int cy_of(int c) { return (c >> 2) & 3; }
+constexpr int cx_of(int c) { return c & 3; }
+constexpr bool in02(int v) { return v >= 0 && v <= 2; }
+
+// ---- layer variants.  A variant says: how wide the gathered rows are (NB 16-channel blocks, ROWCHUNKS 16-byte chunks present
+//      per block), how many accumulator tiles there are (T), how many K-steps of a block a tile consumes (KS, starting at
+//      kfirst(t)), which cells feed a tile (active) and which B fragment of the table a (cell, tile) pair multiplies by (frag).
+//      A fragment is lane-linear: lane l holds its KS K-step values contiguously (one ds_read_b32/b64/b128).  With HALF only
+//      8 of a tile's 16 columns are meaningful: lanes of columns 8-15 alias columns 0-7 (their results are never stored).
+template <int NB_, int NT>
+struct PlainConv {                     // k3 conv Cin = 16 NB -> Cout = 16 NT: tile t = (child j, column tile n), fragment = slice of offset k
+    static constexpr int NB = NB_, ROWCHUNKS = 4, T = 8 * NT, KS = 4;
+    static constexpr bool HALF = false;
+    static constexpr int kfirst(int) { return 0; }
+    static constexpr bool active(int c, int t) { return (cell_reach(c) >> (t / NT)) & 1; }
+    static constexpr int frag(int c, int t) { return cell_k(c, t / NT) * NT + t % NT; }
+};
+template <int NB_>
+struct ClsHead {                       // k3 conv C -> 1: one tile, column j (0..7) = child j; one fragment per cell
+    static constexpr int NB = NB_, ROWCHUNKS = 4, T = 1, KS = 4;
+    static constexpr bool HALF = true;
+    static constexpr int kfirst(int) { return 0; }
+    static constexpr bool active(int, int) { return true; }
+    static constexpr int frag(int c, int) { return c; }
+};
+// InceptionResNet pass A (autoencoder.py:52-57 first half): conv0_0 (k3 C -> Q) and conv1_0 (k1 C -> Q), Q = C/4.
+// Columns pack (child, output channel): 16/Q children per tile.  Tiles [0, T/2) = conv0_0, [T/2, T) = conv1_0 (fed only by the
+// cell that IS the child: offset k = 13).
+template <int C>
+struct PassA {
+    static constexpr int Q = C / 4, NB = C / 16, ROWCHUNKS = 4, CPT = 16 / Q /*children per tile: 4 or 2*/, TH = 8 / CPT, T = 2 * TH, KS = 4;
+    static constexpr bool HALF = false;
+    static constexpr int kfirst(int) { return 0; }
+    // tile geometry: CPT == 4: tile = z-half (children 4 jz + {0..3});  CPT == 2: tile = (jz, jy) quarter (children 4 jz + 2 jy + {0,1})
+    static constexpr int tz(int t) { return CPT == 4 ? (t % TH) : (t % TH) >> 1; }
+    static constexpr int ty(int t) { return (t % TH) & 1; }
+    static constexpr bool active(int c, int t) {
+        const int kz = cz_of(c) - tz(t);
+        if (CPT == 4) {
+            if (t < TH) return in02(kz);
+            return kz == 1 && (cy_of(c) == 1 || cy_of(c) == 2) && (cx_of(c) == 1 || cx_of(c) == 2);
+        }
+        const int ky = cy_of(c) - ty(t);
+        if (t < TH) return in02(kz) && in02(ky);
+        return kz == 1 && ky == 1 && (cx_of(c) == 1 || cx_of(c) == 2);
+    }
+    static constexpr int N0 = CPT == 4 ? 48 : 36;                                   // conv0_0 fragments
+    static constexpr int frag(int c, int t) {
+        const int kz = cz_of(c) - tz(t);
+        if (CPT == 4) return t < TH ? kz * 16 + (c & 15) : N0 + (cy_of(c) - 1) * 2 + (cx_of(c) - 1);
+        const int ky = cy_of(c) - ty(t);
+        return t < TH ? (kz * 3 + ky) * 4 + cx_of(c) : N0 + (cx_of(c) - 1);
+    }
+};
+// InceptionResNet pass B: the gathered rows are t = [relu(conv0_0) | relu(conv1_0)] (2Q wide).  conv0_1 (k3 Q -> 2Q) reads the
+// first Q channels, conv1_1 (k3 Q -> Q) the last Q: with Q = 8 (C = 32) those are K-steps {0,1} / {2,3} of the one 16-channel
+// block, with Q = 4 (C = 16) K-step 0 / 1 of a half-width block.
+template <int C>
+struct PassB {
+    static constexpr int Q = C / 4, NB = 1, ROWCHUNKS = Q / 2 /*2Q floats = Q/2 chunks*/, KS = Q / 4;
+    static constexpr int CPT0 = 16 / (2 * Q) /*children per conv0_1 tile: 1 or 2*/, T0 = 8 / CPT0, CPT1 = 16 / Q, T1 = 8 / CPT1, T = T0 + T1;
+    static constexpr bool HALF = false;
+    static constexpr int kfirst(int t) { return t < T0 ? 0 : KS; }
+    static constexpr bool active(int c, int t) {
+        if (t < T0) {
+            if (CPT0 == 1) return (cell_reach(c) >> t) & 1;
+            return in02(cz_of(c) - (t >> 1)) && in02(cy_of(c) - (t & 1));           // (jz, jy) quarters
+        }
+        const int u = t - T0;
+        if (CPT1 == 2) return in02(cz_of(c) - (u >> 1)) && in02(cy_of(c) - (u & 1));
+        return in02(cz_of(c) - u);                                                    // z halves
+    }
+    static constexpr int N0 = CPT0 == 1 ? 27 : 36;
+    static constexpr int N1 = CPT1 == 2 ? 36 : 48;
+    static constexpr int FRAG_W12 = N0 + N1;                                          // the k1 conv1_2 weights ride behind the table
+    static constexpr int frag(int c, int t) {
+        if (t < T0) {
+            if (CPT0 == 1) return cell_k(c, t);
+            return ((cz_of(c) - (t >> 1)) * 3 + (cy_of(c) - (t & 1))) * 4 + cx_of(c);
+        }
+        const int u = t - T0;
+        if (CPT1 == 2) return N0 + ((cz_of(c) - (u >> 1)) * 3 + (cy_of(c) - (u & 1))) * 4 + cx_of(c);
+        return N0 + (cz_of(c) - u) * 16 + (c & 15);
+    }
+};
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// B-fragment reads with the (compile-time) table offset in the instruction's 16-bit offset field: an address register per
+// fragment would cost ~one VGPR per distinct fragment (hipcc hoists the additions out of the tile loop).
+template <int KS> struct BFrag;
+template <> struct BFrag<4> {
+    f32x4 v;
+    template <int OFF> __device__ __forceinline__ void load(unsigned base) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(OFF) : "memory"); }
+    __device__ __forceinline__ void tie() { asm volatile("" : "+v"(v)); }
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <> struct BFrag<2> {
+    f32x2 v;
+    template <int OFF> __device__ __forceinline__ void load(unsigned base) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(OFF) : "memory"); }
+    __device__ __forceinline__ void tie() { asm volatile("" : "+v"(v)); }
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+};
+template <> struct BFrag<1> {
+    float v;
+    template <int OFF> __device__ __forceinline__ void load(unsigned base) { asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(OFF) : "memory"); }
+    __device__ __forceinline__ void tie() { asm volatile("" : "+v"(v)); }
+    __device__ __forceinline__ float get(int) const { return v; }
+};
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_ld128_off(unsigned base) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(OFF) : "memory");
+    return v;
+}
+
+template <class V> constexpr int frag_floats() { return (V::HALF ? 32 : 64) * V::KS; }
+
+// Persistent tile order: XCD x (workgroups b = x mod 8; each XCD has its own L2) walks one contiguous eighth of the tiles, and
+// inside it consecutive tiles go to different workgroups first, then to the next wave slot: the i-th tile of (workgroup b, wave w).
+// A level's tile count is rarely a multiple of the resident waves (e.g. 4451 tiles on 2048 waves), so waves loop over tiles
+// instead of one-tile workgroups whose last round would run nearly empty; the table is staged once per workgroup.
+template <int NW, bool PERSIST = true>
+__device__ __forceinline__ int64_t child_tile(int i, int wave, int64_t ntiles) {
+    if constexpr (!PERSIST) {                                  // one tile per wave (levels with many more tiles than resident waves)
+        const int64_t tile = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * NW + wave;
+        return (i == 0 && tile < ntiles) ? tile : -1;
+    }
+    const int64_t S = (ntiles + 7) >> 3;
+    const int64_t l = (blockIdx.x >> 3) + (int64_t)(gridDim.x >> 3) * (wave + NW * i);
+    const int64_t tile = (blockIdx.x & 7) * S + l;
+    return (l < S && tile < ntiles) ? tile : -1;
+}
+
+// Stage the B-fragment table into LDS (all waves), once per workgroup.
+template <int NW>
+__device__ __forceinline__ void child_stage_table(const float* __restrict__ table, int table_bytes, unsigned char* lds_raw) {
+    float4* tab = (float4*)lds_raw;
+    for (int i = threadIdx.x; i < table_bytes / 16; i += NW * 64) tab[i] = ((const float4*)table)[i];
+    __syncthreads();
+}
+
+// The gather + MFMA main loop of one 16-parent tile, shared by every variant: leaves acc[t] (t < V::T) for the epilogue.
+template <class V, int D>
+__device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ pnbr, int64_t n_p, int64_t p0,
+                                                    const __amdgpu_buffer_rsrc_t& rs_in, int in_ld, const unsigned char* lds_raw,
+                                                    float4* ring, f32x4 (&acc)[V::T]) {
+    constexpr int NB = V::NB, T = V::T, KS = V::KS;
+    static_assert((D & (D - 1)) == 0, "ring depth must be a power of two");
+    static_assert((D - 1) * NB < 64, "vmcnt is 6 bits");
+    CHILD_T(t_tile0);
+    const int lane = threadIdx.x & 63;
+    const int mi = lane & 15, mq = lane >> 4;
+    const int dma_r = lane >> 2;                               // tile row (parent) this lane fetches for
+    const bool row_ok = p0 + dma_r < n_p;
+    int pn[27];                                                // its 27 neighbour parents (-1 = absent)
+#pragma unroll
+    for (int kp = 0; kp < 27; ++kp) pn[kp] = pnbr[(int64_t)kp * n_p + (row_ok ? p0 + dma_r : 0)];
+    const int f_a = (0x78 >> (2 * (mi >> 2))) & 3;             // read-side swizzle of the A image (see conv.hip v2)
+    const int dma_chunk = (lane & 3) ^ ((0x78 >> (2 * ((dma_r >> 2) & 3))) & 3);
+    const bool chunk_ok = dma_chunk < V::ROWCHUNKS;            // rows narrower than 64 bytes: the other lanes fetch nothing (zeros)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // pn[] loaded (and the previous tile's stores retired): vmcnt now counts DMAs only
+#pragma unroll
+    for (int kp = 0; kp < 27; ++kp) pn[kp] = row_ok ? pn[kp] : -1;
+    CHILD_T(t_loop0);
+
+    auto issue = [&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        const int pr = pn[cell_kp(c)];
+        float4* dst = ring + (c & (D - 1)) * (NB * 64);
+        const int64_t rowoff = (int64_t)(8 * pr + cell_child(c)) * in_ld + dma_chunk * 4;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            const unsigned voff = (pr >= 0 && chunk_ok) ? (unsigned)((rowoff + cb * 16) * 4) : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_ptr)(dst + cb * 64), 16, (int)voff, 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+    };
+
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned tab_lane = (unsigned)(uintptr_t)(lds_void_ptr)((const float*)lds_raw + (V::HALF ? (mq * 8 + (mi & 7)) : lane) * KS);
+    const unsigned a_lane = (unsigned)(uintptr_t)(lds_void_ptr)(ring + mi * 4 + (mq ^ f_a));
+
+    // (A two-deep register pipeline — LDS reads of cell c+1 issued before the MFMAs of cell c — was measured and dropped: no gain
+    // on any variant, 8-30 more registers; with 3-4 waves per SIMD the other waves already cover the two LDS latencies.)
+    static_for<0, D>(issue);
+    static_for<0, 64>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        constexpr int younger = (63 - c) < (D - 1) ? (63 - c) : (D - 1);       // cells issued after c that may stay in flight
+        wait_vmcnt<younger * NB>();
+        f32x4 araw[NB];
+        static_for<0, NB>([&](auto icb) {
+            constexpr int cb = decltype(icb)::value;
+            araw[cb] = lds_ld128_off<((c & (D - 1)) * NB + cb) * 1024>(a_lane);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) lds_tie(araw[cb]);
+        if constexpr (c + D < 64) issue(std::integral_constant<int, c + D>{});    // refill the ring slot cell c was read from
+        static_for<0, NB>([&](auto icb) {
+            constexpr int cb = decltype(icb)::value;
+            float4 a = make_float4(araw[cb][0], araw[cb][1], araw[cb][2], araw[cb][3]);
+            lane_transpose4(a);
+            BFrag<KS> b[T];
+            static_for<0, T>([&](auto it) {
+                constexpr int t = decltype(it)::value;
+                if constexpr (V::active(c, t)) {
+                    constexpr int off = (V::frag(c, t) * NB + cb) * frag_floats<V>() * 4;        // byte offset of the fragment in the table
+                    if constexpr (off < 65536) b[t].template load<off>(tab_lane);
+                    else b[t].template load<off - 65536>(tab_lane + 65536);
+                }
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            static_for<0, T>([&](auto it) {
+                constexpr int t = decltype(it)::value;
+                if constexpr (V::active(c, t)) b[t].tie();
+            });
+            static_for<0, 4>([&](auto ij) {
+                constexpr int jj = decltype(ij)::value;
+                const float av = jj == 0 ? a.x : (jj == 1 ? a.y : (jj == 2 ? a.z : a.w));
+                static_for<0, T>([&](auto it) {
+                    constexpr int t = decltype(it)::value;
+                    if constexpr (V::active(c, t) && jj >= V::kfirst(t) && jj < V::kfirst(t) + KS)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[t].get(jj - V::kfirst(t)), acc[t], 0, 0, 0);
+                });
+            });
+        });
+    });
+#ifdef PCGC_CHILD_TIMING
+    asm volatile("s_nop 0" : "+v"(acc[0]));                     // (keeps the stamp behind the last MFMA's issue)
+    CHILD_T(t_loop1);
+    CHILD_TADD(0, t_tile0, t_loop0);
+    CHILD_TADD(1, t_loop0, t_loop1);
+    CHILD_TADD(3, 0ull, 1ull);
+#endif
+}
+
+// Epilogue staging.  The accumulators hold the tile in MFMA layout (lane = column, 4 rows per lane); written from there,
+// a row reaches memory as 4-byte pieces, 16 lanes to a 64-byte segment — measured at 47 % (plain conv) to 66 % (pass B) of a
+// tile's time.  A tile's 128 output rows are contiguous in memory, so the values go through a per-wave LDS scratch (the gather
+// ring, idle by then) in row-major order, CH rows at a time, and leave as 16-byte-per-lane stores: whole rows, fully coalesced;
+// residual rows are read the same way.  Arithmetic order per element is unchanged: (acc + bias) [+ residual] [relu].
+template <int W>
+__device__ __forceinline__ void child_flush(const float* scratch, int rows, int64_t row0, int64_t rows_total, float* __restrict__ out,
+                                            int out_ld, const float* __restrict__ res, int res_ld, int relu, int lane) {
+    constexpr int C4 = W / 4;
+    for (int i = lane; i < rows * C4; i += 64) {
+        const int lr = i / C4, c4 = i % C4;
+        const int64_t row = row0 + lr;
+        if (row >= rows_total) continue;
+        float4 v = ((const float4*)scratch)[i];
+        if (res) {
+            const float4 x = *(const float4*)(res + row * res_ld + 4 * c4);
+            v.x = v.x + x.x; v.y = v.y + x.y; v.z = v.z + x.z; v.w = v.w + x.w;
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+        *(float4*)(out + row * out_ld + 4 * c4) = v;
+    }
+}
+
+#define CHILD_KERNEL_PROLOGUE(V, NW, D, RING_FLOAT4)                                                                          \
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];                                                   \
+    const int lane = threadIdx.x & 63, mi = lane & 15, mq = lane >> 4;                                                        \
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                                                        \
+    float4* ring = (float4*)(lds_raw + table_bytes) + wave * (RING_FLOAT4);                                                   \
+    child_stage_table<NW>(table, table_bytes, lds_raw);                                                                        \
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(8 * n_p * in_ld * 4), 0x00020000); \
+    const int64_t ntiles = (n_p + 15) >> 4;
+
+// plain conv:  acc[t][r] = out[8 (p0 + 4 mq + r) + j][16 n + mi],  t = j * NT + n
+template <int NB, int NT, int NW, int D>
+__global__ void __launch_bounds__(NW * 64)
+k_child_conv(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in, int in_ld,
+             const float* __restrict__ table, int table_bytes, ChildEpi ep) {
+    using V = PlainConv<NB, NT>;
+    CHILD_KERNEL_PROLOGUE(V, NW, D, D * NB * 64)
+    for (int i = 0;; ++i) {
+        const int64_t tile = child_tile<NW>(i, wave, ntiles);
+        if (tile < 0) break;
+        const int64_t p0 = tile * 16;
+        CHILD_T(t_it0);
+        f32x4 acc[V::T];
+        child_tile_mainloop<V, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
+        // staged epilogue: CH rows (CH / 8 parents) at a time through the ring's LDS
+        constexpr int W = 16 * NT, CH = (64 * W * 4 <= D * NB * 1024) ? 64 : 32, PPC = CH / 8, MQC = PPC / 4;   // MQC: lane quarters per chunk
+        float* scratch = (float*)ring;
+#pragma unroll
+        for (int h = 0; h < 128 / CH; ++h) {
+            if (mq / MQC == h) {
+#pragma unroll
+                for (int t = 0; t < V::T; ++t) {
+                    const int j = t / NT, n = t % NT;
+                    const float bv = ep.bias ? ep.bias[16 * n + mi] : 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[t][r];
+                        if (ep.bias) v = v + bv;
+                        scratch[(8 * (4 * (mq % MQC) + r) + j) * W + 16 * n + mi] = v;
+                    }
+                }
+            }
+            child_flush<W>(scratch, CH, 8 * p0 + h * CH, 8 * n_p, ep.out, ep.out_ld, ep.res, ep.res_ld, ep.relu, lane);
+        }
+#ifdef PCGC_CHILD_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        { CHILD_T(t_it1); CHILD_TADD(4, t_it0, t_it1); }
+#endif
+    }
+}
+
+// classification head C -> 1:  acc[0][r] column j = out[8 (p0 + 4 mq + r) + j]
+template <int NB, int NW, int D>
+__global__ void __launch_bounds__(NW * 64)
+k_child_cls(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in, int in_ld,
+            const float* __restrict__ table, int table_bytes, ChildEpi ep) {
+    using V = ClsHead<NB>;
+    CHILD_KERNEL_PROLOGUE(V, NW, D, D * NB * 64)
+    const float bv = ep.bias ? ep.bias[0] : 0.0f;
+    for (int i = 0;; ++i) {
+        const int64_t tile = child_tile<NW>(i, wave, ntiles);
+        if (tile < 0) break;
+        const int64_t p0 = tile * 16;
+        CHILD_T(t_it0);
+        f32x4 acc[1];
+        child_tile_mainloop<V, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
+        if (mi < 8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t p = p0 + 4 * mq + r;
+                if (p >= n_p) continue;
+                float v = acc[0][r];
+                if (ep.bias) v = v + bv;
+                ep.out[(8 * p + mi) * ep.out_ld] = v;
+            }
+        }
+#ifdef PCGC_CHILD_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        { CHILD_T(t_it1); CHILD_TADD(4, t_it0, t_it1); }
+#endif
+    }
+}
+
+struct IrnEpi {
+    const float* b0;        // pass A: b00 ; pass B: b01
+    const float* b1;        // pass A: b10 ; pass B: b11
+    const float* b2;        // pass B: b12
+    const float* x;         // pass B: the block input (residual), children rows [.., x_ld]
+    int x_ld;
+    float* out;             // pass A: t [.., 2Q] ; pass B: out [.., out_ld]
+    int out_ld;
+};
+
+// pass A:  t[row][0:Q] = relu(conv0_0 + b00), t[row][Q:2Q] = relu(conv1_0 + b10)
+template <int C, int NW, int D>
+__global__ void __launch_bounds__(NW * 64)
+k_child_irn_a(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in, int in_ld,
+              const float* __restrict__ table, int table_bytes, IrnEpi ep) {
+    using V = PassA<C>;
+    constexpr int Q = V::Q, CPT = V::CPT, TH = V::TH;
+    CHILD_KERNEL_PROLOGUE(V, NW, D, D * V::NB * 64)
+    const int co = mi % Q, sub = mi / Q;                       // column -> (child within the tile, output channel)
+    const float b00 = ep.b0[co], b10 = ep.b1[co];
+    for (int i = 0;; ++i) {
+        const int64_t tile = child_tile<NW>(i, wave, ntiles);
+        if (tile < 0) break;
+        const int64_t p0 = tile * 16;
+        CHILD_T(t_it0);
+        f32x4 acc[V::T];
+        child_tile_mainloop<V, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
+        constexpr int W = 2 * Q, CH = (64 * W * 4 <= D * V::NB * 1024) ? 64 : 32, MQC = CH / 32;
+        float* scratch = (float*)ring;
+#pragma unroll
+        for (int h = 0; h < 128 / CH; ++h) {
+            if (mq / MQC == h) {
+#pragma unroll
+                for (int t = 0; t < TH; ++t) {
+                    const int j = t * CPT + sub;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* y = scratch + (8 * (4 * (mq % MQC) + r) + j) * W;
+                        y[co] = fmaxf(acc[t][r] + b00, 0.0f);
+                        y[Q + co] = fmaxf(acc[TH + t][r] + b10, 0.0f);
+                    }
+                }
+            }
+            child_flush<W>(scratch, CH, 8 * p0 + h * CH, 8 * n_p, ep.out, W, nullptr, 0, 0, lane);
+        }
+#ifdef PCGC_CHILD_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        { CHILD_T(t_it1); CHILD_TADD(4, t_it0, t_it1); }
+#endif
+    }
+}
+
+// pass B:  out[row][0:2Q]  = (conv0_1(t[:, :Q]) + b01) + x[row][0:2Q]
+//          out[row][2Q:4Q] = (conv1_2(relu(conv1_1(t[:, Q:]) + b11)) + b12) + x[row][2Q:4Q]
+// conv1_2 (k1, Q -> 2Q) is a second, tiny MFMA product: u = relu(conv1_1 + b11) goes through a per-wave LDS scratch (the gather
+// ring, idle by then) from the accumulator layout (lane = column) into A fragments (lane = row), 16 output rows per product.
+template <int C, int NW, int D>
+__global__ void __launch_bounds__(NW * 64)
+k_child_irn_b(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in /* t */, int in_ld,
+              const float* __restrict__ table, int table_bytes, IrnEpi ep) {
+    using V = PassB<C>;
+    constexpr int Q = V::Q, H = 2 * Q, KQ = Q / 4, T0 = V::T0, T1 = V::T1, CPT0 = V::CPT0, CPT1 = V::CPT1;
+    // epilogue scratch inside the ring's LDS: us [128 rows][Q] (u = relu(conv1_1)), then the CH-row output staging [CH][C]
+    constexpr int CH = ((128 * Q + 64 * C) * 4 <= D * 1024) ? 64 : 32, MQC = CH / 32;
+    constexpr int NEEDF4 = (128 * Q + CH * C) / 4;
+    constexpr int RINGF4 = (D * 64 > NEEDF4) ? D * 64 : NEEDF4;
+    CHILD_KERNEL_PROLOGUE(V, NW, D, RINGF4)
+    float* us = (float*)ring;
+    float* stage = us + 128 * Q;
+    // conv1_2 B fragment: W12[4 jj + mq][mi]  (columns >= 2Q unused)
+    float w12[KQ];
+#pragma unroll
+    for (int jj = 0; jj < KQ; ++jj) w12[jj] = ((const float*)lds_raw)[V::FRAG_W12 * frag_floats<V>() + lane * KQ + jj];
+    for (int i = 0;; ++i) {
+        const int64_t tile = child_tile<NW>(i, wave, ntiles);
+        if (tile < 0) break;
+        const int64_t p0 = tile * 16;
+        CHILD_T(t_it0);
+        f32x4 acc[V::T];
+        child_tile_mainloop<V, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
+        // ---- u = relu(conv1_1 + b11) -> scratch us [local row = 8 (4 mq + r) + child][Q]
+        {
+            const int c1 = mi % Q, sub1 = mi / Q;
+            const float b11 = ep.b1[c1];
+#pragma unroll
+            for (int u = 0; u < T1; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) us[(8 * (4 * mq + r) + u * CPT1 + sub1) * Q + c1] = fmaxf(acc[T0 + u][r] + b11, 0.0f);
+        }
+        // ---- CH rows at a time: [conv0_1 + b01 | conv1_2(u) + b12] staged row-major, then flushed with the residual x
+        {
+            const int c0 = mi % H, sub0 = mi / H;
+            const float b01 = ep.b0[c0];
+            const float b12 = mi < H ? ep.b2[mi] : 0.0f;
+#pragma unroll
+            for (int h = 0; h < 128 / CH; ++h) {
+                if (mq / MQC == h) {
+#pragma unroll
+                    for (int t = 0; t < T0; ++t) {
+                        const int j = t * CPT0 + sub0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) stage[(8 * (4 * (mq % MQC) + r) + j) * C + c0] = acc[t][r] + b01;
+                    }
+                }
+#pragma unroll
+                for (int gg = 0; gg < CH / 16; ++gg) {          // conv1_2 on u, 16 rows per MFMA product
+                    const int g = h * (CH / 16) + gg;
+                    f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int jj = 0; jj < KQ; ++jj) d = __builtin_amdgcn_mfma_f32_16x16x4f32(us[(16 * g + mi) * Q + 4 * jj + mq], w12[jj], d, 0, 0, 0);
+                    if (mi < H) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) stage[(16 * gg + 4 * mq + r) * C + H + mi] = d[r] + b12;
+                    }
+                }
+                child_flush<C>(stage, CH, 8 * p0 + h * CH, 8 * n_p, ep.out, ep.out_ld, ep.x, ep.x_ld, 0, lane);
+            }
+        }
+#ifdef PCGC_CHILD_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        { CHILD_T(t_it1); CHILD_TADD(4, t_it0, t_it1); }
+#endif
+    }
+}
+
+template <typename K>
+int child_lds_limit(K kern, size_t lds, size_t& granted) {
+    if (lds > 160 * 1024) { pcgc_set_error("child kernel: %zu bytes of LDS needed", lds); return -2; }
+    if (lds > 48 * 1024 && lds > granted) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { pcgc_set_error("child kernel: cannot raise the LDS limit to %zu: %s", lds, hipGetErrorString(e)); return -1; }
+        granted = lds;
+    }
+    return 0;
+}
+// persistent grid: as many workgroups as stay resident (LDS-limited, at most 16 waves per CU), a multiple of 8 (one share per XCD)
+static unsigned child_grid(int64_t n_p, int nw, size_t lds) {
+    static int cus = 0;
+    if (!cus) { hipDeviceProp_t p; int dev = 0; hipGetDevice(&dev); cus = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+    int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
+    if (per_cu > 16 / nw) per_cu = 16 / nw;
+    if (per_cu < 1) per_cu = 1;
+    int64_t want = ((n_p + 15) / 16 + nw - 1) / nw;
+    int64_t g = (int64_t)cus * per_cu;
+    if (g > want) g = want;
+    g = (g + 7) / 8 * 8;
+    return (unsigned)g;
+}
+#define CHILD_LAUNCH(KERN, NW, RINGBYTES, EP)                                                                                  \
+    do {                                                                                                                       \
+        const size_t lds = (size_t)table_bytes + (size_t)(NW) * (RINGBYTES);                                                   \
+        auto kern = KERN;                                                                                                      \
+        static size_t granted = 0;                                                                                             \
+        if (int rc = child_lds_limit(kern, lds, granted)) return rc;                                                           \
+        hipLaunchKernelGGL(kern, dim3(child_grid(n_p, NW, lds)), dim3((NW) * 64), lds, s, pnbr, n_p, in, in_ld, table, table_bytes, EP); \
+        return 0;                                                                                                              \
+    } while (0)
+
+template <int NB, int NT, int NW, int D>
+int launch_child_conv(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
+                      const ChildEpi& ep, hipStream_t s) {
+    CHILD_LAUNCH((k_child_conv<NB, NT, NW, D>), NW, D * NB * 1024, ep);
+}
+template <int NB, int NW, int D>
+int launch_child_cls(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
+                     const ChildEpi& ep, hipStream_t s) {
+    CHILD_LAUNCH((k_child_cls<NB, NW, D>), NW, D * NB * 1024, ep);
+}
+template <int C, int NW, int D>
+int launch_child_irn_a(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
+                       const IrnEpi& ep, hipStream_t s) {
+    CHILD_LAUNCH((k_child_irn_a<C, NW, D>), NW, D * (C / 16) * 1024, ep);
+}
+template <int C, int NW, int D>
+int launch_child_irn_b(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
+                       const IrnEpi& ep, hipStream_t s) {
+    constexpr int Q = C / 4, CH = ((128 * Q + 64 * C) * 4 <= D * 1024) ? 64 : 32;
+    constexpr int need = (128 * Q + CH * C) * 4;
+    constexpr int ringb = (D * 1024 > need) ? D * 1024 : need;
+    CHILD_LAUNCH((k_child_irn_b<C, NW, D>), NW, ringb, ep);
+}
+
+}  // namespace
+
+extern int g_child_nw, g_child_depth;                       // A/B switches (pcgc_set_child_tuning); 0 = defaults
+
+#define CHILD_COMMON_CHECKS(ROWS_LD)                                                                                           \
+    PCGC_REQUIRE(parent_nbr && in && table, "null argument");                                                                  \
+    PCGC_REQUIRE(((ROWS_LD) & 3) == 0 && (((uintptr_t)in | (uintptr_t)table) & 15) == 0, "unaligned input");                 \
+    PCGC_REQUIRE(8 * n_parent * (int64_t)(ROWS_LD) * 4 < (int64_t)0xFFFFFFF0, "tensor too large for 32-bit buffer offsets"); \
+    PCGC_REQUIRE(table_bytes % 16 == 0, "table size");                                                                         \
+    if (n_parent == 0) return 0;

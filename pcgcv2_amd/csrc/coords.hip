@@ -220,6 +220,23 @@ __global__ void __launch_bounds__(256) k_kmap_prune(const int32_t* __restrict__ 
         nbr[(int64_t)k * n_out + r] = (m >= 0 && mask[m]) ? prefix[m] : -1;
     }
 }
+// pruned level straight from the PARENT level's map: the candidate (children) level's own [27][8 n_p] map is never built.
+// candidate row o = 8 i + j; its neighbour through offset k is row 8 pnbr[kp][i] + j' (child_offset), kept iff its mask is set.
+__global__ void __launch_bounds__(256) k_kmap_prune_parent(const int32_t* __restrict__ pnbr, int64_t np,
+                                                           const uint8_t* __restrict__ mask, const int32_t* __restrict__ prefix,
+                                                           const int32_t* __restrict__ orig, int64_t n_out, int32_t* __restrict__ nbr) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_out) return;
+    const int64_t o = orig[r];
+    const int64_t i = o >> 3; const int j = (int)(o & 7);
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        int kp, jn; child_offset(j, k, kp, jn);
+        const int32_t pn = pnbr[(int64_t)kp * np + i];
+        const int64_t m = pn < 0 ? -1 : 8 * (int64_t)pn + jn;
+        nbr[(int64_t)k * n_out + r] = (m >= 0 && mask[m]) ? prefix[m] : -1;
+    }
+}
 // strided pyramid (encoder): fine row c has parent row parent_of[c]; down[j][p] = fine row at slot j of coarse row p
 __global__ void __launch_bounds__(256) k_kmap_from_coarse(const int4* __restrict__ fine, int64_t nf, int32_t stride_f,
                                                           const int32_t* __restrict__ parent_of,
@@ -271,6 +288,14 @@ extern "C" int pcgc_kmap_k3_prune(const int32_t* cand_nbr, int64_t n_cand, const
     hipLaunchKernelGGL(k_kmap_prune, dim3(grid_for(n_out, 256)), dim3(256), 0, S(stream), cand_nbr, n_cand, mask, prefix, orig,
                        n_out, nbr);
     PCGC_CHECK_LAUNCH("kmap_k3_prune");
+    return 0;
+}
+extern "C" int pcgc_kmap_k3_prune_parent(const int32_t* parent_nbr, int64_t n_parent, const uint8_t* mask, const int32_t* prefix,
+                                         const int32_t* orig, int64_t n_out, int32_t* nbr, void* stream) {
+    if (n_out == 0) return 0;
+    hipLaunchKernelGGL(k_kmap_prune_parent, dim3(grid_for(n_out, 256)), dim3(256), 0, S(stream), parent_nbr, n_parent, mask, prefix,
+                       orig, n_out, nbr);
+    PCGC_CHECK_LAUNCH("kmap_k3_prune_parent");
     return 0;
 }
 extern "C" int pcgc_kmap_k3_from_coarse(const int32_t* fine, int64_t n_fine, int32_t stride_fine, const int32_t* parent_of,

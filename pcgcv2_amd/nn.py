@@ -37,7 +37,8 @@ class MinkowskiConvolution(_ConvBase):
             # children level (output of a generative transpose): gather through the PARENT level's map, csrc/child.hip
             stamp = (self.kernel.data_ptr(), self.kernel._version)
             if getattr(self, '_child_stamp', None) != stamp:
-                self._child_table, self._child_stamp = ops.child_conv_table(self.kernel), stamp
+                build = ops.child_cls_table if self.out_channels == 1 else ops.child_conv_table
+                self._child_table, self._child_stamp = build(self.kernel), stamp
             y = ops.conv_child(x.cmap.origin[1].k3, x.F, self._child_table, self.bias, self.out_channels, out=out,
                                residual=residual, relu=relu)
             return SparseTensor(y, coordinate_map=x.cmap)

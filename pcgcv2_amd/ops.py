@@ -217,6 +217,15 @@ def kmap_k3_prune(cand_nbr, mask, prefix, orig):
     return nbr
 
 
+def kmap_k3_prune_parent(parent_nbr, mask, prefix, orig):
+    """k3 map of a pruned children level from the PARENT level's map (no [27][8 n_parent] candidate map)."""
+    n_out = orig.shape[0]
+    nbr = torch.empty((27, n_out), dtype=torch.int32, device=parent_nbr.device)
+    check(lib().pcgc_kmap_k3_prune_parent(_p(parent_nbr), parent_nbr.shape[1], _p(mask), _p(prefix), _p(orig), n_out, _p(nbr),
+                                          _stream(parent_nbr)), 'kmap_k3_prune_parent')
+    return nbr
+
+
 def kmap_k3_from_coarse(fine, stride_fine, parent_of, coarse_nbr, down):
     n = fine.shape[0]
     nbr = torch.empty((27, n), dtype=torch.int32, device=fine.device)
@@ -467,8 +476,15 @@ def set_child_tuning(waves=0, depth=0):
 def child_conv_eligible(x, cin, cout):
     """k3 conv of a SparseTensor living on a children level, in a shape the parent-map MFMA kernels are built for."""
     org = x.cmap.origin
-    return (CHILD_MFMA and org is not None and org[0] == 'children' and (cin, cout) in ((16, 16), (32, 32))
+    return (CHILD_MFMA and org is not None and org[0] == 'children' and (cin, cout) in ((16, 16), (32, 32), (16, 1), (32, 1))
             and x.F.shape[0] >= 8192 and x.F.shape[0] * x.F.stride(0) * 4 < 0xFFFFFFF0)
+
+
+def irn_child_eligible(x):
+    """InceptionResNet on a children level with C = 16 or 32 (the two large decoder levels)."""
+    org = x.cmap.origin
+    return (CHILD_MFMA and org is not None and org[0] == 'children' and x.F.shape[1] in (16, 32) and x.F.shape[0] >= 8192
+            and x.F.is_contiguous() and x.F.shape[0] * x.F.shape[1] * 4 < 0xFFFFFFF0)
 
 
 def _halo_cells():
@@ -500,6 +516,130 @@ def child_conv_table(W):
     K, Cin, Cout = W.shape
     NB, NT = Cin // 16, Cout // 16
     return W.detach().reshape(27, NB, 4, 4, NT, 16).permute(0, 4, 1, 3, 5, 2).contiguous().reshape(-1)      # [k][n][cb][mq][mi][jj]
+
+
+def _fragment(col_weights, NB, KS=4, k0=0, half=False):
+    """One B fragment per 16-channel block from `col_weights`: a list of 16 (8 if half) columns, each None (zero column) or an
+    array [Cin_rows] giving that column's weight per input channel.  Layout [cb][lane = mq*16 + mi (mq*8 + mi if half)][jj]:
+    value = column mi at input channel 16 cb + 4 (k0 + jj) + mq."""
+    ncol = 8 if half else 16
+    out = np.zeros((NB, 4, ncol, KS), np.float32)
+    for mi, w in enumerate(col_weights):
+        if w is None:
+            continue
+        for cb in range(NB):
+            for jj in range(KS):
+                for mq in range(4):
+                    ch = 16 * cb + 4 * (k0 + jj) + mq
+                    if ch < len(w):
+                        out[cb, mq, mi, jj] = w[ch]
+    return out.reshape(NB, -1)
+
+
+def child_cls_table(W):
+    """Table of the classification head (k3 conv C -> 1) for pcgc_conv_child: one half fragment per halo cell; column j = child j,
+    holding kernel[k(cell, j)][:, 0] where child j reaches the cell, zero elsewhere."""
+    Wn = W.detach().cpu().numpy().astype(np.float32)
+    NB = Wn.shape[1] // 16
+    frags = []
+    for kp, jc, reach in _halo_cells():
+        cols = [None] * 8
+        for j, k in reach:
+            cols[j] = Wn[k][:, 0]
+        frags.append(_fragment(cols, NB, half=True))
+    return torch.from_numpy(np.concatenate([f.reshape(-1) for f in frags])).to(W.device)
+
+
+def child_irn_tables(params):
+    """(table A, table B) of the parent-map InceptionResNet passes (C = 16 or 32); params as in irn_block.  The fragment order is
+    the one csrc/child.hip's PassA / PassB variants index (frag())."""
+    W00, b00, W01, b01, W10, b10, W11, b11, W12, b12 = [p.detach().cpu().numpy().astype(np.float32) for p in params]
+    C = W00.shape[1]
+    Q, NB = C // 4, C // 16
+    cpt = 16 // Q                                             # children per Q-wide tile: 4 (C=16) or 2 (C=32)
+
+    def packed(Wk3, width, kz, ky, cy, cx):
+        """columns (child-in-tile, channel) of a tile whose children differ in x only (ky given) or in (y, x) (ky None):
+        -> list of 16 columns for the cell at (cy, cx) seen through z-offset kz"""
+        cols = []
+        nchild = 16 // width
+        for sub in range(nchild):
+            if ky is None:                                     # tile = z half: sub = jy*2 + jx
+                jy, jx = sub >> 1, sub & 1
+                kyy = cy - jy
+            else:                                              # tile = (z, y) quarter: sub = jx
+                jx, kyy = sub, ky
+            kxx = cx - jx
+            ok = 0 <= kyy <= 2 and 0 <= kxx <= 2
+            for co in range(width):
+                cols.append(Wk3[kz * 9 + kyy * 3 + kxx][:, co] if ok else None)
+        return cols
+
+    # ---- pass A: conv0_0 (k3 C -> Q) fragments, then conv1_0 (k1) fragments for the cell that is the child itself
+    fa = []
+    if cpt == 4:
+        for kz in range(3):
+            for cy in range(4):
+                for cx in range(4):
+                    fa.append(_fragment(packed(W00, Q, kz, None, cy, cx), NB))
+        for vy in range(2):
+            for vx in range(2):
+                fa.append(_fragment([W10[:, co] if sub == vy * 2 + vx else None for sub in range(4) for co in range(Q)], NB))
+    else:
+        for kz in range(3):
+            for ky in range(3):
+                for cx in range(4):
+                    fa.append(_fragment(packed(W00, Q, kz, ky, None, cx), NB))
+        for vx in range(2):
+            fa.append(_fragment([W10[:, co] if sub == vx else None for sub in range(2) for co in range(Q)], NB))
+    table_a = np.concatenate([f.reshape(-1) for f in fa])
+    # ---- pass B: input rows are t (2Q wide): conv0_1 reads channels [0, Q) = K-steps [0, KS), conv1_1 channels [Q, 2Q) = [KS, 2KS)
+    KS = Q // 4
+    H = 2 * Q
+    fb = []
+    pad = lambda w, lo: np.concatenate([np.zeros(lo, np.float32), w])            # place a Q-vector at channel offset lo of the 2Q row
+    if H == 16:                                                # C = 32: conv0_1 tile = one child, 16 columns
+        for k in range(27):
+            fb.append(_fragment([W01[k][:, co] for co in range(16)], 1, KS=KS, k0=0))
+    else:                                                      # C = 16: conv0_1 tile = (z, y) quarter, (jx, 8 columns)
+        for kz in range(3):
+            for ky in range(3):
+                for cx in range(4):
+                    fb.append(_fragment(packed(W01, H, kz, ky, None, cx), 1, KS=KS, k0=0))
+    W11p = np.stack([np.stack([pad(W11[k][:, co], Q) for co in range(Q)], 1) for k in range(27)])      # [27][2Q][Q]: rows Q.. hold W11
+    if cpt == 2:                                               # C = 32: conv1_1 tile = (z, y) quarter, (jx, 8 columns)
+        for kz in range(3):
+            for ky in range(3):
+                for cx in range(4):
+                    fb.append(_fragment(packed(W11p, Q, kz, ky, None, cx), 1, KS=KS, k0=KS))
+    else:                                                      # C = 16: conv1_1 tile = z half, (jy jx, 4 columns)
+        for kz in range(3):
+            for cy in range(4):
+                for cx in range(4):
+                    fb.append(_fragment(packed(W11p, Q, kz, None, cy, cx), 1, KS=KS, k0=KS))
+    fb.append(_fragment([W12[:, co] if co < H else None for co in range(16)], 1, KS=KS, k0=0))     # conv1_2 (k1 Q -> 2Q)
+    table_b = np.concatenate([f.reshape(-1) for f in fb])
+    dev = params[0].device
+    return torch.from_numpy(table_a).to(dev), torch.from_numpy(table_b).to(dev)
+
+
+def irn_block_child(parent_nbr, x, params, tables):
+    """Fused InceptionResNet on a children level through the parent map (C = 16, 32); bit-identical to irn_block."""
+    _f32(x, 'x')
+    n_p = parent_nbr.shape[1]
+    n, C = x.shape
+    if n != 8 * n_p:
+        raise PcgcError('irn_block_child: feature rows must be 8 x the parent level')
+    ta, tb = tables
+    t = torch.empty((n, C // 2), dtype=torch.float32, device=x.device)
+    out = torch.empty((n, C), dtype=torch.float32, device=x.device)
+    P = [p.data_ptr() for p in params]
+    s = _stream(x)
+    check(lib().pcgc_irn_child_pass(_p(parent_nbr), n_p, C, 1, _p(x), _ld(x), _p(ta), ta.numel() * 4, P[1], P[5], None, None, 0,
+                                    _p(t), C // 2, s), 'irn_child_pass A')
+    check(lib().pcgc_irn_child_pass(_p(parent_nbr), n_p, C, 2, _p(t), C // 2, _p(tb), tb.numel() * 4, P[3], P[7], P[9], _p(x), _ld(x),
+                                    _p(out), C, s), 'irn_child_pass B')
+    return out
 
 
 def conv_child(parent_nbr, x, table, bias, Cout, out=None, residual=None, relu=False):

@@ -60,7 +60,12 @@ class CoordMap:
                 self._k3 = ops.kmap_k3_children(self.origin[1].k3)
             elif kind == 'pruned':
                 _, cand, mask, prefix = self.origin
-                self._k3 = ops.kmap_k3_prune(cand.k3, mask, prefix, ops.compact_index(mask, prefix, len(self)))
+                orig = ops.compact_index(mask, prefix, len(self))
+                if cand._k3 is None and cand.origin is not None and cand.origin[0] == 'children':
+                    # candidates = a children level whose own map was never needed (its convs ran through the parent map)
+                    self._k3 = ops.kmap_k3_prune_parent(cand.origin[1].k3, mask, prefix, orig)
+                else:
+                    self._k3 = ops.kmap_k3_prune(cand.k3, mask, prefix, orig)
             elif len(self) > HASH_LEVEL_MAX and self.stride <= (1 << 18):
                 coarse, down = self.down()
                 self._k3 = ops.kmap_k3_from_coarse(self.C, self.stride, self._parent_of, coarse.k3, down)

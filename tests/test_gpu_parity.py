@@ -660,7 +660,7 @@ def _children_level(name, prune=None):
     return lvl, kids, kids.C.cpu().numpy()
 
 
-@pytest.mark.parametrize('tuning', [(0, 0), (0, 2), (4, 0), (16, 1)], ids=['default', 'ring2', 'waves4', 'waves16_ring1'])
+@pytest.mark.parametrize('tuning', [(0, 0), (0, 1), (4, 0)], ids=['default', 'unpipelined', 'waves4'])
 @pytest.mark.parametrize('cin,cout', [(16, 16), (32, 32)])
 @pytest.mark.parametrize('name,prune', [('shell7', None), ('shell8', 7), ('shell6', 1)])
 def test_conv_child_bit_exact(name, prune, cin, cout, tuning):
@@ -684,3 +684,49 @@ def test_conv_child_bit_exact(name, prune, cin, cout, tuning):
         assert not buf[:, :cout].any()
     finally:
         ops.set_child_tuning(0, 0)
+
+
+@pytest.mark.parametrize('cin', [16, 32])
+@pytest.mark.parametrize('name,prune', [('shell7', None), ('shell8', 7), ('shell6', 1)])
+def test_cls_head_child_bit_exact(name, prune, cin):
+    """Classification head (k3 conv C -> 1) on a children level through the parent map == oracle per-row gather conv."""
+    parent, kids, kc = _children_level(name, prune)
+    n = len(kc)
+    rng = np.random.default_rng(cin + n)
+    x = rng.standard_normal((n, cin)).astype(np.float32)
+    W = (rng.standard_normal((27, cin, 1)) / np.sqrt(27 * cin)).astype(np.float32)
+    b = rng.standard_normal((1, 1)).astype(np.float32)
+    want = orc.conv_gather(orc.kmap_k3(kc, 1), x, W, b)
+    for nw, d in ((0, 0), (4, 0), (0, 1)):
+        ops.set_child_tuning(nw, d)
+        try:
+            got = ops.conv_child(parent.k3, _t(x), ops.child_cls_table(_t(W)), _t(b), 1)
+        finally:
+            ops.set_child_tuning(0, 0)
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('C', [16, 32])
+@pytest.mark.parametrize('name,prune', [('shell7', None), ('shell8', 7), ('shell6', 1)])
+def test_inception_resnet_child_bit_exact(name, prune, C):
+    """pcgc_irn_child_pass A + B (packed-N MFMA through the parent map) == the oracle's five-conv InceptionResNet."""
+    from pcgcv2_amd.autoencoder import InceptionResNet
+    parent, kids, kc = _children_level(name, prune)
+    n = len(kc)
+    rng = np.random.default_rng(C + n)
+    blk = InceptionResNet(C).to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.from_numpy(rng.standard_normal(tuple(p.shape)).astype(np.float32) * 0.2))
+    x = rng.standard_normal((n, C)).astype(np.float32)
+    sd = {'b.' + k: v.detach().cpu().numpy() for k, v in blk.state_dict().items()}
+    want = orc.inception_resnet(sd, 'b', orc.Level(kc, 1), x)
+    params = [p for m in (blk.conv0_0, blk.conv0_1, blk.conv1_0, blk.conv1_1, blk.conv1_2) for p in (m.kernel, m.bias)]
+    tables = ops.child_irn_tables(params)
+    for nw, d in ((0, 0), (4, 0), (0, 1)):
+        ops.set_child_tuning(nw, d)
+        try:
+            got = ops.irn_block_child(parent.k3, _t(x), params, tables)
+        finally:
+            ops.set_child_tuning(0, 0)
+        np.testing.assert_array_equal(got.cpu().numpy(), want)

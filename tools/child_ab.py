@@ -36,23 +36,58 @@ def main():
         tab = ops.child_conv_table(W)
         if only:
             ops.set_child_tuning(only[1], only[2])
-            for _ in range(5): ops.conv_child(parent.k3, x, tab, b, C)
+            what = sys.argv[4] if len(sys.argv) > 4 else 'conv'
+            if what == 'conv':
+                for _ in range(5): ops.conv_child(parent.k3, x, tab, b, C)
+            elif what == 'cls':
+                Wc = torch.randn((27, C, 1), device=dev) * 0.05
+                tc = ops.child_cls_table(Wc)
+                for _ in range(5): ops.conv_child(parent.k3, x, tc, b[:, :1].contiguous(), 1)
+            else:
+                from pcgcv2_amd.autoencoder import InceptionResNet
+                blk = InceptionResNet(C).to(dev)
+                params = [p for m in (blk.conv0_0, blk.conv0_1, blk.conv1_0, blk.conv1_1, blk.conv1_2) for p in (m.kernel, m.bias)]
+                tabs = ops.child_irn_tables(params)
+                for _ in range(5): ops.irn_block_child(parent.k3, x, params, tabs)
             torch.cuda.synchronize()
-            print('pmc run', only)
+            print('pmc run', only, what)
             continue
         nbr = kids.k3
         ref = ops.conv_gather(nbr, x, W, b)
         us_ref = timeit(lambda: ops.conv_gather(nbr, x, W, b))
         tab = ops.child_conv_table(W)
         print(f'children level of {len(parent)} parents: {n} rows, C={C}: per-row kernel {us_ref:.1f} us')
-        for nw, d in ((0, 0), (0, 2), (4, 0), (4, 2), (16, 0), (0, 1)):
-            if C == 32 and (nw, d) in ((4, 2), (16, 0)): continue
-            if C == 16 and (nw, d) == (0, 1): continue
+        for nw, d in ((0, 0), (0, 1), (4, 0)):
             ops.set_child_tuning(nw, d)
             got = ops.conv_child(parent.k3, x, tab, b, C)
             ok = torch.equal(got, ref)
             us = timeit(lambda: ops.conv_child(parent.k3, x, tab, b, C))
             print(f'   conv_child waves={nw or "default"} ring={d or "default"}: {us:.1f} us  bit-exact={ok}')
+        ops.set_child_tuning(0, 0)
+        # classification head and fused InceptionResNet
+        Wc = torch.randn((27, C, 1), device=dev) * 0.05
+        bc = torch.randn((1, 1), device=dev)
+        ref = ops.conv_gather(nbr, x, Wc, bc)
+        us_ref = timeit(lambda: ops.conv_gather(nbr, x, Wc, bc))
+        tc = ops.child_cls_table(Wc)
+        for nw, d in ((0, 0), (4, 0), (0, 1)):
+            ops.set_child_tuning(nw, d)
+            ok = torch.equal(ops.conv_child(parent.k3, x, tc, bc, 1), ref)
+            us = timeit(lambda: ops.conv_child(parent.k3, x, tc, bc, 1))
+            print(f'   cls head: per-row {us_ref:.1f} us, child waves={nw or "default"} ring={d or "default"} {us:.1f} us  bit-exact={ok}')
+        from pcgcv2_amd.autoencoder import InceptionResNet
+        blk = InceptionResNet(C).to(dev)
+        params = [p for m in (blk.conv0_0, blk.conv0_1, blk.conv1_0, blk.conv1_1, blk.conv1_2) for p in (m.kernel, m.bias)]
+        with torch.no_grad():
+            for p_ in params: p_.normal_(0, 0.1)
+        ref = ops.irn_block(nbr, x, params)
+        us_ref = timeit(lambda: ops.irn_block(nbr, x, params))
+        tabs = ops.child_irn_tables(params)
+        for nw, d in ((0, 0), (4, 0), (0, 1)):
+            ops.set_child_tuning(nw, d)
+            ok = torch.equal(ops.irn_block_child(parent.k3, x, params, tabs), ref)
+            us = timeit(lambda: ops.irn_block_child(parent.k3, x, params, tabs))
+            print(f'   InceptionResNet: per-row {us_ref:.1f} us, child waves={nw or "default"} ring={d or "default"} {us:.1f} us  bit-exact={ok}')
         ops.set_child_tuning(0, 0)
 
 

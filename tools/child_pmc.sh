@@ -2,7 +2,7 @@
 # PMC passes (rocprofv3 --pmc with --kernel-trace only) over one configuration of tools/child_ab.py.
 # usage: tools/child_pmc.sh <C 16|32> <waves> <ring>      -> gpurun_out/child_pmc/summary.txt
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/child_pmc; rm -rf $OUT; mkdir -p $OUT
+OUT=$R/gpurun_out/child_pmc; rm -rf $OUT /tmp/cp_*; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
 for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
