@@ -2,18 +2,30 @@
 """bench.py — encode+decode throughput of the PCGCv2 hot path on MI355X.
 
 Metric (BASELINE.json): encode+decode Mpoints/s at fixed rate (r3 stand-in: synthetic weights), vox10 frame.
-A "step" = one full `Coder.encode` + `Coder.decode` of one vox10 frame per GPU (shell10, 786 632 points — the synthetic
-stand-in for longdress_vox10_1300.ply; real PLYs / checkpoints are external downloads), including the four bitstream
-files, exactly what coder.py:155-162 brackets.  The input sparse tensor (coordinates + ones) is resident in HBM when the
-timer starts; the whole geometry pyramid and all coordinate / kernel maps are rebuilt inside every step (nothing cached).
+`--config` picks the BASELINE.json configuration (the headline, and the default, is `frame`):
 
-Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); frames are independent, so ranks shard
-frames with no data-path collective ("weak" scaling: 1 frame per GPU per step); the only collective is the final
-5-scalar all-reduce (bits, N_in, N_out, time) after the timed region.
+  frame   config 2: one vox10 frame per GPU per step — shell10 (786 632 points), the synthetic stand-in for
+          longdress_vox10_1300.ply (real PLYs / checkpoints are external downloads).  A step = one `Coder.encode` + one
+          `Coder.decode` including the four bitstream files: exactly what coder.py:155-162 brackets.
+  batch4  config 3: the four vox10 frames shell10 / _b / _c / _d (8iVFB 4-sequence stand-ins), round-robin over the ranks;
+          a step = every frame of the batch encoded + decoded once.
+  sweep   config 4: shell11 (2.6 M points, dancer_vox11 stand-in) through 7 synthetic "rates" (latent gains), geometry maps
+          shared by the rates as in pcgcv2_amd/test.py; a step = the whole 7-rate sweep (reference: 17.81 s,
+          results/dancer_vox11_00000001.csv).
+  blocks  config 5: shell12 (4.8 M points, House_without_roof vox12 stand-in) scaled by 0.375 and split into 8 octant
+          blocks, round-robin over the ranks; a step = every block encoded + decoded once.
 
-JSON line: see the round contract; extra objects `roofline` (dominant kernel = the k3 sparse-conv gather; found by an untimed
-analysis step that brackets every gather launch, then bracketed alone inside the timed region) and `cpu_baseline` (the CPU
-oracle timed on this host, rank 0, N=1 only; all-core and one-thread figures).
+The input sparse tensors are resident in HBM when the timer starts; every coordinate level / kernel map / hash table derived
+from them is dropped before each step (except inside `sweep`, whose point is the reuse across rates), so each step rebuilds
+the whole geometry pyramid.
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); frames / blocks are independent units, so ranks
+shard them with no data-path collective ("weak" scaling for `frame`: 1 frame per GPU per step); the only collective is the
+final all-reduce of scalars after the timed region.
+
+JSON line: the round contract plus `roofline` (dominant sparse-conv kernel: found by an untimed analysis step that brackets
+every sparse-conv launch with HIP events, then bracketed alone inside the timed region) and `cpu_baseline` (the CPU oracle
+timed on this host on the SAME workload, rank 0, N=1 only).
 """
 import argparse
 import json
@@ -29,6 +41,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+SWEEP_GAINS = (8.0, 16.0, 30.0, 50.0, 80.0, 120.0, 200.0)      # latent gains of the 7 synthetic "rates" (alphabets ~7..160 symbols)
 
 
 def parse():
@@ -36,13 +49,14 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='shell10')
+    ap.add_argument('--config', default='frame', choices=['frame', 'batch4', 'sweep', 'blocks'])
+    ap.add_argument('--workload', default='', help='override the synthetic cloud of the chosen config (e.g. shell9 for a quick run)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', default='shell9', help='bounded sample of the same workload for the CPU oracle')
+    ap.add_argument('--cpu-sample', default='', help='cloud for the CPU oracle (default: the bench workload itself)')
     ap.add_argument('--no-events', action='store_true', help='do not bracket the dominant kernel with HIP events')
     ap.add_argument('--irn-rows', type=int, default=0, help='force the fused-IRN tile height (A/B); 0 = automatic')
     ap.add_argument('--detail', default='', help='optional path for a per-kernel-shape JSON breakdown')
-    ap.add_argument('--serving-frames', type=int, default=16, help='frames of the extra serving-throughput measurement (0 = skip)')
+    ap.add_argument('--serving-frames', type=int, default=16, help='frames of the extra serving-throughput measurement (0 = skip; frame config only)')
     ap.add_argument('--serving-in-flight', type=int, default=4, help='frames in flight per GPU in that measurement')
     return ap.parse_args()
 
@@ -53,9 +67,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f'bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks', file=sys.stderr)
-            sys.exit(2)
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run --nnodes=1 '
+              f'--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...` (one rank per GPU)', file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print('bench.py: no ROCm device visible; the codec has no CPU path', file=sys.stderr)
+        sys.exit(3)
     local = local % max(1, torch.cuda.device_count())      # (test mode: several ranks may share one GPU)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -72,36 +89,80 @@ def main():
 
     import pcgcv2_amd
     pcgcv2_amd.configure_host_threads()
-    from pcgcv2_amd import synthetic, ops
+    from pcgcv2_amd import synthetic, ops, shard
     from pcgcv2_amd.pcc_model import PCCModel
-    from pcgcv2_amd.coder import Coder
+    from pcgcv2_amd.coder import Coder, STREAMS
+    from pcgcv2_amd.data_utils import scale_sparse_tensor
+    from pcgcv2_amd.sparse import SparseTensor
     if args.irn_rows:
         ops.set_irn_rows(args.irn_rows)
-    from pcgcv2_amd.sparse import SparseTensor
 
-    # ---- inputs: one frame per rank (distinct clouds per rank, like the 8iVFB 4-sequence config) ----
-    variants = [args.workload] + [args.workload + s for s in ('_b', '_c', '_d') if args.workload + s in synthetic.SHELLS]
-    name = variants[rank % len(variants)]
-    pts = synthetic.shell(name, device=dev)
-    coords = torch.cat([torch.zeros((len(pts), 1), dtype=torch.int32, device=dev), pts], 1).contiguous()
-    feats = torch.ones((len(pts), 1), dtype=torch.float32, device=dev)
-    n_points = len(pts)
+    def cloud(name):
+        p = synthetic.shell(name, device=dev)
+        c = torch.cat([torch.zeros((len(p), 1), dtype=torch.int32, device=dev), p], 1).contiguous()
+        return SparseTensor(torch.ones((len(p), 1), dtype=torch.float32, device=dev), coordinates=c, tensor_stride=1, device=dev)
+
+    # ---- the units of one step (this rank's share) ----
+    cfg = args.config
+    base = args.workload or {'frame': 'shell10', 'batch4': 'shell10', 'sweep': 'shell11', 'blocks': 'shell12'}[cfg]
+    variants = [base] + [base + s for s in ('_b', '_c', '_d') if base + s in synthetic.SHELLS]
     sd = synthetic.synthetic_state_dict()
     model = PCCModel().to(dev)
     model.load_state_dict(sd)
+    rate_sds = None
+    if cfg == 'frame':                       # one frame per rank (distinct clouds per rank, like the 8iVFB 4-sequence config)
+        units = [(variants[rank % len(variants)], cloud(variants[rank % len(variants)]))]
+        scaling = 'weak'
+        desc = f'{base}: perturbed-sphere vox10 frame, 1 frame per GPU per step'
+    elif cfg == 'batch4':
+        mine = shard.shard_units(len(variants), rank, world)
+        units = [(variants[i], cloud(variants[i])) for i in mine]
+        scaling = 'strong'
+        desc = f'{"+".join(variants)}: 4-frame vox10 batch, frames round-robin over {world} GPU(s)'
+    elif cfg == 'sweep':
+        units = [(base, cloud(base))]                  # every rank sweeps its own copy of the frame (weak scaling)
+        rate_sds = [synthetic.synthetic_state_dict(gain=g) for g in SWEEP_GAINS]
+        scaling = 'weak'
+        desc = f'{base}: vox11 frame through {len(SWEEP_GAINS)} synthetic rates (latent gains {SWEEP_GAINS}), geometry maps shared by the rates'
+    else:
+        whole = cloud(base)
+        x_in = scale_sparse_tensor(whole, 0.375)                               # data_utils.py:112-118
+        blocks = shard.split_octants(x_in.C, levels=1)
+        mine = shard.shard_units(len(blocks), rank, world)
+        units = []
+        for i in mine:
+            c = x_in.C[torch.as_tensor(blocks[i], device=dev)]
+            units.append((f'b{i}', SparseTensor(torch.ones((len(c), 1), device=dev), coordinates=c, tensor_stride=1, device=dev, assume_unique=True)))
+        scaling = 'strong'
+        desc = (f'{base}: vox12 cloud ({len(whole)} points) scaled by 0.375 -> {len(x_in)} points, {len(blocks)} octant blocks '
+                f'round-robin over {world} GPU(s)')
+        del whole
+    n_points = sum(len(u) for _, u in units)
     tmp = tempfile.mkdtemp(prefix=f'pcgc_bench_r{rank}_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
-    coder = Coder(model, os.path.join(tmp, 'frame'))
+    coder = Coder(model, os.path.join(tmp, 'u'))
 
-    # The input sparse tensor is constructed once, like `load_sparse_tensor` in the reference (its dedup is part of the
-    # untimed "Loading Time", coder.py:127-129).  NOTHING derived from it survives a step: every cached level / kernel map /
-    # hash table is dropped before each encode, so each step rebuilds the whole geometry pyramid and all maps.
-    x = SparseTensor(feats, coordinates=coords, tensor_stride=1, device=dev)
-
-    def step():
-        x.cmap.drop_caches()
-        coder.encode(x)
-        out = coder.decode()
-        return out
+    def step(timers=None):
+        """one pass over this rank's units -> (decoded tensors); timers = [enc_s, dec_s] accumulators"""
+        outs = []
+        for name, x in units:
+            x.cmap.drop_caches()
+            rates = rate_sds if rate_sds is not None else [None]
+            for ri, rsd in enumerate(rates):
+                if rsd is not None:
+                    model.load_state_dict(rsd)
+                post = f'_{name}' + (f'_r{ri + 1}' if rsd is not None else '')
+                a = time.perf_counter()
+                coder.encode(x, postfix=post)
+                if timers is not None:
+                    torch.cuda.synchronize()
+                b = time.perf_counter()
+                outs.append(coder.decode(postfix=post))
+                if timers is not None:
+                    torch.cuda.synchronize()
+                    c = time.perf_counter()
+                    timers[0] += b - a
+                    timers[1] += c - b
+        return outs
 
     def barrier():
         torch.cuda.synchronize()
@@ -109,17 +170,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    outs = None
     for _ in range(args.warmup):
-        out = step()
+        outs = step()
     torch.cuda.synchronize()
-    # Untimed analysis passes (not counted as warmup): one step with EVERY gather launch bracketed by HIP events — that finds
-    # the dominant (kernel, level) and gives the all-launch aggregate — and one that counts the kernel-map pairs per level for
-    # the byte formula.  The timed region then brackets only the dominant kernel's launches (3 per step), so the event
-    # overhead (~0.6 ms per step with all 46 launches bracketed) stays out of `value`.
-    dominant, warm_all = None, None
-    if not args.no_events:
+    # Untimed analysis passes (not counted as warmup): one step with EVERY sparse-conv launch bracketed by HIP events — that
+    # finds the dominant (kernel, level) and gives the all-launch aggregate — and one that counts the kernel-map pairs per level
+    # for the byte / flop formulas.  The timed region then brackets only the dominant kernel's launches, so the event overhead
+    # (~0.6 ms per step with every launch bracketed) stays out of `value`.
+    dominant, warm_all, warm_detail, pairs = None, None, None, None
+    if not args.no_events and units:
         ops.PROFILE.reset(enabled=True)
-        out = step()
+        outs = step()
         ops.PROFILE.enabled = False
         ops.PROFILE.counting = True
         step()
@@ -129,114 +191,125 @@ def main():
         warm_all = ops.PROFILE.summary(HBM_PEAK_GBS, 1)
         warm_detail = ops.PROFILE.detail()
         pairs = dict(ops.PROFILE.pairs)
-    elif not args.warmup:
-        out = step()
+    elif outs is None:
+        outs = step()
     # Python's cyclic GC stays enabled, but the ~1e6 long-lived objects created by importing torch & friends are moved
     # to the permanent generation so that full collections do not re-traverse them (tens of ms each) mid-measurement.
     import gc
     gc.collect()
     gc.freeze()
-    n_out = len(out)
-    bits = sum(os.path.getsize(os.path.join(tmp, 'frame' + p)) * 8 for p in ('_C.bin', '_F.bin', '_H.bin', '_num_points.bin'))
+    n_out = sum(len(o) for o in outs)
+    n_coded = n_points * (len(rate_sds) if rate_sds is not None else 1)        # points through encode+decode per step
+    bits = 0
+    for f in os.listdir(tmp):
+        if f.endswith(STREAMS):
+            bits += os.path.getsize(os.path.join(tmp, f)) * 8
 
     # ---- timed region: exactly K steps, with the dominant kernel bracketed by HIP events on its own stream ----
     ops.PROFILE.reset(enabled=dominant is not None, only=dominant)
     if dominant is not None:
         ops.PROFILE.pairs = pairs
+    timers = [0.0, 0.0]
+    step_ms = []
     barrier()
     t0 = time.perf_counter()
-    enc_t = dec_t = 0.0
-    step_ms = []
     for _ in range(args.steps):
-        x.cmap.drop_caches()
         a = time.perf_counter()
-        coder.encode(x)
-        torch.cuda.synchronize()
-        b = time.perf_counter()
-        coder.decode()
-        torch.cuda.synchronize()
-        c = time.perf_counter()
-        enc_t += b - a; dec_t += c - b
-        step_ms.append(round((c - a) * 1e3, 2))
+        step(timers)
+        step_ms.append(round((time.perf_counter() - a) * 1e3, 2))
     barrier()
     elapsed = time.perf_counter() - t0
     ops.PROFILE.enabled = False
     torch.cuda.synchronize()
+    roof = ops.PROFILE.summary(HBM_PEAK_GBS, args.steps) if dominant is not None else None
+    if roof is not None and warm_all is not None:
+        roof['all_launches'] = dict(warm_all['all_launches'], measured='untimed analysis step before the timed region, every sparse-conv launch bracketed')
+
     # serving mode (reported beside the headline, never as `value`): several frames in flight per GPU — each on its own host
     # thread + HIP stream (shard.code_units(in_flight=F)) — so one frame's sequential host stages and small-level kernels
     # overlap with the other frames' GPU work.  Results are byte-identical to sequential coding (tests/test_gpu_parity.py).
     serving = None
-    if world == 1 and args.serving_frames > 0:
-        from pcgcv2_amd import shard
-        units = []
-        for i in range(args.serving_frames):         # distinct frame objects (4 cloud shapes cycling): nothing is shared
-            p_ = synthetic.shell(variants[i % len(variants)], device=dev)
-            c_ = torch.cat([torch.zeros((len(p_), 1), dtype=torch.int32, device=dev), p_], 1).contiguous()
-            units.append((f's{i}', SparseTensor(torch.ones((len(p_), 1), dtype=torch.float32, device=dev), coordinates=c_, tensor_stride=1, device=dev)))
+    if cfg == 'frame' and world == 1 and args.serving_frames > 0:
+        model.load_state_dict(sd)
+        s_units = [(f's{i}', cloud(variants[i % len(variants)])) for i in range(args.serving_frames)]
 
         def fresh(us):
             for _, u in us:
                 u.cmap.drop_caches()                 # no geometry survives between frames here either
             return us
-        shard.code_units(coder, fresh(units[:args.serving_in_flight]), in_flight=args.serving_in_flight)       # warm the worker path
+        shard.code_units(coder, fresh(s_units[:args.serving_in_flight]), in_flight=args.serving_in_flight)       # warm the worker path
         torch.cuda.synchronize()
-        n_s = sum(len(u) for _, u in units)
+        n_s = sum(len(u) for _, u in s_units)
         dt_s = float('inf')
-        for _ in range(2):                           # best of two passes: the figure is auxiliary and worker start-up (threads,
-            fresh(units)                             # streams, pinned staging buffers) occasionally lands inside a pass
+        for _ in range(2):                           # best of two passes: the figure is auxiliary
+            fresh(s_units)
             t_s = time.perf_counter()
-            shard.code_units(coder, units, in_flight=args.serving_in_flight)
+            shard.code_units(coder, s_units, in_flight=args.serving_in_flight)
             torch.cuda.synchronize()
             dt_s = min(dt_s, time.perf_counter() - t_s)
-        serving = {'frames_in_flight': args.serving_in_flight, 'frames': len(units), 'value': round(n_s / dt_s / 1e6, 3), 'unit': 'Mpoints/s',
-                   'note': 'throughput over independent vox10 frames coded concurrently on one GPU (own thread + HIP stream each), best of 2 passes; '
+        serving = {'frames_in_flight': args.serving_in_flight, 'frames': len(s_units), 'value': round(n_s / dt_s / 1e6, 3), 'unit': 'Mpoints/s',
+                   'note': 'independent vox10 frames coded concurrently on one GPU (own thread + HIP stream each), best of 2 passes; '
                            'the headline `value` is the single-frame-at-a-time rate'}
+        del s_units
+
     # the coordinate-coder stage on its own (report with and without it).  Inside a step it runs on a helper
     # thread concurrently with the GPU, so it adds nothing to ms_per_step unless it outlasts the work it hides behind.
-    from pcgcv2_amd import gpcc
-    c8 = gpcc.native_decode(os.path.join(tmp, 'frame_C.bin'))
-    t_c = time.perf_counter(); gpcc.native_encode(c8, os.path.join(tmp, 'probe_C.bin')); t_c1 = time.perf_counter()
-    gpcc.native_decode(os.path.join(tmp, 'probe_C.bin')); t_c2 = time.perf_counter()
-    coord_ms = {'encode': round((t_c1 - t_c) * 1e3, 3), 'decode': round((t_c2 - t_c1) * 1e3, 3), 'points': int(len(c8)),
-                'note': 'host octree coder alone; overlapped with GPU work inside a step'}
+    coord_ms = None
+    if units:
+        from pcgcv2_amd import gpcc
+        first = [f for f in sorted(os.listdir(tmp)) if f.endswith('_C.bin')][0]
+        c8 = gpcc.native_decode(os.path.join(tmp, first))
+        t_c = time.perf_counter(); gpcc.native_encode(c8, os.path.join(tmp, 'probe_C.bin')); t_c1 = time.perf_counter()
+        gpcc.native_decode(os.path.join(tmp, 'probe_C.bin')); t_c2 = time.perf_counter()
+        coord_ms = {'encode': round((t_c1 - t_c) * 1e3, 3), 'decode': round((t_c2 - t_c1) * 1e3, 3), 'points': int(len(c8)),
+                    'note': 'host octree coder alone (one unit); overlapped with GPU work inside a step'}
 
+    enc_t, dec_t = timers
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        t = torch.tensor([elapsed, enc_t, dec_t], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([float(n_points), float(n_out), float(bits)], dtype=torch.float64, device=red_dev)
+        elapsed, enc_t, dec_t = [float(v) for v in t.tolist()]
+        tot = torch.tensor([float(n_coded), float(n_out), float(bits), float(n_points)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_points, total_out, total_bits = [float(v) for v in tot.tolist()]
+        total_coded, total_out, total_bits, total_points = [float(v) for v in tot.tolist()]
     else:
-        total_points, total_out, total_bits = float(n_points), float(n_out), float(bits)
+        total_coded, total_out, total_bits, total_points = float(n_coded), float(n_out), float(bits), float(n_points)
 
-    # quality of this rank's frame (outside the timed region, as coder.py:180-182): D1 on the GPU
-    from pcgcv2_amd.pc_error import d1_psnr_device
-    d1 = d1_psnr_device(x.C, out.C, 1024)
-    roof = ops.PROFILE.summary(HBM_PEAK_GBS, args.steps) if dominant is not None else None
-    if roof is not None and warm_all is not None:
-        # every-launch aggregate: from the untimed analysis step (all 46 gather launches bracketed), not from the timed region
-        roof['all_gather_launches'] = dict(warm_all['all_gather_launches'], measured='untimed analysis step before the timed region, every gather launch bracketed')
+    # quality of this rank's first unit (outside the timed region, as coder.py:180-182): D1 on the GPU
+    d1 = None
+    if units and cfg != 'blocks':
+        from pcgcv2_amd.pc_error import d1_psnr_device
+        d1 = d1_psnr_device(units[0][1].C, outs[0].C, {'shell11': 2048, 'shell12': 4096}.get(base, 1024))
     if rank == 0:
-        value = total_points * args.steps / elapsed / 1e6
+        value = total_coded * args.steps / elapsed / 1e6
+        nbar = None
+        if roof is not None:
+            nbar = round(roof['pairs'] / roof['n_out'], 2)
         line = {
             'metric': 'encode+decode Mpoints/sec at fixed bpp (r3 ckpt), vox10 frame',
             'value': round(value, 4), 'unit': 'Mpoints/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': scaling,
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{args.workload}: perturbed-sphere vox10 frame, {n_points} points/GPU, synthetic r3 stand-in '
-                                   f'weights (seed 1234, gain 50), 1 frame per GPU per step, encode+decode incl. bitstream files',
-                       'points_per_gpu': n_points, 'enc_ms': round(enc_t / args.steps * 1e3, 3),
-                       'dec_ms': round(dec_t / args.steps * 1e3, 3), 'bpp': round(total_bits / total_points, 5),
-                       'points_out': int(total_out), 'coord_codec': 'native-octree (tmc3 absent)', 'coord_coder_ms': coord_ms, 'serving_throughput': serving, 'step_ms_rank0': step_ms,
-                       'd1_psnr_rank0_db': round(d1['mseF,PSNR (p2point)'], 4), 'd1_note': 'synthetic random weights: the value only shows the metric path runs'},
+            'config': {'workload': f'{cfg}: {desc}; synthetic r3 stand-in weights (seed 1234, gain 50), encode+decode incl. bitstream files',
+                       'baseline_config': {'frame': 2, 'batch4': 3, 'sweep': 4, 'blocks': 5}[cfg],
+                       'points_in_per_step_all_gpus': int(total_points), 'points_coded_per_step_all_gpus': int(total_coded),
+                       'enc_ms': round(enc_t / args.steps * 1e3, 3), 'dec_ms': round(dec_t / args.steps * 1e3, 3),
+                       'enc_plus_dec_s_per_step': round((enc_t + dec_t) / args.steps, 4),
+                       'bpp': round(total_bits / max(total_coded, 1), 5), 'points_out': int(total_out),
+                       'coord_codec': 'native-octree (tmc3 absent)', 'coord_coder_ms': coord_ms, 'serving_throughput': serving,
+                       'step_ms_rank0': step_ms,
+                       'd1_psnr_rank0_db': None if d1 is None else round(d1['mseF,PSNR (p2point)'], 4),
+                       'caveats': 'synthetic random weights: the decoder keeps the wrong voxels, so D1 only shows that the metric path runs, and bpp '
+                                  '(~1.0) is ~11x the 0.093 of the real r3 checkpoint; the mean kernel-map occupancy of the dominant level is '
+                                  f'{nbar} neighbours per row here against 18.7 probed for true geometry (SURVEY 8d) — a real checkpoint would see '
+                                  '~20 % more pairs on the stride-1 level'},
             'roofline': roof,
         }
         if roof is not None:
             attach_pmc_traffic(roof)
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(args.cpu_sample, sd)
-        if args.detail and warm_all is not None:
+            line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_sample or base, sd)
+        if args.detail and warm_detail is not None:
             with open(args.detail, 'w') as f:
                 json.dump(warm_detail, f, indent=1)
         print(json.dumps(line), flush=True)
@@ -247,8 +320,8 @@ def main():
 def attach_pmc_traffic(roof):
     """`traffic`: HBM bytes per launch of the dominant kernel from rocprofv3 PMC counters (FETCH_SIZE and WRITE_SIZE in
     separate passes; FETCH_SIZE doubled for 16-byte-per-lane reads as MI355X_MICROARCH.md prescribes for gfx950).  The
-    counters cannot be read from inside the process, so they come from the committed collection of the same command
-    (tools/pmc_traffic.sh -> profiles/pmc_traffic.json); null if no entry matches the dominant kernel + shape."""
+    counters cannot be read from inside the process: the figure is REPLAYED from the committed collection of the same command
+    (tools/pmc_traffic.sh -> profiles/pmc_traffic.json), not measured in this run; null if no entry matches."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if not os.path.exists(path):
         return
@@ -256,28 +329,33 @@ def attach_pmc_traffic(roof):
         table = json.load(open(path))
     except ValueError:
         return
+    short = roof['kernel'].split(' ')[0]
     for e in table.get('kernels', []):
-        rows = e.get('grid_rows', roof['n_out'])
-        if e['kernel'] == roof['kernel'] and (abs(rows - roof['n_out']) < 256 or abs(rows - 4 * ((roof['n_out'] + 127) // 128) * 64) < 512):
-            roof['traffic'] = e['hbm_bytes_per_launch']
-            # what actually crossed to HBM per launch / the measured launch time: the algorithmic rate above can exceed the HBM peak
-            # because the L2 / Infinity Cache serve the ~18x row re-use of a gather
-            roof['traffic_rate'] = {'GBps': round(e['hbm_bytes_per_launch'] / (roof['avg_launch_us'] * 1e-6) / 1e9, 1),
-                                    'frac_of_peak': round(e['hbm_bytes_per_launch'] / (roof['avg_launch_us'] * 1e-6) / 1e9 / roof['peak'], 4)}
-            roof['traffic_detail'] = {k: e[k] for k in ('fetch_bytes_raw', 'fetch_bytes_corrected', 'write_bytes', 'source') if k in e}
-            return
+        if not e['kernel'].replace('(anonymous namespace)::', '').startswith(short.split('>')[0]):
+            continue
+        if e.get('launches_per_step_shape') not in (None, roof['n_out']) and abs(e.get('rows', roof['n_out']) - roof['n_out']) > 512:
+            continue
+        roof['traffic'] = e['hbm_bytes_per_launch']
+        roof['traffic_source'] = 'replayed from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command); not measured in this run'
+        roof['traffic_rate'] = {'GBps': round(e['hbm_bytes_per_launch'] / (roof['avg_launch_us'] * 1e-6) / 1e9, 1),
+                                'frac_of_hbm_peak': round(e['hbm_bytes_per_launch'] / (roof['avg_launch_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        roof['traffic_detail'] = {k: e[k] for k in ('kernel', 'fetch_bytes_raw', 'fetch_bytes_corrected', 'write_bytes', 'source') if k in e}
+        return
 
 
-def cpu_baseline(sample, sd):
-    """The CPU oracle (oracle/: C restatement, OpenMP over output rows) on a bounded sample of the same workload, with all
-    the cores the container may use and — on a smaller sample — with one thread (SURVEY §8d asks for both).
-    kind = "port": MinkowskiEngine's CPU backend cannot be installed here (no network, un-vendored)."""
+def cpu_baseline(cfg, sample, sd):
+    """The CPU oracle (oracle/: C restatement, OpenMP over output rows) on the bench workload itself — one encode+decode of the
+    same cloud with all the cores the container may use — and a one-thread figure on a smaller cloud (SURVEY §8d asks for both).
+    kind = "port": MinkowskiEngine's CPU backend cannot be installed here (no network, un-vendored).  For the multi-unit
+    configs the sample is one unit (one frame / the unscaled cloud's first block-sized piece is not split: the frame itself)."""
     import pcgcv2_amd
     from pcgcv2_amd import synthetic
     cores = pcgcv2_amd.effective_cpus()                     # cgroup quota, not os.cpu_count()
     os.environ['OMP_NUM_THREADS'] = str(cores)
     from oracle import pcgc_oracle as orc
     sd_np = synthetic.state_dict_to_numpy(sd)
+    if cfg in ('sweep', 'blocks'):
+        sample = 'shell10'                                  # bounded: one vox10 frame (~4 s); the vox11/12 clouds would take 15-30 s per rate / block set
 
     def run(name, threads):
         orc.set_threads(threads)
@@ -291,12 +369,13 @@ def cpu_baseline(sample, sd):
         return len(c4), dt
 
     n, dt = run(sample, cores)
-    n1, dt1 = run('shell8', 1)
+    small = 'shell9' if sample in ('shell10', 'shell11', 'shell12') else 'shell7'
+    n1, dt1 = run(small, 1)
     orc.set_threads(cores)
     return {'value': round(n / dt / 1e6, 5), 'unit': 'Mpoints/s', 'cores': cores, 'kind': 'port',
             'sample': f'{sample} ({n} points, one encode+decode, {dt:.1f} s; oracle C restatement, OpenMP threads = the container CPU quota; '
                       'NOT MinkowskiEngine-CPU)',
-            'one_thread': {'value': round(n1 / dt1 / 1e6, 5), 'sample': f'shell8 ({n1} points, one encode+decode, {dt1:.1f} s)'}}
+            'one_thread': {'value': round(n1 / dt1 / 1e6, 5), 'sample': f'{small} ({n1} points, one encode+decode, {dt1:.1f} s)'}}
 
 
 if __name__ == '__main__':

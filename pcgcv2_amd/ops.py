@@ -49,12 +49,33 @@ def _ld(t):
 
 
 # ------------------------------------------------------------------------------------------------ profiling hook
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 MFMA peak
+_CHILD_WEIGHT = None
+
+
+def child_pairs(parent_nbr):
+    """(in,out) pairs of the CHILDREN level's k3 map, counted from the parent map (the children map is never built): a present
+    parent neighbour at offset kp contributes as many (child row, offset) pairs as halo cells of that parent are reached:
+    64 for the centre, 16 per face, 4 per edge, 1 per corner neighbour."""
+    global _CHILD_WEIGHT
+    if _CHILD_WEIGHT is None or _CHILD_WEIGHT.device != parent_nbr.device:
+        w = np.zeros(27, np.int64)
+        for kp, jc, reach in _halo_cells():
+            w[kp] += len(reach)
+        _CHILD_WEIGHT = torch.from_numpy(w).to(parent_nbr.device)
+    return int(((parent_nbr >= 0).sum(1) * _CHILD_WEIGHT).sum().item())
+
+
 class _Profile:
-    """Brackets the gather kernels with HIP events on the stream they are launched on, and turns the timings into the
-    `roofline` object of bench.py.  Algorithmic bytes per launch follow SURVEY.md §8d with P = kernel-map pairs of the level
-    (counted from the map):   k3 conv: P*Cin*4 (gathered rows) + P*8 (int32 in/out pair indices) + N*Cout*4 (output rows);
-    k1 conv: N*(Cin+Cout)*4.  A fused InceptionResNet pass is charged the sum of the convs it computes:
-        pass A (k_irn_a<C>): k3 C->C/4  +  k1 C->C/4           pass B (k_irn_b<C>): k3 C/4->C/2 + k3 C/4->C/4 + k1 C/4->C/2."""
+    """Brackets the sparse-conv launches with HIP events on the stream they are launched on, and turns the timings into the
+    `roofline` object of bench.py.  Per launch, with P = (in,out) pairs of the level's k3 map (counted, not assumed), n rows:
+        gathered bytes      k3 conv: P*Cin*4 + P*8 + n*Cout*4 ;  k1 conv: n*(Cin+Cout)*4 — every (in,out) pair
+                         charged: the re-use of a row by its ~18 outputs is served by L2 / LDS, so this rate can exceed the HBM peak
+        compulsory bytes                   every input row, kernel-map entry and output row once: what HBM has to move
+        flops                              2*P*Cin*Cout (+ 2*n*Cin*Cout for k1 parts)
+        mfma_issued                        fp32 MFMA flops the kernel issues (zero-padded columns and absent rows included)
+    A fused InceptionResNet pass is charged the sum of the convs it computes:
+        pass A: k3 C->C/4 + k1 C->C/4          pass B: k3 C/4->C/2 + k3 C/4->C/4 + k1 C/4->C/2."""
 
     def __init__(self):
         self.reset(False)
@@ -63,7 +84,7 @@ class _Profile:
         self.enabled = enabled
         self.only = only           # bracket just this (kernel, shape) key: keeps the event overhead out of a timed region
         self.counting = False
-        self.records = {}          # key -> dict(kernel, n, bytes(P), flops(P), events=[(e0,e1)])
+        self.records = {}          # key -> dict(kernel, n, formulas, events=[(e0,e1)])
         self.pairs = {}            # n_out -> P of the level's k3 map
 
     def want(self, key):
@@ -78,9 +99,10 @@ class _Profile:
                 best, best_ms = key, ms
         return best
 
-    def bracket(self, key, kernel, n, bytes_fn, flops_fn):
+    def bracket(self, key, kernel, n, gathered, flops, compulsory=None, mfma_issued=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        r = self.records.setdefault(key, {'kernel': kernel, 'n': n, 'bytes': bytes_fn, 'flops': flops_fn, 'events': []})
+        r = self.records.setdefault(key, {'kernel': kernel, 'n': n, 'gathered': gathered, 'flops': flops, 'compulsory': compulsory,
+                                          'mfma_issued': mfma_issued, 'events': []})
         r['events'].append((e0, e1))
         return e0, e1
 
@@ -89,37 +111,69 @@ class _Profile:
         if n not in self.pairs:
             self.pairs[n] = int((nbr >= 0).sum().item())
 
+    def count_children(self, parent_nbr):
+        n = 8 * parent_nbr.shape[1]
+        if n not in self.pairs:
+            self.pairs[n] = child_pairs(parent_nbr)
+
     def detail(self):
         out = []
         for key, r in self.records.items():
             ms = sum(e0.elapsed_time(e1) for e0, e1 in r['events'])
-            d = {'kernel': r['kernel'], 'n_out': r['n'], 'launches': len(r['events']), 'ms': ms, 'avg_us': ms / len(r['events']) * 1e3}
+            us = ms / len(r['events']) * 1e3
+            d = {'kernel': r['kernel'], 'n_out': r['n'], 'launches': len(r['events']), 'ms': ms, 'avg_us': us}
             P = self.pairs.get(r['n'])
             if P is not None:
                 d['pairs'] = P
-                d['alg_bytes_per_launch'] = r['bytes'](P)
-                d['flops_per_launch'] = r['flops'](P)
-                d['GBps'] = d['alg_bytes_per_launch'] / (d['avg_us'] * 1e-6) / 1e9
-                d['TFLOPs'] = d['flops_per_launch'] / (d['avg_us'] * 1e-6) / 1e12
+                d['gathered_bytes'] = r['gathered'](P)
+                d['flops'] = r['flops'](P)
+                d['gathered_GBps'] = d['gathered_bytes'] / (us * 1e-6) / 1e9
+                d['TFLOPs'] = d['flops'] / (us * 1e-6) / 1e12
+                if r['compulsory'] is not None:
+                    d['compulsory_bytes'] = r['compulsory']
+                    d['compulsory_GBps'] = r['compulsory'] / (us * 1e-6) / 1e9
+                if r['mfma_issued'] is not None:
+                    d['mfma_issued_flops'] = r['mfma_issued']
+                    d['mfma_issued_TFLOPs'] = r['mfma_issued'] / (us * 1e-6) / 1e12
             out.append(d)
         return sorted(out, key=lambda d: -d['ms'])
 
     def summary(self, peak_gbs, steps):
-        """`achieved` = the heaviest (kernel, shape) by total time; `all_gather_launches` aggregates every bracketed launch."""
+        """roofline of the heaviest (kernel, shape) by total time; `all_launches` aggregates every bracketed launch.
+        `bound` is the roofline the kernel sits closer to: "mfma" (algorithmic fp32 flops against the dense fp32 MFMA peak) or
+        "hbm" (compulsory bytes against the HBM peak).  The other one and the cache-served gathered-bytes rate ride along."""
         d = [r for r in self.detail() if 'pairs' in r]
         if not d:
             return None
         top = d[0]
-        tot_bytes = sum(r['alg_bytes_per_launch'] * r['launches'] for r in d)
+        hbm_frac = top.get('compulsory_GBps', 0.0) / peak_gbs
+        mfma_frac = top['TFLOPs'] / MFMA_F32_PEAK_TFLOPS
+        is_mfma = 'mfma_issued_flops' in top and mfma_frac >= hbm_frac
+        roof = {'bound': 'mfma' if is_mfma else 'hbm'}
+        if is_mfma:
+            roof.update(achieved=round(top['TFLOPs'], 2), peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s', frac=round(mfma_frac, 4))
+        else:
+            roof.update(achieved=round(top.get('compulsory_GBps', 0.0), 2), peak=peak_gbs, unit='GB/s', frac=round(hbm_frac, 4))
+        roof.update(traffic=None, kernel=top['kernel'], n_out=top['n_out'], pairs=top['pairs'], avg_launch_us=round(top['avg_us'], 2),
+                    launches_timed=top['launches'],
+                    algorithmic={'flops_per_launch': top['flops'], 'TFLOPs': round(top['TFLOPs'], 2), 'frac_of_fp32_mfma_peak': round(mfma_frac, 4),
+                                 'compulsory_bytes_per_launch': top.get('compulsory_bytes'), 'compulsory_GBps': round(top.get('compulsory_GBps', 0.0), 1),
+                                 'frac_of_hbm_peak': round(hbm_frac, 4),
+                                 'gathered_bytes_per_launch': top['gathered_bytes'], 'gathered_GBps': round(top['gathered_GBps'], 1),
+                                 'gathered_note': 'SURVEY 8d formula: every (in,out) pair charged; the row re-use is served by L2/LDS, not HBM'})
+        if 'mfma_issued_flops' in top:
+            roof['mfma_issued'] = {'flops_per_launch': top['mfma_issued_flops'], 'TFLOPs': round(top['mfma_issued_TFLOPs'], 2),
+                                   'pipe_utilisation': round(top['mfma_issued_TFLOPs'] / MFMA_F32_PEAK_TFLOPS, 4),
+                                   'note': 'fp32 MFMA instructions issued x 2048 flop (zero-padded columns and absent rows included) / time'}
+        tot_g = sum(r['gathered_bytes'] * r['launches'] for r in d)
+        tot_c = sum(r.get('compulsory_bytes', 0) * r['launches'] for r in d)
+        tot_f = sum(r['flops'] * r['launches'] for r in d)
         tot_ms = sum(r['ms'] for r in d)
-        ach = top['GBps']
-        return {'bound': 'hbm', 'achieved': round(ach, 2), 'peak': peak_gbs, 'unit': 'GB/s', 'frac': round(ach / peak_gbs, 4),
-                'traffic': None, 'kernel': top['kernel'], 'n_out': top['n_out'], 'pairs': top['pairs'],
-                'alg_bytes_per_launch': top['alg_bytes_per_launch'], 'avg_launch_us': round(top['avg_us'], 2),
-                'launches_timed': top['launches'], 'tflops_fp32': round(top['TFLOPs'], 2),
-                'all_gather_launches': {'achieved': round(tot_bytes / (tot_ms * 1e-3) / 1e9, 2),
-                                        'frac': round(tot_bytes / (tot_ms * 1e-3) / 1e9 / peak_gbs, 4),
-                                        'ms_per_step': round(tot_ms / steps, 3), 'launches_per_step': sum(r['launches'] for r in d) // steps}}
+        roof['all_launches'] = {'ms_per_step': round(tot_ms / steps, 3), 'launches_per_step': sum(r['launches'] for r in d) // steps,
+                                'TFLOPs': round(tot_f / (tot_ms * 1e-3) / 1e12, 2), 'frac_of_fp32_mfma_peak': round(tot_f / (tot_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                'compulsory_GBps': round(tot_c / (tot_ms * 1e-3) / 1e9, 1), 'frac_of_hbm_peak': round(tot_c / (tot_ms * 1e-3) / 1e9 / peak_gbs, 4),
+                                'gathered_GBps': round(tot_g / (tot_ms * 1e-3) / 1e9, 1)}
+        return roof
 
 
 PROFILE = _Profile()
@@ -323,9 +377,12 @@ def conv_gather(nbr, x, W, bias, out=None, residual=None, relu=False, n_out=None
     res_p, res_ld = (None, 0) if residual is None else (_p(_f32(residual)), _ld(residual))
     prof = K == 27 and PROFILE.want(('conv', Cin, Cout, n_out))
     if prof:
-        e0, e1 = PROFILE.bracket(('conv', Cin, Cout, n_out), f'k3 gather conv Cin={Cin} Cout={Cout} (k_conv_gather_mfma/dma)', n_out,
+        mfma = Cin in (16, 32, 64) and Cout in (16, 32, 64) and n_out >= 8192
+        e0, e1 = PROFILE.bracket(('conv', Cin, Cout, n_out), f'k3 gather conv Cin={Cin} Cout={Cout} (k_conv_gather_mfma*/dma, per-row gather)', n_out,
                                  lambda P, a=Cin, b=Cout, n=n_out: P * a * 4 + P * 8 + n * b * 4,
-                                 lambda P, a=Cin, b=Cout: 2 * P * a * b)
+                                 lambda P, a=Cin, b=Cout: 2 * P * a * b,
+                                 compulsory=x.shape[0] * Cin * 4 + 27 * n_out * 4 + n_out * Cout * 4,
+                                 mfma_issued=(2 * 27 * ((n_out + 15) // 16 * 16) * Cin * Cout) if mfma else None)
         e0.record()
     check(lib().pcgc_conv_gather(_p(nbr), K, n_out, _p(x), x.shape[0], Cin, _ld(x), 0, _p(W), _p(bias), res_p, res_ld, 0, int(relu),
                                  _p(out), Cout, _ld(out), 0, _stream(nbr)), 'conv_gather')
@@ -379,6 +436,16 @@ def _irn_rows(n):
 FUSE_IRN = True           # tests flip this to compare the fused block against its five-conv composition
 
 
+def _irn_pass_formulas(n, C, map_bytes, names):
+    """[(pass, name, gathered_bytes(P), flops(P), compulsory_bytes)] of the two fused InceptionResNet passes on n rows."""
+    Q = C // 4
+    return ((1, names[0], lambda P: (P * C * 4 + P * 8 + n * Q * 4) + n * (C + Q) * 4, lambda P: 2 * P * C * Q + 2 * n * C * Q,
+             n * C * 4 + map_bytes + n * 2 * Q * 4),
+            (2, names[1], lambda P: (P * Q * 4 + P * 8 + n * 2 * Q * 4) + (P * Q * 4 + P * 8 + n * Q * 4) + n * 3 * Q * 4,
+             lambda P: 2 * P * Q * 2 * Q + 2 * P * Q * Q + 2 * n * Q * 2 * Q,
+             n * 2 * Q * 4 + map_bytes + n * C * 4 + n * C * 4))
+
+
 def irn_block(nbr, x, params):
     """Fused InceptionResNet block; params = [conv0_0.kernel, .bias, conv0_1.kernel, .bias, conv1_0..., conv1_1..., conv1_2...]."""
     import ctypes
@@ -395,13 +462,11 @@ def irn_block(nbr, x, params):
         check(lib().pcgc_irn_block(_p(nbr), n, _p(x), C, _ld(x), arr, _p(t), _p(out), C, _stream(nbr)), 'irn_block')
         return out
     Q = C // 4
-    passes = ((1, name_a, lambda P, n=n: (P * C * 4 + P * 8 + n * Q * 4) + n * (C + Q) * 4, lambda P, n=n: 2 * P * C * Q + 2 * n * C * Q),
-              (2, f'k_irn_b<{C}, {R}>', lambda P, n=n: (P * Q * 4 + P * 8 + n * 2 * Q * 4) + (P * Q * 4 + P * 8 + n * Q * 4) + n * 3 * Q * 4,
-               lambda P, n=n: 2 * P * Q * 2 * Q + 2 * P * Q * Q + 2 * n * Q * 2 * Q))
-    for ps, name, bf, ff in passes:
+    passes = _irn_pass_formulas(n, C, 27 * n * 4, (name_a, f'k_irn_b<{C}, {R}>'))
+    for ps, name, bf, ff, comp in passes:
         prof = PROFILE.want((name, n))
         if prof:
-            e0, e1 = PROFILE.bracket((name, n), name, n, bf, ff)
+            e0, e1 = PROFILE.bracket((name, n), name + ' (per-row gather, VALU)', n, bf, ff, compulsory=comp)
             e0.record()
         check(lib().pcgc_irn_pass(_p(nbr), n, _p(x), C, _ld(x), arr, _p(t), _p(out), C, ps, _stream(nbr)), 'irn_pass')
         if prof:
@@ -449,10 +514,13 @@ def irn_block_mfma64(nbr, x, f):
          lambda P: 2 * P * Q * 2 * Q + 2 * P * Q * Q + 2 * n * Q * 2 * Q,
          lambda: lib().pcgc_conv_gather_masked(_p(nbr), n, _p(t), n, 32, 32, _p(f['Wb']), 48, _p(f['mask_b']), _p(f['bb']), 0, _p(u), 48, _stream(nbr))),
     )
+    comp = {'k_conv_gather_mfma_wlds<64, 32, 2>': n * 64 * 4 + 27 * n * 4 + n * 32 * 4, 'k_conv_gather_mfma_wlds<32, 48, 2>': n * 32 * 4 + 27 * n * 4 + n * 48 * 4}
+    n16 = (n + 15) // 16 * 16                                 # MFMAs issued: pass A 4 blocks x (1 tile, +1 at the centre offset), pass B 2 blocks x (2 + 1 tiles)
+    issued = {'k_conv_gather_mfma_wlds<64, 32, 2>': 2 * n16 * 16 * 16 * 4 * (27 + 1), 'k_conv_gather_mfma_wlds<32, 48, 2>': 2 * n16 * 16 * 16 * 27 * 3}
     for name, bf, ff, call in steps:
         prof = PROFILE.want((name, n))
         if prof:
-            e0, e1 = PROFILE.bracket((name, n), name, n, bf, ff)
+            e0, e1 = PROFILE.bracket((name, n), name + ' (block-sparse per-row gather)', n, bf, ff, compulsory=comp[name], mfma_issued=issued[name])
             e0.record()
         check(call(), 'conv_gather_masked')
         if prof:
@@ -521,9 +589,10 @@ def child_conv_table(W):
 def _fragment(col_weights, NB, KS=4, k0=0, half=False):
     """One B fragment per 16-channel block from `col_weights`: a list of 16 (8 if half) columns, each None (zero column) or an
     array [Cin_rows] giving that column's weight per input channel.  Layout [cb][lane = mq*16 + mi (mq*8 + mi if half)][jj]:
-    value = column mi at input channel 16 cb + 4 (k0 + jj) + mq."""
+    value = column mi at input channel 16 cb + 4 (k0 + jj) + mq.  Entries nothing maps to are -1 (the builders below run on
+    INDEX-valued weights: each "weight" is its own position in the flat parameter vector, so the result is a gather index)."""
     ncol = 8 if half else 16
-    out = np.zeros((NB, 4, ncol, KS), np.float32)
+    out = np.full((NB, 4, ncol, KS), -1, np.int64)
     for mi, w in enumerate(col_weights):
         if w is None:
             continue
@@ -536,26 +605,46 @@ def _fragment(col_weights, NB, KS=4, k0=0, half=False):
     return out.reshape(NB, -1)
 
 
-def child_cls_table(W):
-    """Table of the classification head (k3 conv C -> 1) for pcgc_conv_child: one half fragment per halo cell; column j = child j,
-    holding kernel[k(cell, j)][:, 0] where child j reaches the cell, zero elsewhere."""
-    Wn = W.detach().cpu().numpy().astype(np.float32)
-    NB = Wn.shape[1] // 16
+_TABLE_INDEX = {}          # (kind, C, device) -> int64 gather index (-1 = zero) into the flat parameter vector
+
+
+def _gather_table(index, flat):
+    return torch.where(index >= 0, flat[index.clamp(min=0)], torch.zeros((), dtype=flat.dtype, device=flat.device)).contiguous()
+
+
+def _cls_index(C):
+    W = np.arange(27 * C, dtype=np.int64).reshape(27, C, 1)
     frags = []
     for kp, jc, reach in _halo_cells():
         cols = [None] * 8
         for j, k in reach:
-            cols[j] = Wn[k][:, 0]
-        frags.append(_fragment(cols, NB, half=True))
-    return torch.from_numpy(np.concatenate([f.reshape(-1) for f in frags])).to(W.device)
+            cols[j] = W[k][:, 0]
+        frags.append(_fragment(cols, C // 16, half=True))
+    return np.concatenate([f.reshape(-1) for f in frags])
 
 
-def child_irn_tables(params):
-    """(table A, table B) of the parent-map InceptionResNet passes (C = 16 or 32); params as in irn_block.  The fragment order is
-    the one csrc/child.hip's PassA / PassB variants index (frag())."""
-    W00, b00, W01, b01, W10, b10, W11, b11, W12, b12 = [p.detach().cpu().numpy().astype(np.float32) for p in params]
-    C = W00.shape[1]
+def child_cls_table(W):
+    """Table of the classification head (k3 conv C -> 1) for pcgc_conv_child: one half fragment per halo cell; column j = child j,
+    holding kernel[k(cell, j)][:, 0] where child j reaches the cell, zero elsewhere.  Built by one device gather through a
+    cached index (the geometry is static)."""
+    C = W.shape[1]
+    key = ('cls', C, W.device)
+    if key not in _TABLE_INDEX:
+        _TABLE_INDEX[key] = torch.from_numpy(_cls_index(C)).to(W.device)
+    return _gather_table(_TABLE_INDEX[key], W.detach().reshape(-1))
+
+
+def _irn_index(C):
+    """Gather indices (into cat(W00, W01, W10, W11, W12) flattened) of the two pass tables; the fragment order is the one
+    csrc/child_kernels.h's PassA / PassB variants index (frag())."""
     Q, NB = C // 4, C // 16
+    shapes = [(27, C, Q), (27, Q, 2 * Q), (C, Q), (27, Q, Q), (Q, 2 * Q)]
+    off, Ws = 0, []
+    for shp in shapes:
+        n = int(np.prod(shp))
+        Ws.append(np.arange(off, off + n, dtype=np.int64).reshape(shp))
+        off += n
+    W00, W01, W10, W11, W12 = Ws
     cpt = 16 // Q                                             # children per Q-wide tile: 4 (C=16) or 2 (C=32)
 
     def packed(Wk3, width, kz, ky, cy, cx):
@@ -597,7 +686,7 @@ def child_irn_tables(params):
     KS = Q // 4
     H = 2 * Q
     fb = []
-    pad = lambda w, lo: np.concatenate([np.zeros(lo, np.float32), w])            # place a Q-vector at channel offset lo of the 2Q row
+    pad = lambda w, lo: np.concatenate([np.full(lo, -1, np.int64), w])          # place a Q-vector at channel offset lo of the 2Q row
     if H == 16:                                                # C = 32: conv0_1 tile = one child, 16 columns
         for k in range(27):
             fb.append(_fragment([W01[k][:, co] for co in range(16)], 1, KS=KS, k0=0))
@@ -619,8 +708,21 @@ def child_irn_tables(params):
                     fb.append(_fragment(packed(W11p, Q, kz, None, cy, cx), 1, KS=KS, k0=KS))
     fb.append(_fragment([W12[:, co] if co < H else None for co in range(16)], 1, KS=KS, k0=0))     # conv1_2 (k1 Q -> 2Q)
     table_b = np.concatenate([f.reshape(-1) for f in fb])
-    dev = params[0].device
-    return torch.from_numpy(table_a).to(dev), torch.from_numpy(table_b).to(dev)
+    return table_a, table_b
+
+
+def child_irn_tables(params):
+    """(table A, table B) of the parent-map InceptionResNet passes (C = 16 or 32); params as in irn_block.  Two device gathers
+    through cached indices: cheap enough to redo whenever a checkpoint is loaded (R-D sweeps load one per rate)."""
+    W00, b00, W01, b01, W10, b10, W11, b11, W12, b12 = params
+    C = W00.shape[1]
+    key = ('irn', C, W00.device)
+    if key not in _TABLE_INDEX:
+        ia, ib = _irn_index(C)
+        _TABLE_INDEX[key] = (torch.from_numpy(ia).to(W00.device), torch.from_numpy(ib).to(W00.device))
+    flat = torch.cat([w.detach().reshape(-1) for w in (W00, W01, W10, W11, W12)])
+    ia, ib = _TABLE_INDEX[key]
+    return _gather_table(ia, flat), _gather_table(ib, flat)
 
 
 def irn_block_child(parent_nbr, x, params, tables):
@@ -635,10 +737,25 @@ def irn_block_child(parent_nbr, x, params, tables):
     out = torch.empty((n, C), dtype=torch.float32, device=x.device)
     P = [p.data_ptr() for p in params]
     s = _stream(x)
-    check(lib().pcgc_irn_child_pass(_p(parent_nbr), n_p, C, 1, _p(x), _ld(x), _p(ta), ta.numel() * 4, P[1], P[5], None, None, 0,
-                                    _p(t), C // 2, s), 'irn_child_pass A')
-    check(lib().pcgc_irn_child_pass(_p(parent_nbr), n_p, C, 2, _p(t), C // 2, _p(tb), tb.numel() * 4, P[3], P[7], P[9], _p(x), _ld(x),
-                                    _p(out), C, s), 'irn_child_pass B')
+    if PROFILE.counting:
+        PROFILE.count_children(parent_nbr)
+    tiles = (n_p + 15) // 16
+    per_tile = {16: (416, 248), 32: (1216, 736)}[C]          # MFMA instructions per 16-parent tile (incl. the conv1_2 products of pass B)
+    names = (f'k_child_irn_a<{C}>', f'k_child_irn_b<{C}>')
+    forms = _irn_pass_formulas(n, C, 27 * n_p * 4, names)
+    calls = (lambda: lib().pcgc_irn_child_pass(_p(parent_nbr), n_p, C, 1, _p(x), _ld(x), _p(ta), ta.numel() * 4, P[1], P[5], None, None, 0,
+                                               _p(t), C // 2, s),
+             lambda: lib().pcgc_irn_child_pass(_p(parent_nbr), n_p, C, 2, _p(t), C // 2, _p(tb), tb.numel() * 4, P[3], P[7], P[9], _p(x), _ld(x),
+                                               _p(out), C, s))
+    for (ps, name, bf, ff, comp), call, mf in zip(forms, calls, per_tile):
+        prof = PROFILE.want((name, n))
+        if prof:
+            e0, e1 = PROFILE.bracket((name, n), name + ' (fused InceptionResNet pass on a children level, packed-N fp32 MFMA)', n, bf, ff,
+                                     compulsory=comp, mfma_issued=tiles * mf * 2048)
+            e0.record()
+        check(call(), 'irn_child_pass')
+        if prof:
+            e1.record()
     return out
 
 
@@ -652,8 +769,24 @@ def conv_child(parent_nbr, x, table, bias, Cout, out=None, residual=None, relu=F
     if out is None:
         out = torch.empty((8 * n_p, Cout), dtype=torch.float32, device=x.device)
     res_p, res_ld = (None, 0) if residual is None else (_p(_f32(residual)), _ld(residual))
+    n = 8 * n_p
+    key = ('child_conv', Cin, Cout, n)
+    prof = PROFILE.want(key)
+    if prof:
+        tiles = (n_p + 15) // 16
+        per_tile = 64 * (Cin // 16) * 4 if Cout == 1 else 216 * (Cin // 16) * (Cout // 16) * 4        # MFMA instructions per 16-parent tile
+        name = f'k_child_cls<{Cin // 16}>' if Cout == 1 else f'k_child_conv<{Cin // 16}, {Cout // 16}>'
+        e0, e1 = PROFILE.bracket(key, name + f' (k3 {Cin}->{Cout} on a children level, parent-map halo gather + fp32 MFMA)', n,
+                                 lambda P, a=Cin, b=Cout: P * a * 4 + P * 8 + n * b * 4, lambda P, a=Cin, b=Cout: 2 * P * a * b,
+                                 compulsory=n * Cin * 4 + 27 * n_p * 4 + n * Cout * 4 + (0 if residual is None else n * Cout * 4),
+                                 mfma_issued=tiles * per_tile * 2048)
+        e0.record()
     check(lib().pcgc_conv_child(_p(parent_nbr), n_p, _p(x), Cin, _ld(x), _p(table), table.numel() * 4, _p(bias), res_p, res_ld,
                                 int(relu), _p(out), Cout, _ld(out), _stream(x)), 'conv_child')
+    if prof:
+        e1.record()
+    elif PROFILE.counting:
+        PROFILE.count_children(parent_nbr)
     return out
 
 

@@ -475,35 +475,51 @@ def test_frames_in_flight_identical_to_sequential(in_flight, sd, sd_np, tmp_path
     np.testing.assert_array_equal(out_par['u2'].C.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize('name,n_expect', [('shell11', None)])
-def test_vox11_frame_roundtrip_properties(name, n_expect, sd, tmp_path):
-    """BASELINE config 4 shape (dancer vox11, res 2048, ~2.6 M points): the stand-in shell11 through encode/decode."""
-    from pcgcv2_amd.coder import Coder
-    pts = synthetic.shell(name, device=DEV)
+def test_vox11_seven_rate_sweep(tmp_path):
+    """BASELINE config 4 at its stated size: the vox11 stand-in shell11 (~2.6 M points, res 2048) through SEVEN rates (seven
+    weight sets = latent gains, postfixes _r1.._r7 like test.py:38), the geometry maps built by the first rate and reused by
+    the others.  Per rate: exact point count, no duplicate voxels, bitstream grows with the latent gain; one mid rate is
+    compared with the oracle on the latent it coded (the full decode of a 2.6 M-point frame per rate would take the oracle
+    ~15 s each; the vox10 frames carry the full-size decode comparison)."""
+    from pcgcv2_amd.coder import Coder, stream_bits
+    pts = synthetic.shell('shell11', device=DEV)
     coords = torch.cat([torch.zeros((len(pts), 1), dtype=torch.int32, device=DEV), pts], 1).contiguous()
     assert 2_400_000 < len(pts) < 2_800_000
-    m = _model(sd)
     x = SparseTensor(torch.ones((len(pts), 1), device=DEV), coordinates=coords, tensor_stride=1, device=DEV)
-    coder = Coder(m, str(tmp_path / name))
-    outs = []
-    for post in ('_r1', '_r2'):                                   # two "rates" = two postfixes, like test.py:38
-        y = coder.encode(x, postfix=post)
-        out = coder.decode(postfix=post)
+    from pcgcv2_amd.pcc_model import PCCModel
+    m = PCCModel().to(DEV)
+    coder = Coder(m, str(tmp_path / 'v11'))
+    gains = (8.0, 16.0, 30.0, 50.0, 80.0, 120.0, 200.0)
+    feat_bits, outs = [], []
+    for i, g in enumerate(gains, start=1):
+        sd_i = synthetic.synthetic_state_dict(gain=g)
+        m.load_state_dict(sd_i)
+        y = coder.encode(x, postfix=f'_r{i}')
+        out = coder.decode(postfix=f'_r{i}')
         oc = out.C.cpu().numpy()
         assert len(oc) == len(pts) and len(np.unique(oc, axis=0)) == len(pts)
-        outs.append(oc)
-    np.testing.assert_array_equal(outs[0], outs[1])
-    n4, n2, n1 = np.frombuffer((tmp_path / f'{name}_r1_num_points.bin').read_bytes(), np.int32)
-    assert n1 == len(pts) and n4 < n2 < n1 and len(y) < n4
+        bits = stream_bits(str(tmp_path / 'v11'), f'_r{i}')
+        feat_bits.append(int(bits[1]))
+        n4, n2, n1 = np.frombuffer((tmp_path / f'v11_r{i}_num_points.bin').read_bytes(), np.int32)
+        assert n1 == len(pts) and n4 < n2 < n1 and len(y) < n4
+        if i == 4:                                                   # the latent this rate coded: bit-exact bitstream vs the oracle's coder
+            sd_np = synthetic.state_dict_to_numpy(sd_i)
+            data, lo, hi = orc.eb_compress(orc.pack_eb_params(sd_np), y.F.cpu().numpy())
+            assert (tmp_path / f'v11_r{i}_F.bin').read_bytes() == data
+            assert (tmp_path / f'v11_r{i}_H.bin').read_bytes() == orc.header_bytes(y.F.shape, lo, hi)
+    assert all(a < b for a, b in zip(feat_bits, feat_bits[1:]))       # larger latent alphabet -> more bits
+    assert len({(tmp_path / f'v11_r{i}_C.bin').read_bytes() for i in range(1, 8)}) == 1     # geometry is rate independent
 
 
-def test_vox12_scaled_octant_blocks(sd, tmp_path):
-    """BASELINE config 5 shape: a vox12-size cloud down-scaled by 0.375 (data_utils.py:112-118), split into 8 octant
-    blocks coded independently with per-block postfixes, decoded, merged and scaled back (coder.py:149-166)."""
+def test_vox12_scaled_octant_blocks(sd, sd_np, tmp_path):
+    """BASELINE config 5 at its stated size: the vox12 stand-in shell12 (~4.8 M points) down-scaled by 0.375
+    (data_utils.py:112-118), split into 8 octant blocks coded independently with per-block postfixes, decoded, and scaled back
+    (coder.py:149-166).  Every block is compared with the oracle bit for bit (bitstream and decoded voxels)."""
     from pcgcv2_amd.coder import Coder
     from pcgcv2_amd.data_utils import scale_sparse_tensor
     from pcgcv2_amd import shard
-    pts = synthetic.shell('shell11', device=DEV) * 2                      # vox12-range coordinates, 2.6 M points
+    pts = synthetic.shell('shell12', device=DEV)
+    assert 4_500_000 < len(pts) < 5_200_000
     coords = torch.cat([torch.zeros((len(pts), 1), dtype=torch.int32, device=DEV), pts], 1).contiguous()
     x = SparseTensor(torch.ones((len(pts), 1), device=DEV), coordinates=coords, tensor_stride=1, device=DEV)
     x_in = scale_sparse_tensor(x, 0.375)
@@ -523,6 +539,10 @@ def test_vox12_scaled_octant_blocks(sd, tmp_path):
         coder.encode(xb, postfix=f'_b{i}')
         ob = coder.decode(postfix=f'_b{i}')
         assert len(ob) == len(xb)
+        ref = orc.encode(sd_np, c.cpu().numpy())
+        for k in ('F', 'H', 'num_points'):
+            assert (tmp_path / f'blk_b{i}_{k}.bin').read_bytes() == ref[k], (i, k)
+        np.testing.assert_array_equal(ob.C.cpu().numpy(), orc.decode(sd_np, ref['coords8'], ref['F'], ref['H'], ref['num_points']))
         total_out += len(scale_sparse_tensor(ob, 1.0 / 0.375))
     assert total_out > 0
 
@@ -730,3 +750,48 @@ def test_inception_resnet_child_bit_exact(name, prune, C):
         finally:
             ops.set_child_tuning(0, 0)
         np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+# ------------------------------------------------------------------------------------------------ bench.py, 2 ranks on one GPU
+def _run_bench(extra, env_extra=None, nproc=1, timeout=600):
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **(env_extra or {}))
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(root, 'bench.py')] + extra
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
+               '--master-port', '29611', os.path.join(root, 'bench.py')] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_two_ranks_over_gloo_on_one_gpu():
+    """The driver's multi-GPU launch line with 2 ranks sharing this box's one GPU (PCGC_DIST_BACKEND=gloo: the collectives of
+    bench.py run over gloo instead of RCCL, everything else — rank / device set-up, per-rank frames, barrier, MAX-over-ranks
+    timing, summed points — is the code an 8-GPU node runs)."""
+    r, line = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--workload', 'shell9', '--no-events'],
+                         {'PCGC_DIST_BACKEND': 'gloo'}, nproc=2)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['steps'] == 2
+    n9, n9b = len(synthetic.shell('shell9')), len(synthetic.shell('shell9'))
+    assert line['config']['points_in_per_step_all_gpus'] == n9 + n9b            # one frame per rank, summed over ranks
+    assert line['config']['points_out'] == line['config']['points_in_per_step_all_gpus']
+    assert line['value'] == pytest.approx(line['config']['points_coded_per_step_all_gpus'] / (line['ms_per_step'] * 1e-3) / 1e6, rel=1e-3)
+    assert 'cpu_baseline' not in line                                            # rank 0 at N=1 only
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    r, line = _run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0'])
+    assert r.returncode == 2 and line is None and 'WORLD_SIZE' in r.stderr
+
+
+@pytest.mark.parametrize('cfg', ['batch4', 'blocks', 'sweep'])
+def test_bench_configs_run_small(cfg):
+    """bench.py --config batch4 / blocks / sweep on small stand-ins (the full-size runs are bench lines, not tests)."""
+    wl = {'batch4': 'shell9', 'blocks': 'shell10', 'sweep': 'shell9'}[cfg]
+    r, line = _run_bench(['--config', cfg, '--steps', '1', '--warmup', '1', '--workload', wl, '--no-cpu-baseline'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line['config']['baseline_config'] == {'batch4': 3, 'sweep': 4, 'blocks': 5}[cfg]
+    assert line['config']['points_out'] > 0 and line['roofline'] is not None and line['roofline']['frac'] <= 1.0
