@@ -329,11 +329,12 @@ def attach_pmc_traffic(roof):
         table = json.load(open(path))
     except ValueError:
         return
-    short = roof['kernel'].split(' ')[0]
+    short = roof['kernel'].split(' (')[0].rstrip('>')                     # e.g. "k_child_irn_a<16" or "k_conv_gather_mfma_wlds<64, 32, 2"
     for e in table.get('kernels', []):
-        if not e['kernel'].replace('(anonymous namespace)::', '').startswith(short.split('>')[0]):
+        name = e['kernel'].replace('(anonymous namespace)::', '').replace('void ', '')
+        if not (name.startswith(short + ',') or name.startswith(short + '>')):
             continue
-        if e.get('launches_per_step_shape') not in (None, roof['n_out']) and abs(e.get('rows', roof['n_out']) - roof['n_out']) > 512:
+        if 'n_rows' in e and abs(e['n_rows'] - roof['n_out']) > 1024:
             continue
         roof['traffic'] = e['hbm_bytes_per_launch']
         roof['traffic_source'] = 'replayed from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command); not measured in this run'

@@ -56,7 +56,28 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n' + r.stderr[-4000:])
+    build_reftable(force=force)
     return LIB
+
+
+REFTABLE_LIB = os.path.join(HERE, 'libpcgc_reftable.so')
+
+
+def build_reftable(force=False):
+    """libpcgc_reftable.so: the reference-arithmetic CDF table as ATen operators issued from C++ (csrc/reftable.cpp).  Host code,
+    plain g++ against the torch headers / libtorch_cpu of this environment."""
+    src = os.path.join(CSRC, 'reftable.cpp')
+    if not (force or _stale(REFTABLE_LIB, [src])):
+        return REFTABLE_LIB
+    import torch
+    tdir = os.path.dirname(torch.__file__)
+    cmd = ['g++', '-O2', '-std=c++17', '-fPIC', '-shared', f'-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}',
+           '-I' + os.path.join(tdir, 'include'), '-I' + os.path.join(tdir, 'include', 'torch', 'csrc', 'api', 'include'), src,
+           '-o', REFTABLE_LIB, '-L' + os.path.join(tdir, 'lib'), '-ltorch_cpu', '-lc10', '-Wl,-rpath,' + os.path.join(tdir, 'lib')]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('g++ failed:\n' + ' '.join(cmd) + '\n' + r.stderr[-4000:])
+    return REFTABLE_LIB
 
 
 if __name__ == '__main__':

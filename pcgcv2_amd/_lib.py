@@ -95,6 +95,24 @@ def lib():
     return _lib
 
 
+REFTABLE_PATH = os.path.join(_HERE, 'libpcgc_reftable.so')
+_reftable = None
+
+
+def reftable_lib():
+    """libpcgc_reftable.so (csrc/reftable.cpp): int pcgc_reference_table(params, C, min_v, max_v, table_u16, cdf_f32)."""
+    global _reftable
+    if _reftable is None:
+        if not os.path.exists(REFTABLE_PATH):
+            raise PcgcError(f'{REFTABLE_PATH} not found: run `python -c "import __graft_entry__ as g; g.build()"`')
+        import torch  # noqa: F401  (libtorch_cpu must be loaded first)
+        l = C.CDLL(REFTABLE_PATH)
+        l.pcgc_reference_table.restype = ci
+        l.pcgc_reference_table.argtypes = [vp, ci, f32, f32, vp, vp]
+        _reftable = l
+    return _reftable
+
+
 def check(rc, what=''):
     if rc != 0:
         raise PcgcError(f'{what or "pcgc call"} failed ({rc}): {lib().pcgc_last_error().decode()}')

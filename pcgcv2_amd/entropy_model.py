@@ -12,7 +12,8 @@ The 8 x (L+1) CDF table decides every bit of `_F.bin`, so encoder and decoder â€
 the same uint16 values.  `table_mode`:
   'reference' (default)  the table is evaluated on the host with the reference's own arithmetic: the same torch-CPU fp32
                          operator sequence on tensors of the same shape and layout as entropy_model.py:82-101,112-130,
-                         142-149, then torchac's published 16-bit normalisation.  Pinned bit for bit to golden tables
+                         142-149, then torchac's published 16-bit normalisation â€” issued from C++ (libpcgc_reftable.so,
+                         csrc/reftable.cpp); 'reference-python' is the same sequence from Python (reference_table).  Pinned bit for bit to golden tables
                          generated from the reference (tests/golden/entropy_tables.npz): a stream written here decodes
                          in the reference on the same host and vice versa.  The table is consumed by the host range
                          coder anyway, so nothing extra crosses PCIe.
@@ -70,7 +71,7 @@ class EntropyBottleneck(nn.Module):
         return self._packed
 
     def invalidate(self):
-        self._packed = self._host = None
+        self._packed = self._host = self._hpacked = None
 
     def _host_params(self):
         """fp32 CPU copies of (matrices, biases, factors), refreshed when the parameters change."""
@@ -127,12 +128,37 @@ class EntropyBottleneck(nn.Module):
         q, f = ops.cdf_table(self.packed_params(device), self._channels, float(min_v), float(max_v))
         return q, f
 
+    def _host_packed(self):
+        """the 44*C parameters as one contiguous fp32 CPU array (matrices | biases | factors), refreshed when they change"""
+        stamp = self._stamp()
+        if getattr(self, '_hpacked', None) is None or self._hpacked_stamp != stamp:
+            parts = [p.detach().reshape(-1).to('cpu', torch.float32) for lst in (self._matrices, self._biases, self._factors)
+                     for p in lst._parameters.values()]
+            self._hpacked, self._hpacked_stamp = torch.cat(parts).contiguous().numpy(), stamp
+        return self._hpacked
+
+    def reference_table_native(self, min_v, max_v, want_cdf=False):
+        """reference_table through libpcgc_reftable.so: the same ATen operator sequence issued from C++ (csrc/reftable.cpp), without
+        ~60 Python dispatches on the critical path of every encode and decode.  -> uint16 ndarray [C, L+1] (and the fp32 cdf)."""
+        from ._lib import reftable_lib
+        P = self._host_packed()
+        L = int(np.float32(max_v) - np.float32(min_v)) + 1
+        q = np.empty((self._channels, L + 1), np.uint16)
+        cdf = np.empty((self._channels, L + 1), np.float32) if want_cdf else None
+        rc = reftable_lib().pcgc_reference_table(P.ctypes.data, self._channels, float(min_v), float(max_v), q.ctypes.data,
+                                                 None if cdf is None else cdf.ctypes.data)
+        if rc != 0:
+            raise PcgcError(f'pcgc_reference_table failed ({rc})')
+        return (q, cdf) if want_cdf else q
+
     def host_table(self, min_v, max_v, device):
         """uint16 ndarray [C, L+1] on the host, by the configured table_mode."""
         if self.table_mode == 'reference':
+            return self.reference_table_native(min_v, max_v)
+        if self.table_mode == 'reference-python':
             return self.reference_table(min_v, max_v)[1]
         if self.table_mode != 'device':
-            raise PcgcError(f"table_mode must be 'reference' or 'device', got {self.table_mode!r}")
+            raise PcgcError(f"table_mode must be 'reference', 'reference-python' or 'device', got {self.table_mode!r}")
         return self.cdf_table(min_v, max_v, device)[0].cpu().numpy().view(np.uint16)
 
     @torch.no_grad()

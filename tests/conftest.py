@@ -18,6 +18,9 @@ def pytest_configure(config):
     if not os.path.exists(_lib.LIB_PATH) and (shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc')):
         from pcgcv2_amd import _build
         _build.build()
+    if not os.path.exists(_lib.REFTABLE_PATH) and shutil.which('g++'):
+        from pcgcv2_amd import _build
+        _build.build_reftable()
     from oracle import pcgc_oracle
     if not os.path.exists(pcgc_oracle._SO) and shutil.which('gcc'):
         pcgc_oracle.build()

@@ -24,6 +24,15 @@ def test_library_exports_every_declared_symbol():
     assert l.pcgc_version() >= 1
 
 
+def test_reftable_library_exports_its_header():
+    from pcgcv2_amd._lib import reftable_lib, REFTABLE_PATH
+    header = open(os.path.join(ROOT, 'include', 'pcgc_reftable.h')).read()
+    declared = set(re.findall(r'\b(pcgc_\w+)\s*\(', re.sub(r'/\*.*?\*/', '', header, flags=re.S)))
+    assert declared == {'pcgc_reference_table'}
+    for name in declared:
+        assert hasattr(reftable_lib(), name), f'{name} not exported by {REFTABLE_PATH}'
+
+
 @pytest.fixture(params=[0, 1], ids=['rc-auto', 'rc-scalar'])
 def rc_impl(request):
     ops.set_rc_impl(request.param)

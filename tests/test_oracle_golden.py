@@ -45,8 +45,27 @@ def test_g1_product_host_table_bit_exact(golden_dir):
         cdf, q = eb.reference_table(lo, hi)
         np.testing.assert_array_equal(cdf.numpy(), g[f'c{ci}_cdf'], err_msg=f'case {ci}')
         np.testing.assert_array_equal(q, orc.cdf_u16(g[f'c{ci}_cdf']), err_msg=f'case {ci}')
+        qn, cdfn = eb.reference_table_native(lo, hi, want_cdf=True)          # the C++ issue of the same operator sequence
+        np.testing.assert_array_equal(cdfn, g[f'c{ci}_cdf'], err_msg=f'native, case {ci}')
+        np.testing.assert_array_equal(qn, q, err_msg=f'native, case {ci}')
         total += q.size
     assert total > 8 * 1000
+
+
+def test_native_and_python_tables_agree_on_any_host(golden_dir):
+    """Whatever the host kind, the C++ and the Python issue of the operator sequence give the same table (same ATen kernels)."""
+    import torch
+    from pcgcv2_amd.entropy_model import EntropyBottleneck
+    g = _load(golden_dir, 'entropy_tables.npz')
+    eb = EntropyBottleneck(8)
+    for ci in range(int(g['n_cases'])):
+        M, B, Fa = orc._eb_unpack(g[f'c{ci}_params'])
+        with torch.no_grad():
+            for dst, src in zip(list(eb._matrices) + list(eb._biases) + list(eb._factors), M + B + Fa):
+                dst.copy_(src)
+        lo, hi = g[f'c{ci}_minmax']
+        np.testing.assert_array_equal(eb.reference_table_native(lo, hi), eb.reference_table(lo, hi)[1])
+        np.testing.assert_array_equal(eb.reference_table_native(lo, hi), orc.cdf_table_ref32(g[f'c{ci}_params'], lo, hi))
 
 
 def test_g1_entropy_tables_fp64_evaluation(golden_dir):
