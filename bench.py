@@ -330,12 +330,16 @@ def attach_pmc_traffic(roof):
     except ValueError:
         return
     short = roof['kernel'].split(' (')[0].rstrip('>')                     # e.g. "k_child_irn_a<16" or "k_conv_gather_mfma_wlds<64, 32, 2"
+    import math
+    cands = []
     for e in table.get('kernels', []):
         name = e['kernel'].replace('(anonymous namespace)::', '').replace('void ', '')
-        if not (name.startswith(short + ',') or name.startswith(short + '>')):
-            continue
-        if 'n_rows' in e and abs(e['n_rows'] - roof['n_out']) > 1024:
-            continue
+        if name.startswith(short + ',') or name.startswith(short + '>'):
+            cands.append(e)
+    # the same template may run on several levels: take the launch geometry closest to this level (grid threads ~ 1-2 x rows;
+    # the persistent children-level kernels have one entry each)
+    cands.sort(key=lambda e: abs(math.log2(max(e.get('grid_size', 1), 1) / max(roof['n_out'], 1)) - 0.5))
+    for e in cands[:1]:
         roof['traffic'] = e['hbm_bytes_per_launch']
         roof['traffic_source'] = 'replayed from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command); not measured in this run'
         roof['traffic_rate'] = {'GBps': round(e['hbm_bytes_per_launch'] / (roof['avg_launch_us'] * 1e-6) / 1e9, 1),

@@ -32,8 +32,9 @@ extern "C" int pcgc_conv_child(const int32_t* parent_nbr, int64_t n_parent, cons
         PCGC_REQUIRE(table_bytes == (int64_t)27 * Cin * Cout * 4, "table size");
         ChildEpi ep{bias, residual, res_ld, relu, out, out_ld, Cout / 16};
         if (Cin == 16 && Cout == 16) {
-            if (nw == 4) rc = launch_child_conv<1, 1, 4, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
-            else rc = launch_child_conv<1, 1, 8, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
+            // measured on 2.05 M rows: 4 waves per group (3 groups = 12 waves per CU) 251 us, 8 waves per group (16 per CU) 272 us
+            if (nw == 4) rc = launch_child_conv<1, 1, 8, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
+            else rc = launch_child_conv<1, 1, 4, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
         } else if (Cin == 32 && Cout == 32) {       // 108 KB of weights: one workgroup per CU
             if (nw == 4) rc = launch_child_conv<2, 2, 4, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
             else rc = launch_child_conv<2, 2, 8, 2>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);

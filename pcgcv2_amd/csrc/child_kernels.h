@@ -187,6 +187,12 @@ template <> struct BFrag<1> {
     __device__ __forceinline__ float get(int) const { return v; }
 };
 template <int OFF>
+__device__ __forceinline__ float lds_ld32_off(unsigned base) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF>
 __device__ __forceinline__ f32x4 lds_ld128_off(unsigned base) {
     f32x4 v;
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(OFF) : "memory");
@@ -232,76 +238,91 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
     const int mi = lane & 15, mq = lane >> 4;
     const int dma_r = lane >> 2;                               // tile row (parent) this lane fetches for
     const bool row_ok = p0 + dma_r < n_p;
-    int pn[27];                                                // its 27 neighbour parents (-1 = absent)
+    // byte offset of each neighbour parent's first child row; absent -> a value no in-row offset can bring back into range (the
+    // entry point checks the tensor is smaller than ABSENT), so the per-cell address is ONE add and needs no select
+    constexpr unsigned ABSENT = 0xF0000000u;
+    unsigned rowb[27];
 #pragma unroll
-    for (int kp = 0; kp < 27; ++kp) pn[kp] = pnbr[(int64_t)kp * n_p + (row_ok ? p0 + dma_r : 0)];
+    for (int kp = 0; kp < 27; ++kp) rowb[kp] = (unsigned)pnbr[(int64_t)kp * n_p + (row_ok ? p0 + dma_r : 0)];
     const int f_a = (0x78 >> (2 * (mi >> 2))) & 3;             // read-side swizzle of the A image (see conv.hip v2)
     const int dma_chunk = (lane & 3) ^ ((0x78 >> (2 * ((dma_r >> 2) & 3))) & 3);
     const bool chunk_ok = dma_chunk < V::ROWCHUNKS;            // rows narrower than 64 bytes: the other lanes fetch nothing (zeros)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // pn[] loaded (and the previous tile's stores retired): vmcnt now counts DMAs only
+    const unsigned row_bytes = (unsigned)in_ld * 4u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // map entries loaded (and the previous tile's stores retired): vmcnt now counts DMAs only
 #pragma unroll
-    for (int kp = 0; kp < 27; ++kp) pn[kp] = row_ok ? pn[kp] : -1;
+    for (int kp = 0; kp < 27; ++kp) rowb[kp] = (row_ok && (int)rowb[kp] >= 0) ? rowb[kp] * (8u * row_bytes) : ABSENT;
+    const unsigned lane_off = chunk_ok ? (unsigned)dma_chunk * 16u : ABSENT;
     CHILD_T(t_loop0);
 
     auto issue = [&](auto ic) {
         constexpr int c = decltype(ic)::value;
-        const int pr = pn[cell_kp(c)];
         float4* dst = ring + (c & (D - 1)) * (NB * 64);
-        const int64_t rowoff = (int64_t)(8 * pr + cell_child(c)) * in_ld + dma_chunk * 4;
+        unsigned voff = rowb[cell_kp(c)] + (unsigned)cell_child(c) * row_bytes + lane_off;
+        if constexpr (V::ROWCHUNKS < 4) voff = chunk_ok ? voff : 0xFFFFFFF0u;       // (ABSENT + ABSENT would wrap)
 #pragma unroll
-        for (int cb = 0; cb < NB; ++cb) {
-            const unsigned voff = (pr >= 0 && chunk_ok) ? (unsigned)((rowoff + cb * 16) * 4) : 0xFFFFFFF0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_ptr)(dst + cb * 64), 16, (int)voff, 0, 0, 0);
-        }
+        for (int cb = 0; cb < NB; ++cb)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_ptr)(dst + cb * 64), 16, (int)(voff + cb * 64), 0, 0, 0);
         asm volatile("" ::: "memory");
     };
 
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const unsigned tab_lane = (unsigned)(uintptr_t)(lds_void_ptr)((const float*)lds_raw + (V::HALF ? (mq * 8 + (mi & 7)) : lane) * KS);
-    const unsigned a_lane = (unsigned)(uintptr_t)(lds_void_ptr)(ring + mi * 4 + (mq ^ f_a));
+    // A operand straight in MFMA layout: lane (mi, mq) needs channel 4 jj + mq of row mi for K-step jj; chunk jj of row mi sits at
+    // slot position jj ^ f(mi >> 2) of the (source-swizzled) image, so four ds_read_b32 — conflict-free: bank = 16 (mi & 3) +
+    // 4 (jj ^ f(mi >> 2)) + mq covers all 64 banks — replace the ds_read_b128 + 4x4 lane transpose (4 permlane swaps + moves per
+    // block and cell): the VALU issue slots those took are what the MFMA pipe was waiting on (2.4-2.8 VALU per MFMA before).
+    unsigned a_addr[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) a_addr[jj] = (unsigned)(uintptr_t)(lds_void_ptr)((const float*)ring + (mi * 4 + (jj ^ f_a)) * 4 + mq);
+    constexpr unsigned ksteps_used = [] { unsigned m = 0; for (int t = 0; t < T; ++t) for (int j = 0; j < KS; ++j) m |= 1u << (V::kfirst(t) + j); return m; }();
 
     // (A two-deep register pipeline — LDS reads of cell c+1 issued before the MFMAs of cell c — was measured and dropped: no gain
-    // on any variant, 8-30 more registers; with 3-4 waves per SIMD the other waves already cover the two LDS latencies.)
+    // on any variant, 8-30 more registers; with 3-4 waves per SIMD the other waves already cover the LDS latency.)
     static_for<0, D>(issue);
     static_for<0, 64>([&](auto ic) {
         constexpr int c = decltype(ic)::value;
         constexpr int younger = (63 - c) < (D - 1) ? (63 - c) : (D - 1);       // cells issued after c that may stay in flight
         wait_vmcnt<younger * NB>();
-        f32x4 araw[NB];
-        static_for<0, NB>([&](auto icb) {
+        float a[NB][4];
+        BFrag<KS> b[NB][T];
+        static_for<0, NB>([&](auto icb) {                                      // all LDS reads of the cell, one wait
             constexpr int cb = decltype(icb)::value;
-            araw[cb] = lds_ld128_off<((c & (D - 1)) * NB + cb) * 1024>(a_lane);
-        });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int cb = 0; cb < NB; ++cb) lds_tie(araw[cb]);
-        if constexpr (c + D < 64) issue(std::integral_constant<int, c + D>{});    // refill the ring slot cell c was read from
-        static_for<0, NB>([&](auto icb) {
-            constexpr int cb = decltype(icb)::value;
-            float4 a = make_float4(araw[cb][0], araw[cb][1], araw[cb][2], araw[cb][3]);
-            lane_transpose4(a);
-            BFrag<KS> b[T];
+            static_for<0, 4>([&](auto ij) {
+                constexpr int jj = decltype(ij)::value;
+                if constexpr ((ksteps_used >> jj) & 1)
+                    a[cb][jj] = lds_ld32_off<((c & (D - 1)) * NB + cb) * 1024>(a_addr[jj]);
+            });
             static_for<0, T>([&](auto it) {
                 constexpr int t = decltype(it)::value;
                 if constexpr (V::active(c, t)) {
                     constexpr int off = (V::frag(c, t) * NB + cb) * frag_floats<V>() * 4;        // byte offset of the fragment in the table
-                    if constexpr (off < 65536) b[t].template load<off>(tab_lane);
-                    else b[t].template load<off - 65536>(tab_lane + 65536);
+                    if constexpr (off < 65536) b[cb][t].template load<off>(tab_lane);
+                    else b[cb][t].template load<off - 65536>(tab_lane + 65536);
                 }
             });
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            static_for<0, T>([&](auto it) {
-                constexpr int t = decltype(it)::value;
-                if constexpr (V::active(c, t)) b[t].tie();
-            });
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        static_for<0, NB>([&](auto icb) {
+            constexpr int cb = decltype(icb)::value;
             static_for<0, 4>([&](auto ij) {
                 constexpr int jj = decltype(ij)::value;
-                const float av = jj == 0 ? a.x : (jj == 1 ? a.y : (jj == 2 ? a.z : a.w));
+                if constexpr ((ksteps_used >> jj) & 1) lds_tie(a[cb][jj]);
+            });
+            static_for<0, T>([&](auto it) {
+                constexpr int t = decltype(it)::value;
+                if constexpr (V::active(c, t)) b[cb][t].tie();
+            });
+        });
+        if constexpr (c + D < 64) issue(std::integral_constant<int, c + D>{});    // refill the ring slot cell c was read from
+        static_for<0, NB>([&](auto icb) {
+            constexpr int cb = decltype(icb)::value;
+            static_for<0, 4>([&](auto ij) {
+                constexpr int jj = decltype(ij)::value;
                 static_for<0, T>([&](auto it) {
                     constexpr int t = decltype(it)::value;
                     if constexpr (V::active(c, t) && jj >= V::kfirst(t) && jj < V::kfirst(t) + KS)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[t].get(jj - V::kfirst(t)), acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][jj], b[cb][t].get(jj - V::kfirst(t)), acc[t], 0, 0, 0);
                 });
             });
         });
@@ -609,6 +630,6 @@ extern int g_child_nw, g_child_depth;                       // A/B switches (pcg
 #define CHILD_COMMON_CHECKS(ROWS_LD)                                                                                           \
     PCGC_REQUIRE(parent_nbr && in && table, "null argument");                                                                  \
     PCGC_REQUIRE(((ROWS_LD) & 3) == 0 && (((uintptr_t)in | (uintptr_t)table) & 15) == 0, "unaligned input");                 \
-    PCGC_REQUIRE(8 * n_parent * (int64_t)(ROWS_LD) * 4 < (int64_t)0xFFFFFFF0, "tensor too large for 32-bit buffer offsets"); \
+    PCGC_REQUIRE(8 * n_parent * (int64_t)(ROWS_LD) * 4 < (int64_t)0xF0000000, "tensor too large for 32-bit buffer offsets"); \
     PCGC_REQUIRE(table_bytes % 16 == 0, "table size");                                                                         \
     if (n_parent == 0) return 0;
