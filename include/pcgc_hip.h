@@ -40,6 +40,10 @@ int pcgc_hash_clear(uint64_t* keys /*[dev cap]*/, int32_t* vals /*[dev cap]*/, i
  * insert, first_mask and the kmap builders of one table must all be given the same stride. */
 int pcgc_hash_insert(const int32_t* coords /*[dev n,4]*/, int64_t n, int32_t stride, uint64_t* keys, int32_t* vals,
                      int64_t cap, void* stream);                         /* vals[slot] = smallest row with that key */
+/* dedup policy as an argument: keep_last = 0 is pcgc_hash_insert; 1 keeps the LARGEST row per key (ME's dedup policy for equal
+ * coordinates is a ‡ convention; hash_first_mask then marks the kept rows either way: keep[i] = (vals[slot] == i)). */
+int pcgc_hash_insert_policy(const int32_t* coords, int64_t n, int32_t stride, uint64_t* keys, int32_t* vals, int64_t cap,
+                            int keep_last, void* stream);
 int pcgc_hash_first_mask(const int32_t* coords, int64_t n, int32_t stride, const uint64_t* keys, const int32_t* vals,
                          int64_t cap, uint8_t* keep /*[dev n]*/, int32_t* first_row /*[dev n] or NULL*/, void* stream);
                          /* keep[i] = row i is the first occurrence of its coordinate; first_row[i] = that first row */
@@ -165,6 +169,11 @@ int pcgc_set_child_tuning(int waves_per_group, int ring_depth);       /* A/B swi
 int pcgc_irn_child_pass(const int32_t* parent_nbr, int64_t n_parent, int C, int pass, const float* in, int in_ld,
                         const float* table, int64_t table_bytes, const float* b0, const float* b1, const float* b2,
                         const float* x, int x_ld, float* out, int out_ld, void* stream);
+
+/* ‡ conventions the reference's results depend on but its sources do not pin (un-vendored MinkowskiEngine / torch.topk on ME's row
+ * order): what = 0: top-k tie rule, value 0 = the lower row wins (default), 1 = the higher row wins.  The dedup policy is an argument of
+ * pcgc_hash_insert_policy; the kernel-offset order is a weight permutation done by the host (pcgcv2_amd/conventions.py). */
+int pcgc_set_convention(int what, int value);
 
 /* ---- top-k pruning mask: istopk (data_utils.py:77-89).  mask[i]=1 for the k largest logits;
  *      ties -> lower row index; -0.0 == +0.0. ---- */

@@ -80,6 +80,34 @@ def unique_first(coords):
     return coords[keep.astype(bool)]
 
 
+# ‡ conventions, mirrored from pcgcv2_amd/conventions.py (same names, same defaults); tests flip both sides together
+CONVENTIONS = {'kernel_offset_order': 'xyz', 'topk_tie': 'low', 'dedup_keep': 'first'}
+
+
+def unique_keep(coords):
+    """dedup by the configured policy: 'first' = unique_first; 'last' = keep the last occurrence, input order preserved."""
+    coords = _c(coords, np.int32)
+    if CONVENTIONS['dedup_keep'] == 'first':
+        return unique_first(coords)
+    rev = coords[::-1].copy()
+    keep = np.zeros(len(rev), np.uint8)
+    lib().orc_unique_first(_p(rev), len(rev), _p(keep))
+    return coords[keep[::-1].astype(bool)]
+
+
+def apply_offset_order(sd):
+    """kernel-offset convention as a permutation of the checkpoint's kernels (x-fastest here; 'zyx': the checkpoint is z-fastest)."""
+    if CONVENTIONS['kernel_offset_order'] == 'xyz':
+        return sd
+    out = dict(sd)
+    for k, v in sd.items():
+        if k.endswith('.kernel') and v.ndim == 3 and v.shape[0] in (27, 8):
+            n = 3 if v.shape[0] == 27 else 2
+            perm = [(kk // (n * n)) + n * ((kk // n) % n) + n * n * (kk % n) for kk in range(v.shape[0])]
+            out[k] = np.ascontiguousarray(v[perm])
+    return out
+
+
 def stride2_coords(coords, stride_out):
     coords = _c(coords, np.int32)
     out = np.empty_like(coords)
@@ -214,7 +242,10 @@ def topk_mask(vals, k):
     -0.0 == +0.0."""
     v = np.asarray(vals, np.float32).ravel() + np.float32(0)
     k = int(min(len(v), k))
-    order = np.argsort(-v, kind='stable')
+    if CONVENTIONS['topk_tie'] == 'high':                    # equal logits -> the higher row index wins
+        order = (len(v) - 1 - np.argsort(-v[::-1], kind='stable'))
+    else:
+        order = np.argsort(-v, kind='stable')
     mask = np.zeros(len(v), bool)
     mask[order[:k]] = True
     return mask

@@ -16,6 +16,8 @@ SIGNATURES = {
     'pcgc_hash_capacity': (i64, [i64]),
     'pcgc_hash_clear': (ci, [vp, vp, i64, vp]),
     'pcgc_hash_insert': (ci, [vp, i64, i32, vp, vp, i64, vp]),
+    'pcgc_hash_insert_policy': (ci, [vp, i64, i32, vp, vp, i64, ci, vp]),
+    'pcgc_set_convention': (ci, [ci, ci]),
     'pcgc_hash_first_mask': (ci, [vp, i64, i32, vp, vp, i64, vp, vp, vp]),
     'pcgc_coords_check': (ci, [vp, i64, vp, vp]),
     'pcgc_coords_quantize': (ci, [vp, i64, i32, vp, vp]),

@@ -46,6 +46,29 @@ __global__ void k_hash_insert(const int4* __restrict__ coords, int64_t n, int sh
         h = (h + 1) & cap_mask;
     }
 }
+// dedup policy "keep the LAST occurrence" (the default everywhere is the first): same table, vals[slot] = LARGEST row with the key
+__global__ void k_hash_insert_last(const int4* __restrict__ coords, int64_t n, int sh, uint64_t* keys, int32_t* vals, uint64_t cap_mask) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 c = coords[i];
+    if (!coord_in_range(c.x, c.y, c.z, c.w)) return;
+    uint64_t key = coord_key(c.x, c.y, c.z, c.w);
+    uint64_t h = hash_slot(c.x, c.y, c.z, c.w, sh, cap_mask);
+    for (;;) {
+        unsigned long long prev = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)PCGC_EMPTY_KEY, (unsigned long long)key);
+        if (prev == PCGC_EMPTY_KEY || prev == key) {
+            // slots are cleared to INT_MAX (the minimum-keeping insert's neutral element): it counts as "no row" when maximising
+            int32_t old = __builtin_nontemporal_load(&vals[h]);
+            while (old == 0x7fffffff || old < (int32_t)i) {
+                int32_t seen = atomicCAS(&vals[h], old, (int32_t)i);
+                if (seen == old) break;
+                old = seen;
+            }
+            return;
+        }
+        h = (h + 1) & cap_mask;
+    }
+}
 __global__ void k_hash_first_mask(const int4* __restrict__ coords, int64_t n, int sh, const uint64_t* __restrict__ keys,
                                   const int32_t* __restrict__ vals, uint64_t cap_mask, uint8_t* keep, int32_t* first_row) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -86,6 +109,16 @@ extern "C" int pcgc_hash_insert(const int32_t* coords, int64_t n, int32_t stride
     hipLaunchKernelGGL(k_hash_insert, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n,
                        stride_shift(stride), keys, vals, (uint64_t)(cap - 1));
     PCGC_CHECK_LAUNCH("hash_insert");
+    return 0;
+}
+extern "C" int pcgc_hash_insert_policy(const int32_t* coords, int64_t n, int32_t stride, uint64_t* keys, int32_t* vals, int64_t cap,
+                                       int keep_last, void* stream) {
+    if (!keep_last) return pcgc_hash_insert(coords, n, stride, keys, vals, cap, stream);
+    PCGC_REQUIRE(cap >= 2 * n && (cap & (cap - 1)) == 0, "capacity must be a power of two >= 2n");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_hash_insert_last, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n,
+                       stride_shift(stride), keys, vals, (uint64_t)(cap - 1));
+    PCGC_CHECK_LAUNCH("hash_insert_policy");
     return 0;
 }
 extern "C" int pcgc_hash_first_mask(const int32_t* coords, int64_t n, int32_t stride, const uint64_t* keys,

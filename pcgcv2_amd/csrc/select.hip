@@ -191,14 +191,25 @@ __global__ void k_topk_flags(const float* __restrict__ v, int ld, int64_t n, con
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) eq[i] = order_key(v[i * ld]) == st->prefix;
 }
+// tie_high = 0: among logits equal to the threshold the LOWER row indices are kept (canonical); 1: the HIGHER ones
 __global__ void k_topk_mask(const float* __restrict__ v, int ld, int64_t n, const TopkState* st,
-                            const int32_t* __restrict__ eq_rank, uint8_t* mask) {
+                            const int32_t* __restrict__ eq_rank, const int32_t* __restrict__ eq_total, int tie_high, uint8_t* mask) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t key = order_key(v[i * ld]), T = st->prefix;
-    mask[i] = (key > T) || (key == T && (int64_t)eq_rank[i] < st->k_remaining);
+    const int64_t need = st->k_remaining, r = eq_rank[i];
+    mask[i] = (key > T) || (key == T && (tie_high ? r >= (int64_t)eq_total[0] - need : r < need));
 }
 
+static int g_topk_tie_high = 0;
+// ‡ conventions of the un-vendored dependencies that the reference's results depend on but its sources do not pin:
+//   what = 0  top-k tie rule (data_utils.py:85-87, torch.topk on ME's row order): value 0 = lower row wins (default), 1 = higher row wins
+// (the dedup policy is an argument of pcgc_hash_insert_policy; the kernel-offset order is a weight permutation done by the host).
+extern "C" int pcgc_set_convention(int what, int value) {
+    if (what == 0) { g_topk_tie_high = value ? 1 : 0; return 0; }
+    pcgc_set_error("set_convention: unknown convention %d", what);
+    return -2;
+}
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" size_t pcgc_topk_workspace_bytes(int64_t n) {
     return 256 + 1024 + align256((size_t)n) + align256((size_t)n * 4) + 256 + align256(pcgc_scan_workspace_bytes(n));
@@ -225,7 +236,7 @@ extern "C" int pcgc_topk_mask(const float* logits, int ld, int64_t n, int64_t k,
     hipLaunchKernelGGL(k_topk_flags, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), logits, ld, n, st, eq);
     int rc = pcgc_mask_scan(eq, n, rank, total, scan_ws, pcgc_scan_workspace_bytes(n), stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_topk_mask, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), logits, ld, n, st, rank, mask);
+    hipLaunchKernelGGL(k_topk_mask, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), logits, ld, n, st, rank, total, g_topk_tie_high, mask);
     PCGC_CHECK_LAUNCH("topk_mask");
     return 0;
 }

@@ -183,15 +183,15 @@ PROFILE = _Profile()
 class HashTable:
     """Coordinate hash of one level (keys/vals device buffers + the stride its spatial blocking was built with)."""
 
-    def __init__(self, coords, stride):
+    def __init__(self, coords, stride, keep_last=False):
         n = coords.shape[0]
         self.cap = int(lib().pcgc_hash_capacity(n))
         self.stride = int(stride)
         self.keys = torch.empty(self.cap, dtype=torch.int64, device=coords.device)
         self.vals = torch.empty(self.cap, dtype=torch.int32, device=coords.device)
         check(lib().pcgc_hash_clear(_p(self.keys), _p(self.vals), self.cap, _stream(self.keys)), 'hash_clear')
-        check(lib().pcgc_hash_insert(_p(_i32(coords)), n, self.stride, _p(self.keys), _p(self.vals), self.cap, _stream(coords)),
-              'hash_insert')
+        check(lib().pcgc_hash_insert_policy(_p(_i32(coords)), n, self.stride, _p(self.keys), _p(self.vals), self.cap, int(keep_last),
+                                            _stream(coords)), 'hash_insert')
 
 
 def check_coords(coords, what='coordinates'):

@@ -15,8 +15,9 @@ class PCCModel(torch.nn.Module):
         self.entropy_bottleneck = EntropyBottleneck(8)
 
     def load_state_dict(self, state_dict, strict=True, **kw):
+        from . import conventions
         self.entropy_bottleneck.invalidate()
-        return super().load_state_dict(state_dict, strict=strict, **kw)
+        return super().load_state_dict(conventions.permute_state_dict(state_dict), strict=strict, **kw)
 
     def forward(self, x, training=True):
         raise NotImplementedError('PCCModel.forward is the training graph (pcc_model.py:26-45); use coder.Coder for encode/decode')

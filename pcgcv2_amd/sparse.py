@@ -104,7 +104,8 @@ class CoordMap:
 
 def dedup(coords, feats, stride):
     """ME.SparseTensor construction collapses duplicate coordinates; canonical: keep the first occurrence."""
-    table = ops.HashTable(coords, stride)
+    from . import conventions
+    table = ops.HashTable(coords, stride, keep_last=conventions.get('dedup_keep') == 'last')
     keep = ops.first_occurrence_mask(coords, table)
     prefix, total = ops.mask_scan(keep)
     n = int(total.item())

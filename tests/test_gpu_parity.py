@@ -795,3 +795,59 @@ def test_bench_configs_run_small(cfg):
     assert r.returncode == 0, r.stderr[-2000:]
     assert line['config']['baseline_config'] == {'batch4': 3, 'sweep': 4, 'blocks': 5}[cfg]
     assert line['config']['points_out'] > 0 and line['roofline'] is not None and line['roofline']['frac'] <= 1.0
+
+
+# ------------------------------------------------------------------------------------------------ ‡ convention switches
+@pytest.fixture
+def conventions_reset():
+    from pcgcv2_amd import conventions
+    yield conventions
+    conventions.reset()
+    orc.CONVENTIONS.update(kernel_offset_order='xyz', topk_tie='low', dedup_keep='first')
+
+
+@pytest.mark.parametrize('setting', [('topk_tie', 'high'), ('dedup_keep', 'last'), ('kernel_offset_order', 'zyx')])
+def test_convention_switches_are_self_consistent(setting, conventions_reset, sd, sd_np, tmp_path):
+    """Each ‡ convention flipped on BOTH sides (library / host and oracle): the codec still equals the oracle bit for bit, and the
+    flipped setting really changes something observable (so the switch is live, not decorative)."""
+    from pcgcv2_amd.coder import Coder
+    name, value = setting
+    rng = np.random.default_rng(11)
+    # operator-level effect
+    if name == 'topk_tie':
+        v = np.round(rng.standard_normal(5000) * 2).astype(np.float32)              # heavy ties
+        low = ops.topk_mask(_t(v).reshape(-1, 1), 1234).cpu().numpy().astype(bool)
+        conventions_reset.set_convention(name, value); orc.CONVENTIONS[name] = value
+        high = ops.topk_mask(_t(v).reshape(-1, 1), 1234).cpu().numpy().astype(bool)
+        np.testing.assert_array_equal(high, orc.topk_mask(v, 1234))
+        assert high.sum() == low.sum() == 1234 and (high != low).any()
+    elif name == 'dedup_keep':
+        base = np.unique(rng.integers(0, 30, size=(400, 3)), axis=0).astype(np.int32)
+        c = np.concatenate([base, base[::2], base[3:90]], 0)
+        c4 = np.concatenate([np.zeros((len(c), 1), np.int32), c], 1)
+        f = np.arange(len(c4), dtype=np.float32).reshape(-1, 1)
+        first = SparseTensor(_t(f), coordinates=_t(c4), tensor_stride=1, device=DEV)
+        conventions_reset.set_convention(name, value); orc.CONVENTIONS[name] = value
+        last = SparseTensor(_t(f), coordinates=_t(c4), tensor_stride=1, device=DEV)
+        np.testing.assert_array_equal(last.C.cpu().numpy(), orc.unique_keep(c4))
+        assert len(last) == len(first) == len(base) and not np.array_equal(last.F.cpu().numpy(), first.F.cpu().numpy())
+    else:
+        conventions_reset.set_convention(name, value); orc.CONVENTIONS[name] = value
+    # end to end under the flipped convention
+    c4 = _coords('shell7')
+    if name == 'dedup_keep':
+        c4 = np.concatenate([c4, c4[::5]], 0)
+    m = _model(sd)                                               # load_state_dict applies the kernel-offset convention
+    sd_o = orc.apply_offset_order(sd_np)
+    x = SparseTensor(torch.ones((len(c4), 1)), coordinates=_t(c4), tensor_stride=1, device=DEV)
+    uniq = orc.unique_keep(c4)
+    np.testing.assert_array_equal(x.C.cpu().numpy(), uniq)
+    coder = Coder(m, str(tmp_path / 'cv'))
+    coder.encode(x)
+    ref = orc.encode(sd_o, uniq)
+    for k in ('F', 'H', 'num_points'):
+        assert (tmp_path / f'cv_{k}.bin').read_bytes() == ref[k], k
+    out = coder.decode(rho=0.9)
+    np.testing.assert_array_equal(out.C.cpu().numpy(), orc.decode(sd_o, ref['coords8'], ref['F'], ref['H'], ref['num_points'], rho=0.9))
+    if name == 'kernel_offset_order':                            # the permuted kernels give a different bitstream than the default order
+        assert ref['F'] != orc.encode(sd_np, uniq)['F']

@@ -37,9 +37,11 @@ for cls, names in ((Coder, ['encode', 'decode', '_decode_geometry']), (coder_mod
                    (type(model.encoder), ['forward']), (type(model.decoder), ['forward'])):
     for n in names:
         wrap(cls, n, f'{cls.__name__}.{n}')
-for n in ('rc_encode', 'rc_decode', 'compress_prepare', 'cdf_table', 'sort_zyx', 'desymbolize'):
+for n in ('rc_encode', 'rc_decode', 'quantize_symbols', 'sort_zyx', 'desymbolize', 'topk_mask'):
     wrap(ops, n, 'ops.' + n)
 wrap(coder_mod, '_dump'); wrap(coder_mod, '_slurp')
+from pcgcv2_amd import entropy_model
+wrap(entropy_model.EntropyBottleneck, 'host_table', 'EB.host_table')
 
 def step():
     x.cmap.drop_caches()
