@@ -1,4 +1,6 @@
 set -x
+# Round-end collection on the GPU box: PMC traffic (FETCH_SIZE / WRITE_SIZE passes), rocprofv3 kernel trace of the bench command, SQ counters
+# of the dominant children-level kernels, FETCH_SIZE calibration, and the bench lines of every config.  Everything lands in gpurun_out/final/.
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/final
 timeout 600 bash $R/tools/pmc_traffic.sh > $R/gpurun_out/final/pmc.log 2>&1
@@ -8,5 +10,12 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 cd $R
 python tools/rocprof_summary.py gpurun_out/final/kt/*/*kernel_stats.csv at::native > gpurun_out/final/kernel_trace.txt 2>&1 || true
 find gpurun_out/final/kt -name '*kernel_trace.csv' -delete
-python bench.py --steps 20 --warmup 5 --detail gpurun_out/final/detail.json > gpurun_out/final/bench_line.json 2> gpurun_out/final/bench.err
-tail -c 1500 gpurun_out/final/bench_line.json
+bash tools/fetch_calib.sh > /dev/null 2>&1; cp gpurun_out/r02_fetch_calibration.txt gpurun_out/final/
+for cfg in 16:irn 16:conv 32:irn; do
+  bash tools/child_pmc.sh ${cfg%%:*} 0 0 ${cfg##*:} > /dev/null 2>&1; cp gpurun_out/child_pmc/summary.txt gpurun_out/final/child_pmc_${cfg%%:*}_${cfg##*:}.txt
+done
+python bench.py --steps 20 --warmup 5 --detail gpurun_out/final/detail.json > gpurun_out/final/bench_frame.json 2> gpurun_out/final/bench.err
+python bench.py --config batch4 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/final/bench_batch4.json 2>> gpurun_out/final/bench.err
+python bench.py --config sweep --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/final/bench_sweep.json 2>> gpurun_out/final/bench.err
+python bench.py --config blocks --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/final/bench_blocks.json 2>> gpurun_out/final/bench.err
+tail -c 1200 gpurun_out/final/bench_frame.json

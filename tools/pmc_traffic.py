@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """Aggregate rocprofv3 counter_collection CSVs (FETCH_SIZE / WRITE_SIZE passes) into per-(kernel, grid) HBM bytes per launch.
-FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 B? -> rocprofv3 reports kilobytes (x1024).  On gfx950 FETCH_SIZE
-counts 128-byte requests as 64 B for wide (16 B/lane) reads (MI355X_MICROARCH.md §HBM): the corrected figure doubles it."""
+rocprofv3 reports kilobytes (x1024).  On gfx950 FETCH_SIZE tallies 64 B per memory-side request whatever its size (calibrated on known
+byte counts, profiles/r02_fetch_calibration.txt): wide streaming reads and gathers of 128- / 256-byte row segments issue 128-byte
+requests and read back HALF their bytes (correction x2, as MI355X_MICROARCH.md says); gathers of 64-byte rows read back exactly their
+bytes (x1); 32-byte rows read back 2x their bytes, which is true traffic (64-byte sectors).  So kernels whose traffic is dominated by
+gathers of rows of at most 64 bytes (the C = 16 level) take x1, everything else x2; mixed kernels lie in between."""
 import csv, glob, json, re, sys, collections
 src, dst = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(src + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         name = r['Kernel_Name']
-        m = re.search(r'(k_[a-z0-9_]+<[^>]*>|k_[a-z0-9_]+)', name)
+        m = re.search(r'(k_[a-z0-9_]+<[^>]*>|k_[a-z0-9_]+)', name.replace('(anonymous namespace)::', ''))
         if not m:
             continue
         acc[(m.group(1), int(r['Grid_Size']))][r['Counter_Name']].append(float(r['Counter_Value']))
@@ -18,10 +21,13 @@ for (k, grid), d in acc.items():
         continue
     fetch = sum(d['FETCH_SIZE']) / len(d['FETCH_SIZE']) * 1024
     write = sum(d['WRITE_SIZE']) / len(d['WRITE_SIZE']) * 1024
+    narrow = bool(re.match(r'k_(irn_[ab]<16|child_irn_[ab]<16|child_conv<1, 1|child_cls<1,|conv_gather_\w+<16,)', k))
+    f = 1.0 if narrow else 2.0
     out.append({'kernel': k, 'grid_size': grid, 'grid_rows': grid, 'launches_sampled': len(d['FETCH_SIZE']),
-                'fetch_bytes_raw': round(fetch), 'fetch_bytes_corrected': round(2 * fetch), 'write_bytes': round(write),
-                'hbm_bytes_per_launch': round(2 * fetch + write),
-                'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py; FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B)'})
+                'fetch_bytes_raw': round(fetch), 'fetch_correction': f, 'fetch_bytes_corrected': round(f * fetch), 'write_bytes': round(write),
+                'hbm_bytes_per_launch': round(f * fetch + write),
+                'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py; FETCH_SIZE x%g (calibrated: 64 B tallied per '
+                          'request; %s)' % (f, '64-byte row gathers read back their bytes' if narrow else '128-byte requests read back half')})
 out.sort(key=lambda e: -e['hbm_bytes_per_launch'])
 json.dump({'kernels': out}, open(dst, 'w'), indent=1)
 for e in out[:12]:
