@@ -100,13 +100,17 @@ struct ClsHead {                       // k3 conv C -> 1: one tile, column j (0.
 // cell that IS the child: offset k = 13).
 template <int C>
 struct PassA {
-    static constexpr int Q = C / 4, NB = C / 16, ROWCHUNKS = 4, CPT = 16 / Q /*children per tile: 4 or 2*/, TH = 8 / CPT, T = 2 * TH, KS = 4;
+    static constexpr int Q = C / 4, NB = C / 16, ROWCHUNKS = 4, CPT = 16 / Q /*children per tile: 4, 2 or 1*/, TH = 8 / CPT, T = 2 * TH, KS = 4;
     static constexpr bool HALF = false;
     static constexpr int kfirst(int) { return 0; }
     // tile geometry: CPT == 4: tile = z-half (children 4 jz + {0..3});  CPT == 2: tile = (jz, jy) quarter (children 4 jz + 2 jy + {0,1})
     static constexpr int tz(int t) { return CPT == 4 ? (t % TH) : (t % TH) >> 1; }
     static constexpr int ty(int t) { return (t % TH) & 1; }
     static constexpr bool active(int c, int t) {
+        if (CPT == 1) {                                         // C = 64: one child per tile; conv1_0 is fed only by the cell that IS the child
+            if (t < TH) return (cell_reach(c) >> t) & 1;
+            return ((cell_reach(c) >> (t - TH)) & 1) && cell_k(c, t - TH) == 13;
+        }
         const int kz = cz_of(c) - tz(t);
         if (CPT == 4) {
             if (t < TH) return in02(kz);
@@ -116,8 +120,9 @@ struct PassA {
         if (t < TH) return in02(kz) && in02(ky);
         return kz == 1 && ky == 1 && (cx_of(c) == 1 || cx_of(c) == 2);
     }
-    static constexpr int N0 = CPT == 4 ? 48 : 36;                                   // conv0_0 fragments
+    static constexpr int N0 = CPT == 4 ? 48 : (CPT == 2 ? 36 : 27);                 // conv0_0 fragments
     static constexpr int frag(int c, int t) {
+        if (CPT == 1) return t < TH ? cell_k(c, t) : N0;
         const int kz = cz_of(c) - tz(t);
         if (CPT == 4) return t < TH ? kz * 16 + (c & 15) : N0 + (cy_of(c) - 1) * 2 + (cx_of(c) - 1);
         const int ky = cy_of(c) - ty(t);
@@ -285,23 +290,48 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
         constexpr int younger = (63 - c) < (D - 1) ? (63 - c) : (D - 1);       // cells issued after c that may stay in flight
         wait_vmcnt<younger * NB>();
         float a[NB][4];
-        BFrag<KS> b[NB][T];
-        static_for<0, NB>([&](auto icb) {                                      // all LDS reads of the cell, one wait
+        constexpr bool BLOCKWISE = NB * T > 32;                                // wide layers: B fragments one 16-channel block at a time
+        constexpr int NBB = BLOCKWISE ? 1 : NB;
+        BFrag<KS> b[NBB][T];
+        auto load_b = [&](auto icb) {
+            constexpr int cb = decltype(icb)::value;
+            static_for<0, T>([&](auto it) {
+                constexpr int t = decltype(it)::value;
+                if constexpr (V::active(c, t)) {
+                    constexpr int off = (V::frag(c, t) * NB + cb) * frag_floats<V>() * 4;        // byte offset of the fragment in the table
+                    if constexpr (off < 65536) b[BLOCKWISE ? 0 : cb][t].template load<off>(tab_lane);
+                    else b[BLOCKWISE ? 0 : cb][t].template load<off - 65536>(tab_lane + 65536);
+                }
+            });
+        };
+        auto tie_b = [&](auto icb) {
+            constexpr int cb = decltype(icb)::value;
+            static_for<0, T>([&](auto it) {
+                constexpr int t = decltype(it)::value;
+                if constexpr (V::active(c, t)) b[BLOCKWISE ? 0 : cb][t].tie();
+            });
+        };
+        auto mfma_block = [&](auto icb) {
+            constexpr int cb = decltype(icb)::value;
+            static_for<0, 4>([&](auto ij) {
+                constexpr int jj = decltype(ij)::value;
+                static_for<0, T>([&](auto it) {
+                    constexpr int t = decltype(it)::value;
+                    if constexpr (V::active(c, t) && jj >= V::kfirst(t) && jj < V::kfirst(t) + KS)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][jj], b[BLOCKWISE ? 0 : cb][t].get(jj - V::kfirst(t)), acc[t], 0, 0, 0);
+                });
+            });
+        };
+        static_for<0, NB>([&](auto icb) {                                      // all LDS reads of the cell (A; and B unless block-wise), one wait
             constexpr int cb = decltype(icb)::value;
             static_for<0, 4>([&](auto ij) {
                 constexpr int jj = decltype(ij)::value;
                 if constexpr ((ksteps_used >> jj) & 1)
                     a[cb][jj] = lds_ld32_off<((c & (D - 1)) * NB + cb) * 1024>(a_addr[jj]);
             });
-            static_for<0, T>([&](auto it) {
-                constexpr int t = decltype(it)::value;
-                if constexpr (V::active(c, t)) {
-                    constexpr int off = (V::frag(c, t) * NB + cb) * frag_floats<V>() * 4;        // byte offset of the fragment in the table
-                    if constexpr (off < 65536) b[cb][t].template load<off>(tab_lane);
-                    else b[cb][t].template load<off - 65536>(tab_lane + 65536);
-                }
-            });
+            if constexpr (!BLOCKWISE) load_b(icb);
         });
+        if constexpr (BLOCKWISE) load_b(std::integral_constant<int, 0>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         static_for<0, NB>([&](auto icb) {
             constexpr int cb = decltype(icb)::value;
@@ -309,22 +339,18 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
                 constexpr int jj = decltype(ij)::value;
                 if constexpr ((ksteps_used >> jj) & 1) lds_tie(a[cb][jj]);
             });
-            static_for<0, T>([&](auto it) {
-                constexpr int t = decltype(it)::value;
-                if constexpr (V::active(c, t)) b[cb][t].tie();
-            });
+            if constexpr (!BLOCKWISE) tie_b(icb);
         });
+        if constexpr (BLOCKWISE) tie_b(std::integral_constant<int, 0>{});
         if constexpr (c + D < 64) issue(std::integral_constant<int, c + D>{});    // refill the ring slot cell c was read from
         static_for<0, NB>([&](auto icb) {
             constexpr int cb = decltype(icb)::value;
-            static_for<0, 4>([&](auto ij) {
-                constexpr int jj = decltype(ij)::value;
-                static_for<0, T>([&](auto it) {
-                    constexpr int t = decltype(it)::value;
-                    if constexpr (V::active(c, t) && jj >= V::kfirst(t) && jj < V::kfirst(t) + KS)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][jj], b[cb][t].get(jj - V::kfirst(t)), acc[t], 0, 0, 0);
-                });
-            });
+            if constexpr (BLOCKWISE && cb > 0) {
+                load_b(icb);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                tie_b(icb);
+            }
+            mfma_block(icb);
         });
     });
 #ifdef PCGC_CHILD_TIMING

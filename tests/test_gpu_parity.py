@@ -726,7 +726,7 @@ def test_cls_head_child_bit_exact(name, prune, cin):
         np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize('C', [16, 32])
+@pytest.mark.parametrize('C', [16, 32, 64])
 @pytest.mark.parametrize('name,prune', [('shell7', None), ('shell8', 7), ('shell6', 1)])
 def test_inception_resnet_child_bit_exact(name, prune, C):
     """pcgc_irn_child_pass A + B (packed-N MFMA through the parent map) == the oracle's five-conv InceptionResNet."""
@@ -743,10 +743,13 @@ def test_inception_resnet_child_bit_exact(name, prune, C):
     want = orc.inception_resnet(sd, 'b', orc.Level(kc, 1), x)
     params = [p for m in (blk.conv0_0, blk.conv0_1, blk.conv1_0, blk.conv1_1, blk.conv1_2) for p in (m.kernel, m.bias)]
     tables = ops.child_irn_tables(params)
-    for nw, d in ((0, 0), (4, 0), (0, 1)):
+    for nw, d in ((0, 0), (4, 0)):
         ops.set_child_tuning(nw, d)
         try:
-            got = ops.irn_block_child(parent.k3, _t(x), params, tables)
+            if C == 64:                                       # pass A through the parent map + per-row pass B
+                got = ops.irn_block_child64(parent.k3, kids.k3, _t(x), params, tables[0], ops.fuse_irn64(params))
+            else:
+                got = ops.irn_block_child(parent.k3, _t(x), params, tables)
         finally:
             ops.set_child_tuning(0, 0)
         np.testing.assert_array_equal(got.cpu().numpy(), want)

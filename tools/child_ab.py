@@ -26,6 +26,24 @@ def main():
     c4 = torch.cat([torch.zeros((len(pts), 1), dtype=torch.int32, device=dev), pts], 1).contiguous()
     l1 = CoordMap(c4, 1, unique=True)
     l2 = l1.down()[0]; l4 = l2.down()[0]
+    l8 = l4.down()[0]
+    if not only:                                               # C = 64: InceptionResNet on the children of the stride-8 level (149 856 rows)
+        from pcgcv2_amd.autoencoder import InceptionResNet
+        kids = l8.up(); n = len(kids); x = torch.randn((n, 64), device=dev)
+        blk = InceptionResNet(64).to(dev)
+        params = [p for m in (blk.conv0_0, blk.conv0_1, blk.conv1_0, blk.conv1_1, blk.conv1_2) for p in (m.kernel, m.bias)]
+        with torch.no_grad():
+            for p_ in params: p_.normal_(0, 0.1)
+        f = ops.fuse_irn64(params); nbr = kids.k3
+        ref = ops.irn_block_mfma64(nbr, x, f)
+        us_ref = timeit(lambda: ops.irn_block_mfma64(nbr, x, f))
+        ta = ops.child_irn_tables(params)[0]
+        for nw in (0, 4):
+            ops.set_child_tuning(nw, 0)
+            ok = torch.equal(ops.irn_block_child64(l8.k3, nbr, x, params, ta, f), ref)
+            us = timeit(lambda: ops.irn_block_child64(l8.k3, nbr, x, params, ta, f))
+            print(f'C=64 InceptionResNet on {n} rows: per-row {us_ref:.1f} us, pass A through the parent map (waves={nw or "default"}) {us:.1f} us  bit-exact={ok}')
+        ops.set_child_tuning(0, 0)
     for parent, C in ((l2, 16), (l4, 32)):
         if only and only[0] != C: continue
         kids = parent.up()
