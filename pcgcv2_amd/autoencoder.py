@@ -32,11 +32,8 @@ class InceptionResNet(torch.nn.Module):
                 stamp = tuple((p.data_ptr(), p._version) for p in params)
                 if getattr(self, '_child_stamp', None) != stamp:
                     self._child_tables, self._child_stamp = ops.child_irn_tables(params), stamp
-                    self._fused = ops.fuse_irn64(params) if c == 64 else None
-                    self._fused_stamp = stamp
-                if c == 64:                                 # pass A through the parent map, pass B on the per-row block-sparse kernel
-                    return SparseTensor(ops.irn_block_child64(x.cmap.origin[1].k3, x.cmap.k3, x.F, params, self._child_tables[0], self._fused),
-                                        coordinate_map=x.cmap)
+                if c == 64:
+                    return SparseTensor(ops.irn_block_child64(x.cmap.origin[1].k3, x.F, params, self._child_tables), coordinate_map=x.cmap)
                 return SparseTensor(ops.irn_block_child(x.cmap.origin[1].k3, x.F, params, self._child_tables), coordinate_map=x.cmap)
             if c == 64 and ops.MFMA_IRN and x.F.shape[0] >= 30000:
                 # block-sparse MFMA path; the fused weights are rebuilt whenever a parameter tensor was replaced or modified

@@ -19,12 +19,13 @@ extern "C" int pcgc_conv_child(const int32_t* parent_nbr, int64_t n_parent, cons
     int rc = -2;
     const int nw = g_child_nw;
     const int tb = (int)table_bytes;
-    if (Cout == 1 && (Cin == 16 || Cin == 32)) {        // classification head: 8 columns = the 8 children
+    if (Cout == 1 && (Cin == 16 || Cin == 32 || Cin == 64)) {        // classification head: 8 columns = the 8 children
         PCGC_REQUIRE(table_bytes == (int64_t)64 * (Cin / 16) * 32 * 4 * 4, "cls table size");
         PCGC_REQUIRE(residual == nullptr && !relu, "cls head has no fused epilogue");
         ChildEpi ep{bias, nullptr, 0, 0, out, out_ld, 0};
         // <16-channel blocks, waves per group, ring depth>: the table (32 / 64 KB) decides how many waves fit a CU
-        if (Cin == 16) rc = (nw == 4) ? launch_child_cls<1, 4, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s)
+        if (Cin == 64) rc = launch_child_cls<4, 4, 1>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);       // 128 KB table: 4 waves, one ring slot
+        else if (Cin == 16) rc = (nw == 4) ? launch_child_cls<1, 4, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s)
                                       : launch_child_cls<1, 8, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
         else rc = (nw == 4) ? launch_child_cls<2, 4, 2>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s)
                             : launch_child_cls<2, 16, 2>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
@@ -39,7 +40,7 @@ extern "C" int pcgc_conv_child(const int32_t* parent_nbr, int64_t n_parent, cons
             if (nw == 4) rc = launch_child_conv<2, 2, 4, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
             else rc = launch_child_conv<2, 2, 8, 2>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
         } else {
-            pcgc_set_error("conv_child: unsupported shape %d -> %d (16->16, 32->32, 16->1, 32->1)", Cin, Cout);
+            pcgc_set_error("conv_child: unsupported shape %d -> %d (16->16, 32->32, 16->1, 32->1, 64->1)", Cin, Cout);
             return -2;
         }
     }

@@ -86,6 +86,10 @@ struct PlainConv {                     // k3 conv Cin = 16 NB -> Cout = 16 NT: t
     static constexpr int kfirst(int) { return 0; }
     static constexpr bool active(int c, int t) { return (cell_reach(c) >> (t / NT)) & 1; }
     static constexpr int frag(int c, int t) { return cell_k(c, t / NT) * NT + t % NT; }
+    static constexpr bool uses_block(int, int) { return true; }
+    static constexpr int NBATCH = 1;
+    static constexpr int batch(int) { return 0; }
+    static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 64 * KS * 4; }      // byte offset in the table
 };
 template <int NB_>
 struct ClsHead {                       // k3 conv C -> 1: one tile, column j (0..7) = child j; one fragment per cell
@@ -94,6 +98,10 @@ struct ClsHead {                       // k3 conv C -> 1: one tile, column j (0.
     static constexpr int kfirst(int) { return 0; }
     static constexpr bool active(int, int) { return true; }
     static constexpr int frag(int c, int) { return c; }
+    static constexpr bool uses_block(int, int) { return true; }
+    static constexpr int NBATCH = 1;
+    static constexpr int batch(int) { return 0; }
+    static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 32 * KS * 4; }
 };
 // InceptionResNet pass A (autoencoder.py:52-57 first half): conv0_0 (k3 C -> Q) and conv1_0 (k1 C -> Q), Q = C/4.
 // Columns pack (child, output channel): 16/Q children per tile.  Tiles [0, T/2) = conv0_0, [T/2, T) = conv1_0 (fed only by the
@@ -128,6 +136,10 @@ struct PassA {
         const int ky = cy_of(c) - ty(t);
         return t < TH ? (kz * 3 + ky) * 4 + cx_of(c) : N0 + (cx_of(c) - 1);
     }
+    static constexpr bool uses_block(int, int) { return true; }
+    static constexpr int NBATCH = 1;
+    static constexpr int batch(int) { return 0; }
+    static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 64 * KS * 4; }
 };
 // InceptionResNet pass B: the gathered rows are t = [relu(conv0_0) | relu(conv1_0)] (2Q wide).  conv0_1 (k3 Q -> 2Q) reads the
 // first Q channels, conv1_1 (k3 Q -> Q) the last Q: with Q = 8 (C = 32) those are K-steps {0,1} / {2,3} of the one 16-channel
@@ -159,6 +171,25 @@ struct PassB {
         if (CPT1 == 2) return N0 + ((cz_of(c) - (u >> 1)) * 3 + (cy_of(c) - (u & 1))) * 4 + cx_of(c);
         return N0 + (cz_of(c) - u) * 16 + (c & 15);
     }
+    static constexpr bool uses_block(int, int) { return true; }
+    static constexpr int NBATCH = 1;
+    static constexpr int batch(int) { return 0; }
+    static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 64 * KS * 4; }
+};
+// pass B at C = 64 (Q = 16): t is 32 wide = two 16-channel blocks; block 0 feeds conv0_1 (k3 16 -> 32: two column tiles per child),
+// block 1 feeds conv1_1 (k3 16 -> 16: one tile per child).  Fragments: conv0_1 (k, n) = 54, conv1_1 k = 27, conv1_2 (k1 16 -> 32) = 2.
+struct PassB64 {
+    static constexpr int Q = 16, NB = 2, ROWCHUNKS = 4, KS = 4, T0 = 16, T1 = 8, T = 24;
+    static constexpr bool HALF = false;
+    static constexpr int kfirst(int) { return 0; }
+    static constexpr int child_of(int t) { return t < T0 ? t / 2 : t - T0; }
+    static constexpr bool active(int c, int t) { return (cell_reach(c) >> child_of(t)) & 1; }
+    static constexpr bool uses_block(int t, int cb) { return t < T0 ? cb == 0 : cb == 1; }
+    static constexpr int NBATCH = 2;                       // B fragments of a block in two batches (16 at once would not fit the registers)
+    static constexpr int batch(int t) { return t < T0 ? (t & 1) : 0; }
+    static constexpr int frag(int c, int t) { return t < T0 ? cell_k(c, t / 2) * 2 + (t & 1) : 54 + cell_k(c, t - T0); }
+    static constexpr int frag_off(int c, int t, int) { return frag(c, t) * 1024; }
+    static constexpr int FRAG_W12 = 81;
 };
 
 template <int I, int N, typename F>
@@ -290,34 +321,38 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
         constexpr int younger = (63 - c) < (D - 1) ? (63 - c) : (D - 1);       // cells issued after c that may stay in flight
         wait_vmcnt<younger * NB>();
         float a[NB][4];
-        constexpr bool BLOCKWISE = NB * T > 32;                                // wide layers: B fragments one 16-channel block at a time
+        constexpr bool BLOCKWISE = NB * T > 32;                                // wide layers: B fragments one 16-channel block (and batch) at a time
+        static_assert(BLOCKWISE || V::NBATCH == 1, "batches only exist in the block-wise form");
         constexpr int NBB = BLOCKWISE ? 1 : NB;
         BFrag<KS> b[NBB][T];
-        auto load_b = [&](auto icb) {
+        auto load_b = [&](auto icb, auto ibt) {
             constexpr int cb = decltype(icb)::value;
+            constexpr int bt = decltype(ibt)::value;
             static_for<0, T>([&](auto it) {
                 constexpr int t = decltype(it)::value;
-                if constexpr (V::active(c, t)) {
-                    constexpr int off = (V::frag(c, t) * NB + cb) * frag_floats<V>() * 4;        // byte offset of the fragment in the table
+                if constexpr (V::active(c, t) && V::uses_block(t, cb) && V::batch(t) == bt) {
+                    constexpr int off = V::frag_off(c, t, cb);                                   // byte offset of the fragment in the table
                     if constexpr (off < 65536) b[BLOCKWISE ? 0 : cb][t].template load<off>(tab_lane);
                     else b[BLOCKWISE ? 0 : cb][t].template load<off - 65536>(tab_lane + 65536);
                 }
             });
         };
-        auto tie_b = [&](auto icb) {
+        auto tie_b = [&](auto icb, auto ibt) {
             constexpr int cb = decltype(icb)::value;
+            constexpr int bt = decltype(ibt)::value;
             static_for<0, T>([&](auto it) {
                 constexpr int t = decltype(it)::value;
-                if constexpr (V::active(c, t)) b[BLOCKWISE ? 0 : cb][t].tie();
+                if constexpr (V::active(c, t) && V::uses_block(t, cb) && V::batch(t) == bt) b[BLOCKWISE ? 0 : cb][t].tie();
             });
         };
-        auto mfma_block = [&](auto icb) {
+        auto mfma_block = [&](auto icb, auto ibt) {
             constexpr int cb = decltype(icb)::value;
+            constexpr int bt = decltype(ibt)::value;
             static_for<0, 4>([&](auto ij) {
                 constexpr int jj = decltype(ij)::value;
                 static_for<0, T>([&](auto it) {
                     constexpr int t = decltype(it)::value;
-                    if constexpr (V::active(c, t) && jj >= V::kfirst(t) && jj < V::kfirst(t) + KS)
+                    if constexpr (V::active(c, t) && V::uses_block(t, cb) && V::batch(t) == bt && jj >= V::kfirst(t) && jj < V::kfirst(t) + KS)
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][jj], b[BLOCKWISE ? 0 : cb][t].get(jj - V::kfirst(t)), acc[t], 0, 0, 0);
                 });
             });
@@ -329,9 +364,8 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
                 if constexpr ((ksteps_used >> jj) & 1)
                     a[cb][jj] = lds_ld32_off<((c & (D - 1)) * NB + cb) * 1024>(a_addr[jj]);
             });
-            if constexpr (!BLOCKWISE) load_b(icb);
+            if constexpr (!BLOCKWISE) load_b(icb, std::integral_constant<int, 0>{});
         });
-        if constexpr (BLOCKWISE) load_b(std::integral_constant<int, 0>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         static_for<0, NB>([&](auto icb) {
             constexpr int cb = decltype(icb)::value;
@@ -339,18 +373,20 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
                 constexpr int jj = decltype(ij)::value;
                 if constexpr ((ksteps_used >> jj) & 1) lds_tie(a[cb][jj]);
             });
-            if constexpr (!BLOCKWISE) tie_b(icb);
+            if constexpr (!BLOCKWISE) tie_b(icb, std::integral_constant<int, 0>{});
         });
-        if constexpr (BLOCKWISE) tie_b(std::integral_constant<int, 0>{});
         if constexpr (c + D < 64) issue(std::integral_constant<int, c + D>{});    // refill the ring slot cell c was read from
         static_for<0, NB>([&](auto icb) {
-            constexpr int cb = decltype(icb)::value;
-            if constexpr (BLOCKWISE && cb > 0) {
-                load_b(icb);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                tie_b(icb);
+            if constexpr (BLOCKWISE) {
+                static_for<0, V::NBATCH>([&](auto ibt) {
+                    load_b(icb, ibt);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    tie_b(icb, ibt);
+                    mfma_block(icb, ibt);
+                });
+            } else {
+                mfma_block(icb, std::integral_constant<int, 0>{});
             }
-            mfma_block(icb);
         });
     });
 #ifdef PCGC_CHILD_TIMING
@@ -360,6 +396,15 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
     CHILD_TADD(1, t_loop0, t_loop1);
     CHILD_TADD(3, 0ull, 1ull);
 #endif
+}
+
+// Lanes of one wave exchange data through LDS in the epilogues (one group of lanes writes, all lanes read).  The hardware runs a wave's
+// LDS operations in order, but the compiler reasons per thread: this fence + wave barrier tells it other lanes' stores become visible
+// here (no instruction is emitted beyond the waits the reordering restriction implies).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Epilogue staging.  The accumulators hold the tile in MFMA layout (lane = column, 4 rows per lane); written from there,
@@ -426,7 +471,9 @@ k_child_conv(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restr
                     }
                 }
             }
+            wave_lds_sync();
             child_flush<W>(scratch, CH, 8 * p0 + h * CH, 8 * n_p, ep.out, ep.out_ld, ep.res, ep.res_ld, ep.relu, lane);
+            wave_lds_sync();
         }
 #ifdef PCGC_CHILD_TIMING
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -510,7 +557,9 @@ k_child_irn_a(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
                     }
                 }
             }
+            wave_lds_sync();
             child_flush<W>(scratch, CH, 8 * p0 + h * CH, 8 * n_p, ep.out, W, nullptr, 0, 0, lane);
+            wave_lds_sync();
         }
 #ifdef PCGC_CHILD_TIMING
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -556,6 +605,7 @@ k_child_irn_b(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
 #pragma unroll
                 for (int r = 0; r < 4; ++r) us[(8 * (4 * mq + r) + u * CPT1 + sub1) * Q + c1] = fmaxf(acc[T0 + u][r] + b11, 0.0f);
         }
+        wave_lds_sync();
         // ---- CH rows at a time: [conv0_1 + b01 | conv1_2(u) + b12] staged row-major, then flushed with the residual x
         {
             const int c0 = mi % H, sub0 = mi / H;
@@ -582,7 +632,9 @@ k_child_irn_b(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
                         for (int r = 0; r < 4; ++r) stage[(16 * gg + 4 * mq + r) * C + H + mi] = d[r] + b12;
                     }
                 }
+                wave_lds_sync();
                 child_flush<C>(stage, CH, 8 * p0 + h * CH, 8 * n_p, ep.out, ep.out_ld, ep.x, ep.x_ld, 0, lane);
+                wave_lds_sync();
             }
         }
 #ifdef PCGC_CHILD_TIMING
@@ -592,20 +644,84 @@ k_child_irn_b(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
     }
 }
 
+// pass B at C = 64.  Epilogue per 16-row group g (parents 2g, 2g+1 x 8 children; held by the lanes of quarter g >> 1 in accumulator
+// elements r = 2 (g & 1) + {0, 1}): u = relu(conv1_1 + b11) and conv0_1 + b01 go to the scratch, conv1_2 (k1 16 -> 32) is 8 MFMAs on u,
+// then the 16 rows x 64 columns leave coalesced with the residual x added.
+template <int NW, int D>
+__global__ void __launch_bounds__(NW * 64)
+k_child_irn_b64(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in /* t [.., 32] */, int in_ld,
+                const float* __restrict__ table, int table_bytes, IrnEpi ep) {
+    using V = PassB64;
+    constexpr int NEEDF4 = (16 * 16 + 16 * 64) / 4;                                        // us [16][16] + stage [16][64]
+    constexpr int RINGF4 = (D * V::NB * 64 > NEEDF4) ? D * V::NB * 64 : NEEDF4;
+    CHILD_KERNEL_PROLOGUE(V, NW, D, RINGF4)
+    float* us = (float*)ring;
+    float* stage = us + 16 * 16;
+    f32x4 w12[2];                                                                          // conv1_2 B fragments: W12[4 jj + mq][16 n + mi]
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2) w12[n2] = *((const f32x4*)(lds_raw + (V::FRAG_W12 + n2) * 1024) + lane);
+    const float b01a = ep.b0[mi], b01b = ep.b0[16 + mi], b11 = ep.b1[mi], b12a = ep.b2[mi], b12b = ep.b2[16 + mi];
+    for (int i = 0;; ++i) {
+        const int64_t tile = child_tile<NW>(i, wave, ntiles);
+        if (tile < 0) break;
+        const int64_t p0 = tile * 16;
+        CHILD_T(t_it0);
+        f32x4 acc[V::T];
+        child_tile_mainloop<V, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
+        static_for<0, 8>([&](auto ig) {
+            constexpr int g = decltype(ig)::value;
+            if (mq == (g >> 1)) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    constexpr int r0 = 2 * (g & 1);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int lr = 8 * rr + j;
+                        us[lr * 16 + mi] = fmaxf(acc[16 + j][r0 + rr] + b11, 0.0f);
+                        stage[lr * 64 + mi] = acc[2 * j][r0 + rr] + b01a;
+                        stage[lr * 64 + 16 + mi] = acc[2 * j + 1][r0 + rr] + b01b;
+                    }
+                }
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) {
+                f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) d = __builtin_amdgcn_mfma_f32_16x16x4f32(us[mi * 16 + 4 * jj + mq], w12[n2][jj], d, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stage[(4 * mq + r) * 64 + 32 + 16 * n2 + mi] = d[r] + (n2 ? b12b : b12a);
+            }
+            wave_lds_sync();
+            child_flush<64>(stage, 16, 8 * p0 + 16 * g, 8 * n_p, ep.out, ep.out_ld, ep.x, ep.x_ld, 0, lane);
+            wave_lds_sync();
+        });
+#ifdef PCGC_CHILD_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        { CHILD_T(t_it1); CHILD_TADD(4, t_it0, t_it1); }
+#endif
+    }
+}
+
+// kernels above the default dynamic-LDS limit need the attribute raised once per (kernel, device)
+struct ChildLdsGrant { size_t bytes[16] = {0}; };
 template <typename K>
-int child_lds_limit(K kern, size_t lds, size_t& granted) {
+int child_lds_limit(K kern, size_t lds, ChildLdsGrant& granted) {
     if (lds > 160 * 1024) { pcgc_set_error("child kernel: %zu bytes of LDS needed", lds); return -2; }
-    if (lds > 48 * 1024 && lds > granted) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t& g = granted.bytes[dev & 15];
+    if (lds > 48 * 1024 && lds > g) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { pcgc_set_error("child kernel: cannot raise the LDS limit to %zu: %s", lds, hipGetErrorString(e)); return -1; }
-        granted = lds;
+        g = lds;
     }
     return 0;
 }
 // persistent grid: as many workgroups as stay resident (LDS-limited, at most 16 waves per CU), a multiple of 8 (one share per XCD)
 static unsigned child_grid(int64_t n_p, int nw, size_t lds) {
     static int cus = 0;
-    if (!cus) { hipDeviceProp_t p; int dev = 0; hipGetDevice(&dev); cus = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+    if (!cus) { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); cus = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
     int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
     if (per_cu > 16 / nw) per_cu = 16 / nw;
     if (per_cu < 1) per_cu = 1;
@@ -619,7 +735,7 @@ static unsigned child_grid(int64_t n_p, int nw, size_t lds) {
     do {                                                                                                                       \
         const size_t lds = (size_t)table_bytes + (size_t)(NW) * (RINGBYTES);                                                   \
         auto kern = KERN;                                                                                                      \
-        static size_t granted = 0;                                                                                             \
+        static ChildLdsGrant granted;                                                                                          \
         if (int rc = child_lds_limit(kern, lds, granted)) return rc;                                                           \
         hipLaunchKernelGGL(kern, dim3(child_grid(n_p, NW, lds)), dim3((NW) * 64), lds, s, pnbr, n_p, in, in_ld, table, table_bytes, EP); \
         return 0;                                                                                                              \
@@ -647,6 +763,14 @@ int launch_child_irn_b(const int32_t* pnbr, int64_t n_p, const float* in, int in
     constexpr int need = (128 * Q + CH * C) * 4;
     constexpr int ringb = (D * 1024 > need) ? D * 1024 : need;
     CHILD_LAUNCH((k_child_irn_b<C, NW, D>), NW, ringb, ep);
+}
+
+template <int NW, int D>
+int launch_child_irn_b64(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
+                         const IrnEpi& ep, hipStream_t s) {
+    constexpr int need = (16 * 16 + 16 * 64) * 4;
+    constexpr int ringb = (D * 2 * 1024 > need) ? D * 2 * 1024 : need;
+    CHILD_LAUNCH((k_child_irn_b64<NW, D>), NW, ringb, ep);
 }
 
 }  // namespace

@@ -529,46 +529,34 @@ def irn_block_mfma64(nbr, x, f):
     return out
 
 
-def irn_block_child64(parent_nbr, nbr, x, params, table_a, f):
-    """C = 64 InceptionResNet on a children level: pass A (conv0_0 k3 64->16 + conv1_0 k1 64->16) through the PARENT level's map
-    (pcgc_irn_child_pass), pass B on the block-sparse per-row kernel + pointwise tail as in irn_block_mfma64 (its fragment table
-    would not fit LDS).  nbr = the children level's own map (pass B), f = fuse_irn64(params).  Bit-identical to irn_block."""
+def irn_block_child64(parent_nbr, x, params, tables):
+    """C = 64 InceptionResNet on a children level, both passes through the PARENT level's map (k_child_irn_a<64>, k_child_irn_b64);
+    bit-identical to irn_block / irn_block_mfma64."""
     _f32(x, 'x')
     n, n_p = x.shape[0], parent_nbr.shape[1]
+    ta, tb = tables
     t = torch.empty((n, 32), dtype=torch.float32, device=x.device)
-    u = torch.empty((n, 48), dtype=torch.float32, device=x.device)
     out = torch.empty((n, 64), dtype=torch.float32, device=x.device)
     P = [p.data_ptr() for p in params]
     s = _stream(x)
     if PROFILE.counting:
-        PROFILE.count(nbr)
-    Q, C = 16, 64
+        PROFILE.count_children(parent_nbr)
     tiles = (n_p + 15) // 16
-    key_a = ('k_child_irn_a<64>', n)
-    prof = PROFILE.want(key_a)
-    if prof:
-        e0, e1 = PROFILE.bracket(key_a, 'k_child_irn_a<64> (InceptionResNet pass A on a children level, parent-map halo gather + fp32 MFMA)', n,
-                                 lambda P_: (P_ * C * 4 + P_ * 8 + n * Q * 4) + n * (C + Q) * 4, lambda P_: 2 * P_ * C * Q + 2 * n * C * Q,
-                                 compulsory=n * 64 * 4 + 27 * n_p * 4 + n * 32 * 4, mfma_issued=tiles * (216 * 16 + 8 * 16) * 2048)
-        e0.record()
-    check(lib().pcgc_irn_child_pass(_p(parent_nbr), n_p, 64, 1, _p(x), _ld(x), _p(table_a), table_a.numel() * 4, P[1], P[5], None, None, 0,
-                                    _p(t), 32, s), 'irn_child_pass A')
-    if prof:
-        e1.record()
-    name = 'k_conv_gather_mfma_wlds<32, 48, 2>'
-    prof = PROFILE.want((name, n))
-    if prof:
-        n16 = (n + 15) // 16 * 16
-        e0, e1 = PROFILE.bracket((name, n), name + ' (block-sparse per-row gather)', n,
-                                 lambda P_: (P_ * Q * 4 + P_ * 8 + n * 2 * Q * 4) + (P_ * Q * 4 + P_ * 8 + n * Q * 4) + n * 3 * Q * 4,
-                                 lambda P_: 2 * P_ * Q * 2 * Q + 2 * P_ * Q * Q + 2 * n * Q * 2 * Q,
-                                 compulsory=n * 32 * 4 + 27 * n * 4 + n * 48 * 4, mfma_issued=2 * n16 * 16 * 16 * 27 * 3)
-        e0.record()
-    check(lib().pcgc_conv_gather_masked(_p(nbr), n, _p(t), n, 32, 32, _p(f['Wb']), 48, _p(f['mask_b']), _p(f['bb']), 0, _p(u), 48, s),
-          'conv_gather_masked')
-    if prof:
-        e1.record()
-    check(lib().pcgc_irn_tail(_p(u), _p(x), 64, _ld(x), _p(f['W12']), _p(f['b12']), _p(out), 64, n, s), 'irn_tail')
+    forms = _irn_pass_formulas(n, 64, 27 * n_p * 4, ('k_child_irn_a<64>', 'k_child_irn_b64'))
+    per_tile = (216 * 16 + 8 * 16, 216 * 12 + 64)            # MFMA instructions per 16-parent tile (pass B incl. the conv1_2 products)
+    calls = (lambda: lib().pcgc_irn_child_pass(_p(parent_nbr), n_p, 64, 1, _p(x), _ld(x), _p(ta), ta.numel() * 4, P[1], P[5], None, None, 0,
+                                               _p(t), 32, s),
+             lambda: lib().pcgc_irn_child_pass(_p(parent_nbr), n_p, 64, 2, _p(t), 32, _p(tb), tb.numel() * 4, P[3], P[7], P[9], _p(x), _ld(x),
+                                               _p(out), 64, s))
+    for (ps, name, bf, ff, comp), call, mf in zip(forms, calls, per_tile):
+        prof = PROFILE.want((name, n))
+        if prof:
+            e0, e1 = PROFILE.bracket((name, n), name + ' (fused InceptionResNet pass on a children level, parent-map halo gather + fp32 MFMA)', n, bf, ff,
+                                     compulsory=comp, mfma_issued=tiles * mf * 2048)
+            e0.record()
+        check(call(), 'irn_child_pass')
+        if prof:
+            e1.record()
     return out
 
 
@@ -587,15 +575,15 @@ def set_child_tuning(waves=0, depth=0):
 def child_conv_eligible(x, cin, cout):
     """k3 conv of a SparseTensor living on a children level, in a shape the parent-map MFMA kernels are built for."""
     org = x.cmap.origin
-    return (CHILD_MFMA and org is not None and org[0] == 'children' and (cin, cout) in ((16, 16), (32, 32), (16, 1), (32, 1))
-            and x.F.shape[0] >= 8192 and x.F.shape[0] * x.F.stride(0) * 4 < 0xFFFFFFF0)
+    return (CHILD_MFMA and org is not None and org[0] == 'children' and (cin, cout) in ((16, 16), (32, 32), (16, 1), (32, 1), (64, 1))
+            and x.F.shape[0] >= 8192 and x.F.shape[0] * x.F.stride(0) * 4 < 0xF0000000)
 
 
 def irn_child_eligible(x):
     """InceptionResNet on a children level with C = 16 or 32 (the two large decoder levels)."""
     org = x.cmap.origin
     return (CHILD_MFMA and org is not None and org[0] == 'children' and x.F.shape[1] in (16, 32, 64) and x.F.shape[0] >= 8192
-            and x.F.is_contiguous() and x.F.shape[0] * x.F.shape[1] * 4 < 0xFFFFFFF0)
+            and x.F.is_contiguous() and x.F.shape[0] * x.F.shape[1] * 4 < 0xF0000000)
 
 
 def _halo_cells():
@@ -713,7 +701,16 @@ def _irn_index(C):
         for k in range(27):
             fa.append(_fragment([W00[k][:, co] for co in range(16)], NB))
         fa.append(_fragment([W10[:, co] for co in range(16)], NB))
-        return np.concatenate([f.reshape(-1) for f in fa]), None
+        # pass B: conv0_1 (k3 16 -> 32) fragments (k, n), conv1_1 (k3 16 -> 16) fragments k, conv1_2 (k1 16 -> 32) fragments n: one 16-channel block each
+        fb = []
+        for k in range(27):
+            for n2 in range(2):
+                fb.append(_fragment([W01[k][:, 16 * n2 + co] for co in range(16)], 1))
+        for k in range(27):
+            fb.append(_fragment([W11[k][:, co] for co in range(16)], 1))
+        for n2 in range(2):
+            fb.append(_fragment([W12[:, 16 * n2 + co] for co in range(16)], 1))
+        return np.concatenate([f.reshape(-1) for f in fa]), np.concatenate([f.reshape(-1) for f in fb])
     if cpt == 4:
         for kz in range(3):
             for cy in range(4):

@@ -706,7 +706,7 @@ def test_conv_child_bit_exact(name, prune, cin, cout, tuning):
         ops.set_child_tuning(0, 0)
 
 
-@pytest.mark.parametrize('cin', [16, 32])
+@pytest.mark.parametrize('cin', [16, 32, 64])
 @pytest.mark.parametrize('name,prune', [('shell7', None), ('shell8', 7), ('shell6', 1)])
 def test_cls_head_child_bit_exact(name, prune, cin):
     """Classification head (k3 conv C -> 1) on a children level through the parent map == oracle per-row gather conv."""
@@ -746,8 +746,8 @@ def test_inception_resnet_child_bit_exact(name, prune, C):
     for nw, d in ((0, 0), (4, 0)):
         ops.set_child_tuning(nw, d)
         try:
-            if C == 64:                                       # pass A through the parent map + per-row pass B
-                got = ops.irn_block_child64(parent.k3, kids.k3, _t(x), params, tables[0], ops.fuse_irn64(params))
+            if C == 64:
+                got = ops.irn_block_child64(parent.k3, _t(x), params, tables)
             else:
                 got = ops.irn_block_child(parent.k3, _t(x), params, tables)
         finally:
