@@ -147,6 +147,9 @@ int pcgc_irn_tail(const float* u /*[n,48]*/, const float* x, int C, int x_ld, co
  * same arguments; used to time the passes individually. */
 int pcgc_irn_pass(const int32_t* nbr, int64_t n, const float* x, int C, int x_ld, const float* const* params,
                   float* t_scratch, float* out, int out_ld, int pass, void* stream);
+/* which instantiation pcgc_irn_block / pcgc_irn_pass run for (C, n): rows per wave tile and channels per sub-step of pass A (profiling
+ * records name the kernel; the policy lives in the library only). */
+int pcgc_irn_config(int C, int64_t n, int* rows, int* pass_a_channels_per_substep);
 /* MinkowskiGenerativeConvolutionTranspose(k=2,s=2): out[8i+k] = in[i] @ W[k] + bias (+ReLU). */
 int pcgc_conv_up2(int64_t n_in, const float* in, int Cin, int in_ld, const float* W /*[8,Cin,Cout]*/, const float* bias,
                   int relu, float* out /*[dev 8n,Cout]*/, int Cout, void* stream);

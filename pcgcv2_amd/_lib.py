@@ -46,6 +46,7 @@ SIGNATURES = {
     'pcgc_irn_block': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, ci, vp]),
     'pcgc_conv_gather_masked': (ci, [vp, i64, vp, i64, ci, ci, vp, ci, vp, vp, ci, vp, ci, vp]),
     'pcgc_irn_tail': (ci, [vp, vp, ci, ci, vp, vp, vp, ci, i64, vp]),
+    'pcgc_irn_config': (ci, [ci, i64, vp, vp]),
     'pcgc_irn_pass': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, ci, ci, vp]),
     'pcgc_conv_child': (ci, [vp, i64, vp, ci, ci, vp, i64, vp, vp, ci, ci, vp, ci, ci, vp]),
     'pcgc_set_child_tuning': (ci, [ci, ci]),

@@ -758,6 +758,7 @@ static int g_irn_rows = 0;          // 0 = choose the tile height from the level
 static int64_t g_irn_cb16_rows = 400000;   // C = 32 pass A: 16-channel sub-steps from this many rows on (0 = always, for tests)
 extern "C" int pcgc_set_irn_cb16_rows(int64_t min_rows) { g_irn_cb16_rows = min_rows < 0 ? 400000 : min_rows; return 0; }
 extern "C" int pcgc_set_irn_rows(int rows) { g_irn_rows = rows; return 0; }
+static int irn_rows_for(int64_t n) { return g_irn_rows > 0 ? g_irn_rows : (n < 40000 ? 16 : 64); }   // (measurements: launch_irn_rows)
 
 // kernel offsets gathered per wait (27 = 9 x 3): more gathers in flight per wave.  Pays only while the extra row buffers do
 // not cut occupancy: measured irn_b<16> 194 -> 167 us, but irn_b<32> 127 -> 160 us and irn_b<64> 196 -> 433 us with 3.
@@ -965,12 +966,20 @@ static void launch_irn_rows(const int32_t* nbr, int64_t n, const float* x, int x
     // measured per level (bench.py --irn-rows, us for pass A / pass B at C = 32): 18.7 k rows: 64 -> 62.7 / 45.8, 32 -> 51.8 / 38.0,
     // 16 -> 43.7 / 32.8 (a level that small is 73 tiles of 64 rows: the extra waves win); 256 k rows: 68.5 / 54.3, 93.1 / 66.3,
     // 141.7 / 100.4 and likewise above (shorter tiles lose more DMA efficiency than the extra waves gain).
-    const int rows = g_irn_rows > 0 ? g_irn_rows : (n < 40000 ? 16 : 64);
+    const int rows = irn_rows_for(n);
     if (rows == 64) launch_irn<C, 64>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
     else if (rows == 32) launch_irn<C, 32>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
     else launch_irn<C, 16>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
 }
 
+// the tile height / channel sub-step the dispatcher below picks for (C, n): the single source of that policy, also for the host's
+// profile records (which name the exact kernel instantiation)
+extern "C" int pcgc_irn_config(int C, int64_t n, int* rows, int* pass_a_channels_per_substep) {
+    const int r = irn_rows_for(n);
+    if (rows) *rows = r;
+    if (pass_a_channels_per_substep) *pass_a_channels_per_substep = (C == 32 && r == 64 && n >= g_irn_cb16_rows) ? 16 : 32;
+    return 0;
+}
 // params: {W00,b00, W01,b01, W10,b10, W11,b11, W12,b12} = conv0_0, conv0_1, conv1_0, conv1_1, conv1_2 (kernel, bias)
 static int irn_launch(const int32_t* nbr, int64_t n, const float* x, int C, int x_ld, const float* const* params,
                       float* t_scratch, float* out, int out_ld, int phase, void* stream);

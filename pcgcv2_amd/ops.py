@@ -403,34 +403,22 @@ def set_mfma_pipe(mode):
     check(lib().pcgc_set_mfma_pipe(int(mode)), 'set_mfma_pipe')
 
 
-_IRN_ROWS = 0
-
-
 def set_irn_rows(rows):
     """rows per wave of the fused InceptionResNet passes: 0 = by level size (default), or force 64 / 32 / 16."""
-    global _IRN_ROWS
     check(lib().pcgc_set_irn_rows(int(rows)), 'set_irn_rows')
-    _IRN_ROWS = int(rows)
-
-
-_IRN_CB16_ROWS = 400000
 
 
 def set_irn_cb16_rows(min_rows):
     """C = 32 pass A uses 16-channel sub-steps on levels of at least `min_rows` rows (negative = default 400 000, 0 = always)."""
-    global _IRN_CB16_ROWS
     check(lib().pcgc_set_irn_cb16_rows(int(min_rows)), 'set_irn_cb16_rows')
-    _IRN_CB16_ROWS = 400000 if min_rows < 0 else int(min_rows)
 
 
-def _irn_a_cb(C, R, n):
-    """channels per sub-step of the pass-A kernel launch_irn picks (conv.hip): exact kernel names for the profile records"""
-    return 16 if (C == 32 and R == 64 and n >= _IRN_CB16_ROWS) else 32
-
-
-def _irn_rows(n):
-    """the tile height pcgc_irn_block picks (conv.hip launch_irn_rows): exact kernel names for the profile records"""
-    return _IRN_ROWS if _IRN_ROWS > 0 else (16 if n < 40000 else 64)
+def _irn_config(C, n):
+    """(rows per wave tile, pass-A channels per sub-step) the library picks for this level: asked, not re-derived."""
+    import ctypes
+    rows, cb = ctypes.c_int(0), ctypes.c_int(0)
+    check(lib().pcgc_irn_config(int(C), int(n), ctypes.addressof(rows), ctypes.addressof(cb)), 'irn_config')
+    return rows.value, cb.value
 
 
 FUSE_IRN = True           # tests flip this to compare the fused block against its five-conv composition
@@ -456,8 +444,8 @@ def irn_block(nbr, x, params):
     arr = (ctypes.c_void_p * 10)(*[p.data_ptr() for p in params])
     if PROFILE.counting:
         PROFILE.count(nbr)
-    R = _irn_rows(n)
-    name_a = f'k_irn_a<{C}, {R}, {_irn_a_cb(C, R, n)}>'
+    R, cb_a = _irn_config(C, n)
+    name_a = f'k_irn_a<{C}, {R}, {cb_a}>'
     if not (PROFILE.want((name_a, n)) or PROFILE.want((f'k_irn_b<{C}, {R}>', n))):
         check(lib().pcgc_irn_block(_p(nbr), n, _p(x), C, _ld(x), arr, _p(t), _p(out), C, _stream(nbr)), 'irn_block')
         return out
