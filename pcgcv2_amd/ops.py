@@ -148,7 +148,9 @@ class _Profile:
         top = d[0]
         hbm_frac = top.get('compulsory_GBps', 0.0) / peak_gbs
         mfma_frac = top['TFLOPs'] / MFMA_F32_PEAK_TFLOPS
-        is_mfma = 'mfma_issued_flops' in top and mfma_frac >= hbm_frac
+        # an MFMA kernel is priced against the matrix peak unless its compulsory traffic rate is the larger fraction of ITS peak even
+        # compared with the pipe utilisation (issued flops), i.e. unless it really is the memory side that is closer to its limit
+        is_mfma = 'mfma_issued_flops' in top and max(mfma_frac, top['mfma_issued_TFLOPs'] / MFMA_F32_PEAK_TFLOPS) >= hbm_frac
         roof = {'bound': 'mfma' if is_mfma else 'hbm'}
         if is_mfma:
             roof.update(achieved=round(top['TFLOPs'], 2), peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s', frac=round(mfma_frac, 4))
