@@ -251,6 +251,23 @@ def main():
                    'note': 'independent vox10 frames coded concurrently on one GPU (own thread + HIP stream each), best of 2 passes; '
                            'the headline `value` is the single-frame-at-a-time rate'}
         del s_units
+    elif cfg in ('batch4', 'blocks') and args.serving_in_flight > 1 and len(units) > 1:
+        # the same units of this rank, several in flight (blocks / frames are independent; only the single-unit latency needs them one by one)
+        for _, u in units:
+            u.cmap.drop_caches()
+        shard.code_units(coder, units, in_flight=args.serving_in_flight)
+        torch.cuda.synchronize()
+        dt_s = float('inf')
+        for _ in range(2):
+            for _, u in units:
+                u.cmap.drop_caches()
+            t_s = time.perf_counter()
+            shard.code_units(coder, units, in_flight=args.serving_in_flight)
+            torch.cuda.synchronize()
+            dt_s = min(dt_s, time.perf_counter() - t_s)
+        serving = {'units_in_flight': args.serving_in_flight, 'units': len(units), 'value': round(n_points / dt_s / 1e6, 3), 'unit': 'Mpoints/s',
+                   'ms_per_step': round(dt_s * 1e3, 3),
+                   'note': "this rank's units of one step coded concurrently (own thread + HIP stream each), best of 2 passes; `value` codes them one by one"}
 
     # the coordinate-coder stage on its own (report with and without it).  Inside a step it runs on a helper
     # thread concurrently with the GPU, so it adds nothing to ms_per_step unless it outlasts the work it hides behind.
