@@ -2,6 +2,11 @@
 #include "child_kernels.h"
 
 
+// wide instantiations: one translation unit each (child_conv_w.hip) so they compile in parallel
+#define DECL_CONV_LAUNCH(NAME) int NAME(const int32_t* parent_nbr, int64_t n_parent, const float* in, int in_ld, const float* table, \
+                                        int table_bytes, const ChildEpi& ep, hipStream_t s)
+DECL_CONV_LAUNCH(pcgc_child_conv32); DECL_CONV_LAUNCH(pcgc_child_cls32); DECL_CONV_LAUNCH(pcgc_child_cls64);
+
 int g_child_nw = 0, g_child_depth = 0;                         // 0 = default; A/B switches
 extern "C" int pcgc_set_child_tuning(int waves, int depth) { g_child_nw = waves; g_child_depth = depth; return 0; }
 
@@ -24,11 +29,10 @@ extern "C" int pcgc_conv_child(const int32_t* parent_nbr, int64_t n_parent, cons
         PCGC_REQUIRE(residual == nullptr && !relu, "cls head has no fused epilogue");
         ChildEpi ep{bias, nullptr, 0, 0, out, out_ld, 0};
         // <16-channel blocks, waves per group, ring depth>: the table (32 / 64 KB) decides how many waves fit a CU
-        if (Cin == 64) rc = launch_child_cls<4, 4, 1>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);       // 128 KB table: 4 waves, one ring slot
+        if (Cin == 64) rc = pcgc_child_cls64(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
         else if (Cin == 16) rc = (nw == 4) ? launch_child_cls<1, 4, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s)
                                       : launch_child_cls<1, 8, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
-        else rc = (nw == 4) ? launch_child_cls<2, 4, 2>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s)
-                            : launch_child_cls<2, 16, 2>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
+        else rc = pcgc_child_cls32(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
     } else {
         PCGC_REQUIRE(table_bytes == (int64_t)27 * Cin * Cout * 4, "table size");
         ChildEpi ep{bias, residual, res_ld, relu, out, out_ld, Cout / 16};
@@ -37,8 +41,7 @@ extern "C" int pcgc_conv_child(const int32_t* parent_nbr, int64_t n_parent, cons
             if (nw == 4) rc = launch_child_conv<1, 1, 8, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
             else rc = launch_child_conv<1, 1, 4, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
         } else if (Cin == 32 && Cout == 32) {       // 108 KB of weights: one workgroup per CU
-            if (nw == 4) rc = launch_child_conv<2, 2, 4, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
-            else rc = launch_child_conv<2, 2, 8, 2>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
+            rc = pcgc_child_conv32(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
         } else {
             pcgc_set_error("conv_child: unsupported shape %d -> %d (16->16, 32->32, 16->1, 32->1, 64->1)", Cin, Cout);
             return -2;

@@ -3,10 +3,13 @@
 
 // Fused InceptionResNet passes on a children level (C = 16, 32).  pass 1 (A): in = x [8 n_parent, C] -> t [8 n_parent, C/2];
 // pass 2 (B): in = t -> out [.., C] with the residual x.  tables: ops.child_irn_tables.
-// C = 64 instantiations live in child_irn64.hip (compile time)
-int pcgc_irn_child64_launch(int pass, int nw, const int32_t* parent_nbr, int64_t n_parent, const float* in, int in_ld, const float* table,
-                            int table_bytes, const float* b0, const float* b1, const float* b2, const float* x, int x_ld, float* out,
-                            int out_ld, hipStream_t s);
+// The instantiations live in one translation unit each (child_irn_*.hip): every kernel is a fully unrolled 64-cell pipeline and takes
+// 1-3 minutes to compile; separate units build in parallel.
+#define DECL_IRN_LAUNCH(NAME) int NAME(int nw, const int32_t* parent_nbr, int64_t n_parent, const float* in, int in_ld, const float* table, \
+                                       int table_bytes, const IrnEpi& ep, hipStream_t s)
+DECL_IRN_LAUNCH(pcgc_irn_child_a16); DECL_IRN_LAUNCH(pcgc_irn_child_b16);
+DECL_IRN_LAUNCH(pcgc_irn_child_a32); DECL_IRN_LAUNCH(pcgc_irn_child_b32);
+DECL_IRN_LAUNCH(pcgc_irn_child_a64); DECL_IRN_LAUNCH(pcgc_irn_child_b64);
 
 extern "C" int pcgc_irn_child_pass(const int32_t* parent_nbr, int64_t n_parent, int C, int pass, const float* in, int in_ld,
                                    const float* table, int64_t table_bytes, const float* b0, const float* b1, const float* b2,
@@ -25,24 +28,14 @@ extern "C" int pcgc_irn_child_pass(const int32_t* parent_nbr, int64_t n_parent, 
     int rc;
     if (pass == 1) {
         PCGC_REQUIRE(table_bytes == (int64_t)(C == 16 ? 52 : (C == 32 ? 38 : 28)) * (C / 16) * 1024, "pass A table size");
-        // C = 64: the 112 KB table leaves one 8-wave group per CU and a single ring slot per wave (the next cell's gather flies behind
-        // the ~54 MFMAs of the current one)
-        if (C == 64) rc = pcgc_irn_child64_launch(1, nw, parent_nbr, n_parent, in, in_ld, table, tb, b0, b1, b2, x, x_ld, out, out_ld, s);
-        else
-        // <C, waves per group, ring depth>; the table (52 / 76 KB) leaves room for shallow rings only
-        if (C == 16) rc = (nw == 4) ? launch_child_irn_a<16, 4, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s)
-                                    : launch_child_irn_a<16, 16, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
-        else rc = (nw == 4) ? launch_child_irn_a<32, 4, 2>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s)
-                            : launch_child_irn_a<32, 12, 2>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
-    } else if (C == 64) {
-        PCGC_REQUIRE(table_bytes == (int64_t)83 * 1024, "pass B table size");
-        rc = pcgc_irn_child64_launch(2, nw, parent_nbr, n_parent, in, in_ld, table, tb, b0, b1, b2, x, x_ld, out, out_ld, s);
+        rc = C == 16 ? pcgc_irn_child_a16(nw, parent_nbr, n_parent, in, in_ld, table, tb, ep, s)
+           : C == 32 ? pcgc_irn_child_a32(nw, parent_nbr, n_parent, in, in_ld, table, tb, ep, s)
+                     : pcgc_irn_child_a64(nw, parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
     } else {
-        PCGC_REQUIRE(table_bytes == (int64_t)(C == 16 ? 85 * 64 : 64 * 128) * 4, "pass B table size");
-        if (C == 16) rc = (nw == 4) ? launch_child_irn_b<16, 4, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s)
-                                    : launch_child_irn_b<16, 16, 8>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
-        else rc = (nw == 4) ? launch_child_irn_b<32, 4, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s)
-                            : launch_child_irn_b<32, 12, 8>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
+        PCGC_REQUIRE(table_bytes == (int64_t)(C == 16 ? 85 * 64 * 4 : (C == 32 ? 64 * 128 * 4 : 83 * 1024)), "pass B table size");
+        rc = C == 16 ? pcgc_irn_child_b16(nw, parent_nbr, n_parent, in, in_ld, table, tb, ep, s)
+           : C == 32 ? pcgc_irn_child_b32(nw, parent_nbr, n_parent, in, in_ld, table, tb, ep, s)
+                     : pcgc_irn_child_b64(nw, parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
     }
     if (rc) return rc;
     PCGC_CHECK_LAUNCH("irn_child_pass");

@@ -42,8 +42,6 @@ static __device__ unsigned long long g_child_dbg[8];
 #define CHILD_TADD(slot, a, b)
 #endif
 
-namespace {
-
 struct ChildEpi {
     const float* bias;      // [cols]
     const float* res;       // residual rows (children level) or nullptr
@@ -53,6 +51,17 @@ struct ChildEpi {
     int out_ld;
     int nt;                 // EPI 0: column tiles per child
 };
+struct IrnEpi {
+    const float* b0;        // pass A: b00 ; pass B: b01
+    const float* b1;        // pass A: b10 ; pass B: b11
+    const float* b2;        // pass B: b12
+    const float* x;         // pass B: the block input (residual), children rows [.., x_ld]
+    int x_ld;
+    float* out;             // pass A: t [.., 2Q] ; pass B: out [.., out_ld]
+    int out_ld;
+};
+namespace {
+
 
 // ---- static halo geometry (cell index c = (cz'*4 + cy')*4 + cx', c' = c + 1 in 0..3) -------------------------------------
 constexpr int halo_p1(int c) { return c == 0 ? 0 : (c == 3 ? 2 : 1); }           // neighbour-parent offset + 1
@@ -514,15 +523,7 @@ k_child_cls(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restri
     }
 }
 
-struct IrnEpi {
-    const float* b0;        // pass A: b00 ; pass B: b01
-    const float* b1;        // pass A: b10 ; pass B: b11
-    const float* b2;        // pass B: b12
-    const float* x;         // pass B: the block input (residual), children rows [.., x_ld]
-    int x_ld;
-    float* out;             // pass A: t [.., 2Q] ; pass B: out [.., out_ld]
-    int out_ld;
-};
+
 
 // pass A:  t[row][0:Q] = relu(conv0_0 + b00), t[row][Q:2Q] = relu(conv1_0 + b10)
 template <int C, int NW, int D>
