@@ -116,8 +116,9 @@ int pcgc_compact_index(const uint8_t* mask, const int32_t* prefix, int64_t n, in
 int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in /*rows of `in`*/, int Cin,
                      int in_ld, int in_coff, const float* W, const float* bias, const float* residual, int res_ld,
                      int res_coff, int relu, float* out, int Cout, int out_ld, int out_coff, void* stream);
-/* kernel selection for the gather conv: -1 auto (default), 0 = v0 direct-load kernel, 1 = v1 LDS-DMA kernel where eligible.
- * Both produce bit-identical results; the switch exists for A/B measurements and tests. */
+/* kernel selection for the gather conv: -1 auto (default), 0 = v0 direct-load kernel, 1 = v1 LDS-DMA kernel, 2 / 3 = the fp32-MFMA
+ * kernels, 5 = the 16-row "burst" form of v1 that small levels get (each where eligible).  All produce bit-identical results; the
+ * switch exists for A/B measurements and tests. */
 int pcgc_set_conv_impl(int impl);
 /* the LDS-shared-weight MFMA kernels come in two schedules (v2b: 16-channel sub-steps; v2c: 32-channel steps with the next
  * step's loads in flight): -1 choose by level size (default), 0 always v2b, 1 always v2c.  Bit-identical. */

@@ -218,6 +218,103 @@ static void launch_dma(const int32_t* nbr, int K, int64_t n_out, const float* in
                        n_in, in_ld, W, Cout, bias, res, res_ld, relu, out, out_ld);
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// v1 for levels of a few ten thousand rows ("burst"): 16 output rows per wave and KG = 9 kernel offsets gathered per wait.
+// Such a level is 1-2 workgroups per CU, so nothing hides the gather latency: three waits per row instead of 27 (the
+// LDS the 9 row buffers take is free there).  Same fmaf chain: offsets ascending inside and across the groups.
+// ----------------------------------------------------------------------------------------------------------------
+template <int CIN, int CT, int ROWS, int KG>
+__global__ void __launch_bounds__(256)
+k_conv_gather_burst(const int32_t* __restrict__ nbr, int64_t n_out, const float* __restrict__ in, int64_t n_in, int in_ld,
+                    const float* __restrict__ W, int Cout, const float* __restrict__ bias, const float* __restrict__ res,
+                    int res_ld, int relu, float* __restrict__ out, int out_ld) {
+    static_assert(CIN <= 32 && 27 % KG == 0, "one sub-step per offset; offset groups tile the 27 offsets");
+    constexpr int CH = CIN / 4;
+    using RG = RowGather<CH, ROWS>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4* rowbuf = (float4*)lds_raw + (size_t)wave * (KG * RG::SLOTS);
+    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * ROWS;
+    if (row0 >= n_out) return;
+    const int co0 = blockIdx.y * CT;
+    const int64_t my_row = row0 + lane;
+    const bool valid = lane < ROWS && my_row < n_out;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(n_in * in_ld * 4), 0x00020000);
+    __attribute__((aligned(8))) float acc[CT];
+#pragma unroll
+    for (int co = 0; co < CT; ++co) acc[co] = 0.0f;
+    int idx[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) idx[g] = valid ? nbr[(int64_t)g * n_out + my_row] : -1;
+    for (int k0 = 0; k0 < 27; k0 += KG) {
+#pragma unroll
+        for (int g = 0; g < KG; ++g) RG::fetch(rs, rowbuf + g * RG::SLOTS, idx[g], in_ld, 0, lane);
+        int idx_n[KG];
+#pragma unroll
+        for (int g = 0; g < KG; ++g) idx_n[g] = (valid && k0 + KG + g < 27) ? nbr[(int64_t)(k0 + KG + g) * n_out + my_row] : -1;
+        asm volatile("" ::: "memory");
+        if (k0 + KG < 27) wait_vmcnt<KG>(); else wait_vmcnt<0>();        // only the map prefetches (issued after the DMAs) stay in flight
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            float4 xv[CH];
+            RG::read(rowbuf + g * RG::SLOTS, lane, xv);
+            if (idx[g] >= 0) {
+                const float* w = W + (int64_t)(k0 + g) * CIN * Cout + co0;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) fma4<CT>(acc, xv[c], w + (int64_t)(4 * c) * Cout, Cout);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < KG; ++g) idx[g] = idx_n[g];
+    }
+    if (!valid) return;
+    float* y = out + my_row * out_ld + co0;
+    const float* rr = res ? res + my_row * res_ld + co0 : nullptr;
+#pragma unroll
+    for (int co = 0; co < CT; ++co) {
+        float v = acc[co];
+        if (bias) v = v + bias[co0 + co];
+        if (rr) v = v + rr[co];
+        if (relu) v = fmaxf(v, 0.0f);
+        y[co] = v;
+    }
+}
+template <int CIN, int CT>
+static int launch_burst(const int32_t* nbr, int64_t n_out, const float* in, int64_t n_in, int in_ld, const float* W, int Cout,
+                        const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld, hipStream_t s) {
+    constexpr int ROWS = 16, KG = 9;
+    constexpr size_t lds = 4 * (size_t)(KG * RowGather<CIN / 4, ROWS>::SLOTS * 16);
+    static size_t granted[16] = {0};
+    auto kern = k_conv_gather_burst<CIN, CT, ROWS, KG>;
+    if (lds > 48 * 1024) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (lds > granted[dev & 15]) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                pcgc_set_error("conv_gather burst: cannot raise the LDS limit to %zu", lds); return -1;
+            }
+            granted[dev & 15] = lds;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(grid_for(n_out, 4 * ROWS), Cout / CT), dim3(256), lds, s, nbr, n_out, in, n_in, in_ld, W, Cout,
+                       bias, res, res_ld, relu, out, out_ld);
+    return 0;
+}
+// -> 0 launched, 1 shape not covered, < 0 error
+template <int CIN>
+static int dispatch_burst(int Cout, const int32_t* nbr, int64_t n_out, const float* in, int64_t n_in, int in_ld, const float* W,
+                          const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld, hipStream_t s) {
+    switch (Cout) {
+        case 1: return launch_burst<CIN, 1>(nbr, n_out, in, n_in, in_ld, W, Cout, bias, res, res_ld, relu, out, out_ld, s);
+        case 4: return launch_burst<CIN, 4>(nbr, n_out, in, n_in, in_ld, W, Cout, bias, res, res_ld, relu, out, out_ld, s);
+        case 8: return launch_burst<CIN, 8>(nbr, n_out, in, n_in, in_ld, W, Cout, bias, res, res_ld, relu, out, out_ld, s);
+        case 16: return launch_burst<CIN, 16>(nbr, n_out, in, n_in, in_ld, W, Cout, bias, res, res_ld, relu, out, out_ld, s);
+    }
+    return 1;
+}
+
 // output-channel tile per wave: whole Cout up to 16; 16 or 32 beyond (smaller tiles on small levels = more waves)
 template <int CIN>
 static bool dispatch_dma_cout(int Cout, const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int in_ld,
@@ -768,7 +865,7 @@ template <int C> struct IrnKGA { static constexpr int value = 1; };             
 // CBMAX = channels gathered per sub-step (32, or 16): at C = 32 the 32-channel form holds 117 VGPRs (4 waves/SIMD); 16-channel
 // sub-steps double the gather/wait steps but run 6 waves/SIMD — faster on the big level (570 k rows: 206 -> 175 us), slower on
 // the small ones (256 k: 68 -> 74 us), so launch_irn picks by level size.
-template <int C, int ROWS, int CBMAX = 32>
+template <int C, int ROWS, int CBMAX = 32, int KG = IrnKGA<C>::value>
 __global__ void __launch_bounds__(256)
 k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x, int x_ld,
         const float* __restrict__ W00, const float* __restrict__ b00, const float* __restrict__ W10,
@@ -779,7 +876,7 @@ k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x,
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     using RG = RowGather<CH, ROWS>;
-    float4* rowbuf = (float4*)lds_raw + (size_t)wave * (IrnKGA<C>::value * RG::SLOTS);
+    float4* rowbuf = (float4*)lds_raw + (size_t)wave * (KG * RG::SLOTS);
     const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * ROWS;
     if (row0 >= n) return;
     const int64_t my_row = row0 + lane;
@@ -789,8 +886,8 @@ k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x,
     __attribute__((aligned(8))) float acc1[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
-    if constexpr (NB == 1 && IrnKGA<C>::value > 1) {
-        constexpr int KG = IrnKGA<C>::value;
+    static_assert(KG == 1 || NB == 1, "offset groups need the whole row in one sub-step");
+    if constexpr (KG > 1) {
         int idx[KG];
 #pragma unroll
         for (int g = 0; g < KG; ++g) idx[g] = valid ? nbr[(int64_t)g * n + my_row] : -1;
@@ -859,7 +956,7 @@ k_irn_a(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x,
     for (int i = 0; i < Q; ++i) y[Q + i] = fmaxf(acc1[i] + b10[i], 0.0f);
 }
 
-template <int C, int ROWS>
+template <int C, int ROWS, int KG = IrnKG<C>::value>
 __global__ void __launch_bounds__(256)
 k_irn_b(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ t /*[n, C/2]*/, const float* __restrict__ x,
         int x_ld, const float* __restrict__ W01, const float* __restrict__ b01, const float* __restrict__ W11,
@@ -868,7 +965,6 @@ k_irn_b(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ t 
     constexpr int Q = C / 4, H = C / 2;
     constexpr int CH = H / 4;                        // gathered row = H floats: 2, 4 or 8 chunks
     constexpr int CQ = Q / 4;                        // chunks per branch: 1, 2 or 4
-    constexpr int KG = IrnKG<C>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -944,32 +1040,59 @@ k_irn_b(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ t 
 
 // phase: 1 = pass A only, 2 = pass B only, 3 = both.  ROWS = rows per wave (64 by default; 32 / 16 exist for A/B tests: the
 // idea was to give small levels more waves per SIMD — a 71 k-row level is only 1.1 waves per SIMD with 64-row tiles).
+// dynamic LDS above the default limit: raise the attribute once per (kernel, device)
+static int irn_lds_limit(const void* kern, size_t lds, size_t (&granted)[16]) {
+    if (lds <= 48 * 1024) return 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (lds > granted[dev & 15]) {
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        granted[dev & 15] = lds;
+    }
+    return 0;
+}
+// 16-row tiles are what levels of a few ten thousand rows get (1-2 workgroups per CU): nothing hides the gather latency
+// there, so those kernels keep 9 kernel offsets in flight per wave (three waits per pass instead of 27; the LDS is free).
+template <int C, int ROWS> struct IrnBurst {
+    static constexpr int A = (ROWS == 16 && C <= 32) ? 9 : IrnKGA<C>::value;      // pass A needs the whole row in one sub-step
+    static constexpr int B = (ROWS == 16) ? 9 : IrnKG<C>::value;
+};
 template <int C, int ROWS>
-static void launch_irn(const int32_t* nbr, int64_t n, const float* x, int x_ld, const float* const* P, float* t, float* out,
+static int launch_irn(const int32_t* nbr, int64_t n, const float* x, int x_ld, const float* const* P, float* t, float* out,
                        int out_ld, int phase, hipStream_t s) {
     constexpr int CBA = C < 32 ? C : 32;
-    const size_t lds_a = 4 * (size_t)(IrnKGA<C>::value * RowGather<CBA / 4, ROWS>::SLOTS * 16);
-    const size_t lds_b = 4 * (size_t)(IrnKG<C>::value * RowGather<C / 8, ROWS>::SLOTS * 16);
+    constexpr int KGA = IrnBurst<C, ROWS>::A, KGB = IrnBurst<C, ROWS>::B;
+    const size_t lds_a = 4 * (size_t)(KGA * RowGather<CBA / 4, ROWS>::SLOTS * 16);
+    const size_t lds_b = 4 * (size_t)(KGB * RowGather<C / 8, ROWS>::SLOTS * 16);
     const dim3 grid(grid_for(n, 4 * ROWS));
     if ((phase & 1) && C == 32 && ROWS == 64 && n >= g_irn_cb16_rows) {
         const size_t lds16 = 4 * (size_t)(IrnKGA<C>::value * RowGather<4, ROWS>::SLOTS * 16);
         hipLaunchKernelGGL((k_irn_a<C, ROWS, 16>), grid, dim3(256), lds16, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
-    } else if (phase & 1)
-        hipLaunchKernelGGL((k_irn_a<C, ROWS>), grid, dim3(256), lds_a, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
-    if (phase & 2)
-        hipLaunchKernelGGL((k_irn_b<C, ROWS>), grid, dim3(256), lds_b, s, nbr, n, t, x, x_ld, P[2], P[3], P[6], P[7], P[8], P[9],
+    } else if (phase & 1) {
+        static size_t granted[16] = {0};
+        auto kern = k_irn_a<C, ROWS, 32, KGA>;
+        if (irn_lds_limit((const void*)kern, lds_a, granted)) { pcgc_set_error("irn pass A: cannot raise the LDS limit to %zu", lds_a); return -1; }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds_a, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
+    }
+    if (phase & 2) {
+        static size_t granted[16] = {0};
+        auto kern = k_irn_b<C, ROWS, KGB>;
+        if (irn_lds_limit((const void*)kern, lds_b, granted)) { pcgc_set_error("irn pass B: cannot raise the LDS limit to %zu", lds_b); return -1; }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds_b, s, nbr, n, t, x, x_ld, P[2], P[3], P[6], P[7], P[8], P[9],
                            out, out_ld);
+    }
+    return 0;
 }
 template <int C>
-static void launch_irn_rows(const int32_t* nbr, int64_t n, const float* x, int x_ld, const float* const* P, float* t, float* out,
+static int launch_irn_rows(const int32_t* nbr, int64_t n, const float* x, int x_ld, const float* const* P, float* t, float* out,
                             int out_ld, int phase, hipStream_t s) {
     // measured per level (bench.py --irn-rows, us for pass A / pass B at C = 32): 18.7 k rows: 64 -> 62.7 / 45.8, 32 -> 51.8 / 38.0,
     // 16 -> 43.7 / 32.8 (a level that small is 73 tiles of 64 rows: the extra waves win); 256 k rows: 68.5 / 54.3, 93.1 / 66.3,
     // 141.7 / 100.4 and likewise above (shorter tiles lose more DMA efficiency than the extra waves gain).
     const int rows = irn_rows_for(n);
-    if (rows == 64) launch_irn<C, 64>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
-    else if (rows == 32) launch_irn<C, 32>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
-    else launch_irn<C, 16>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
+    if (rows == 64) return launch_irn<C, 64>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
+    if (rows == 32) return launch_irn<C, 32>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
+    return launch_irn<C, 16>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
 }
 
 // the tile height / channel sub-step the dispatcher below picks for (C, n): the single source of that policy, also for the host's
@@ -1001,15 +1124,17 @@ static int irn_launch(const int32_t* nbr, int64_t n, const float* x, int C, int 
     for (int i = 0; i < 10; ++i) PCGC_REQUIRE(params[i] != nullptr, "null parameter tensor");
     PCGC_REQUIRE((((uintptr_t)x | (uintptr_t)t_scratch | (uintptr_t)out) & 15) == 0, "buffers must be 16-byte aligned");
     if (n == 0) return 0;
-    if (C == 16) launch_irn_rows<16>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
-    else if (C == 32) launch_irn_rows<32>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
-    else launch_irn_rows<64>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
+    int rc;
+    if (C == 16) rc = launch_irn_rows<16>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
+    else if (C == 32) rc = launch_irn_rows<32>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
+    else rc = launch_irn_rows<64>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
+    if (rc) return rc;
     PCGC_CHECK_LAUNCH("irn_block");
     return 0;
 }
 
 // kernel selection for pcgc_conv_gather (all variants are bit-identical; tests run every one of them):
-//   -1 auto | 0 v0 direct loads + VALU | 1 v1 LDS-DMA + VALU | 2 v2 LDS-DMA + MFMA | 3 v2b MFMA with LDS-shared weights
+//   -1 auto | 0 v0 direct loads + VALU | 1 v1 LDS-DMA + VALU | 2 v2 LDS-DMA + MFMA | 3 v2b MFMA with LDS-shared weights | 5 v1 burst (16-row tiles, 9 offsets per wait)
 // auto policy (measured per shape, tools/conv_ab.py, tools/conv32_ab.py): >= 30 k rows: 64->64 and 32->32 -> v2b (v2c below 110 k rows for 64->64); Cin in {16,32,64} & Cout in {16,32,64} -> v2;
 // other gathered shapes with Cin in {8,16,32,64} -> v1; everything else (Cin 1/4, k1 convs, tiny levels) -> v0.
 static int g_conv_impl = -1;
@@ -1058,6 +1183,16 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
         else if (Cin == 32) ok = dispatch_mfma<32>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         else ok = dispatch_mfma<64>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         if (ok) { PCGC_CHECK_LAUNCH("conv_gather_mfma"); return 0; }
+    }
+    if (v1_eligible && K == 27 && Cin <= 32 && Cout <= 16 && (g_conv_impl == 5 || (g_conv_impl < 0 && n_out < 40000))) {   // (conv3 32->8 at 18.7 k rows: 71 us on v0)
+        const float* res0 = residual ? residual + res_coff : nullptr;
+        float* out0 = out + out_coff;
+        int rc = 1;
+        if (Cin == 8) rc = dispatch_burst<8>(Cout, nbr, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        else if (Cin == 16) rc = dispatch_burst<16>(Cout, nbr, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        else if (Cin == 32) rc = dispatch_burst<32>(Cout, nbr, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        if (rc < 0) return rc;
+        if (rc == 0) { PCGC_CHECK_LAUNCH("conv_gather_burst"); return 0; }
     }
     if (v1_eligible && v1_wanted) {
         const float* res0 = residual ? residual + res_coff : nullptr;

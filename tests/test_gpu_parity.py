@@ -112,9 +112,9 @@ CONV_SHAPES = [(27, 1, 16), (27, 16, 16), (27, 32, 8), (27, 8, 16), (27, 8, 8), 
                (8, 16, 32), (8, 32, 64), (8, 64, 32), (1, 32, 8), (1, 8, 16), (1, 64, 16), (1, 16, 32), (1, 16, 4), (1, 4, 8)]
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4], ids=['v0_direct', 'v1_ldsdma', 'v2_mfma', 'v2b_mfma_wlds', 'v2c_mfma_pipe'])
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5], ids=['v0_direct', 'v1_ldsdma', 'v2_mfma', 'v2b_mfma_wlds', 'v2c_mfma_pipe', 'v1_burst'])
 def conv_impl(request):
-    ops.set_conv_impl(min(request.param, 3))
+    ops.set_conv_impl(5 if request.param == 5 else min(request.param, 3))
     ops.set_mfma_pipe(1 if request.param == 4 else 0)
     yield request.param
     ops.set_conv_impl(-1)
