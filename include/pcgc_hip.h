@@ -117,7 +117,7 @@ int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const float* in, 
                      int in_ld, int in_coff, const float* W, const float* bias, const float* residual, int res_ld,
                      int res_coff, int relu, float* out, int Cout, int out_ld, int out_coff, void* stream);
 /* kernel selection for the gather conv: -1 auto (default), 0 = v0 direct-load kernel, 1 = v1 LDS-DMA kernel, 2 / 3 = the fp32-MFMA
- * kernels, 5 = the 16-row "burst" form of v1 that small levels get (each where eligible).  All produce bit-identical results; the
+ * kernels, 5 / 6 = the 16-row "burst" and row-split forms that small levels get (each where eligible).  All produce bit-identical results; the
  * switch exists for A/B measurements and tests. */
 int pcgc_set_conv_impl(int impl);
 /* the LDS-shared-weight MFMA kernels come in two schedules (v2b: 16-channel sub-steps; v2c: 32-channel steps with the next
@@ -127,6 +127,9 @@ int pcgc_set_mfma_pipe(int mode);
 int pcgc_set_up2_impl(int mfma);
 /* rows per wave of the fused InceptionResNet passes: 0 = by level size (default), or force 64 / 32 / 16 (A/B tests). */
 int pcgc_set_irn_rows(int rows);
+/* 16-row tiles at C <= 32: 1 = row-split kernels (lanes split the output channels, weights staged in LDS; default),
+ * 0 = lane-per-row kernels.  Bit-identical (A/B tests). */
+int pcgc_set_irn_split(int on);
 /* C = 32 pass A gathers 16 instead of 32 channels per sub-step on levels of at least `min_rows` rows (default 400 000; 0 =
  * always, negative = default).  Bit-identical; a speed/occupancy trade measured per level size. */
 int pcgc_set_irn_cb16_rows(int64_t min_rows);

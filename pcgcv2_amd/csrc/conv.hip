@@ -855,6 +855,8 @@ static int g_irn_rows = 0;          // 0 = choose the tile height from the level
 static int64_t g_irn_cb16_rows = 400000;   // C = 32 pass A: 16-channel sub-steps from this many rows on (0 = always, for tests)
 extern "C" int pcgc_set_irn_cb16_rows(int64_t min_rows) { g_irn_cb16_rows = min_rows < 0 ? 400000 : min_rows; return 0; }
 extern "C" int pcgc_set_irn_rows(int rows) { g_irn_rows = rows; return 0; }
+static int g_irn_split = 1;         // 16-row tiles at C <= 32: row-split kernels (1, default) or the lane = row kernels (0; A/B tests)
+extern "C" int pcgc_set_irn_split(int on) { g_irn_split = on ? 1 : 0; return 0; }
 static int irn_rows_for(int64_t n) { return g_irn_rows > 0 ? g_irn_rows : (n < 40000 ? 16 : 64); }   // (measurements: launch_irn_rows)
 
 // kernel offsets gathered per wait (27 = 9 x 3): more gathers in flight per wave.  Pays only while the extra row buffers do
@@ -1040,6 +1042,240 @@ k_irn_b(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ t 
 
 // phase: 1 = pass A only, 2 = pass B only, 3 = both.  ROWS = rows per wave (64 by default; 32 / 16 exist for A/B tests: the
 // idea was to give small levels more waves per SIMD — a 71 k-row level is only 1.1 waves per SIMD with 64-row tiles).
+// ----------------------------------------------------------------------------------------------------------------
+// Row-split kernels for levels of a few ten thousand rows (16 output rows per wave, 1-2 workgroups per CU).  With lane = row
+// such a wave keeps 16 lanes busy and streams every weight through the scalar cache (27.6 KB per pass against a 16 KB cache:
+// each s_load batch pays an L2 round trip with nothing to hide it — 40 us for 18.7 k rows).  Here the four 16-lane groups of
+// a wave split the OUTPUT channels of the same 16 rows (lane = (row, part)), and the weights are restaged once per workgroup
+// into LDS as [k][part][ci][channels of the part] (+16 bytes per block: the four parts read four different bank groups).
+// Every output element still sees ci ascending inside k ascending.
+// ----------------------------------------------------------------------------------------------------------------
+template <int CI, int CO>
+struct SplitW {
+    static constexpr int P = CO / 4;                 // output channels per lane
+    static constexpr int BLK = CI * P + 4;           // floats per (k, part) block
+    static_assert(CO % 4 == 0 && (CI * P) % 4 == 0, "parts are whole float4 runs");
+    static constexpr int floats(int K) { return K * 4 * BLK; }
+    __device__ static inline void stage(float* lds, const float* __restrict__ W, int K, int tid, int nthreads) {
+        for (int e = tid; e < K * CI * CO; e += nthreads) {
+            const int k = e / (CI * CO), rem = e % (CI * CO), ci = rem / CO, co = rem % CO;
+            lds[(k * 4 + co / P) * BLK + ci * P + co % P] = W[e];
+        }
+    }
+    // acc[j] = fmaf(x[ci], W[k][ci][part * P + j], acc[j]), ci ascending; x = CI floats held as float4 chunks
+    __device__ static inline void fma(float (&acc)[P], const float4* xv, const float* blk) {
+#pragma unroll
+        for (int m = 0; m < CI * P / 4; ++m) {
+            const float4 w = *(const float4*)(blk + 4 * m);
+            const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * m + i, ci = e / P, j = e % P;
+                const float4 xc = xv[ci / 4];
+                const float xs = (ci % 4 == 0) ? xc.x : (ci % 4 == 1) ? xc.y : (ci % 4 == 2) ? xc.z : xc.w;
+                acc[j] = fmaf(xs, wv[i], acc[j]);
+            }
+        }
+    }
+};
+// offsets in flight per wave: 9 while weights + the four waves' row buffers leave two workgroups per CU, else 3
+template <int WFLOATS, int SLOTS> struct SplitKG { static constexpr int value = (WFLOATS * 4 + 4 * 9 * SLOTS * 16 <= 80 * 1024) ? 9 : 3; };
+
+template <int CIN, int CT>
+__global__ void __launch_bounds__(256)
+k_conv_gather_split(const int32_t* __restrict__ nbr, int64_t n_out, const float* __restrict__ in, int64_t n_in, int in_ld,
+                    const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ res, int res_ld,
+                    int relu, float* __restrict__ out, int out_ld) {
+    constexpr int ROWS = 16, CH = CIN / 4, P = CT / 4;
+    using RG = RowGather<CH, ROWS>;
+    using SW = SplitW<CIN, CT>;
+    constexpr int KG = SplitKG<SW::floats(27), RG::SLOTS>::value;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float* wl = (float*)lds_raw;
+    const int lane = threadIdx.x & 63, r = lane & 15, part = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4* rowbuf = (float4*)(wl + SW::floats(27)) + (size_t)wave * (KG * RG::SLOTS);
+    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * ROWS;
+    const int64_t my_row = row0 + r;
+    const bool valid = my_row < n_out;
+    int idx[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) idx[g] = valid ? nbr[(int64_t)g * n_out + my_row] : -1;
+    SW::stage(wl, W, 27, threadIdx.x, 256);
+    __syncthreads();
+    if (row0 >= n_out) return;                        // (after the barrier: every wave takes part in the staging)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(n_in * in_ld * 4), 0x00020000);
+    float acc[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) acc[j] = 0.0f;
+    for (int k0 = 0; k0 < 27; k0 += KG) {
+#pragma unroll
+        for (int g = 0; g < KG; ++g) RG::fetch(rs, rowbuf + g * RG::SLOTS, idx[g], in_ld, 0, lane);
+        int idx_n[KG];
+#pragma unroll
+        for (int g = 0; g < KG; ++g) idx_n[g] = (valid && k0 + KG + g < 27) ? nbr[(int64_t)(k0 + KG + g) * n_out + my_row] : -1;
+        asm volatile("" ::: "memory");
+        static_assert(27 % KG == 0, "offset groups must tile the 27 offsets");
+        if (k0 + KG < 27) wait_vmcnt<KG>(); else wait_vmcnt<0>();
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            float4 xv[CH];
+            RG::read(rowbuf + g * RG::SLOTS, r, xv);
+            if (idx[g] >= 0) SW::fma(acc, xv, wl + ((k0 + g) * 4 + part) * SW::BLK);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < KG; ++g) idx[g] = idx_n[g];
+    }
+    if (!valid) return;
+    float* y = out + my_row * out_ld + part * P;
+    const float* rr = res ? res + my_row * res_ld + part * P : nullptr;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        float v = acc[j];
+        if (bias) v = v + bias[part * P + j];
+        if (rr) v = v + rr[j];
+        if (relu) v = fmaxf(v, 0.0f);
+        y[j] = v;
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256)
+k_irn_a_split(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ x, int x_ld, const float* __restrict__ W00,
+              const float* __restrict__ b00, const float* __restrict__ W10, const float* __restrict__ b10, float* __restrict__ t) {
+    constexpr int ROWS = 16, Q = C / 4, P = Q / 4, CH = C / 4;
+    using RG = RowGather<CH, ROWS>;
+    using SW = SplitW<C, Q>;
+    constexpr int KG = SplitKG<SW::floats(28), RG::SLOTS>::value;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float* w00 = (float*)lds_raw;
+    float* w10 = w00 + SW::floats(27);
+    const int lane = threadIdx.x & 63, r = lane & 15, part = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4* rowbuf = (float4*)(w00 + SW::floats(28)) + (size_t)wave * (KG * RG::SLOTS);
+    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * ROWS;
+    const int64_t my_row = row0 + r;
+    const bool valid = my_row < n;
+    int idx[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) idx[g] = valid ? nbr[(int64_t)g * n + my_row] : -1;
+    SW::stage(w00, W00, 27, threadIdx.x, 256);
+    SW::stage(w10, W10, 1, threadIdx.x, 256);
+    __syncthreads();
+    if (row0 >= n) return;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(n * x_ld * 4), 0x00020000);
+    float acc0[P], acc1[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) { acc0[j] = 0.0f; acc1[j] = 0.0f; }
+    for (int k0 = 0; k0 < 27; k0 += KG) {
+#pragma unroll
+        for (int g = 0; g < KG; ++g) RG::fetch(rs, rowbuf + g * RG::SLOTS, idx[g], x_ld, 0, lane);
+        int idx_n[KG];
+#pragma unroll
+        for (int g = 0; g < KG; ++g) idx_n[g] = (valid && k0 + KG + g < 27) ? nbr[(int64_t)(k0 + KG + g) * n + my_row] : -1;
+        asm volatile("" ::: "memory");
+        static_assert(27 % KG == 0, "offset groups must tile the 27 offsets");
+        if (k0 + KG < 27) wait_vmcnt<KG>(); else wait_vmcnt<0>();
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            float4 xv[CH];
+            RG::read(rowbuf + g * RG::SLOTS, r, xv);
+            if (idx[g] >= 0) {
+                SW::fma(acc0, xv, w00 + ((k0 + g) * 4 + part) * SW::BLK);
+                if (k0 + g == 13) SW::fma(acc1, xv, w10 + part * SW::BLK);        // own row: the k1 branch conv1_0
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < KG; ++g) idx[g] = idx_n[g];
+    }
+    if (!valid) return;
+    float* y = t + my_row * (2 * Q) + part * P;
+#pragma unroll
+    for (int j = 0; j < P; ++j) y[j] = fmaxf(acc0[j] + b00[part * P + j], 0.0f);
+#pragma unroll
+    for (int j = 0; j < P; ++j) y[Q + j] = fmaxf(acc1[j] + b10[part * P + j], 0.0f);
+}
+
+template <int C>
+__global__ void __launch_bounds__(256)
+k_irn_b_split(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ t /*[n, C/2]*/, const float* __restrict__ x,
+              int x_ld, const float* __restrict__ W01, const float* __restrict__ b01, const float* __restrict__ W11,
+              const float* __restrict__ b11, const float* __restrict__ W12, const float* __restrict__ b12,
+              float* __restrict__ out, int out_ld) {
+    constexpr int ROWS = 16, Q = C / 4, H = C / 2, CH = H / 4, CQ = Q / 4, HP = H / 4, QP = Q / 4;
+    using RG = RowGather<CH, ROWS>;
+    using SW0 = SplitW<Q, H>;                        // conv0_1: t[:, 0:Q]  -> H
+    using SW1 = SplitW<Q, Q>;                        // conv1_1: t[:, Q:2Q] -> Q
+    constexpr int KG = SplitKG<SW0::floats(27) + SW1::floats(27), RG::SLOTS>::value;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float* w01 = (float*)lds_raw;
+    float* w11 = w01 + SW0::floats(27);
+    const int lane = threadIdx.x & 63, r = lane & 15, part = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4* rowbuf = (float4*)(w11 + SW1::floats(27)) + (size_t)wave * (KG * RG::SLOTS);
+    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * ROWS;
+    const int64_t my_row = row0 + r;
+    const bool valid = my_row < n;
+    int idx[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) idx[g] = valid ? nbr[(int64_t)g * n + my_row] : -1;
+    SW0::stage(w01, W01, 27, threadIdx.x, 256);
+    SW1::stage(w11, W11, 27, threadIdx.x, 256);
+    __syncthreads();
+    if (row0 >= n) return;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)t, 0, (int)(n * H * 4), 0x00020000);
+    float acc0[HP], acc1[QP];
+#pragma unroll
+    for (int j = 0; j < HP; ++j) acc0[j] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < QP; ++j) acc1[j] = 0.0f;
+    for (int k0 = 0; k0 < 27; k0 += KG) {
+#pragma unroll
+        for (int g = 0; g < KG; ++g) RG::fetch(rs, rowbuf + g * RG::SLOTS, idx[g], H, 0, lane);
+        int idx_n[KG];
+#pragma unroll
+        for (int g = 0; g < KG; ++g) idx_n[g] = (valid && k0 + KG + g < 27) ? nbr[(int64_t)(k0 + KG + g) * n + my_row] : -1;
+        asm volatile("" ::: "memory");
+        static_assert(27 % KG == 0, "offset groups must tile the 27 offsets");
+        if (k0 + KG < 27) wait_vmcnt<KG>(); else wait_vmcnt<0>();
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            float4 tv[CH];
+            RG::read(rowbuf + g * RG::SLOTS, r, tv);
+            if (idx[g] >= 0) {
+                SW0::fma(acc0, tv, w01 + ((k0 + g) * 4 + part) * SW0::BLK);
+                SW1::fma(acc1, tv + CQ, w11 + ((k0 + g) * 4 + part) * SW1::BLK);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < KG; ++g) idx[g] = idx_n[g];
+    }
+    // conv1_2 (k1, Q -> H) on u = relu(conv1_1 + bias): every part needs the row's Q values of u, held QP per part
+    float u[QP];
+#pragma unroll
+    for (int j = 0; j < QP; ++j) u[j] = fmaxf(acc1[j] + b11[part * QP + j], 0.0f);
+    float acc2[HP];
+#pragma unroll
+    for (int j = 0; j < HP; ++j) acc2[j] = 0.0f;
+#pragma unroll
+    for (int ci = 0; ci < Q; ++ci) {
+        const float uc = __shfl(u[ci % QP], r + 16 * (ci / QP), 64);
+#pragma unroll
+        for (int j = 0; j < HP; ++j) acc2[j] = fmaf(uc, W12[ci * H + part * HP + j], acc2[j]);
+    }
+    if (!valid) return;
+    const float* xr = x + my_row * x_ld + part * HP;
+    float* y = out + my_row * out_ld + part * HP;
+#pragma unroll
+    for (int j = 0; j < HP; ++j) {
+        y[j] = (acc0[j] + b01[part * HP + j]) + xr[j];
+        y[H + j] = (acc2[j] + b12[part * HP + j]) + xr[H + j];
+    }
+}
+
 // dynamic LDS above the default limit: raise the attribute once per (kernel, device)
 static int irn_lds_limit(const void* kern, size_t lds, size_t (&granted)[16]) {
     if (lds <= 48 * 1024) return 0;
@@ -1050,6 +1286,37 @@ static int irn_lds_limit(const void* kern, size_t lds, size_t (&granted)[16]) {
         granted[dev & 15] = lds;
     }
     return 0;
+}
+template <int C> struct IrnSplit {
+    static constexpr int Q = C / 4, H = C / 2;
+    using RGA = RowGather<C / 4, 16>;
+    using RGB = RowGather<H / 4, 16>;
+    static constexpr int WA = SplitW<C, Q>::floats(28), WB = SplitW<Q, H>::floats(27) + SplitW<Q, Q>::floats(27);
+    static constexpr size_t LDS_A = (size_t)WA * 4 + 4 * (size_t)(SplitKG<WA, RGA::SLOTS>::value * RGA::SLOTS * 16);
+    static constexpr size_t LDS_B = (size_t)WB * 4 + 4 * (size_t)(SplitKG<WB, RGB::SLOTS>::value * RGB::SLOTS * 16);
+};
+template <int CIN, int CT>
+static int launch_split(const int32_t* nbr, int64_t n_out, const float* in, int64_t n_in, int in_ld, const float* W, const float* bias,
+                        const float* res, int res_ld, int relu, float* out, int out_ld, hipStream_t s) {
+    using RG = RowGather<CIN / 4, 16>;
+    constexpr int WF = SplitW<CIN, CT>::floats(27);
+    constexpr size_t lds = (size_t)WF * 4 + 4 * (size_t)(SplitKG<WF, RG::SLOTS>::value * RG::SLOTS * 16);
+    static size_t granted[16] = {0};
+    auto kern = k_conv_gather_split<CIN, CT>;
+    if (irn_lds_limit((const void*)kern, lds, granted)) { pcgc_set_error("conv_gather split: cannot raise the LDS limit to %zu", lds); return -1; }
+    hipLaunchKernelGGL(kern, dim3(grid_for(n_out, 64)), dim3(256), lds, s, nbr, n_out, in, n_in, in_ld, W, bias, res, res_ld, relu, out, out_ld);
+    return 0;
+}
+// -> 0 launched, 1 shape not covered, < 0 error
+template <int CIN>
+static int dispatch_split(int Cout, const int32_t* nbr, int64_t n_out, const float* in, int64_t n_in, int in_ld, const float* W,
+                          const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld, hipStream_t s) {
+    switch (Cout) {
+        case 4: return launch_split<CIN, 4>(nbr, n_out, in, n_in, in_ld, W, bias, res, res_ld, relu, out, out_ld, s);
+        case 8: return launch_split<CIN, 8>(nbr, n_out, in, n_in, in_ld, W, bias, res, res_ld, relu, out, out_ld, s);
+        case 16: return launch_split<CIN, 16>(nbr, n_out, in, n_in, in_ld, W, bias, res, res_ld, relu, out, out_ld, s);
+    }
+    return 1;
 }
 // 16-row tiles are what levels of a few ten thousand rows get (1-2 workgroups per CU): nothing hides the gather latency
 // there, so those kernels keep 9 kernel offsets in flight per wave (three waits per pass instead of 27; the LDS is free).
@@ -1065,6 +1332,23 @@ static int launch_irn(const int32_t* nbr, int64_t n, const float* x, int x_ld, c
     const size_t lds_a = 4 * (size_t)(KGA * RowGather<CBA / 4, ROWS>::SLOTS * 16);
     const size_t lds_b = 4 * (size_t)(KGB * RowGather<C / 8, ROWS>::SLOTS * 16);
     const dim3 grid(grid_for(n, 4 * ROWS));
+    if constexpr (ROWS == 16 && C <= 32) {
+        if (g_irn_split) {                               // lane = (row, output-channel part), weights in LDS
+            if (phase & 1) {
+                static size_t granted[16] = {0};
+                auto kern = k_irn_a_split<C>;
+                if (irn_lds_limit((const void*)kern, IrnSplit<C>::LDS_A, granted)) { pcgc_set_error("irn pass A: cannot raise the LDS limit"); return -1; }
+                hipLaunchKernelGGL(kern, grid, dim3(256), IrnSplit<C>::LDS_A, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
+            }
+            if (phase & 2) {
+                static size_t granted[16] = {0};
+                auto kern = k_irn_b_split<C>;
+                if (irn_lds_limit((const void*)kern, IrnSplit<C>::LDS_B, granted)) { pcgc_set_error("irn pass B: cannot raise the LDS limit"); return -1; }
+                hipLaunchKernelGGL(kern, grid, dim3(256), IrnSplit<C>::LDS_B, s, nbr, n, t, x, x_ld, P[2], P[3], P[6], P[7], P[8], P[9], out, out_ld);
+            }
+            return 0;
+        }
+    }
     if ((phase & 1) && C == 32 && ROWS == 64 && n >= g_irn_cb16_rows) {
         const size_t lds16 = 4 * (size_t)(IrnKGA<C>::value * RowGather<4, ROWS>::SLOTS * 16);
         hipLaunchKernelGGL((k_irn_a<C, ROWS, 16>), grid, dim3(256), lds16, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
@@ -1134,7 +1418,7 @@ static int irn_launch(const int32_t* nbr, int64_t n, const float* x, int C, int 
 }
 
 // kernel selection for pcgc_conv_gather (all variants are bit-identical; tests run every one of them):
-//   -1 auto | 0 v0 direct loads + VALU | 1 v1 LDS-DMA + VALU | 2 v2 LDS-DMA + MFMA | 3 v2b MFMA with LDS-shared weights | 5 v1 burst (16-row tiles, 9 offsets per wait)
+//   -1 auto | 0 v0 direct loads + VALU | 1 v1 LDS-DMA + VALU | 2 v2 LDS-DMA + MFMA | 3 v2b MFMA with LDS-shared weights | 5 v1 burst (16-row tiles, 9 offsets per wait) | 6 row-split (16-row tiles, lanes split the output channels, weights in LDS)
 // auto policy (measured per shape, tools/conv_ab.py, tools/conv32_ab.py): >= 30 k rows: 64->64 and 32->32 -> v2b (v2c below 110 k rows for 64->64); Cin in {16,32,64} & Cout in {16,32,64} -> v2;
 // other gathered shapes with Cin in {8,16,32,64} -> v1; everything else (Cin 1/4, k1 convs, tiny levels) -> v0.
 static int g_conv_impl = -1;
@@ -1184,7 +1468,17 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
         else ok = dispatch_mfma<64>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         if (ok) { PCGC_CHECK_LAUNCH("conv_gather_mfma"); return 0; }
     }
-    if (v1_eligible && K == 27 && Cin <= 32 && Cout <= 16 && (g_conv_impl == 5 || (g_conv_impl < 0 && n_out < 40000))) {   // (conv3 32->8 at 18.7 k rows: 71 us on v0)
+    if (v1_eligible && K == 27 && Cin <= 32 && Cout <= 16 && (Cout & 3) == 0 && (g_conv_impl == 6 || (g_conv_impl < 0 && n_out < 40000))) {
+        const float* res0 = residual ? residual + res_coff : nullptr;       // (conv3 32->8 at 18.7 k rows: 71 us on v0, 42 us on the burst form)
+        float* out0 = out + out_coff;
+        int rc = 1;
+        if (Cin == 8) rc = dispatch_split<8>(Cout, nbr, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        else if (Cin == 16) rc = dispatch_split<16>(Cout, nbr, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        else if (Cin == 32) rc = dispatch_split<32>(Cout, nbr, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        if (rc < 0) return rc;
+        if (rc == 0) { PCGC_CHECK_LAUNCH("conv_gather_split"); return 0; }
+    }
+    if (v1_eligible && K == 27 && Cin <= 32 && Cout <= 16 && (g_conv_impl == 5 || (g_conv_impl < 0 && n_out < 40000))) {
         const float* res0 = residual ? residual + res_coff : nullptr;
         float* out0 = out + out_coff;
         int rc = 1;

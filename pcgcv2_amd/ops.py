@@ -405,6 +405,11 @@ def set_mfma_pipe(mode):
     check(lib().pcgc_set_mfma_pipe(int(mode)), 'set_mfma_pipe')
 
 
+def set_irn_split(on):
+    """16-row InceptionResNet passes at C <= 32: row-split kernels (default) or lane-per-row kernels (A/B tests)."""
+    check(lib().pcgc_set_irn_split(int(on)), 'set_irn_split')
+
+
 def set_irn_rows(rows):
     """rows per wave of the fused InceptionResNet passes: 0 = by level size (default), or force 64 / 32 / 16."""
     check(lib().pcgc_set_irn_rows(int(rows)), 'set_irn_rows')

@@ -112,9 +112,9 @@ CONV_SHAPES = [(27, 1, 16), (27, 16, 16), (27, 32, 8), (27, 8, 16), (27, 8, 8), 
                (8, 16, 32), (8, 32, 64), (8, 64, 32), (1, 32, 8), (1, 8, 16), (1, 64, 16), (1, 16, 32), (1, 16, 4), (1, 4, 8)]
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4, 5], ids=['v0_direct', 'v1_ldsdma', 'v2_mfma', 'v2b_mfma_wlds', 'v2c_mfma_pipe', 'v1_burst'])
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5, 6], ids=['v0_direct', 'v1_ldsdma', 'v2_mfma', 'v2b_mfma_wlds', 'v2c_mfma_pipe', 'v1_burst', 'row_split'])
 def conv_impl(request):
-    ops.set_conv_impl(5 if request.param == 5 else min(request.param, 3))
+    ops.set_conv_impl(request.param if request.param >= 5 else min(request.param, 3))
     ops.set_mfma_pipe(1 if request.param == 4 else 0)
     yield request.param
     ops.set_conv_impl(-1)
@@ -178,6 +178,13 @@ def test_fused_inception_resnet_bit_exact(C, rows):
         ops.set_irn_rows(0)
     np.testing.assert_array_equal(unfused, want)
     np.testing.assert_array_equal(fused, want)
+    if rows == 16 and C <= 32:                               # lane-per-row form of the 16-row tiles (the default is the row-split form)
+        ops.set_irn_split(0)
+        try:
+            with torch.no_grad():
+                np.testing.assert_array_equal(blk(xs).F.cpu().numpy(), want)
+        finally:
+            ops.set_irn_split(1)
     if C == 32 and rows == 64:                               # 16-channel sub-step form of pass A (the default above 400 k rows)
         ops.set_irn_cb16_rows(0)
         try:
