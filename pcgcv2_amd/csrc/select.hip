@@ -5,8 +5,13 @@
 #include <rocprim/rocprim.hpp>
 
 // ------------------------------------------------------------------------------------------- mask scan
-// Three launches: per-tile popcounts -> single-block scan of tile sums -> per-tile exclusive scan.
-// Tile = 2048 mask bytes per 256-thread block (8 per thread, loaded as one 8-byte word).
+// One launch: a single-pass scan with decoupled look-back.  Tile = 2048 mask bytes per 256-thread block (8 per thread, loaded
+// as one 8-byte word); tiles take their index from a ticket counter (a tile only ever waits for tiles that are already
+// running), publish (status, value) descriptors — 1 = the tile's own count, 2 = inclusive prefix — and wave 0 of each tile
+// walks back 64 descriptors at a time until it meets an inclusive prefix.  Descriptors and ticket must be zero at launch.
+// A descriptor is ONE 64-bit word carrying status and value, read and written with relaxed device-scope atomics: nothing else
+// is communicated between tiles, so no fences (on this multi-XCD part an acquire / release at device scope is an L2
+// invalidate / write-back: 24 us per scan instead of 6).
 constexpr int SCAN_TILE = 2048;
 
 __device__ static inline int block_exclusive_scan_256(int v, int* total_out) {
@@ -39,53 +44,68 @@ __device__ static inline int load_mask8(const uint8_t* mask, int64_t n, int64_t 
     return cnt;
 }
 
-__global__ void __launch_bounds__(256) k_scan_tile_sums(const uint8_t* __restrict__ mask, int64_t n, int32_t* tile_sums) {
-    uint8_t m[8];
-    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * 8;
-    int cnt = load_mask8(mask, n, base, m);
-    int tot;
-    block_exclusive_scan_256(cnt, &tot);
-    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
-}
-__global__ void __launch_bounds__(256) k_scan_tile_offsets(int32_t* tile_sums, int64_t n_tiles, int32_t* total) {
-    // single block, sequential over chunks of 256 tiles
-    __shared__ int carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
+constexpr uint64_t SCAN_AGG = 1ull << 62, SCAN_INCL = 2ull << 62;
+// `enable` (may be null): a device flag; the launch is a no-op when it reads 0 (the top-k tie path below)
+__global__ void __launch_bounds__(256) k_scan_lookback(const uint8_t* __restrict__ mask, int64_t n, int64_t n_tiles,
+                                                       unsigned long long* desc, int32_t* ticket, int32_t* __restrict__ prefix,
+                                                       int32_t* total, const uint32_t* enable) {
+    if (enable && *enable == 0) return;
+    __shared__ int tile_s, excl_s;
+    if (threadIdx.x == 0) tile_s = atomicAdd(ticket, 1);
     __syncthreads();
-    for (int64_t c = 0; c < n_tiles; c += 256) {
-        int64_t i = c + threadIdx.x;
-        int v = i < n_tiles ? tile_sums[i] : 0;
-        int tot;
-        int ex = block_exclusive_scan_256(v, &tot);
-        int carry = carry_s;
-        if (i < n_tiles) tile_sums[i] = carry + ex;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total = carry_s;
-}
-__global__ void __launch_bounds__(256) k_scan_apply(const uint8_t* __restrict__ mask, int64_t n,
-                                                    const int32_t* __restrict__ tile_offsets, int32_t* __restrict__ prefix) {
+    const int64_t tile = tile_s;
     uint8_t m[8];
-    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * 8;
-    int cnt = load_mask8(mask, n, base, m);
-    int ex = block_exclusive_scan_256(cnt, nullptr) + tile_offsets[blockIdx.x];
+    const int64_t base = tile * SCAN_TILE + threadIdx.x * 8;
+    const int cnt = load_mask8(mask, n, base, m);
+    int tot;
+    int ex = block_exclusive_scan_256(cnt, &tot);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int excl = 0;
+        if (tile == 0) {
+            if (lane == 0) __hip_atomic_store(&desc[0], SCAN_INCL | (uint64_t)(uint32_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&desc[tile], SCAN_AGG | (uint64_t)(uint32_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int64_t j = tile - 1;; j -= 64) {
+                const int64_t idx = j - lane;
+                unsigned long long d = SCAN_INCL;                        // before tile 0: an inclusive prefix of 0
+                if (idx >= 0) {
+                    do { d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((d >> 62) == 0);
+                }
+                const unsigned long long incl = __ballot((d >> 62) == 2);
+                const int first = incl ? (int)__ffsll((long long)incl) - 1 : 63;     // nearest inclusive prefix, or the whole window
+                int v = lane <= first ? (int)(uint32_t)d : 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                excl += v;
+                if (incl) break;
+            }
+            if (lane == 0) __hip_atomic_store(&desc[tile], SCAN_INCL | (uint64_t)(uint32_t)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) { excl_s = excl; if (tile == n_tiles - 1) *total = excl + tot; }
+    }
+    __syncthreads();
+    ex += excl_s;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { if (base + j < n) prefix[base + j] = ex; ex += m[j]; }
 }
 
-extern "C" size_t pcgc_scan_workspace_bytes(int64_t n) { return (size_t)((n + SCAN_TILE - 1) / SCAN_TILE + 1) * sizeof(int32_t); }
+static int64_t scan_tiles(int64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
+extern "C" size_t pcgc_scan_workspace_bytes(int64_t n) { return (size_t)(scan_tiles(n) + 2) * sizeof(uint64_t); }   // descriptors | ticket
 
+// workspace already zeroed by the caller
+static void launch_scan(const uint8_t* mask, int64_t n, int32_t* prefix, int32_t* total, void* workspace, const uint32_t* enable, hipStream_t s) {
+    const int64_t tiles = scan_tiles(n);
+    unsigned long long* desc = (unsigned long long*)workspace;
+    hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)tiles), dim3(256), 0, s, mask, n, tiles, desc, (int32_t*)(desc + tiles), prefix, total, enable);
+}
 extern "C" int pcgc_mask_scan(const uint8_t* mask, int64_t n, int32_t* prefix, int32_t* total, void* workspace,
                               size_t workspace_bytes, void* stream) {
     PCGC_REQUIRE(workspace_bytes >= pcgc_scan_workspace_bytes(n), "workspace too small");
+    PCGC_REQUIRE(((uintptr_t)workspace & 7) == 0, "workspace must be 8-byte aligned");
     if (n == 0) { (void)hipMemsetAsync(total, 0, 4, S(stream)); return 0; }
-    int64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-    int32_t* ts = (int32_t*)workspace;
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)tiles), dim3(256), 0, S(stream), mask, n, ts);
-    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(256), 0, S(stream), ts, tiles, total);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)tiles), dim3(256), 0, S(stream), mask, n, ts, prefix);
+    (void)hipMemsetAsync(workspace, 0, pcgc_scan_workspace_bytes(n), S(stream));
+    launch_scan(mask, n, prefix, total, workspace, nullptr, S(stream));
     PCGC_CHECK_LAUNCH("mask_scan");
     return 0;
 }
@@ -132,43 +152,55 @@ extern "C" int pcgc_compact_feats(const float* in, int C, int in_ld, const uint8
 
 // ------------------------------------------------------------------------------------------- top-k mask
 // MSB-first radix select on the order-preserving integer image of the fp32 logits: 4 passes of 8 bits, each a
-// block-privatised LDS histogram + a one-block digit pick.  Then mask = key > T, plus the first `need` rows (by
-// index) among key == T, ranked by an exclusive scan of the equality flags (canonical tie rule: lower row wins).
-struct TopkState { uint32_t prefix; uint32_t pad; int64_t k_remaining; };   // lives at workspace[0]
+// block-privatised LDS histogram whose LAST block to finish picks the digit (no separate pick launch).  Then
+// mask = key > T, plus the first `need` rows (by index) among key == T (canonical tie rule: lower row wins).  The final
+// pick knows how many keys equal T: unless fewer than all of them are needed (a genuine tie at the threshold) every one is
+// kept and the ranking launches (equality flags scanned, mask fixed up) return at once.
+struct TopkState { uint32_t prefix; uint32_t tie; int64_t k_remaining; uint32_t done; uint32_t count_eq; };   // lives at workspace[0]
 
 __device__ static inline uint32_t order_key(float f) {
     f = f + 0.0f;                                      // -0.0 -> +0.0
     uint32_t b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u); // ascending in float order
 }
-__global__ void k_topk_init(TopkState* st, uint32_t* hist, int64_t k) {
-    if (threadIdx.x == 0) { st->prefix = 0; st->k_remaining = k; }
+// zeroes the state, the histogram and the tie path's scan workspace
+__global__ void k_topk_init(TopkState* st, uint32_t* hist, int64_t k, unsigned long long* scan_ws, int64_t scan_words) {
+    if (threadIdx.x == 0) { st->prefix = 0; st->tie = 0; st->k_remaining = k; st->done = 0; st->count_eq = 0; }
     hist[threadIdx.x] = 0;
+    for (int64_t i = threadIdx.x; i < scan_words; i += blockDim.x) scan_ws[i] = 0;
 }
 // Block-local LDS histogram, flushed with one global atomic per non-empty bin.  The grid is kept SMALL (<= 256 blocks):
 // the flush is up to 256 same-address atomics per block, and with 2048 blocks those serialised in L2 for ~30 us per pass
 // on the 2 M-candidate level (the element loop itself is ~3 us).
-__global__ void __launch_bounds__(256) k_topk_hist(const float* __restrict__ v, int ld, int64_t n, const TopkState* st,
-                                                   int pass, uint32_t* __restrict__ hist) {
+__global__ void __launch_bounds__(256) k_topk_hist(const float* __restrict__ v, int ld, int64_t n, TopkState* st,
+                                                   int pass, uint32_t* hist) {
     __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+    __shared__ int64_t S[257];
+    __shared__ bool last_s;
+    const int t = threadIdx.x;
+    h[t] = 0;
     __syncthreads();
     int shift = 24 - 8 * pass;
     uint32_t prefix = st->prefix;
     uint32_t pmask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + t; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         uint32_t key = order_key(v[i * ld]);
         if ((key & pmask) == prefix) atomicAdd(&h[(key >> shift) & 0xff], 1u);
     }
     __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
-}
-__global__ void __launch_bounds__(256) k_topk_pick(TopkState* st, uint32_t* hist, int pass) {
+    // the last block to arrive picks the digit.  No fences (a device-scope release is a whole-L2 write-back here): the bin
+    // updates are device-scope atomics, i.e. performed at the memory side; each thread waits for the RETURN of its own update
+    // before the block's arrival is counted, and the last block reads the bins with device-scope atomic loads.
+    uint32_t seen = 0;
+    if (h[t]) seen = atomicAdd(&hist[t], h[t]);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(seen) :: "memory");
+    __syncthreads();
+    if (t == 0) last_s = atomicAdd(&st->done, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last_s) return;
     // digit d = the largest one whose inclusive suffix count S[d] = sum_{e >= d} hist[e] reaches k_remaining (d = 0 if none):
-    // parallel suffix scan over the 256 bins instead of a serial walk of dependent global loads
-    __shared__ int64_t S[257];
-    const int t = threadIdx.x;
-    const int64_t mine = hist[t];
+    // parallel suffix scan over the 256 bins
+    const int64_t mine = __hip_atomic_load(&hist[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     S[t] = mine;
     if (t == 0) S[256] = 0;
     __syncthreads();
@@ -182,23 +214,31 @@ __global__ void __launch_bounds__(256) k_topk_pick(TopkState* st, uint32_t* hist
     __syncthreads();                                   // every thread has read k_remaining before it is rewritten
     const bool hit = t == 0 ? (S[1] < need) : (S[t] >= need && (S[t + 1] < need || t == 255));     // (t = 255 also covers k = 0)
     if (hit) {
-        st->prefix |= (uint32_t)t << (24 - 8 * pass);
-        st->k_remaining = need - S[t + 1];             // how many to take among keys sharing the new prefix
+        const int64_t rem = need - S[t + 1];           // how many to take among keys sharing the new prefix
+        st->prefix = prefix | ((uint32_t)t << shift);
+        st->k_remaining = rem;
+        st->done = 0;
+        if (pass == 3) { st->count_eq = (uint32_t)mine; st->tie = rem < mine ? 1u : 0u; }
     }
     hist[t] = 0;                                       // ready for the next pass
 }
-__global__ void k_topk_flags(const float* __restrict__ v, int ld, int64_t n, const TopkState* st, uint8_t* eq) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) eq[i] = order_key(v[i * ld]) == st->prefix;
-}
-// tie_high = 0: among logits equal to the threshold the LOWER row indices are kept (canonical); 1: the HIGHER ones
-__global__ void k_topk_mask(const float* __restrict__ v, int ld, int64_t n, const TopkState* st,
-                            const int32_t* __restrict__ eq_rank, const int32_t* __restrict__ eq_total, int tie_high, uint8_t* mask) {
+// mask = key > T, or key == T when every such row is kept; on a genuine tie the equal rows are flagged for the ranking below
+__global__ void k_topk_mask(const float* __restrict__ v, int ld, int64_t n, const TopkState* st, uint8_t* mask, uint8_t* eq) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t key = order_key(v[i * ld]), T = st->prefix;
+    const uint32_t key = order_key(v[i * ld]), T = st->prefix;
+    const bool tie = st->tie != 0;
+    mask[i] = (key > T) || (key == T && !tie);
+    if (tie) eq[i] = key == T;
+}
+// tie_high = 0: among logits equal to the threshold the LOWER row indices are kept (canonical); 1: the HIGHER ones
+__global__ void k_topk_tie_fix(const TopkState* st, const uint8_t* __restrict__ eq, const int32_t* __restrict__ eq_rank, int64_t n,
+                               int tie_high, uint8_t* mask) {
+    if (st->tie == 0) return;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !eq[i]) return;
     const int64_t need = st->k_remaining, r = eq_rank[i];
-    mask[i] = (key > T) || (key == T && (tie_high ? r >= (int64_t)eq_total[0] - need : r < need));
+    mask[i] = tie_high ? r >= (int64_t)st->count_eq - need : r < need;
 }
 
 static int g_topk_tie_high = 0;
@@ -217,6 +257,7 @@ extern "C" size_t pcgc_topk_workspace_bytes(int64_t n) {
 extern "C" int pcgc_topk_mask(const float* logits, int ld, int64_t n, int64_t k, uint8_t* mask, void* workspace,
                               size_t workspace_bytes, void* stream) {
     PCGC_REQUIRE(workspace_bytes >= pcgc_topk_workspace_bytes(n), "workspace too small");
+    PCGC_REQUIRE(((uintptr_t)workspace & 7) == 0, "workspace must be 8-byte aligned");
     if (n == 0) return 0;
     if (k >= n) { (void)hipMemsetAsync(mask, 1, (size_t)n, S(stream)); return 0; }
     if (k <= 0) { (void)hipMemsetAsync(mask, 0, (size_t)n, S(stream)); return 0; }
@@ -228,15 +269,14 @@ extern "C" int pcgc_topk_mask(const float* logits, int ld, int64_t n, int64_t k,
     int32_t* total = (int32_t*)ws; ws += 256;
     void* scan_ws = ws;
     unsigned g = grid_for(n, 256 * 8); if (g > 256) g = 256; if (g < 1) g = 1;
-    hipLaunchKernelGGL(k_topk_init, dim3(1), dim3(256), 0, S(stream), st, hist, k);
-    for (int pass = 0; pass < 4; ++pass) {
+    hipLaunchKernelGGL(k_topk_init, dim3(1), dim3(256), 0, S(stream), st, hist, k, (unsigned long long*)scan_ws,
+                       (int64_t)(pcgc_scan_workspace_bytes(n) / 8));
+    for (int pass = 0; pass < 4; ++pass)
         hipLaunchKernelGGL(k_topk_hist, dim3(g), dim3(256), 0, S(stream), logits, ld, n, st, pass, hist);
-        hipLaunchKernelGGL(k_topk_pick, dim3(1), dim3(256), 0, S(stream), st, hist, pass);
-    }
-    hipLaunchKernelGGL(k_topk_flags, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), logits, ld, n, st, eq);
-    int rc = pcgc_mask_scan(eq, n, rank, total, scan_ws, pcgc_scan_workspace_bytes(n), stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_topk_mask, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), logits, ld, n, st, rank, total, g_topk_tie_high, mask);
+    hipLaunchKernelGGL(k_topk_mask, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), logits, ld, n, st, mask, eq);
+    // genuine tie at the threshold only (st->tie): rank the equal rows and keep `need` of them
+    launch_scan(eq, n, rank, total, scan_ws, &st->tie, S(stream));
+    hipLaunchKernelGGL(k_topk_tie_fix, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), st, eq, rank, n, g_topk_tie_high, mask);
     PCGC_CHECK_LAUNCH("topk_mask");
     return 0;
 }

@@ -255,8 +255,8 @@ def test_sort_zyx_matches_reference_golden(golden_dir):
 
 def test_mask_scan_and_compaction():
     rng = np.random.default_rng(9)
-    for n in (1, 7, 2048, 2049, 300001):
-        m = (rng.random(n) < 0.4).astype(np.uint8)
+    for n, density in ((1, 0.4), (7, 0.4), (2048, 0.4), (2049, 0.4), (300001, 0.4), (5000003, 0.4), (2100000, 1.1), (2100000, -1.0)):
+        m = (rng.random(n) < density).astype(np.uint8)           # (single-pass look-back scan: 1 ... 2442 tiles, all-ones / all-zeros)
         prefix, total = ops.mask_scan(_t(m))
         np.testing.assert_array_equal(prefix.cpu().numpy(), np.cumsum(m) - m)
         assert int(total.item()) == m.sum()
