@@ -36,8 +36,8 @@ int pcgc_version(void);
  *      data_utils.py:96,108,116 and coder.py:102).  Open addressing, 64-slot spatial blocks (4x4x4 voxels). ---- */
 int64_t pcgc_hash_capacity(int64_t n);                                   /* slots needed for n coordinates (pow2) */
 int pcgc_hash_clear(uint64_t* keys /*[dev cap]*/, int32_t* vals /*[dev cap]*/, int64_t cap, void* stream);
-/* `stride` = tensor stride of the level the table indexes (the spatial blocking works on the level's own lattice);
- * insert, first_mask and the kmap builders of one table must all be given the same stride. */
+/* `stride` = tensor stride of the level the table indexes.  Kept in the signatures for the callers' bookkeeping: the slot of a
+ * key is a mix of the whole coordinate key and does not depend on it (the round-1 spatially blocked layout did). */
 int pcgc_hash_insert(const int32_t* coords /*[dev n,4]*/, int64_t n, int32_t stride, uint64_t* keys, int32_t* vals,
                      int64_t cap, void* stream);                         /* vals[slot] = smallest row with that key */
 /* dedup policy as an argument: keep_last = 0 is pcgc_hash_insert; 1 keeps the LARGEST row per key (ME's dedup policy for equal

@@ -17,21 +17,23 @@ extern "C" int64_t pcgc_hash_capacity(int64_t n) {
     return cap;
 }
 
-// The lattice shift used by the blocked hash: derived from the coordinates' stride.  Levels are inserted and probed
-// with the same shift; we fold it into the table by storing it nowhere — callers pass `stride` where needed and the
-// insert kernels below recover it from a kernel argument.
 __global__ void k_hash_clear(uint64_t* keys, int32_t* vals, int64_t cap) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cap) { keys[i] = PCGC_EMPTY_KEY; vals[i] = 0x7fffffff; }
 }
 
-__global__ void k_hash_insert(const int4* __restrict__ coords, int64_t n, int sh, uint64_t* keys, int32_t* vals, uint64_t cap_mask) {
+__global__ void k_hash_insert(const int4* __restrict__ coords, int64_t n, uint64_t* keys, int32_t* vals, uint64_t cap_mask) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int4 c = coords[i];                               // (b, x, y, z)
-    if (!coord_in_range(c.x, c.y, c.z, c.w)) return;  // never found again; the host rejects such input up front (pcgc_coords_check)
-    uint64_t key = coord_key(c.x, c.y, c.z, c.w);
-    uint64_t h = hash_slot(c.x, c.y, c.z, c.w, sh, cap_mask);
+    int4 c = make_int4(-1, -1, -1, -1);               // (b, x, y, z)
+    if (i < n) c = coords[i];
+    // rows outside the key range are never found again; the host rejects such input up front (pcgc_coords_check)
+    const bool ok = i < n && coord_in_range(c.x, c.y, c.z, c.w);
+    const uint64_t key = ok ? coord_key(c.x, c.y, c.z, c.w) : PCGC_EMPTY_KEY;
+    // a run of equal keys in consecutive lanes (quantised x-neighbours of a raster-ordered cloud) is inserted by its first lane only:
+    // that lane has the smallest row of the run.  (Shuffle before any lane leaves: every lane holds a defined key.)
+    const uint64_t left = __shfl_up((unsigned long long)key, 1, 64);
+    if (!ok || ((threadIdx.x & 63) != 0 && left == key)) return;
+    uint64_t h = hash_slot(key, cap_mask);
     // Quantised coordinates arrive up to 8 times each.  Test before the atomics: a slot only ever goes EMPTY -> key and its
     // row value only ever decreases, so a plain (possibly stale) load that already shows this key / a smaller row lets the
     // thread skip the CAS / the atomicMin; a stale load merely falls through to the atomic path.
@@ -47,13 +49,13 @@ __global__ void k_hash_insert(const int4* __restrict__ coords, int64_t n, int sh
     }
 }
 // dedup policy "keep the LAST occurrence" (the default everywhere is the first): same table, vals[slot] = LARGEST row with the key
-__global__ void k_hash_insert_last(const int4* __restrict__ coords, int64_t n, int sh, uint64_t* keys, int32_t* vals, uint64_t cap_mask) {
+__global__ void k_hash_insert_last(const int4* __restrict__ coords, int64_t n, uint64_t* keys, int32_t* vals, uint64_t cap_mask) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int4 c = coords[i];
     if (!coord_in_range(c.x, c.y, c.z, c.w)) return;
     uint64_t key = coord_key(c.x, c.y, c.z, c.w);
-    uint64_t h = hash_slot(c.x, c.y, c.z, c.w, sh, cap_mask);
+    uint64_t h = hash_slot(key, cap_mask);
     for (;;) {
         unsigned long long prev = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)PCGC_EMPTY_KEY, (unsigned long long)key);
         if (prev == PCGC_EMPTY_KEY || prev == key) {
@@ -69,12 +71,12 @@ __global__ void k_hash_insert_last(const int4* __restrict__ coords, int64_t n, i
         h = (h + 1) & cap_mask;
     }
 }
-__global__ void k_hash_first_mask(const int4* __restrict__ coords, int64_t n, int sh, const uint64_t* __restrict__ keys,
+__global__ void k_hash_first_mask(const int4* __restrict__ coords, int64_t n, const uint64_t* __restrict__ keys,
                                   const int32_t* __restrict__ vals, uint64_t cap_mask, uint8_t* keep, int32_t* first_row) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int4 c = coords[i];
-    int32_t f = hash_lookup(keys, vals, cap_mask, sh, c.x, c.y, c.z, c.w);
+    int32_t f = hash_lookup(keys, vals, cap_mask, c.x, c.y, c.z, c.w);
     keep[i] = f == (int32_t)i;
     if (first_row) first_row[i] = f;
 }
@@ -101,13 +103,13 @@ extern "C" int pcgc_hash_clear(uint64_t* keys, int32_t* vals, int64_t cap, void*
     PCGC_CHECK_LAUNCH("hash_clear");
     return 0;
 }
-static inline int stride_shift(int32_t stride) { int sh = 0; while ((2 << sh) <= stride) ++sh; return sh; }
 extern "C" int pcgc_hash_insert(const int32_t* coords, int64_t n, int32_t stride, uint64_t* keys, int32_t* vals, int64_t cap,
                                 void* stream) {
+    (void)stride;                                     // (the slot no longer depends on the level's lattice: see pcgc_common.h)
     PCGC_REQUIRE(cap >= 2 * n && (cap & (cap - 1)) == 0, "capacity must be a power of two >= 2n");
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_hash_insert, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n,
-                       stride_shift(stride), keys, vals, (uint64_t)(cap - 1));
+                       keys, vals, (uint64_t)(cap - 1));
     PCGC_CHECK_LAUNCH("hash_insert");
     return 0;
 }
@@ -117,15 +119,16 @@ extern "C" int pcgc_hash_insert_policy(const int32_t* coords, int64_t n, int32_t
     PCGC_REQUIRE(cap >= 2 * n && (cap & (cap - 1)) == 0, "capacity must be a power of two >= 2n");
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_hash_insert_last, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n,
-                       stride_shift(stride), keys, vals, (uint64_t)(cap - 1));
+                       keys, vals, (uint64_t)(cap - 1));
     PCGC_CHECK_LAUNCH("hash_insert_policy");
     return 0;
 }
 extern "C" int pcgc_hash_first_mask(const int32_t* coords, int64_t n, int32_t stride, const uint64_t* keys,
                                     const int32_t* vals, int64_t cap, uint8_t* keep, int32_t* first_row, void* stream) {
+    (void)stride;
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_hash_first_mask, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n,
-                       stride_shift(stride), keys, vals, (uint64_t)(cap - 1), keep, first_row);
+                       keys, vals, (uint64_t)(cap - 1), keep, first_row);
     PCGC_CHECK_LAUNCH("hash_first_mask");
     return 0;
 }
@@ -178,7 +181,7 @@ extern "C" int pcgc_coords_scale(const int32_t* coords, int64_t n, float factor,
 // One thread per (offset, site) pair, site fastest: 27x more threads than sites — this kernel only runs on the coarsest
 // levels (<= 32k sites), where a thread-per-site version is latency-bound (27 serial probe chains on ~70 workgroups).
 // nbr is offset-major [27][n] so the conv kernels read it coalesced.
-__global__ void __launch_bounds__(256) k_kmap_k3(const int4* __restrict__ coords, int64_t n, int32_t s, int sh,
+__global__ void __launch_bounds__(256) k_kmap_k3(const int4* __restrict__ coords, int64_t n, int32_t s,
                                                  const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
                                                  uint64_t cap_mask, int32_t* __restrict__ nbr) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -186,9 +189,9 @@ __global__ void __launch_bounds__(256) k_kmap_k3(const int4* __restrict__ coords
     int k = (int)(t / n); int64_t o = t - (int64_t)k * n;
     int4 c = coords[o];
     int dx = (k % 3 - 1) * s, dy = ((k / 3) % 3 - 1) * s, dz = (k / 9 - 1) * s;
-    nbr[t] = (k == 13) ? (int32_t)o : hash_lookup(keys, vals, cap_mask, sh, c.x, c.y + dx, c.z + dy, c.w + dz);
+    nbr[t] = (k == 13) ? (int32_t)o : hash_lookup(keys, vals, cap_mask, c.x, c.y + dx, c.z + dy, c.w + dz);
 }
-__global__ void __launch_bounds__(256) k_kmap_down(const int4* __restrict__ coarse, int64_t n, int32_t s, int sh,
+__global__ void __launch_bounds__(256) k_kmap_down(const int4* __restrict__ coarse, int64_t n, int32_t s,
                                                    const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
                                                    uint64_t cap_mask, int32_t* __restrict__ nbr) {
     int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -196,14 +199,14 @@ __global__ void __launch_bounds__(256) k_kmap_down(const int4* __restrict__ coar
     int4 c = coarse[o];
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-        nbr[(int64_t)k * n + o] = hash_lookup(keys, vals, cap_mask, sh, c.x, c.y + (k & 1) * s, c.z + ((k >> 1) & 1) * s,
+        nbr[(int64_t)k * n + o] = hash_lookup(keys, vals, cap_mask, c.x, c.y + (k & 1) * s, c.z + ((k >> 1) & 1) * s,
                                               c.w + (k >> 2) * s);
 }
 extern "C" int pcgc_kmap_k3(const int32_t* coords, int64_t n, int32_t stride, const uint64_t* keys, const int32_t* vals,
                             int64_t cap, int32_t* nbr, void* stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_kmap_k3, dim3(grid_for(27 * n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n, stride,
-                       stride_shift(stride), keys, vals, (uint64_t)(cap - 1), nbr);
+                       keys, vals, (uint64_t)(cap - 1), nbr);
     PCGC_CHECK_LAUNCH("kmap_k3");
     return 0;
 }
@@ -211,7 +214,7 @@ extern "C" int pcgc_kmap_down(const int32_t* coarse, int64_t n_coarse, int32_t s
                               const int32_t* fine_vals, int64_t fine_cap, int32_t* nbr, void* stream) {
     if (n_coarse == 0) return 0;
     hipLaunchKernelGGL(k_kmap_down, dim3(grid_for(n_coarse, 256)), dim3(256), 0, S(stream), (const int4*)coarse, n_coarse,
-                       stride_fine, stride_shift(stride_fine), fine_keys, fine_vals, (uint64_t)(fine_cap - 1), nbr);
+                       stride_fine, fine_keys, fine_vals, (uint64_t)(fine_cap - 1), nbr);
     PCGC_CHECK_LAUNCH("kmap_down");
     return 0;
 }
@@ -397,7 +400,7 @@ __global__ void __launch_bounds__(256) k_d1_nn(const int4* __restrict__ a, int64
         int found = -1;
         for (int t = 0; t < n_off; ++t) {
             const int4 o = offsets[t];
-            if (hash_lookup(keys, vals, cap_mask, 0, c.x, c.y + o.x, c.z + o.y, c.w + o.z) >= 0) { found = o.w; break; }
+            if (hash_lookup(keys, vals, cap_mask, c.x, c.y + o.x, c.z + o.y, c.w + o.z) >= 0) { found = o.w; break; }
         }
         if (found >= 0) { mine = (double)found; mymax = (unsigned long long)found; } else miss = 1;
     }

@@ -4,14 +4,6 @@
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
-// XCD-aware tile order: workgroup b is observed to run on XCD b % 8 (each XCD has its own 4 MiB L2).  Remap so every XCD
-// walks a contiguous slab of tiles: neighbouring tiles gather overlapping rows, which then hit the same L2.  Bijective
-// for any grid size; placement only affects speed, never results.
-__device__ static inline unsigned xcd_tile(unsigned b, unsigned nb) {
-    const unsigned q = nb >> 3, r = nb & 7, x = b & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-}
-
 template <int N>
 __device__ static inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 

@@ -19,6 +19,14 @@ void pcgc_set_error(const char* fmt, ...);
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
+// XCD-aware tile order: workgroup b is observed to run on XCD b % 8 (each XCD has its own 4 MiB L2).  Remap so every XCD
+// walks a contiguous slab of tiles: neighbouring tiles gather overlapping rows, which then hit the same L2.  Bijective
+// for any grid size; placement only affects speed, never results.
+__device__ static inline unsigned xcd_tile(unsigned b, unsigned nb) {
+    const unsigned q = nb >> 3, r = nb & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
 // ---- coordinate key: 4-bit batch | 20-bit z | 20-bit y | 20-bit x ------------------------------------------
 #define PCGC_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 __host__ __device__ static inline bool coord_in_range(int32_t b, int32_t x, int32_t y, int32_t z) {
@@ -27,23 +35,19 @@ __host__ __device__ static inline bool coord_in_range(int32_t b, int32_t x, int3
 __host__ __device__ static inline uint64_t coord_key(int32_t b, int32_t x, int32_t y, int32_t z) {
     return ((uint64_t)b << 60) | ((uint64_t)z << 40) | ((uint64_t)y << 20) | (uint64_t)x;
 }
-// Spatially blocked hash: a 4x4x4 voxel block (in units of the level's own lattice: callers pre-divide by stride)
-// maps to 64 consecutive slots, so the 27 probes of neighbouring outputs share cache lines.
+// Open addressing with linear probing on a mixed key.  (Round 1 mapped each 4x4x4 block of cells to 64 consecutive slots so that the 27
+// probes of a row would share cache lines.  Measured on MI355X it lost everywhere: surfaces fill a block to ~15 %, several blocks overlay
+// one slot group and probe chains — above all those of ABSENT neighbours, which run to the next empty slot — get long, and the inserts of
+// neighbouring rows queue up on the same few lines: 18.7 k keys inserted in 63 us vs 12 us, their 27-neighbour probe 34 us vs 8 us.)
 __device__ static inline uint64_t mix64(uint64_t v) {
     v ^= v >> 33; v *= 0xff51afd7ed558ccdull; v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ull; v ^= v >> 33; return v;
 }
-__device__ static inline uint64_t hash_slot(int32_t b, int32_t x, int32_t y, int32_t z, int sh, uint64_t cap_mask) {
-    // sh = log2(stride) of the level; lattice coordinates are (x>>sh) etc.
-    uint32_t lx = (uint32_t)x >> sh, ly = (uint32_t)y >> sh, lz = (uint32_t)z >> sh;
-    uint64_t blk = ((uint64_t)b << 54) | ((uint64_t)(lz >> 2) << 36) | ((uint64_t)(ly >> 2) << 18) | (uint64_t)(lx >> 2);
-    uint64_t local = ((lz & 3) << 4) | ((ly & 3) << 2) | (lx & 3);
-    return ((mix64(blk) << 6) | local) & cap_mask;
-}
+__device__ static inline uint64_t hash_slot(uint64_t key, uint64_t cap_mask) { return mix64(key) & cap_mask; }
 __device__ static inline int32_t hash_lookup(const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
-                                             uint64_t cap_mask, int sh, int32_t b, int32_t x, int32_t y, int32_t z) {
+                                             uint64_t cap_mask, int32_t b, int32_t x, int32_t y, int32_t z) {
     if (!coord_in_range(b, x, y, z)) return -1;
     uint64_t key = coord_key(b, x, y, z);
-    uint64_t h = hash_slot(b, x, y, z, sh, cap_mask);
+    uint64_t h = hash_slot(key, cap_mask);
     for (;;) {
         uint64_t k = keys[h];
         if (k == key) return vals[h];
