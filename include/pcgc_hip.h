@@ -106,6 +106,12 @@ int pcgc_down_prepare(const int32_t* fine /*[dev n,4]*/, int64_t n, int32_t stri
 int pcgc_down_finish(const int32_t* fine, const int32_t* q, const uint8_t* keep, const int32_t* first_row, const int32_t* prefix,
                      int64_t n, int32_t stride_fine, int64_t n_coarse, int32_t* coarse /*[dev n_coarse,4]*/,
                      int32_t* parent_of /*[dev n]*/, int32_t* down /*[dev 8,n_coarse]*/, void* stream);
+/* prepare + read-back of n_coarse (synchronises `stream`) + finish in one call.  coarse / down are caller buffers of upper-bound
+ * size ([n,4] and 8*n int32: a coarse level has at most n rows); down is written as [8][n_coarse] at the front of its buffer. */
+int pcgc_down_level(const int32_t* fine /*[dev n,4]*/, int64_t n, int32_t stride_fine, int32_t* q, uint64_t* keys, int32_t* vals,
+                    int64_t cap, uint8_t* keep, int32_t* first_row, int32_t* prefix, int32_t* total, void* scan_ws,
+                    size_t scan_ws_bytes, int32_t* coarse /*[dev n,4] capacity*/, int32_t* parent_of /*[dev n]*/,
+                    int32_t* down /*[dev 8*n] capacity*/, int64_t* n_coarse_out /*host*/, void* stream);
 /* orig[prefix[i]] = i for set mask bytes (row indices that survive a compaction) */
 int pcgc_compact_index(const uint8_t* mask, const int32_t* prefix, int64_t n, int32_t* orig /*[dev total]*/, void* stream);
 

@@ -133,13 +133,16 @@ class Coder():
         lvl8 = x.cmap
         for _ in range(3):
             lvl8 = lvl8.down()[0]                               # cached on the levels: the encoder reuses these maps
-        order = ops.sort_zyx(lvl8.C)                            # (z, y, x, batch) order of sort_spare_tensor
-        y_C = ops.gather_coords(lvl8.C, order)
-        # the stride-8 coordinates leave on a side stream into pinned memory (N8 x 16 B); the helper thread waits for that
-        # copy and runs the host coordinate coder, while this thread goes straight on to enqueue the encoder
-        arrived, host_C = self._stage_to_host(y_C)
+        # Side stream: the (z, y, x, batch) order of sort_spare_tensor, the sorted stride-8 coordinates and their copy into pinned
+        # memory (N8 x 16 B).  None of it is needed before the latent exists, so the dozen small sort launches run beside the
+        # encoder's convolutions instead of in front of them; the helper thread waits for the copy and runs the host coordinate coder.
+        order, y_C, sorted_ev, arrived, host_C = self._sort_and_stage(lvl8.C)
         coded = _POOL.submit(self._encode_geometry, arrived, host_C, lvl8.stride, postfix)
         y_list = self.model.encoder(x)                          # ~40 kernel launches, enqueued while the octree is coded
+        main = torch.cuda.current_stream(x.device)
+        main.wait_event(sorted_ev)
+        order.record_stream(main)
+        y_C.record_stream(main)
         y = SparseTensor(ops.gather_feats(y_list[0].F, order), coordinate_map=CoordMap(y_C, lvl8.stride, unique=True))
         budgets = [len(t) for t in (y_list[1], y_list[2], x)]
         _dump(self.filename + postfix + '_num_points.bin', _COUNTS.pack(*budgets))
@@ -147,24 +150,29 @@ class Coder():
         coded.result()                                          # (re-raises a coordinate-coder failure)
         return y
 
-    def _stage_to_host(self, t):
-        """Asynchronous device->host copy of a small tensor on a side stream; -> (event to wait for, pinned host view)."""
-        dev = t.device
+    def _sort_and_stage(self, C):
+        """On a side stream: canonical order of the rows of C, the sorted coordinates, and their asynchronous copy into pinned host
+        memory -> (order, sorted C, event after the sort, event after the copy, pinned host view)."""
+        dev = C.device
         if getattr(self, '_side', None) is None or self._side.device != dev:
             self._side = torch.cuda.Stream(device=dev)
             self._pinned = None
-        if self._pinned is None or self._pinned.numel() < t.numel() or self._pinned.dtype != t.dtype:
-            self._pinned = torch.empty(max(t.numel(), 1 << 16), dtype=t.dtype, pin_memory=True)
-        host = self._pinned[:t.numel()].view(t.shape)
+        if self._pinned is None or self._pinned.numel() < C.numel() or self._pinned.dtype != C.dtype:
+            self._pinned = torch.empty(max(C.numel(), 1 << 16), dtype=C.dtype, pin_memory=True)
+        host = self._pinned[:C.numel()].view(C.shape)
         ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(dev))             # on t's device's current stream: t is complete after this
+        ready.record(torch.cuda.current_stream(dev))             # on C's device's current stream: C is complete after this
         with torch.cuda.stream(self._side):
             self._side.wait_event(ready)
-            host.copy_(t, non_blocking=True)
+            order = ops.sort_zyx(C)
+            y_C = ops.gather_coords(C, order)
+            sorted_ev = torch.cuda.Event()
+            sorted_ev.record(self._side)
+            host.copy_(y_C, non_blocking=True)
             arrived = torch.cuda.Event()
             arrived.record(self._side)
-        t.record_stream(self._side)
-        return arrived, host
+        C.record_stream(self._side)
+        return order, y_C, sorted_ev, arrived, host
 
     def _encode_geometry(self, arrived, host_C, stride, postfix):
         torch.cuda.set_device(self._side.device)                 # the current device is per thread

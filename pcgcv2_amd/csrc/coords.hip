@@ -375,6 +375,28 @@ extern "C" int pcgc_down_finish(const int32_t* fine, const int32_t* q, const uin
     if ((rc = pcgc_compact_coords(q, keep, prefix, n, coarse, stream))) return rc;
     return pcgc_down_maps(fine, first_row, prefix, n, stride_fine, n_coarse, parent_of, down, stream);
 }
+// The same level in ONE call: prepare, read the coarse count back (the stream is synchronised here), finish into caller-provided
+// buffers of upper-bound size (a coarse level has at most n rows; `down` is written as [8][n_coarse] at the front of its buffer).
+// Between the read-back and the next launch the host does nothing but this function: the two-call form left the GPU idle for
+// ~30 us per level while the interpreter sized and allocated the outputs.
+extern "C" int pcgc_down_level(const int32_t* fine, int64_t n, int32_t stride_fine, int32_t* q, uint64_t* keys, int32_t* vals,
+                               int64_t cap, uint8_t* keep, int32_t* first_row, int32_t* prefix, int32_t* total, void* scan_ws,
+                               size_t scan_ws_bytes, int32_t* coarse, int32_t* parent_of, int32_t* down, int64_t* n_coarse_out,
+                               void* stream) {
+    PCGC_REQUIRE(n_coarse_out != nullptr, "null count");
+    int rc = pcgc_down_prepare(fine, n, stride_fine, q, keys, vals, cap, keep, first_row, prefix, total, scan_ws, scan_ws_bytes, stream);
+    if (rc) return rc;
+    static thread_local int32_t* host_total = nullptr;         // pinned: the 4-byte copy does not go through a staging buffer
+    if (!host_total && hipHostMalloc((void**)&host_total, 64, hipHostMallocDefault) != hipSuccess) {
+        host_total = nullptr; pcgc_set_error("down_level: cannot allocate pinned memory"); return -1;
+    }
+    hipError_t e = hipMemcpyAsync(host_total, total, sizeof(int32_t), hipMemcpyDeviceToHost, S(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
+    if (e != hipSuccess) { pcgc_set_error("down_level: %s", hipGetErrorString(e)); return -1; }
+    const int64_t n_coarse = *host_total;
+    *n_coarse_out = n_coarse;
+    return pcgc_down_finish(fine, q, keep, first_row, prefix, n, stride_fine, n_coarse, coarse, parent_of, down, stream);
+}
 extern "C" int pcgc_compact_index(const uint8_t* mask, const int32_t* prefix, int64_t n, int32_t* orig, void* stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_compact_index, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), mask, prefix, n, orig);

@@ -227,9 +227,11 @@ def down_maps(fine, first_row, prefix, stride_fine, n_coarse):
 
 
 def down_level(fine, stride_fine):
-    """One strided pyramid level (MinkowskiConvolution k=2 s=2, coordinate side) in two library calls around the one
-    host read-back of the coarse count -> (coarse int32 [n_coarse,4], parent_of int32 [n], down int32 [8,n_coarse]).
-    Canonical order: coarse rows in first-occurrence order of the quantised fine rows."""
+    """One strided pyramid level (MinkowskiConvolution k=2 s=2, coordinate side) in one library call, which reads the coarse
+    count back in the middle (the one host synchronisation of a level) and finishes into upper-bound buffers
+    -> (coarse int32 [n_coarse,4], parent_of int32 [n], down int32 [8,n_coarse]); coarse and down are views of buffers
+    sized for n rows.  Canonical order: coarse rows in first-occurrence order of the quantised fine rows."""
+    import ctypes
     fine = _i32(fine)
     n, dev = fine.shape[0], fine.device
     cap = int(lib().pcgc_hash_capacity(n))
@@ -240,16 +242,15 @@ def down_level(fine, stride_fine):
     keep = torch.empty(n, dtype=torch.uint8, device=dev)
     ws_bytes = int(lib().pcgc_scan_workspace_bytes(n))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    s = _stream(fine)
-    check(lib().pcgc_down_prepare(_p(fine), n, int(stride_fine), _p(q), _p(keys), _p(vals), cap, _p(keep), _p(first_row), _p(prefix),
-                                  _p(total), _p(ws), ws_bytes, s), 'down_prepare')
-    n_coarse = int(total.item())                               # host sync: sizes the coarse level
-    coarse = torch.empty((n_coarse, 4), dtype=torch.int32, device=dev)
+    coarse_ub = torch.empty((n, 4), dtype=torch.int32, device=dev)
     parent_of = torch.empty(n, dtype=torch.int32, device=dev)
-    down = torch.empty((8, n_coarse), dtype=torch.int32, device=dev)
-    check(lib().pcgc_down_finish(_p(fine), _p(q), _p(keep), _p(first_row), _p(prefix), n, int(stride_fine), n_coarse, _p(coarse),
-                                 _p(parent_of), _p(down), s), 'down_finish')
-    return coarse, parent_of, down
+    down_ub = torch.empty(8 * n, dtype=torch.int32, device=dev)
+    n_coarse = ctypes.c_int64(0)
+    check(lib().pcgc_down_level(_p(fine), n, int(stride_fine), _p(q), _p(keys), _p(vals), cap, _p(keep), _p(first_row), _p(prefix),
+                                _p(total), _p(ws), ws_bytes, _p(coarse_ub), _p(parent_of), _p(down_ub), ctypes.byref(n_coarse),
+                                _stream(fine)), 'down_level')
+    nc = int(n_coarse.value)
+    return coarse_ub[:nc], parent_of, down_ub[:8 * nc].view(8, nc)
 
 
 def compact_index(mask, prefix, n_out):
