@@ -1591,8 +1591,10 @@ __global__ void __launch_bounds__(256)
 k_conv_up2_mfma(int64_t n_in, const float* __restrict__ in, int in_ld, const float* __restrict__ W,
                 const float* __restrict__ bias, int relu, float* __restrict__ out) {
     constexpr int NB = CIN / 16, NT = COUT / 16;
+    __shared__ __attribute__((aligned(16))) float stage_all[4][2 * 16 * (COUT + 4)];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    float* stage = stage_all[wave];
     const int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * MT);
     if (p0 >= n_in) return;
     const int mi = lane & 15, mq = lane >> 4;
@@ -1630,22 +1632,35 @@ k_conv_up2_mfma(int64_t n_in, const float* __restrict__ in, int in_ld, const flo
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j][n], acc[m][n], 0, 0, 0);
                     }
         }
+        // Epilogue through a per-wave LDS scratch, two k at a time: from the MFMA layout (lane = column, 4 rows per lane) a row
+        // would reach memory as 4-byte pieces; staged, the 2 * COUT floats of (parent, k, k + 1) are contiguous in memory and
+        // leave as 16-byte-per-lane stores (rows padded by 4 floats in LDS: the four lane quarters write four different bank groups).
+        static_assert(MT == 1, "the staged epilogue covers one M tile per wave");
+        constexpr int LDW = COUT + 4, F4 = COUT / 4;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t p = p0 + 16 * m + 4 * mq + r;
-                if (p >= n_in) continue;
-                float* y = out + (8 * p + k) * COUT;
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int col = 16 * n + mi;
-                    float v = acc[m][n][r];
-                    if (bias) v = v + bias[col];
-                    if (relu) v = fmaxf(v, 0.0f);
-                    y[col] = v;
-                }
+            for (int n = 0; n < NT; ++n) {
+                const int col = 16 * n + mi;
+                float v = acc[0][n][r];
+                if (bias) v = v + bias[col];
+                if (relu) v = fmaxf(v, 0.0f);
+                stage[((k & 1) * 16 + 4 * mq + r) * LDW + col] = v;
             }
+        if (k & 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < (16 * 2 * F4) / 64; ++it) {
+                const int f = lane + 64 * it, pr = f / (2 * F4), rem = f % (2 * F4), kk = rem / F4, c4 = rem % F4;
+                const float4 v = *(const float4*)(stage + (kk * 16 + pr) * LDW + 4 * c4);
+                if (p0 + pr < n_in) *(float4*)(out + (8 * (p0 + pr) + (k - 1) + kk) * COUT + 4 * c4) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
     }
 }
 template <int CIN, int COUT>
