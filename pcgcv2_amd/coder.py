@@ -136,7 +136,10 @@ class Coder():
         # Side stream: the (z, y, x, batch) order of sort_spare_tensor, the sorted stride-8 coordinates and their copy into pinned
         # memory (N8 x 16 B).  None of it is needed before the latent exists, so the dozen small sort launches run beside the
         # encoder's convolutions instead of in front of them; the helper thread waits for the copy and runs the host coordinate coder.
-        order, y_C, sorted_ev, arrived, host_C = self._sort_and_stage(lvl8.C)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(x.device))       # the pyramid is complete after this
+        x.cmap.k3                                               # the encoder's kernel maps, coarse to fine: enqueued first, so the GPU has
+        order, y_C, sorted_ev, arrived, host_C = self._sort_and_stage(lvl8.C, ready)     # work while the host sets up the side stream
         coded = _POOL.submit(self._encode_geometry, arrived, host_C, lvl8.stride, postfix)
         y_list = self.model.encoder(x)                          # ~40 kernel launches, enqueued while the octree is coded
         main = torch.cuda.current_stream(x.device)
@@ -150,9 +153,10 @@ class Coder():
         coded.result()                                          # (re-raises a coordinate-coder failure)
         return y
 
-    def _sort_and_stage(self, C):
-        """On a side stream: canonical order of the rows of C, the sorted coordinates, and their asynchronous copy into pinned host
-        memory -> (order, sorted C, event after the sort, event after the copy, pinned host view)."""
+    def _sort_and_stage(self, C, ready):
+        """On a side stream, once `ready` (C is complete) has fired: canonical order of the rows of C, the sorted coordinates, and
+        their asynchronous copy into pinned host memory -> (order, sorted C, event after the sort, event after the copy, pinned
+        host view)."""
         dev = C.device
         if getattr(self, '_side', None) is None or self._side.device != dev:
             self._side = torch.cuda.Stream(device=dev)
@@ -160,8 +164,6 @@ class Coder():
         if self._pinned is None or self._pinned.numel() < C.numel() or self._pinned.dtype != C.dtype:
             self._pinned = torch.empty(max(C.numel(), 1 << 16), dtype=C.dtype, pin_memory=True)
         host = self._pinned[:C.numel()].view(C.shape)
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(dev))             # on C's device's current stream: C is complete after this
         with torch.cuda.stream(self._side):
             self._side.wait_event(ready)
             order = ops.sort_zyx(C)
@@ -208,10 +210,10 @@ class Coder():
         # this thread waits for the table instead of competing for the interpreter lock.
         stream = torch.cuda.current_stream(dev)
         pending = []
+        n4, n2, n1 = _COUNTS.unpack(_slurp(self.filename + postfix + '_num_points.bin')[:_COUNTS.size])
         y_F = self.feature_coder.decode(postfix=postfix, device=dev,
                                         on_table_launched=lambda: pending.append(_POOL.submit(self._decode_geometry, postfix, dev, stream)))
         y = SparseTensor(features=y_F, coordinate_map=pending[0].result())
-        n4, n2, n1 = _COUNTS.unpack(_slurp(self.filename + postfix + '_num_points.bin')[:_COUNTS.size])
         budgets = [[n4], [n2], [int(rho * n1)]]                  # coder.py:105-108
         _, out = self.model.decoder(y, nums_list=budgets, ground_truth_list=[None] * 3, training=False)
         return out

@@ -235,16 +235,19 @@ def down_level(fine, stride_fine):
     fine = _i32(fine)
     n, dev = fine.shape[0], fine.device
     cap = int(lib().pcgc_hash_capacity(n))
-    q = torch.empty_like(fine)
-    keys = torch.empty(cap, dtype=torch.int64, device=dev)
-    i32buf = torch.empty(cap + 2 * n + 1, dtype=torch.int32, device=dev)          # vals | first_row | prefix | total
-    vals, first_row, prefix, total = i32buf[:cap], i32buf[cap:cap + n], i32buf[cap + n:cap + 2 * n], i32buf[cap + 2 * n:]
-    keep = torch.empty(n, dtype=torch.uint8, device=dev)
     ws_bytes = int(lib().pcgc_scan_workspace_bytes(n))
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    coarse_ub = torch.empty((n, 4), dtype=torch.int32, device=dev)
-    parent_of = torch.empty(n, dtype=torch.int32, device=dev)
-    down_ub = torch.empty(8 * n, dtype=torch.int32, device=dev)
+    # two allocations per level (scratch, outputs) instead of eleven: this runs between two device synchronisations, where every
+    # microsecond of interpreter time is GPU idle time
+    a8 = lambda v: (v + 7) & ~7
+    off, sizes = 0, []
+    for nbytes in (16 * n, 8 * cap, 4 * cap, 4 * n, 4 * n, 8, n, ws_bytes):        # q | keys | vals | first_row | prefix | total | keep | scan ws
+        sizes.append((off, nbytes)); off += a8(nbytes)
+    scratch = torch.empty(off, dtype=torch.uint8, device=dev)
+    part = lambda i, dt: scratch[sizes[i][0]:sizes[i][0] + sizes[i][1]].view(dt)
+    q, keys, vals, first_row, prefix, total, keep, ws = (part(0, torch.int32), part(1, torch.int64), part(2, torch.int32), part(3, torch.int32),
+                                                       part(4, torch.int32), part(5, torch.int32), part(6, torch.uint8), part(7, torch.uint8))
+    outbuf = torch.empty(13 * n, dtype=torch.int32, device=dev)                     # coarse [n,4] | parent_of [n] | down [8n]
+    coarse_ub, parent_of, down_ub = outbuf[:4 * n].view(n, 4), outbuf[4 * n:5 * n], outbuf[5 * n:]
     n_coarse = ctypes.c_int64(0)
     check(lib().pcgc_down_level(_p(fine), n, int(stride_fine), _p(q), _p(keys), _p(vals), cap, _p(keep), _p(first_row), _p(prefix),
                                 _p(total), _p(ws), ws_bytes, _p(coarse_ub), _p(parent_of), _p(down_ub), ctypes.byref(n_coarse),
