@@ -231,6 +231,17 @@ int pcgc_compress_prepare(const float* feats, int64_t count, const float* params
 int64_t pcgc_rc_encode(const uint16_t* cdf /*[host C,Lp]*/, int C, int Lp, const int16_t* sym /*[host n]*/, int64_t n,
                        uint8_t* out /*[host cap]*/, int64_t cap);          /* returns bytes, or -needed if cap too small */
 int pcgc_rc_decode(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int64_t nbytes, int16_t* sym, int64_t n);
+/* The same stream plus a decoding index.  A range-coded stream is sequential, but only because the decoder state at a later symbol is
+ * unknown: pcgc_rc_encode_indexed also returns that state — (first symbol, bit position, low, span - 1, value - low), PCGC_RC_CKPT_WORDS
+ * uint32 each — at n_ckpt evenly spread row boundaries, and pcgc_rc_decode_indexed decodes the segments in between on several threads
+ * (pcgc_set_rc_threads; 0 = min(8, hardware threads)).  `_F.bin` is bit-identical with or without the index and decodes without it
+ * (pcgc_rc_decode, torchac); the host side stores the index in a sidecar file next to it (`_F.idx`, coder.py). */
+#define PCGC_RC_CKPT_WORDS 6
+int64_t pcgc_rc_encode_indexed(const uint16_t* cdf, int C, int Lp, const int16_t* sym, int64_t n, uint8_t* out, int64_t cap, int n_ckpt,
+                               uint32_t* ckpt /*[host n_ckpt][PCGC_RC_CKPT_WORDS]; unused entries have first symbol 0xFFFFFFFF*/);
+int pcgc_rc_decode_indexed(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int64_t nbytes, int16_t* sym, int64_t n, int n_ckpt,
+                           const uint32_t* ckpt);
+int pcgc_set_rc_threads(int threads);
 /* decoder selection for A/B tests: 0 automatic (AVX-512 boundary count when the host CPU has it and Lp <= 64, else the
  * portable scalar search), 1 portable scalar.  Both are bit-identical. */
 int pcgc_set_rc_impl(int impl);
@@ -240,6 +251,10 @@ int pcgc_set_rc_impl(int impl);
 int64_t pcgc_oct_encode(const int32_t* xyz /*[host n,3]*/, int64_t n, uint8_t* out, int64_t cap);   /* bytes or -needed */
 int64_t pcgc_oct_decode_count(const uint8_t* in, int64_t nbytes);                                   /* points or <0 */
 int pcgc_oct_decode(const uint8_t* in, int64_t nbytes, int32_t* xyz /*[host n,3]*/, int64_t n);
+/* clouds of >= 8192 points are coded as up to 8 independent groups of subtrees (stream version 3), encoded and decoded side by side on
+ * the threads of pcgc_set_rc_threads; 0 = always the single-stream form (version 2); n > 1 = that many groups (A/B tests).  The
+ * decoder reads both versions. */
+int pcgc_set_oct_tiled(int on);
 
 /* ---- D1 point-to-point distortion (pc_error.py:27-74 -> mpeg-pcc-dmetric ‡): sum and max over A of the squared distance to
  *      the nearest point of B, B given by its coordinate hash (stride 1).  offsets: int32 [n,4] = (dx,dy,dz,d2) sorted by d2. ---- */

@@ -30,4 +30,7 @@ def configure_host_threads(max_threads=4):
     """The host side of the codec is a single-threaded launcher + sequential entropy coder; keep torch's CPU thread pool
     small so its workers do not spin away the container's CPU quota."""
     import torch
-    torch.set_num_threads(max(1, min(max_threads, effective_cpus())))
+    cpus = effective_cpus()
+    torch.set_num_threads(max(1, min(max_threads, cpus)))
+    from . import ops
+    ops.set_rc_threads(max(1, min(8, cpus - 2)))                 # segments of an indexed `_F.bin` decoded side by side

@@ -162,8 +162,9 @@ class EntropyBottleneck(nn.Module):
         return self.cdf_table(min_v, max_v, device)[0].cpu().numpy().view(np.uint16)
 
     @torch.no_grad()
-    def compress(self, inputs):
-        """entropy_model.py:151-176 -> (bytes, min_v ndarray[1], max_v ndarray[1])."""
+    def compress(self, inputs, checkpoints=0):
+        """entropy_model.py:151-176 -> (bytes, min_v ndarray[1], max_v ndarray[1]); with checkpoints > 0 a fourth element: the
+        decoding index of ops.rc_encode (decoder states at that many row boundaries; the bytes are the same either way)."""
         if inputs.dim() != 2 or inputs.shape[1] != self._channels:
             raise PcgcError(f'compress expects [N, {self._channels}] features')
         if self.table_mode == 'device':
@@ -180,13 +181,17 @@ class EntropyBottleneck(nn.Module):
             # (reference arithmetic) where the range coder consumes it
             min_v, max_v, sym_h = ops.quantize_symbols(inputs)
             table_h = self.host_table(min_v, max_v, inputs.device)
+        if checkpoints > 0:
+            strings, index = ops.rc_encode(table_h, sym_h, checkpoints=checkpoints)
+            return strings, np.array([min_v], np.float32), np.array([max_v], np.float32), index
         strings = ops.rc_encode(table_h, sym_h)
         return strings, np.array([min_v], np.float32), np.array([max_v], np.float32)
 
     @torch.no_grad()
-    def decompress(self, strings, min_v, max_v, shape, channels, device=None, on_table_launched=None):
+    def decompress(self, strings, min_v, max_v, shape, channels, device=None, on_table_launched=None, index=None):
         """entropy_model.py:178-196 -> fp32 [shape[0], channels] on `device`.  `on_table_launched` (optional) is called
-        before this thread starts on the table: the place to start concurrent host work."""
+        before this thread starts on the table: the place to start concurrent host work.  `index` (optional): the decoding
+        index compress(..., checkpoints=k) returned for these bytes -> the segments are decoded in parallel."""
         device = torch.device('cuda') if device is None else device
         min_v, max_v = np.float32(np.asarray(min_v).reshape(-1)[0]), np.float32(np.asarray(max_v).reshape(-1)[0])
         if self.table_mode == 'device':
@@ -199,6 +204,6 @@ class EntropyBottleneck(nn.Module):
                 on_table_launched()
             table_h = self.host_table(min_v, max_v, device)
         n = int(shape[0]) * int(channels)
-        sym_h = ops.rc_decode(table_h, strings, n)
+        sym_h = ops.rc_decode(table_h, strings, n, index=index)
         sym = torch.from_numpy(sym_h.reshape(int(shape[0]), int(channels))).to(device)
         return ops.desymbolize(sym, min_v)

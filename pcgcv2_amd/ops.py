@@ -983,28 +983,55 @@ def set_rc_impl(impl):
     check(lib().pcgc_set_rc_impl(int(impl)), 'set_rc_impl')
 
 
-def rc_encode(cdf_u16, sym):
+RC_CKPT_WORDS = 6            # include/pcgc_hip.h PCGC_RC_CKPT_WORDS
+
+
+def set_rc_threads(threads):
+    """Threads of the indexed range decoder (0 = min(8, hardware threads))."""
+    check(lib().pcgc_set_rc_threads(int(threads)), 'set_rc_threads')
+
+
+def rc_encode(cdf_u16, sym, checkpoints=0):
+    """-> stream bytes, or (stream bytes, index uint32 [checkpoints, RC_CKPT_WORDS]) when checkpoints > 0: the decoder state at
+    evenly spread row boundaries, for rc_decode(index=...).  The stream is the same either way."""
     cdf = _np(cdf_u16, np.uint16)
     sym = _np(sym, np.int16).ravel()
     C, Lp = cdf.shape
     cap = sym.size * 2 + 64
+    index = np.zeros((int(checkpoints), RC_CKPT_WORDS), np.uint32) if checkpoints > 0 else None
     while True:
         buf = np.empty(cap, np.uint8)
-        n = int(lib().pcgc_rc_encode(cdf.ctypes.data, C, Lp, sym.ctypes.data, sym.size, buf.ctypes.data, cap))
+        if index is None:
+            n = int(lib().pcgc_rc_encode(cdf.ctypes.data, C, Lp, sym.ctypes.data, sym.size, buf.ctypes.data, cap))
+        else:
+            n = int(lib().pcgc_rc_encode_indexed(cdf.ctypes.data, C, Lp, sym.ctypes.data, sym.size, buf.ctypes.data, cap,
+                                                 index.shape[0], index.ctypes.data))
         if n >= 0:
-            return buf[:n].tobytes()
+            return buf[:n].tobytes() if index is None else (buf[:n].tobytes(), index)
         if n == -(2 ** 63):
             raise PcgcError('rc_encode: symbol outside the CDF table')
         cap = -n
 
 
-def rc_decode(cdf_u16, data, n):
+def rc_decode(cdf_u16, data, n, index=None):
+    """`index` (optional): the checkpoints rc_encode(..., checkpoints=k) returned for this stream -> segments decoded in parallel."""
     cdf = _np(cdf_u16, np.uint16)
     C, Lp = cdf.shape
     src = np.frombuffer(data, np.uint8)
     out = np.empty(n, np.int16)
-    check(lib().pcgc_rc_decode(cdf.ctypes.data, C, Lp, src.ctypes.data, src.size, out.ctypes.data, n), 'rc_decode')
+    if index is None:
+        check(lib().pcgc_rc_decode(cdf.ctypes.data, C, Lp, src.ctypes.data, src.size, out.ctypes.data, n), 'rc_decode')
+    else:
+        idx = np.ascontiguousarray(index, dtype=np.uint32).reshape(-1, RC_CKPT_WORDS)
+        check(lib().pcgc_rc_decode_indexed(cdf.ctypes.data, C, Lp, src.ctypes.data, src.size, out.ctypes.data, n, idx.shape[0],
+                                           idx.ctypes.data), 'rc_decode_indexed')
     return out
+
+
+def set_oct_tiled(on):
+    """Coordinate codec: groups of subtrees coded independently (1, the default for clouds of >= 8192 points; n > 1: that many
+    groups) or always one stream (0).  A/B tests."""
+    check(lib().pcgc_set_oct_tiled(int(on)), 'set_oct_tiled')
 
 
 def oct_encode(xyz):

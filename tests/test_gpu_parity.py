@@ -450,6 +450,25 @@ def test_full_size_frame_properties(sd, tmp_path):
     # the entropy-coded latent round-trips exactly
     yF = coder.feature_coder.decode(device=DEV)
     np.testing.assert_array_equal(yF.cpu().numpy(), np.rint(y.F.cpu().numpy()) + np.float32(0))
+    # the decoding index (`_F.idx`) is an accelerator only: the same voxels without it (serial decode, as for a reference-made
+    # stream), with a sidecar of another stream (ignored), and `_F.bin` is the same when no index is written at all
+    from pcgcv2_amd import coder as coder_mod
+    idx = tmp_path / 'full_F.idx'
+    assert idx.exists() and coder_mod.index_bits(str(tmp_path / 'full')) == 8 * (16 + 8 * 4 * ops.RC_CKPT_WORDS)
+    blob = idx.read_bytes()
+    idx.unlink()
+    np.testing.assert_array_equal(coder.decode().C.cpu().numpy(), oc)
+    idx.write_bytes(blob[:12] + bytes([blob[12] ^ 1]) + blob[13:])            # CRC of a different stream
+    np.testing.assert_array_equal(coder.decode().C.cpu().numpy(), oc)
+    coder_mod.INDEX_SEGMENTS = 0
+    try:
+        coder3 = Coder(m, str(tmp_path / 'plain'))
+        coder3.encode(x)
+        assert not (tmp_path / 'plain_F.idx').exists()
+        assert (tmp_path / 'plain_F.bin').read_bytes() == files['F']
+        np.testing.assert_array_equal(coder3.decode().C.cpu().numpy(), oc)
+    finally:
+        coder_mod.INDEX_SEGMENTS = 8
 
 
 @pytest.mark.parametrize('in_flight', [2, 4])

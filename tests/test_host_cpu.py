@@ -91,9 +91,58 @@ def test_range_coder_adversarial_tables(shape, rc_impl):
             assert a == orc.rc_encode(table, sym)
             np.testing.assert_array_equal(orc.rc_decode(table, a, sym.size), sym.ravel())
         np.testing.assert_array_equal(ops.rc_decode(table, a, sym.size), sym.ravel())
+        # decoding index: same stream; segments decoded from the recorded decoder states give the same symbols (E3 tails, p = 1/2
+        # chains and no-shift symbols all cross segment boundaries in these tables)
+        for k in (1, 3, 8):
+            a2, index = ops.rc_encode(table, sym, checkpoints=k)
+            assert a2 == a
+            for threads in (1, 3):
+                ops.set_rc_threads(threads)
+                np.testing.assert_array_equal(ops.rc_decode(table, a, sym.size, index=index), sym.ravel())
+            ops.set_rc_threads(0)
     # a truncated / corrupt stream must not crash either decoder
     ops.rc_decode(table, a[:len(a) // 2], sym.size)
     ops.rc_decode(table, bytes(rng.integers(0, 256, 64, dtype=np.uint8)), 4096)
+    with pytest.raises(PcgcError):                                   # (its index points beyond the truncated stream: refused)
+        ops.rc_decode(table, a[:len(a) // 2], sym.size, index=index)
+
+
+def test_range_decoder_rejects_malformed_index():
+    rng = np.random.default_rng(5)
+    table = _table_from_pmf(np.tile(np.exp(-0.5 * ((np.arange(21) - 10) / 2.0) ** 2), (8, 1)))
+    sym = np.clip(np.rint(rng.normal(10, 2, (4000, 8))), 0, 20).astype(np.int16)
+    a, index = ops.rc_encode(table, sym, checkpoints=4)
+    np.testing.assert_array_equal(ops.rc_decode(table, a, sym.size, index=index), sym.ravel())
+    for breakage in ('order', 'range', 'phase', 'start', 'bitpos'):
+        bad = index.copy()
+        if breakage == 'order':
+            bad[[1, 2]] = bad[[2, 1]]
+        elif breakage == 'range':
+            bad[3, 0] = sym.size + 8
+        elif breakage == 'phase':
+            bad[2, 0] += 1                                   # not a row boundary
+        elif breakage == 'start':
+            bad[0, 3] = 7                                    # the first segment must start from the initial coder state
+        else:
+            bad[1, 1] = 8 * len(a) + 1000                    # bit position beyond the stream
+        with pytest.raises(PcgcError):
+            ops.rc_decode(table, a, sym.size, index=bad)
+
+
+def test_feature_index_sidecar_is_tied_to_its_stream(tmp_path):
+    """coder._pack_index / _load_index: the sidecar is used only for the stream it was written with."""
+    from pcgcv2_amd import coder
+    index = np.arange(2 * ops.RC_CKPT_WORDS, dtype=np.uint32).reshape(2, -1)
+    path = str(tmp_path / 'x_F.idx')
+    with open(path, 'wb') as fh:
+        fh.write(coder._pack_index(b'stream-bytes', index))
+    np.testing.assert_array_equal(coder._load_index(path, b'stream-bytes'), index)
+    assert coder._load_index(path, b'stream-bytez') is None          # same length, other content
+    assert coder._load_index(path, b'stream-bytes+') is None
+    assert coder._load_index(str(tmp_path / 'missing.idx'), b'stream-bytes') is None
+    with open(path, 'wb') as fh:
+        fh.write(b'PCGI')                                             # truncated
+    assert coder._load_index(path, b'stream-bytes') is None
 
 
 def test_range_coder_rejects_out_of_table_symbol():
@@ -127,6 +176,32 @@ def test_octree_codec_roundtrip(case):
     if case == 'shell':
         bits_per_point = 8 * len(data) / len(pts)
         assert bits_per_point < 2.1, bits_per_point              # neighbour-context model: 1.88 bit/pt here, 1.47 on the vox10 frame
+
+
+@pytest.mark.parametrize('groups', [0, 1, 3, 12])
+def test_octree_codec_groups_of_subtrees(groups):
+    """Stream version 3 (independent groups of subtrees, coded and decoded side by side) against version 2 on the stride-8 level
+    of the vox10 bench frame: same voxels, in the same (Morton) order, for every group count and thread count."""
+    pts = np.unique(synthetic.shell('shell10').numpy() // 8, axis=0).astype(np.int32)              # 18 732 voxels
+    ops.set_oct_tiled(0)
+    plain = ops.oct_encode(pts)
+    try:
+        ops.set_oct_tiled(groups)
+        data = ops.oct_encode(pts)
+        assert data[4] == (2 if groups == 0 else 3)
+        for threads in (1, 4):
+            ops.set_rc_threads(threads)
+            np.testing.assert_array_equal(ops.oct_decode(data), ops.oct_decode(plain))
+        assert 8 * len(data) / len(pts) < (1.5 if groups == 0 else 2.0)
+        if groups:                                                 # damage in one group is detected, not decoded into garbage silently
+            bad = bytearray(data); bad[len(bad) // 2] ^= 0x55; bad[len(bad) // 2 + 1] ^= 0xAA
+            try:
+                back = ops.oct_decode(bytes(bad))
+                assert len(back) == len(pts)
+            except PcgcError:
+                pass
+    finally:
+        ops.set_oct_tiled(1); ops.set_oct_tiled(8); ops.set_rc_threads(0)
 
 
 def test_octree_rejects_foreign_stream():
