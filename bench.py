@@ -200,10 +200,12 @@ def main():
     gc.freeze()
     n_out = sum(len(o) for o in outs)
     n_coded = n_points * (len(rate_sds) if rate_sds is not None else 1)        # points through encode+decode per step
-    bits = 0
+    bits = index_bits = 0
     for f in os.listdir(tmp):
         if f.endswith(STREAMS):
             bits += os.path.getsize(os.path.join(tmp, f)) * 8
+        elif f.endswith('_F.idx'):                              # decoding index of `_F.bin` (not one of the reference's four files)
+            index_bits += os.path.getsize(os.path.join(tmp, f)) * 8
 
     # ---- timed region: exactly K steps, with the dominant kernel bracketed by HIP events on its own stream ----
     ops.PROFILE.reset(enabled=dominant is not None, only=dominant)
@@ -313,6 +315,10 @@ def main():
                        'enc_ms': round(enc_t / args.steps * 1e3, 3), 'dec_ms': round(dec_t / args.steps * 1e3, 3),
                        'enc_plus_dec_s_per_step': round((enc_t + dec_t) / args.steps, 4),
                        'bpp': round(total_bits / max(total_coded, 1), 5), 'points_out': int(total_out),
+                       'bpp_incl_decoding_index_rank0': round((bits + index_bits) / max(n_coded, 1), 5),
+                       'entropy_decode': '`_F.bin` (bit-identical to the reference-format stream, decodable without it) comes with a sidecar '
+                                         '`_F.idx` of decoder states at 8 row boundaries: its segments are decoded on 8 threads; `_C.bin` '
+                                         '(native octree, tmc3 absent) is coded as up to 8 independent groups of subtrees',
                        'coord_codec': 'native-octree (tmc3 absent)', 'coord_coder_ms': coord_ms, 'serving_throughput': serving,
                        'step_ms_rank0': step_ms,
                        'd1_psnr_rank0_db': None if d1 is None else round(d1['mseF,PSNR (p2point)'], 4),
