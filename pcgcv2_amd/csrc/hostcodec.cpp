@@ -262,8 +262,8 @@ namespace {
 class SegmentPool {
     std::vector<std::thread> workers; std::mutex m; std::condition_variable work, done;
     std::mutex serial;                                 // one run() at a time per pool
-    const std::function<void(int)>* job = nullptr; int n_tasks = 0; std::atomic<int> next{0}; int busy = 0; uint64_t gen = 0; bool stop = false;
-    void drain() { for (int i; (i = next.fetch_add(1)) < n_tasks;) (*job)(i); }
+    const std::function<void(int)>* job = nullptr; int n_tasks = 0; std::atomic<int> next{0}; int active = 0; uint64_t gen = 0; bool stop = false;
+    static void drain(const std::function<void(int)>& fn, std::atomic<int>& next, int n) { for (int i; (i = next.fetch_add(1)) < n;) fn(i); }
     void loop() {
         uint64_t seen = 0;
         for (;;) {
@@ -271,27 +271,30 @@ class SegmentPool {
             work.wait(lk, [&] { return stop || gen != seen; });
             if (stop) return;
             seen = gen;
+            const std::function<void(int)>* fn = job;  // null once run() has finished: a worker that wakes late has nothing to do,
+            if (!fn) continue;                         // and run() does not wait for it
+            const int n = n_tasks;
+            ++active;
             lk.unlock();
-            drain();
+            drain(*fn, next, n);
             lk.lock();
-            if (--busy == 0) done.notify_one();
+            if (--active == 0) done.notify_one();
         }
     }
 public:
     ~SegmentPool() { { std::lock_guard<std::mutex> lk(m); stop = true; } work.notify_all(); for (auto& t : workers) t.join(); }
-    int size() { std::lock_guard<std::mutex> lk(m); return (int)workers.size(); }
-    // run fn(0..tasks-1) on the calling thread plus up to `helpers` pool threads; one call at a time (callers are serialised)
+    // run fn(0..tasks-1) on the calling thread plus up to `helpers` pool threads
     void run(int tasks, int helpers, const std::function<void(int)>& fn) {
         std::lock_guard<std::mutex> one(serial);
         {
             std::lock_guard<std::mutex> lk(m);
             while ((int)workers.size() < helpers) workers.emplace_back([this] { loop(); });
-            job = &fn; n_tasks = tasks; next.store(0); busy = (int)workers.size(); ++gen;
+            job = &fn; n_tasks = tasks; next.store(0); ++gen;
         }
         work.notify_all();
-        drain();
+        drain(fn, next, tasks);                        // returns once every task has been taken
         std::unique_lock<std::mutex> lk(m);
-        done.wait(lk, [&] { return busy == 0; });
+        done.wait(lk, [&] { return active == 0; });    // ... and the ones taken by workers are finished
         job = nullptr;
     }
 };
