@@ -68,6 +68,9 @@ size_t pcgc_scan_workspace_bytes(int64_t n);
 /* prefix[i] = number of set mask bytes before i; *total = number set. */
 int pcgc_mask_scan(const uint8_t* mask /*[dev n]*/, int64_t n, int32_t* prefix /*[dev n]*/, int32_t* total /*[dev 1]*/,
                    void* workspace /*[dev]*/, size_t workspace_bytes, void* stream);
+/* the same for a workspace (and *total, if n may be 0) the caller has already zeroed: several scans behind one memset */
+int pcgc_mask_scan_zeroed(const uint8_t* mask, int64_t n, int32_t* prefix, int32_t* total, void* workspace, size_t workspace_bytes,
+                          void* stream);
 int pcgc_compact_coords(const int32_t* coords, const uint8_t* mask, const int32_t* prefix, int64_t n,
                         int32_t* out /*[dev total,4]*/, void* stream);
 int pcgc_compact_feats(const float* in, int C, int in_ld, const uint8_t* mask, const int32_t* prefix, int64_t n,
@@ -112,6 +115,14 @@ int pcgc_down_level(const int32_t* fine /*[dev n,4]*/, int64_t n, int32_t stride
                     int64_t cap, uint8_t* keep, int32_t* first_row, int32_t* prefix, int32_t* total, void* scan_ws,
                     size_t scan_ws_bytes, int32_t* coarse /*[dev n,4] capacity*/, int32_t* parent_of /*[dev n]*/,
                     int32_t* down /*[dev 8*n] capacity*/, int64_t* n_coarse_out /*host*/, void* stream);
+/* `levels` (1..4) successive levels at once, every one deduplicated straight from the input rows (the canonical order of a level —
+ * first occurrence in the level below — equals first occurrence in the input), so that the sizes of all levels come back in ONE
+ * synchronising copy.  Level l (0-based) has stride `stride << (l + 1)`; coarse[l] / down[l] are caller buffers of upper-bound size
+ * ([n,4] and 8*n int32), parent_of[l] has one entry per row of the level below it ([n] for l = 0, counts[l-1] after); counts[l] (host)
+ * = rows of level l.  scratch: pcgc_pyramid_scratch_bytes(n, levels) device bytes, 16-byte aligned. */
+size_t pcgc_pyramid_scratch_bytes(int64_t n, int levels);
+int pcgc_pyramid(const int32_t* fine /*[dev n,4]*/, int64_t n, int32_t stride, int levels, void* scratch, size_t scratch_bytes,
+                 int32_t* const* coarse, int32_t* const* parent_of, int32_t* const* down, int64_t* counts /*host*/, void* stream);
 /* orig[prefix[i]] = i for set mask bytes (row indices that survive a compaction) */
 int pcgc_compact_index(const uint8_t* mask, const int32_t* prefix, int64_t n, int32_t* orig /*[dev total]*/, void* stream);
 

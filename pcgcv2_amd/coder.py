@@ -176,9 +176,7 @@ class Coder():
             return self._encode(x, postfix)
 
     def _encode(self, x, postfix):
-        lvl8 = x.cmap
-        for _ in range(3):
-            lvl8 = lvl8.down()[0]                               # cached on the levels: the encoder reuses these maps
+        lvl8 = x.cmap.build_pyramid(3)                          # cached on the levels: the encoder reuses these maps
         # Side stream: the (z, y, x, batch) order of sort_spare_tensor, the sorted stride-8 coordinates and their copy into pinned
         # memory (N8 x 16 B).  None of it is needed before the latent exists, so the dozen small sort launches run beside the
         # encoder's convolutions instead of in front of them; the helper thread waits for the copy and runs the host coordinate coder.

@@ -397,6 +397,127 @@ extern "C" int pcgc_down_level(const int32_t* fine, int64_t n, int32_t stride_fi
     *n_coarse_out = n_coarse;
     return pcgc_down_finish(fine, q, keep, first_row, prefix, n, stride_fine, n_coarse, coarse, parent_of, down, stream);
 }
+// ---- the whole strided pyramid behind ONE read-back ------------------------------------------------------------------------------
+// Level l+1 in canonical order is "the distinct keys floor(c / 2^(l+1) s) of level l, by first occurrence in level-l order"; level l
+// is itself in first-occurrence order of the input, so level l+1 is equally "the distinct keys of the INPUT rows, by first occurrence
+// in input order".  Hence every level can be deduplicated straight from the input rows, all levels in the same launches, and the
+// sizes of all of them come back in one synchronising copy (the level-by-level form waits for the GPU once per level, with ~50 us
+// of idle device around each wait).  Costs two more passes over the n input rows than the nested form; wins ~0.15 ms per vox10 frame.
+constexpr int PYR_MAX = 4;
+struct PyrArgs {
+    uint64_t* keys[PYR_MAX]; int32_t* vals[PYR_MAX]; int32_t* first[PYR_MAX]; uint8_t* keep[PYR_MAX];
+    int32_t s[PYR_MAX]; uint64_t cap_mask; int levels;
+};
+__device__ static inline int4 pyr_quantise(int4 c, int32_t s) { return make_int4(c.x, c.y / s * s, c.z / s * s, c.w / s * s); }   // (coordinates are >= 0 here)
+__global__ void k_pyr_insert(const int4* __restrict__ fine, int64_t n, PyrArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int4 c = make_int4(-1, -1, -1, -1);
+    if (i < n) c = fine[i];
+    const bool ok = i < n && coord_in_range(c.x, c.y, c.z, c.w);
+#pragma unroll
+    for (int l = 0; l < PYR_MAX; ++l) {
+        if (l >= a.levels) break;
+        const int4 q = pyr_quantise(c, a.s[l]);
+        const uint64_t key = ok ? coord_key(q.x, q.y, q.z, q.w) : PCGC_EMPTY_KEY;
+        const uint64_t left = __shfl_up((unsigned long long)key, 1, 64);          // runs of equal keys in consecutive lanes: first lane inserts
+        if (!ok || ((threadIdx.x & 63) != 0 && left == key)) continue;
+        uint64_t* keys = a.keys[l]; int32_t* vals = a.vals[l];
+        uint64_t h = hash_slot(key, a.cap_mask);
+        for (;;) {
+            unsigned long long prev = __builtin_nontemporal_load((const unsigned long long*)&keys[h]);
+            if (prev == PCGC_EMPTY_KEY) prev = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)PCGC_EMPTY_KEY, (unsigned long long)key);
+            if (prev == PCGC_EMPTY_KEY || prev == key) { if (__builtin_nontemporal_load(&vals[h]) > (int32_t)i) atomicMin(&vals[h], (int32_t)i); break; }
+            h = (h + 1) & a.cap_mask;
+        }
+    }
+}
+__global__ void k_pyr_first(const int4* __restrict__ fine, int64_t n, PyrArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = fine[i];
+#pragma unroll
+    for (int l = 0; l < PYR_MAX; ++l) {
+        if (l >= a.levels) break;
+        const int4 q = pyr_quantise(c, a.s[l]);
+        const int32_t f = hash_lookup(a.keys[l], a.vals[l], a.cap_mask, q.x, q.y, q.z, q.w);
+        a.first[l][i] = f;
+        a.keep[l][i] = f == (int32_t)i;
+    }
+}
+// After the read-back: for every level at once, the compacted coarse coordinates, and for the level below each (rows = the input rows kept
+// by the previous level's mask, all of them for the first) parent_of and the 8-slot down map (pre-filled with -1).
+struct PyrOut { int4* coarse[PYR_MAX]; int32_t* parent_of[PYR_MAX]; int32_t* down[PYR_MAX]; const int32_t* prefix[PYR_MAX]; int64_t count[PYR_MAX]; int32_t stride; };
+__global__ void k_pyr_finish(const int4* __restrict__ fine, int64_t n, PyrArgs a, PyrOut o) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = fine[i];
+    bool kept_below = true; int32_t j = (int32_t)i;                 // row i of the input is row j of the level below coarse level l
+#pragma unroll
+    for (int l = 0; l < PYR_MAX; ++l) {
+        if (l >= a.levels || !kept_below) break;
+        const int32_t s_cur = o.stride << l;
+        const int k = ((c.y / s_cur) & 1) | (((c.z / s_cur) & 1) << 1) | (((c.w / s_cur) & 1) << 2);
+        const int32_t p = o.prefix[l][a.first[l][i]];
+        o.parent_of[l][j] = p;
+        o.down[l][(int64_t)k * o.count[l] + p] = j;
+        kept_below = a.keep[l][i] != 0;
+        if (kept_below) { o.coarse[l][p] = pyr_quantise(c, a.s[l]); j = p; }
+    }
+}
+extern "C" size_t pcgc_pyramid_scratch_bytes(int64_t n, int levels) {
+    const size_t cap = (size_t)pcgc_hash_capacity(n), scan = (pcgc_scan_workspace_bytes(n) + 15) & ~(size_t)15, nn = ((size_t)n + 15) & ~(size_t)15;
+    return 64 + (size_t)levels * (scan + cap * 12 + nn * 4 * 2 + nn) + 64;
+}
+extern "C" int pcgc_pyramid(const int32_t* fine, int64_t n, int32_t stride, int levels, void* scratch, size_t scratch_bytes,
+                            int32_t* const* coarse, int32_t* const* parent_of, int32_t* const* down, int64_t* counts, void* stream) {
+    PCGC_REQUIRE(levels >= 1 && levels <= PYR_MAX, "1 to 4 levels");
+    PCGC_REQUIRE(fine && scratch && coarse && parent_of && down && counts, "null argument");
+    PCGC_REQUIRE(scratch_bytes >= pcgc_pyramid_scratch_bytes(n, levels) && ((uintptr_t)scratch & 15) == 0, "scratch too small or misaligned");
+    PCGC_REQUIRE(stride >= 1 && (int64_t)stride << levels < ((int64_t)1 << 30), "bad stride");
+    if (n == 0) { for (int l = 0; l < levels; ++l) counts[l] = 0; return 0; }
+    hipStream_t s = S(stream);
+    const size_t cap = (size_t)pcgc_hash_capacity(n), scan = (pcgc_scan_workspace_bytes(n) + 15) & ~(size_t)15, nn = ((size_t)n + 15) & ~(size_t)15;
+    PyrArgs a; a.levels = levels; a.cap_mask = (uint64_t)cap - 1;
+    int32_t* prefix[PYR_MAX]; void* scan_ws[PYR_MAX];
+    // scratch: totals[4] (64 B) | scan workspaces (zeroed together with the totals by ONE memset) | per level keys, vals, first, prefix, keep
+    char* p = (char*)scratch;
+    int32_t* totals = (int32_t*)p; p += 64;
+    for (int l = 0; l < levels; ++l) { scan_ws[l] = p; p += scan; }
+    const size_t zero_bytes = (size_t)(p - (char*)scratch);
+    uint64_t* keys0 = (uint64_t*)p;                                  // all levels' keys are contiguous, then all vals: one clear
+    for (int l = 0; l < levels; ++l) { a.keys[l] = (uint64_t*)p; p += cap * 8; }
+    int32_t* vals0 = (int32_t*)p;
+    for (int l = 0; l < levels; ++l) { a.vals[l] = (int32_t*)p; p += cap * 4; }
+    for (int l = 0; l < levels; ++l) {
+        a.first[l] = (int32_t*)p; p += nn * 4;
+        prefix[l] = (int32_t*)p; p += nn * 4;
+        a.keep[l] = (uint8_t*)p; p += nn;
+        a.s[l] = stride << (l + 1);
+    }
+    int rc;
+    hipError_t e = hipMemsetAsync(scratch, 0, zero_bytes, s);
+    if (e != hipSuccess) { pcgc_set_error("pyramid: %s", hipGetErrorString(e)); return -1; }
+    hipLaunchKernelGGL(k_hash_clear, dim3(grid_for((int64_t)cap * levels, 256)), dim3(256), 0, s, keys0, vals0, (int64_t)cap * levels);
+    const dim3 g(grid_for(n, 256)), b(256);
+    hipLaunchKernelGGL(k_pyr_insert, g, b, 0, s, (const int4*)fine, n, a);
+    hipLaunchKernelGGL(k_pyr_first, g, b, 0, s, (const int4*)fine, n, a);
+    for (int l = 0; l < levels; ++l)
+        if ((rc = pcgc_mask_scan_zeroed(a.keep[l], n, prefix[l], totals + l, scan_ws[l], pcgc_scan_workspace_bytes(n), stream))) return rc;
+    static thread_local int32_t* host_total = nullptr;
+    if (!host_total && hipHostMalloc((void**)&host_total, 64, hipHostMallocDefault) != hipSuccess) { host_total = nullptr; pcgc_set_error("pyramid: cannot allocate pinned memory"); return -1; }
+    e = hipMemcpyAsync(host_total, totals, (size_t)levels * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { pcgc_set_error("pyramid: %s", hipGetErrorString(e)); return -1; }
+    PyrOut o; o.stride = stride;
+    for (int l = 0; l < levels; ++l) {
+        counts[l] = host_total[l];
+        o.coarse[l] = (int4*)coarse[l]; o.parent_of[l] = parent_of[l]; o.down[l] = down[l]; o.prefix[l] = prefix[l]; o.count[l] = counts[l];
+        if (counts[l] > 0 && (e = hipMemsetAsync(down[l], 0xFF, (size_t)counts[l] * 8 * sizeof(int32_t), s)) != hipSuccess) { pcgc_set_error("pyramid: %s", hipGetErrorString(e)); return -1; }
+    }
+    hipLaunchKernelGGL(k_pyr_finish, g, b, 0, s, (const int4*)fine, n, a, o);
+    PCGC_CHECK_LAUNCH("pyramid");
+    return 0;
+}
 extern "C" int pcgc_compact_index(const uint8_t* mask, const int32_t* prefix, int64_t n, int32_t* orig, void* stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_compact_index, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), mask, prefix, n, orig);

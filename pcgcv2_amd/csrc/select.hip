@@ -99,6 +99,16 @@ static void launch_scan(const uint8_t* mask, int64_t n, int32_t* prefix, int32_t
     unsigned long long* desc = (unsigned long long*)workspace;
     hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)tiles), dim3(256), 0, s, mask, n, tiles, desc, (int32_t*)(desc + tiles), prefix, total, enable);
 }
+// as pcgc_mask_scan, for a workspace the caller has zeroed already (several scans behind one memset)
+extern "C" int pcgc_mask_scan_zeroed(const uint8_t* mask, int64_t n, int32_t* prefix, int32_t* total, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    PCGC_REQUIRE(workspace_bytes >= pcgc_scan_workspace_bytes(n), "workspace too small");
+    PCGC_REQUIRE(((uintptr_t)workspace & 7) == 0, "workspace must be 8-byte aligned");
+    if (n == 0) return 0;                              // (total stays as the caller zeroed it)
+    launch_scan(mask, n, prefix, total, workspace, nullptr, S(stream));
+    PCGC_CHECK_LAUNCH("mask_scan");
+    return 0;
+}
 extern "C" int pcgc_mask_scan(const uint8_t* mask, int64_t n, int32_t* prefix, int32_t* total, void* workspace,
                               size_t workspace_bytes, void* stream) {
     PCGC_REQUIRE(workspace_bytes >= pcgc_scan_workspace_bytes(n), "workspace too small");

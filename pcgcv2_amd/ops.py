@@ -256,6 +256,30 @@ def down_level(fine, stride_fine):
     return coarse_ub[:nc], parent_of, down_ub[:8 * nc].view(8, nc)
 
 
+def pyramid(fine, stride_fine, levels):
+    """`levels` strided levels below `fine` in one library call with ONE host synchronisation (pcgc_pyramid): every level is
+    deduplicated straight from the input rows.  -> [(coarse, parent_of, down)] per level, the same tensors `levels` nested
+    down_level() calls return (views of upper-bound buffers)."""
+    import ctypes
+    fine = _i32(fine)
+    n, dev = fine.shape[0], fine.device
+    nbytes = int(lib().pcgc_pyramid_scratch_bytes(n, levels))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    outbuf = torch.empty(levels * 13 * n, dtype=torch.int32, device=dev)            # per level: coarse [n,4] | parent_of [n] | down [8n]
+    parts = [(outbuf[13 * n * l:13 * n * l + 4 * n].view(n, 4), outbuf[13 * n * l + 4 * n:13 * n * l + 5 * n], outbuf[13 * n * l + 5 * n:13 * n * (l + 1)])
+             for l in range(levels)]
+    ptrs = lambda k: (ctypes.c_void_p * levels)(*[p[k].data_ptr() for p in parts])
+    counts = (ctypes.c_int64 * levels)()
+    check(lib().pcgc_pyramid(_p(fine), n, int(stride_fine), int(levels), _p(scratch), nbytes, ptrs(0), ptrs(1), ptrs(2), counts, _stream(fine)),
+          'pyramid')
+    out, below = [], n
+    for l, (coarse_ub, parent_ub, down_ub) in enumerate(parts):
+        nc = int(counts[l])
+        out.append((coarse_ub[:nc], parent_ub[:below], down_ub[:8 * nc].view(8, nc)))
+        below = nc
+    return out
+
+
 def compact_index(mask, prefix, n_out):
     orig = torch.empty(n_out, dtype=torch.int32, device=mask.device)
     check(lib().pcgc_compact_index(_p(mask), _p(prefix), mask.shape[0], _p(orig), _stream(mask)), 'compact_index')

@@ -81,6 +81,21 @@ class CoordMap:
             self._down = (CoordMap(coarse_C, 2 * self.stride, unique=True), down)
         return self._down
 
+    def build_pyramid(self, levels):
+        """The next `levels` strided levels at once (one host synchronisation instead of one per level); fills the same caches
+        down() fills and returns the coarsest level.  Levels that are cached already are kept."""
+        chain, lvl = [], self
+        while lvl._down is not None and len(chain) < levels:
+            lvl = lvl._down[0]; chain.append(lvl)
+        todo = levels - len(chain)
+        if todo > 0:
+            for coarse_C, parent_of, down in ops.pyramid(lvl.C, lvl.stride, todo):
+                lvl._parent_of = parent_of
+                nxt = CoordMap(coarse_C, 2 * lvl.stride, unique=True)
+                lvl._down = (nxt, down)
+                lvl = nxt
+        return lvl
+
     def up(self):
         """-> children CoordMap at stride/2, rows 8*i+k: MinkowskiGenerativeConvolutionTranspose(k=2, stride=2).
         Not cached on the parent: the child keeps a strong reference to its parent (to derive its kernel map), and a

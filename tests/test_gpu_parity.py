@@ -66,6 +66,35 @@ def test_pyramid_and_kernel_maps(name):
     np.testing.assert_array_equal(kids.k3.cpu().numpy(), orc.kmap_k3(kids.C.cpu().numpy(), stride // 2))
 
 
+@pytest.mark.parametrize('name,levels,stride', [('shell6', 3, 1), ('shell8', 3, 1), ('shell8', 2, 2), ('shell10', 3, 1), ('shell7', 4, 1), ('shell7', 1, 4)])
+def test_pyramid_in_one_call_equals_nested_levels(name, levels, stride):
+    """pcgc_pyramid (every level deduplicated straight from the input rows, one host synchronisation) against the level-by-level
+    form and the oracle: coarse coordinates in canonical order, parent_of and the 8-slot down maps, incl. a shuffled input."""
+    c4 = _coords(name).copy()
+    c4[:, 1:] *= stride
+    for shuffle in (False, True):
+        if shuffle:
+            c4 = c4[np.random.default_rng(7).permutation(len(c4))]
+        top = CoordMap(_t(c4), stride, unique=True)
+        coarsest = top.build_pyramid(levels)
+        ref = CoordMap(_t(c4), stride, unique=True)
+        a, b, fine_np, s = top, ref, c4, stride
+        for _ in range(levels):
+            (ca, da), (cb, db) = a._down, b.down()
+            np.testing.assert_array_equal(ca.C.cpu().numpy(), cb.C.cpu().numpy())
+            np.testing.assert_array_equal(da.cpu().numpy(), db.cpu().numpy())
+            np.testing.assert_array_equal(a._parent_of.cpu().numpy(), b._parent_of.cpu().numpy())
+            if len(fine_np) < 100000:
+                want_c, _ = orc.stride2_coords(fine_np, 2 * s)
+                np.testing.assert_array_equal(ca.C.cpu().numpy(), want_c)
+                np.testing.assert_array_equal(da.cpu().numpy(), orc.kmap_down(fine_np, want_c, s))
+                fine_np = want_c
+            a, b, s = ca, cb, 2 * s
+        assert a is coarsest and a._down is None
+        assert top.build_pyramid(levels) is coarsest                                # cached levels are kept
+    np.testing.assert_array_equal(top.k3.cpu().numpy(), ref.k3.cpu().numpy())      # and the maps derived through them
+
+
 def test_hierarchical_kmaps_equal_oracle(monkeypatch):
     """Force the derived (parent-gather) kernel maps at every level, incl. children and pruned levels."""
     from pcgcv2_amd import sparse
