@@ -25,6 +25,7 @@ SIGNATURES = {
     'pcgc_coords_scale': (ci, [vp, i64, f32, vp, vp]),
     'pcgc_scan_workspace_bytes': (sz, [i64]),
     'pcgc_mask_scan': (ci, [vp, i64, vp, vp, vp, sz, vp]),
+    'pcgc_mask_scan_zeroed': (ci, [vp, i64, vp, vp, vp, sz, vp]),
     'pcgc_compact_coords': (ci, [vp, vp, vp, i64, vp, vp]),
     'pcgc_compact_feats': (ci, [vp, ci, ci, vp, vp, i64, vp, vp]),
     'pcgc_kmap_k3': (ci, [vp, i64, i32, vp, vp, i64, vp, vp]),
