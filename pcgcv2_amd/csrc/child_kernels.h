@@ -322,58 +322,107 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
     for (int jj = 0; jj < 4; ++jj) a_addr[jj] = (unsigned)(uintptr_t)(lds_void_ptr)((const float*)ring + (mi * 4 + (jj ^ f_a)) * 4 + mq);
     constexpr unsigned ksteps_used = [] { unsigned m = 0; for (int t = 0; t < T; ++t) for (int j = 0; j < KS; ++j) m |= 1u << (V::kfirst(t) + j); return m; }();
 
-    // (A two-deep register pipeline — LDS reads of cell c+1 issued before the MFMAs of cell c — was measured and dropped: no gain
-    // on any variant, 8-30 more registers; with 3-4 waves per SIMD the other waves already cover the LDS latency.)
+    constexpr bool BLOCKWISE = NB * T > 32;                                    // wide layers: B fragments one 16-channel block (and batch) at a time
+    static_assert(BLOCKWISE || V::NBATCH == 1, "batches only exist in the block-wise form");
+    if constexpr (BLOCKWISE) {
+        // C = 64 variants: one or two waves per SIMD and one tile per wave, so little but the wave itself covers an LDS round trip.
+        // Every LDS read is requested one step ahead of its use: the B fragments of the next block / batch, and — during a cell's last
+        // step — the A operand and the first B fragments of the next cell (two register sets each).  A step is: wait for what was
+        // requested a step ago; request the next step's operands; MFMAs.  (Worth 1-3 % only: SQ counters show the wave waiting on the
+        // MFMA pipe, not on memory.  A tile is 3584 MFMAs = 48 us of one SIMD's pipe; the 150 k-row level is 1171 tiles on 1024 SIMDs,
+        // so 147 SIMDs run two tiles and the launch takes two tile times — only finer work units than 16 parents x 8 children would
+        // change that.)
+        constexpr int STEPS = NB * V::NBATCH;
+        static_assert(STEPS % 2 == 0, "the register sets alternate per step: an even number of steps per cell");
+        static_assert(D >= 2, "the next cell's rows must have been requested a cell earlier");
+        BFrag<KS> bp[2][T];
+        float ap[2][NB][4];
+        auto load_b = [&](auto icell, auto icb, auto ibt, auto ibuf) {
+            constexpr int cell = decltype(icell)::value, cb = decltype(icb)::value, bt = decltype(ibt)::value, buf = decltype(ibuf)::value;
+            static_for<0, T>([&](auto it) {
+                constexpr int t = decltype(it)::value;
+                if constexpr (V::active(cell, t) && V::uses_block(t, cb) && V::batch(t) == bt) {
+                    constexpr int off = V::frag_off(cell, t, cb);                                // byte offset of the fragment in the table
+                    if constexpr (off < 65536) bp[buf][t].template load<off>(tab_lane);
+                    else bp[buf][t].template load<off - 65536>(tab_lane + 65536);
+                }
+            });
+        };
+        auto load_a = [&](auto icell) {                                        // once the cell's rows have landed in its ring slot
+            constexpr int cell = decltype(icell)::value;
+            constexpr int younger = (63 - cell) < (D - 1) ? (63 - cell) : (D - 1);
+            wait_vmcnt<younger * NB>();
+            static_for<0, NB>([&](auto icb) {
+                constexpr int cb = decltype(icb)::value;
+                static_for<0, 4>([&](auto ij) {
+                    constexpr int jj = decltype(ij)::value;
+                    if constexpr ((ksteps_used >> jj) & 1) ap[cell & 1][cb][jj] = lds_ld32_off<((cell & (D - 1)) * NB + cb) * 1024>(a_addr[jj]);
+                });
+            });
+        };
+        using I0 = std::integral_constant<int, 0>;
+        static_for<0, D>(issue);
+        load_a(I0{});
+        load_b(I0{}, I0{}, I0{}, I0{});
+        static_for<0, 64>([&](auto ic) {
+            constexpr int c = decltype(ic)::value;
+            static_for<0, STEPS>([&](auto is) {
+                constexpr int s = decltype(is)::value, cb = s / V::NBATCH, bt = s % V::NBATCH, cur = s & 1;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // requested one step ago
+                if constexpr (s == 0) {
+                    static_for<0, NB>([&](auto icb2) {
+                        static_for<0, 4>([&](auto ij) {
+                            constexpr int jj = decltype(ij)::value;
+                            if constexpr ((ksteps_used >> jj) & 1) lds_tie(ap[c & 1][decltype(icb2)::value][jj]);
+                        });
+                    });
+                    if constexpr (c + D < 64) issue(std::integral_constant<int, c + D>{});    // the ring slot of cell c has been read: refill it
+                }
+                static_for<0, T>([&](auto it) {
+                    constexpr int t = decltype(it)::value;
+                    if constexpr (V::active(c, t) && V::uses_block(t, cb) && V::batch(t) == bt) bp[cur][t].tie();
+                });
+                if constexpr (s + 1 < STEPS) {
+                    load_b(ic, std::integral_constant<int, (s + 1) / V::NBATCH>{}, std::integral_constant<int, (s + 1) % V::NBATCH>{}, std::integral_constant<int, cur ^ 1>{});
+                } else if constexpr (c + 1 < 64) {
+                    load_a(std::integral_constant<int, c + 1>{});
+                    load_b(std::integral_constant<int, c + 1>{}, I0{}, I0{}, std::integral_constant<int, cur ^ 1>{});
+                }
+                static_for<0, 4>([&](auto ij) {
+                    constexpr int jj = decltype(ij)::value;
+                    static_for<0, T>([&](auto it) {
+                        constexpr int t = decltype(it)::value;
+                        if constexpr (V::active(c, t) && V::uses_block(t, cb) && V::batch(t) == bt && jj >= V::kfirst(t) && jj < V::kfirst(t) + KS)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[c & 1][cb][jj], bp[cur][t].get(jj - V::kfirst(t)), acc[t], 0, 0, 0);
+                    });
+                });
+            });
+        });
+    } else {
+    // (A two-deep register pipeline — LDS reads of cell c+1 issued before the MFMAs of cell c — was measured and dropped on these
+    // variants: no gain, 8-30 more registers; with 3-4 waves per SIMD the other waves already cover the LDS latency.)
     static_for<0, D>(issue);
     static_for<0, 64>([&](auto ic) {
         constexpr int c = decltype(ic)::value;
         constexpr int younger = (63 - c) < (D - 1) ? (63 - c) : (D - 1);       // cells issued after c that may stay in flight
         wait_vmcnt<younger * NB>();
         float a[NB][4];
-        constexpr bool BLOCKWISE = NB * T > 32;                                // wide layers: B fragments one 16-channel block (and batch) at a time
-        static_assert(BLOCKWISE || V::NBATCH == 1, "batches only exist in the block-wise form");
-        constexpr int NBB = BLOCKWISE ? 1 : NB;
-        BFrag<KS> b[NBB][T];
-        auto load_b = [&](auto icb, auto ibt) {
-            constexpr int cb = decltype(icb)::value;
-            constexpr int bt = decltype(ibt)::value;
-            static_for<0, T>([&](auto it) {
-                constexpr int t = decltype(it)::value;
-                if constexpr (V::active(c, t) && V::uses_block(t, cb) && V::batch(t) == bt) {
-                    constexpr int off = V::frag_off(c, t, cb);                                   // byte offset of the fragment in the table
-                    if constexpr (off < 65536) b[BLOCKWISE ? 0 : cb][t].template load<off>(tab_lane);
-                    else b[BLOCKWISE ? 0 : cb][t].template load<off - 65536>(tab_lane + 65536);
-                }
-            });
-        };
-        auto tie_b = [&](auto icb, auto ibt) {
-            constexpr int cb = decltype(icb)::value;
-            constexpr int bt = decltype(ibt)::value;
-            static_for<0, T>([&](auto it) {
-                constexpr int t = decltype(it)::value;
-                if constexpr (V::active(c, t) && V::uses_block(t, cb) && V::batch(t) == bt) b[BLOCKWISE ? 0 : cb][t].tie();
-            });
-        };
-        auto mfma_block = [&](auto icb, auto ibt) {
-            constexpr int cb = decltype(icb)::value;
-            constexpr int bt = decltype(ibt)::value;
-            static_for<0, 4>([&](auto ij) {
-                constexpr int jj = decltype(ij)::value;
-                static_for<0, T>([&](auto it) {
-                    constexpr int t = decltype(it)::value;
-                    if constexpr (V::active(c, t) && V::uses_block(t, cb) && V::batch(t) == bt && jj >= V::kfirst(t) && jj < V::kfirst(t) + KS)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][jj], b[BLOCKWISE ? 0 : cb][t].get(jj - V::kfirst(t)), acc[t], 0, 0, 0);
-                });
-            });
-        };
-        static_for<0, NB>([&](auto icb) {                                      // all LDS reads of the cell (A; and B unless block-wise), one wait
+        BFrag<KS> b[NB][T];
+        static_for<0, NB>([&](auto icb) {                                      // all LDS reads of the cell, one wait
             constexpr int cb = decltype(icb)::value;
             static_for<0, 4>([&](auto ij) {
                 constexpr int jj = decltype(ij)::value;
                 if constexpr ((ksteps_used >> jj) & 1)
                     a[cb][jj] = lds_ld32_off<((c & (D - 1)) * NB + cb) * 1024>(a_addr[jj]);
             });
-            if constexpr (!BLOCKWISE) load_b(icb, std::integral_constant<int, 0>{});
+            static_for<0, T>([&](auto it) {
+                constexpr int t = decltype(it)::value;
+                if constexpr (V::active(c, t) && V::uses_block(t, cb)) {
+                    constexpr int off = V::frag_off(c, t, cb);                                   // byte offset of the fragment in the table
+                    if constexpr (off < 65536) b[cb][t].template load<off>(tab_lane);
+                    else b[cb][t].template load<off - 65536>(tab_lane + 65536);
+                }
+            });
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         static_for<0, NB>([&](auto icb) {
@@ -382,22 +431,25 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
                 constexpr int jj = decltype(ij)::value;
                 if constexpr ((ksteps_used >> jj) & 1) lds_tie(a[cb][jj]);
             });
-            if constexpr (!BLOCKWISE) tie_b(icb, std::integral_constant<int, 0>{});
+            static_for<0, T>([&](auto it) {
+                constexpr int t = decltype(it)::value;
+                if constexpr (V::active(c, t) && V::uses_block(t, cb)) b[cb][t].tie();
+            });
         });
         if constexpr (c + D < 64) issue(std::integral_constant<int, c + D>{});    // refill the ring slot cell c was read from
         static_for<0, NB>([&](auto icb) {
-            if constexpr (BLOCKWISE) {
-                static_for<0, V::NBATCH>([&](auto ibt) {
-                    load_b(icb, ibt);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    tie_b(icb, ibt);
-                    mfma_block(icb, ibt);
+            constexpr int cb = decltype(icb)::value;
+            static_for<0, 4>([&](auto ij) {
+                constexpr int jj = decltype(ij)::value;
+                static_for<0, T>([&](auto it) {
+                    constexpr int t = decltype(it)::value;
+                    if constexpr (V::active(c, t) && V::uses_block(t, cb) && jj >= V::kfirst(t) && jj < V::kfirst(t) + KS)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][jj], b[cb][t].get(jj - V::kfirst(t)), acc[t], 0, 0, 0);
                 });
-            } else {
-                mfma_block(icb, std::integral_constant<int, 0>{});
-            }
+            });
         });
     });
+    }
 #ifdef PCGC_CHILD_TIMING
     asm volatile("s_nop 0" : "+v"(acc[0]));                     // (keeps the stamp behind the last MFMA's issue)
     CHILD_T(t_loop1);

@@ -6,6 +6,8 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 template <int N>
 __device__ static inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N>
+__device__ static inline void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
