@@ -88,7 +88,7 @@ def main():
     red_dev = dev if backend == 'nccl' else torch.device('cpu')
 
     import pcgcv2_amd
-    pcgcv2_amd.configure_host_threads()
+    pcgcv2_amd.configure_host_threads(local_world=world)          # one node: the ranks share its CPUs (quota-aware pool sizes)
     from pcgcv2_amd import synthetic, ops, shard
     from pcgcv2_amd.pcc_model import PCCModel
     from pcgcv2_amd.coder import Coder, STREAMS

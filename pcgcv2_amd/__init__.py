@@ -26,11 +26,16 @@ def effective_cpus():
     return n
 
 
-def configure_host_threads(max_threads=4):
-    """The host side of the codec is a single-threaded launcher + sequential entropy coder; keep torch's CPU thread pool
-    small so its workers do not spin away the container's CPU quota."""
+def configure_host_threads(max_threads=4, local_world=None):
+    """The host side of the codec is a single-threaded launcher + sequential entropy coder (+ a few short-lived helper threads for the
+    indexed entropy decoders); keep torch's CPU thread pool small so its workers do not spin away the container's CPU quota, and size
+    the decoder pools from this process's SHARE of the CPUs: `local_world` = processes on this node that share them (one rank per GPU;
+    default: LOCAL_WORLD_SIZE or 1)."""
+    import os
     import torch
-    cpus = effective_cpus()
+    if local_world is None:
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1)
+    cpus = max(1, effective_cpus() // max(1, int(local_world)))
     torch.set_num_threads(max(1, min(max_threads, cpus)))
     from . import ops
-    ops.set_rc_threads(max(1, min(8, cpus - 2)))                 # segments of an indexed `_F.bin` decoded side by side
+    ops.set_rc_threads(max(1, min(8, cpus - 2)))                 # segments of an indexed `_F.bin` / groups of `_C.bin` decoded side by side
