@@ -5,4 +5,4 @@
                                       int table_bytes, const IrnEpi& ep, hipStream_t s)
 // The 112 KB table leaves 48 KB for the rings: six waves with two ring slots each (the block-wise main loop requests every operand one
 // step ahead and needs the next cell's rows to have been requested a cell earlier).
-DEF_IRN_LAUNCH(pcgc_irn_child_a64) { (void)nw; return launch_child_irn_a<64, 6, 2>(parent_nbr, n_parent, in, in_ld, table, table_bytes, ep, s); }
+DEF_IRN_LAUNCH(pcgc_irn_child_a64) { (void)nw; return launch_child_irn_a_split<64, 6, 2>(parent_nbr, n_parent, in, in_ld, table, table_bytes, ep, s); }      // half units

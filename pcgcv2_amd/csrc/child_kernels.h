@@ -115,9 +115,12 @@ struct ClsHead {                       // k3 conv C -> 1: one tile, column j (0.
 // InceptionResNet pass A (autoencoder.py:52-57 first half): conv0_0 (k3 C -> Q) and conv1_0 (k1 C -> Q), Q = C/4.
 // Columns pack (child, output channel): 16/Q children per tile.  Tiles [0, T/2) = conv0_0, [T/2, T) = conv1_0 (fed only by the
 // cell that IS the child: offset k = 13).
-template <int C>
+// HZ (C = 64 only): -1 = all eight children; 0 / 1 = only the four children with that z bit (a half unit: see k_child_irn_a)
+template <int C, int HZ = -1>
 struct PassA {
     static constexpr int Q = C / 4, NB = C / 16, ROWCHUNKS = 4, CPT = 16 / Q /*children per tile: 4, 2 or 1*/, TH = 8 / CPT, T = 2 * TH, KS = 4;
+    static_assert(HZ < 0 || CPT == 1, "half units exist for one-child tiles only");
+    static constexpr int Z_HALF = HZ;
     static constexpr bool HALF = false;
     static constexpr int kfirst(int) { return 0; }
     // tile geometry: CPT == 4: tile = z-half (children 4 jz + {0..3});  CPT == 2: tile = (jz, jy) quarter (children 4 jz + 2 jy + {0,1})
@@ -125,6 +128,7 @@ struct PassA {
     static constexpr int ty(int t) { return (t % TH) & 1; }
     static constexpr bool active(int c, int t) {
         if (CPT == 1) {                                         // C = 64: one child per tile; conv1_0 is fed only by the cell that IS the child
+            if (HZ >= 0 && (((t < TH ? t : t - TH) >> 2) & 1) != HZ) return false;
             if (t < TH) return (cell_reach(c) >> t) & 1;
             return ((cell_reach(c) >> (t - TH)) & 1) && cell_k(c, t - TH) == 13;
         }
@@ -187,12 +191,14 @@ struct PassB {
 };
 // pass B at C = 64 (Q = 16): t is 32 wide = two 16-channel blocks; block 0 feeds conv0_1 (k3 16 -> 32: two column tiles per child),
 // block 1 feeds conv1_1 (k3 16 -> 16: one tile per child).  Fragments: conv0_1 (k, n) = 54, conv1_1 k = 27, conv1_2 (k1 16 -> 32) = 2.
+template <int HZ = -1>
 struct PassB64 {
     static constexpr int Q = 16, NB = 2, ROWCHUNKS = 4, KS = 4, T0 = 16, T1 = 8, T = 24;
+    static constexpr int Z_HALF = HZ;                      // -1 = all eight children; 0 / 1 = the four children with that z bit (half units)
     static constexpr bool HALF = false;
     static constexpr int kfirst(int) { return 0; }
     static constexpr int child_of(int t) { return t < T0 ? t / 2 : t - T0; }
-    static constexpr bool active(int c, int t) { return (cell_reach(c) >> child_of(t)) & 1; }
+    static constexpr bool active(int c, int t) { return (HZ < 0 || ((child_of(t) >> 2) & 1) == HZ) && ((cell_reach(c) >> child_of(t)) & 1); }
     static constexpr bool uses_block(int t, int cb) { return t < T0 ? cb == 0 : cb == 1; }
     static constexpr int NBATCH = 2;                       // B fragments of a block in two batches (16 at once would not fit the registers)
     static constexpr int batch(int t) { return t < T0 ? (t & 1) : 0; }
@@ -270,6 +276,19 @@ __device__ __forceinline__ void child_stage_table(const float* __restrict__ tabl
     __syncthreads();
 }
 
+// The cells a variant uses, ascending (= every cell for whole tiles; a variant that computes a subset of the children — the z-half
+// units of the C = 64 kernels — skips the cells none of its children reaches: they are neither gathered nor read).
+struct ChildCells { int n; int c[64]; };
+template <class V> constexpr ChildCells child_cells() {
+    ChildCells L{};
+    for (int c = 0; c < 64; ++c) {
+        bool used = false;
+        for (int t = 0; t < V::T; ++t) used = used || V::active(c, t);
+        if (used) L.c[L.n++] = c;
+    }
+    return L;
+}
+
 // The gather + MFMA main loop of one 16-parent tile, shared by every variant: leaves acc[t] (t < V::T) for the epilogue.
 template <class V, int D>
 __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ pnbr, int64_t n_p, int64_t p0,
@@ -299,9 +318,11 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
     const unsigned lane_off = chunk_ok ? (unsigned)dma_chunk * 16u : ABSENT;
     CHILD_T(t_loop0);
 
-    auto issue = [&](auto ic) {
-        constexpr int c = decltype(ic)::value;
-        float4* dst = ring + (c & (D - 1)) * (NB * 64);
+    constexpr ChildCells CL = child_cells<V>();
+    constexpr int NC = CL.n;                                   // cells of this variant; position i in the list uses ring slot i mod D
+    auto issue = [&](auto ii) {
+        constexpr int i = decltype(ii)::value, c = CL.c[i];
+        float4* dst = ring + (i & (D - 1)) * (NB * 64);
         unsigned voff = rowb[cell_kp(c)] + (unsigned)cell_child(c) * row_bytes + lane_off;
         if constexpr (V::ROWCHUNKS < 4) voff = chunk_ok ? voff : 0xFFFFFFF0u;       // (ABSENT + ABSENT would wrap)
 #pragma unroll
@@ -348,24 +369,25 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
                 }
             });
         };
-        auto load_a = [&](auto icell) {                                        // once the cell's rows have landed in its ring slot
-            constexpr int cell = decltype(icell)::value;
-            constexpr int younger = (63 - cell) < (D - 1) ? (63 - cell) : (D - 1);
+        auto load_a = [&](auto ii) {                                           // once the cell's rows have landed in its ring slot
+            constexpr int i = decltype(ii)::value;
+            constexpr int younger = (NC - 1 - i) < (D - 1) ? (NC - 1 - i) : (D - 1);
             wait_vmcnt<younger * NB>();
             static_for<0, NB>([&](auto icb) {
                 constexpr int cb = decltype(icb)::value;
                 static_for<0, 4>([&](auto ij) {
                     constexpr int jj = decltype(ij)::value;
-                    if constexpr ((ksteps_used >> jj) & 1) ap[cell & 1][cb][jj] = lds_ld32_off<((cell & (D - 1)) * NB + cb) * 1024>(a_addr[jj]);
+                    if constexpr ((ksteps_used >> jj) & 1) ap[i & 1][cb][jj] = lds_ld32_off<((i & (D - 1)) * NB + cb) * 1024>(a_addr[jj]);
                 });
             });
         };
         using I0 = std::integral_constant<int, 0>;
-        static_for<0, D>(issue);
+        static_for<0, (D < NC ? D : NC)>(issue);
         load_a(I0{});
-        load_b(I0{}, I0{}, I0{}, I0{});
-        static_for<0, 64>([&](auto ic) {
-            constexpr int c = decltype(ic)::value;
+        load_b(std::integral_constant<int, CL.c[0]>{}, I0{}, I0{}, I0{});
+        static_for<0, NC>([&](auto ii) {
+            constexpr int i = decltype(ii)::value, c = CL.c[i];
+            using IC = std::integral_constant<int, c>;
             static_for<0, STEPS>([&](auto is) {
                 constexpr int s = decltype(is)::value, cb = s / V::NBATCH, bt = s % V::NBATCH, cur = s & 1;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // requested one step ago
@@ -373,27 +395,27 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
                     static_for<0, NB>([&](auto icb2) {
                         static_for<0, 4>([&](auto ij) {
                             constexpr int jj = decltype(ij)::value;
-                            if constexpr ((ksteps_used >> jj) & 1) lds_tie(ap[c & 1][decltype(icb2)::value][jj]);
+                            if constexpr ((ksteps_used >> jj) & 1) lds_tie(ap[i & 1][decltype(icb2)::value][jj]);
                         });
                     });
-                    if constexpr (c + D < 64) issue(std::integral_constant<int, c + D>{});    // the ring slot of cell c has been read: refill it
+                    if constexpr (i + D < NC) issue(std::integral_constant<int, i + D>{});    // the ring slot of this cell has been read: refill it
                 }
                 static_for<0, T>([&](auto it) {
                     constexpr int t = decltype(it)::value;
                     if constexpr (V::active(c, t) && V::uses_block(t, cb) && V::batch(t) == bt) bp[cur][t].tie();
                 });
                 if constexpr (s + 1 < STEPS) {
-                    load_b(ic, std::integral_constant<int, (s + 1) / V::NBATCH>{}, std::integral_constant<int, (s + 1) % V::NBATCH>{}, std::integral_constant<int, cur ^ 1>{});
-                } else if constexpr (c + 1 < 64) {
-                    load_a(std::integral_constant<int, c + 1>{});
-                    load_b(std::integral_constant<int, c + 1>{}, I0{}, I0{}, std::integral_constant<int, cur ^ 1>{});
+                    load_b(IC{}, std::integral_constant<int, (s + 1) / V::NBATCH>{}, std::integral_constant<int, (s + 1) % V::NBATCH>{}, std::integral_constant<int, cur ^ 1>{});
+                } else if constexpr (i + 1 < NC) {
+                    load_a(std::integral_constant<int, i + 1>{});
+                    load_b(std::integral_constant<int, CL.c[i + 1 < NC ? i + 1 : i]>{}, I0{}, I0{}, std::integral_constant<int, cur ^ 1>{});
                 }
                 static_for<0, 4>([&](auto ij) {
                     constexpr int jj = decltype(ij)::value;
                     static_for<0, T>([&](auto it) {
                         constexpr int t = decltype(it)::value;
                         if constexpr (V::active(c, t) && V::uses_block(t, cb) && V::batch(t) == bt && jj >= V::kfirst(t) && jj < V::kfirst(t) + KS)
-                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[c & 1][cb][jj], bp[cur][t].get(jj - V::kfirst(t)), acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i & 1][cb][jj], bp[cur][t].get(jj - V::kfirst(t)), acc[t], 0, 0, 0);
                     });
                 });
             });
@@ -401,10 +423,10 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
     } else {
     // (A two-deep register pipeline — LDS reads of cell c+1 issued before the MFMAs of cell c — was measured and dropped on these
     // variants: no gain, 8-30 more registers; with 3-4 waves per SIMD the other waves already cover the LDS latency.)
-    static_for<0, D>(issue);
-    static_for<0, 64>([&](auto ic) {
-        constexpr int c = decltype(ic)::value;
-        constexpr int younger = (63 - c) < (D - 1) ? (63 - c) : (D - 1);       // cells issued after c that may stay in flight
+    static_for<0, (D < NC ? D : NC)>(issue);
+    static_for<0, NC>([&](auto ii) {
+        constexpr int i = decltype(ii)::value, c = CL.c[i];
+        constexpr int younger = (NC - 1 - i) < (D - 1) ? (NC - 1 - i) : (D - 1);       // cells issued after this one that may stay in flight
         wait_vmcnt<younger * NB>();
         float a[NB][4];
         BFrag<KS> b[NB][T];
@@ -413,7 +435,7 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
             static_for<0, 4>([&](auto ij) {
                 constexpr int jj = decltype(ij)::value;
                 if constexpr ((ksteps_used >> jj) & 1)
-                    a[cb][jj] = lds_ld32_off<((c & (D - 1)) * NB + cb) * 1024>(a_addr[jj]);
+                    a[cb][jj] = lds_ld32_off<((i & (D - 1)) * NB + cb) * 1024>(a_addr[jj]);
             });
             static_for<0, T>([&](auto it) {
                 constexpr int t = decltype(it)::value;
@@ -436,7 +458,7 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
                 if constexpr (V::active(c, t) && V::uses_block(t, cb)) b[cb][t].tie();
             });
         });
-        if constexpr (c + D < 64) issue(std::integral_constant<int, c + D>{});    // refill the ring slot cell c was read from
+        if constexpr (i + D < NC) issue(std::integral_constant<int, i + D>{});    // refill the ring slot this cell was read from
         static_for<0, NB>([&](auto icb) {
             constexpr int cb = decltype(icb)::value;
             static_for<0, 4>([&](auto ij) {
@@ -473,14 +495,15 @@ __device__ __forceinline__ void wave_lds_sync() {
 // tile's time.  A tile's 128 output rows are contiguous in memory, so the values go through a per-wave LDS scratch (the gather
 // ring, idle by then) in row-major order, CH rows at a time, and leave as 16-byte-per-lane stores: whole rows, fully coalesced;
 // residual rows are read the same way.  Arithmetic order per element is unchanged: (acc + bias) [+ residual] [relu].
+// `half` (0 / 1, or -1 = all rows): only the rows of the children with that z bit (rows 4 half .. 4 half + 3 of every parent's eight).
 template <int W>
 __device__ __forceinline__ void child_flush(const float* scratch, int rows, int64_t row0, int64_t rows_total, float* __restrict__ out,
-                                            int out_ld, const float* __restrict__ res, int res_ld, int relu, int lane) {
+                                            int out_ld, const float* __restrict__ res, int res_ld, int relu, int lane, int half = -1) {
     constexpr int C4 = W / 4;
     for (int i = lane; i < rows * C4; i += 64) {
         const int lr = i / C4, c4 = i % C4;
         const int64_t row = row0 + lr;
-        if (row >= rows_total) continue;
+        if (row >= rows_total || (half >= 0 && ((lr >> 2) & 1) != half)) continue;
         float4 v = ((const float4*)scratch)[i];
         if (res) {
             const float4 x = *(const float4*)(res + row * res_ld + 4 * c4);
@@ -578,22 +601,25 @@ k_child_cls(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restri
 
 
 // pass A:  t[row][0:Q] = relu(conv0_0 + b00), t[row][Q:2Q] = relu(conv1_0 + b10)
-template <int C, int NW, int D>
+// SPLIT (C = 64): the level is ~1.14 tiles per SIMD, and a tile is 48 us of one SIMD's MFMA pipe — whole tiles quantise to TWO tile times
+// per launch.  Half units (the four children with z bit 0 / 1 of 16 parents: half the MFMAs, 48 of the 64 cells) quantise to three
+// half-tile times.  Both halves are separate instantiations of the statically unrolled body; a wave picks one per unit.
+template <class T_> struct child_type_tag { using type = T_; };
+template <int C, int NW, int D, bool SPLIT = false>
 __global__ void __launch_bounds__(NW * 64)
 k_child_irn_a(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in, int in_ld,
               const float* __restrict__ table, int table_bytes, IrnEpi ep) {
     using V = PassA<C>;
     constexpr int Q = V::Q, CPT = V::CPT, TH = V::TH;
+    static_assert(!SPLIT || CPT == 1, "half units exist for one-child tiles only");
     CHILD_KERNEL_PROLOGUE(V, NW, D, D * V::NB * 64)
     const int co = mi % Q, sub = mi / Q;                       // column -> (child within the tile, output channel)
     const float b00 = ep.b0[co], b10 = ep.b1[co];
-    for (int i = 0;; ++i) {
-        const int64_t tile = child_tile<NW>(i, wave, ntiles);
-        if (tile < 0) break;
-        const int64_t p0 = tile * 16;
-        CHILD_T(t_it0);
-        f32x4 acc[V::T];
-        child_tile_mainloop<V, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
+    auto unit = [&](auto tag, const int64_t p0) {
+        using VV = typename decltype(tag)::type;
+        constexpr int HZ = VV::Z_HALF;
+        f32x4 acc[VV::T];
+        child_tile_mainloop<VV, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
         constexpr int W = 2 * Q, CH = (64 * W * 4 <= D * V::NB * 1024) ? 64 : 32, MQC = CH / 32;
         float* scratch = (float*)ring;
 #pragma unroll
@@ -601,6 +627,7 @@ k_child_irn_a(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
             if (mq / MQC == h) {
 #pragma unroll
                 for (int t = 0; t < TH; ++t) {
+                    if (HZ >= 0 && ((t >> 2) & 1) != HZ) continue;             // (one-child tiles: t is the child)
                     const int j = t * CPT + sub;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -611,8 +638,20 @@ k_child_irn_a(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
                 }
             }
             wave_lds_sync();
-            child_flush<W>(scratch, CH, 8 * p0 + h * CH, 8 * n_p, ep.out, W, nullptr, 0, 0, lane);
+            child_flush<W>(scratch, CH, 8 * p0 + h * CH, 8 * n_p, ep.out, W, nullptr, 0, 0, lane, HZ);
             wave_lds_sync();
+        }
+    };
+    const int64_t nunits = SPLIT ? 2 * ntiles : ntiles;
+    for (int i = 0;; ++i) {
+        const int64_t u = child_tile<NW>(i, wave, nunits);
+        if (u < 0) break;
+        CHILD_T(t_it0);
+        if constexpr (SPLIT) {
+            if (u & 1) unit(child_type_tag<PassA<C, 1>>{}, (u >> 1) * 16);
+            else unit(child_type_tag<PassA<C, 0>>{}, (u >> 1) * 16);
+        } else {
+            unit(child_type_tag<V>{}, u * 16);
         }
 #ifdef PCGC_CHILD_TIMING
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -700,11 +739,11 @@ k_child_irn_b(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
 // pass B at C = 64.  Epilogue per 16-row group g (parents 2g, 2g+1 x 8 children; held by the lanes of quarter g >> 1 in accumulator
 // elements r = 2 (g & 1) + {0, 1}): u = relu(conv1_1 + b11) and conv0_1 + b01 go to the scratch, conv1_2 (k1 16 -> 32) is 8 MFMAs on u,
 // then the 16 rows x 64 columns leave coalesced with the residual x added.
-template <int NW, int D>
+template <int NW, int D, bool SPLIT = false>
 __global__ void __launch_bounds__(NW * 64)
 k_child_irn_b64(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in /* t [.., 32] */, int in_ld,
                 const float* __restrict__ table, int table_bytes, IrnEpi ep) {
-    using V = PassB64;
+    using V = PassB64<>;
     constexpr int NEEDF4 = (16 * 16 + 16 * 64) / 4;                                        // us [16][16] + stage [16][64]
     constexpr int RINGF4 = (D * V::NB * 64 > NEEDF4) ? D * V::NB * 64 : NEEDF4;
     CHILD_KERNEL_PROLOGUE(V, NW, D, RINGF4)
@@ -714,13 +753,12 @@ k_child_irn_b64(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __re
 #pragma unroll
     for (int n2 = 0; n2 < 2; ++n2) w12[n2] = *((const f32x4*)(lds_raw + (V::FRAG_W12 + n2) * 1024) + lane);
     const float b01a = ep.b0[mi], b01b = ep.b0[16 + mi], b11 = ep.b1[mi], b12a = ep.b2[mi], b12b = ep.b2[16 + mi];
-    for (int i = 0;; ++i) {
-        const int64_t tile = child_tile<NW>(i, wave, ntiles);
-        if (tile < 0) break;
-        const int64_t p0 = tile * 16;
-        CHILD_T(t_it0);
-        f32x4 acc[V::T];
-        child_tile_mainloop<V, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
+    // one unit: a whole tile, or (SPLIT) the four children with one z bit of its 16 parents — see k_child_irn_a
+    auto unit = [&](auto tag, const int64_t p0) {
+        using VV = typename decltype(tag)::type;
+        constexpr int HZ = VV::Z_HALF;
+        f32x4 acc[VV::T];
+        child_tile_mainloop<VV, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
         static_for<0, 8>([&](auto ig) {
             constexpr int g = decltype(ig)::value;
             if (mq == (g >> 1)) {
@@ -729,7 +767,8 @@ k_child_irn_b64(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __re
                     constexpr int r0 = 2 * (g & 1);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const int lr = 8 * rr + j;
+                        if (HZ >= 0 && ((j >> 2) & 1) != HZ) continue;                     // (the other half's rows: computed below from stale
+                        const int lr = 8 * rr + j;                                         //  scratch, never stored)
                         us[lr * 16 + mi] = fmaxf(acc[16 + j][r0 + rr] + b11, 0.0f);
                         stage[lr * 64 + mi] = acc[2 * j][r0 + rr] + b01a;
                         stage[lr * 64 + 16 + mi] = acc[2 * j + 1][r0 + rr] + b01b;
@@ -746,9 +785,21 @@ k_child_irn_b64(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __re
                 for (int r = 0; r < 4; ++r) stage[(4 * mq + r) * 64 + 32 + 16 * n2 + mi] = d[r] + (n2 ? b12b : b12a);
             }
             wave_lds_sync();
-            child_flush<64>(stage, 16, 8 * p0 + 16 * g, 8 * n_p, ep.out, ep.out_ld, ep.x, ep.x_ld, 0, lane);
+            child_flush<64>(stage, 16, 8 * p0 + 16 * g, 8 * n_p, ep.out, ep.out_ld, ep.x, ep.x_ld, 0, lane, HZ);
             wave_lds_sync();
         });
+    };
+    const int64_t nunits = SPLIT ? 2 * ntiles : ntiles;
+    for (int i = 0;; ++i) {
+        const int64_t u = child_tile<NW>(i, wave, nunits);
+        if (u < 0) break;
+        CHILD_T(t_it0);
+        if constexpr (SPLIT) {
+            if (u & 1) unit(child_type_tag<PassB64<1>>{}, (u >> 1) * 16);
+            else unit(child_type_tag<PassB64<0>>{}, (u >> 1) * 16);
+        } else {
+            unit(child_type_tag<V>{}, u * 16);
+        }
 #ifdef PCGC_CHILD_TIMING
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         { CHILD_T(t_it1); CHILD_TADD(4, t_it0, t_it1); }
@@ -772,13 +823,13 @@ int child_lds_limit(K kern, size_t lds, ChildLdsGrant& granted) {
     return 0;
 }
 // persistent grid: as many workgroups as stay resident (LDS-limited, at most 16 waves per CU), a multiple of 8 (one share per XCD)
-static unsigned child_grid(int64_t n_p, int nw, size_t lds) {
+static unsigned child_grid(int64_t n_p, int nw, size_t lds, int units_per_tile = 1) {
     static int cus = 0;
     if (!cus) { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); cus = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
     int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
     if (per_cu > 16 / nw) per_cu = 16 / nw;
     if (per_cu < 1) per_cu = 1;
-    int64_t want = ((n_p + 15) / 16 + nw - 1) / nw;
+    int64_t want = (((n_p + 15) / 16) * units_per_tile + nw - 1) / nw;
     int64_t g = (int64_t)cus * per_cu;
     if (g > want) g = want;
     g = (g + 7) / 8 * 8;
@@ -810,6 +861,16 @@ int launch_child_irn_a(const int32_t* pnbr, int64_t n_p, const float* in, int in
     CHILD_LAUNCH((k_child_irn_a<C, NW, D>), NW, D * (C / 16) * 1024, ep);
 }
 template <int C, int NW, int D>
+int launch_child_irn_a_split(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
+                             const IrnEpi& ep, hipStream_t s) {
+    const size_t lds = (size_t)table_bytes + (size_t)NW * (D * (C / 16) * 1024);
+    auto kern = k_child_irn_a<C, NW, D, true>;
+    static ChildLdsGrant granted;
+    if (int rc = child_lds_limit(kern, lds, granted)) return rc;
+    hipLaunchKernelGGL(kern, dim3(child_grid(n_p, NW, lds, 2)), dim3(NW * 64), lds, s, pnbr, n_p, in, in_ld, table, table_bytes, ep);
+    return 0;
+}
+template <int C, int NW, int D>
 int launch_child_irn_b(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
                        const IrnEpi& ep, hipStream_t s) {
     constexpr int Q = C / 4, CH = ((128 * Q + 64 * C) * 4 <= D * 1024) ? 64 : 32;
@@ -824,6 +885,18 @@ int launch_child_irn_b64(const int32_t* pnbr, int64_t n_p, const float* in, int 
     constexpr int need = (16 * 16 + 16 * 64) * 4;
     constexpr int ringb = (D * 2 * 1024 > need) ? D * 2 * 1024 : need;
     CHILD_LAUNCH((k_child_irn_b64<NW, D>), NW, ringb, ep);
+}
+template <int NW, int D>
+int launch_child_irn_b64_split(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
+                               const IrnEpi& ep, hipStream_t s) {
+    constexpr int need = (16 * 16 + 16 * 64) * 4;
+    constexpr int ringb = (D * 2 * 1024 > need) ? D * 2 * 1024 : need;
+    const size_t lds = (size_t)table_bytes + (size_t)NW * ringb;
+    auto kern = k_child_irn_b64<NW, D, true>;
+    static ChildLdsGrant granted;
+    if (int rc = child_lds_limit(kern, lds, granted)) return rc;
+    hipLaunchKernelGGL(kern, dim3(child_grid(n_p, NW, lds, 2)), dim3(NW * 64), lds, s, pnbr, n_p, in, in_ld, table, table_bytes, ep);
+    return 0;
 }
 
 }  // namespace
