@@ -129,6 +129,34 @@ def test_range_decoder_rejects_malformed_index():
             ops.rc_decode(table, a, sym.size, index=bad)
 
 
+def test_entropy_pools_under_concurrent_callers():
+    """Frames in flight: several host threads use the indexed range decoder and the grouped coordinate codec at the same time
+    (each pool serialises its callers; the two pools run side by side)."""
+    import threading
+    table = _table_from_pmf(np.tile(np.exp(-0.5 * ((np.arange(21) - 10) / 2.0) ** 2), (8, 1)))
+    pts = np.unique(synthetic.shell('shell10').numpy() // 8, axis=0).astype(np.int32)
+    want_pts = ops.oct_decode(ops.oct_encode(pts))
+    errors = []
+
+    def worker(seed):
+        rng = np.random.default_rng(seed)
+        for _ in range(8):
+            sym = np.clip(np.rint(rng.normal(10, 2, (5000, 8))), 0, 20).astype(np.int16)
+            stream, index = ops.rc_encode(table, sym, checkpoints=8)
+            if not np.array_equal(ops.rc_decode(table, stream, sym.size, index=index), sym.ravel()):
+                errors.append(('range', seed))
+            if not np.array_equal(ops.oct_decode(ops.oct_encode(pts)), want_pts):
+                errors.append(('octree', seed))
+    ops.set_rc_threads(4)
+    try:
+        threads = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+    finally:
+        ops.set_rc_threads(0)
+    assert not errors, errors
+
+
 def test_feature_index_sidecar_is_tied_to_its_stream(tmp_path):
     """coder._pack_index / _load_index: the sidecar is used only for the stream it was written with."""
     from pcgcv2_amd import coder
