@@ -30,7 +30,9 @@ __device__ static inline unsigned xcd_tile(unsigned b, unsigned nb) {
 // ---- coordinate key: 4-bit batch | 20-bit z | 20-bit y | 20-bit x ------------------------------------------
 #define PCGC_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 __host__ __device__ static inline bool coord_in_range(int32_t b, int32_t x, int32_t y, int32_t z) {
-    return ((uint32_t)x < (1u << 20)) && ((uint32_t)y < (1u << 20)) && ((uint32_t)z < (1u << 20)) && ((uint32_t)b < 16u);
+    // (the one key that equals PCGC_EMPTY_KEY — batch 15 at the far corner of the 2^20 cube — is out of range too)
+    return ((uint32_t)x < (1u << 20)) && ((uint32_t)y < (1u << 20)) && ((uint32_t)z < (1u << 20)) && ((uint32_t)b < 16u) &&
+           !(b == 15 && (x & y & z) == 0xFFFFF);
 }
 __host__ __device__ static inline uint64_t coord_key(int32_t b, int32_t x, int32_t y, int32_t z) {
     return ((uint64_t)b << 60) | ((uint64_t)z << 40) | ((uint64_t)y << 20) | (uint64_t)x;
