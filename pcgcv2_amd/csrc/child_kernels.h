@@ -88,12 +88,14 @@ constexpr bool in02(int v) { return v >= 0 && v <= 2; }
 //      kfirst(t)), which cells feed a tile (active) and which B fragment of the table a (cell, tile) pair multiplies by (frag).
 //      A fragment is lane-linear: lane l holds its KS K-step values contiguously (one ds_read_b32/b64/b128).  With HALF only
 //      8 of a tile's 16 columns are meaningful: lanes of columns 8-15 alias columns 0-7 (their results are never stored).
-template <int NB_, int NT>
+// HZ: -1 = all eight children; 0 / 1 = the four children with that z bit (half units: see k_child_irn_a)
+template <int NB_, int NT, int HZ = -1>
 struct PlainConv {                     // k3 conv Cin = 16 NB -> Cout = 16 NT: tile t = (child j, column tile n), fragment = slice of offset k
     static constexpr int NB = NB_, ROWCHUNKS = 4, T = 8 * NT, KS = 4;
+    static constexpr int Z_HALF = HZ;
     static constexpr bool HALF = false;
     static constexpr int kfirst(int) { return 0; }
-    static constexpr bool active(int c, int t) { return (cell_reach(c) >> (t / NT)) & 1; }
+    static constexpr bool active(int c, int t) { return (HZ < 0 || (((t / NT) >> 2) & 1) == HZ) && ((cell_reach(c) >> (t / NT)) & 1); }
     static constexpr int frag(int c, int t) { return cell_k(c, t / NT) * NT + t % NT; }
     static constexpr bool uses_block(int, int) { return true; }
     static constexpr int NBATCH = 1;
@@ -119,7 +121,7 @@ struct ClsHead {                       // k3 conv C -> 1: one tile, column j (0.
 template <int C, int HZ = -1>
 struct PassA {
     static constexpr int Q = C / 4, NB = C / 16, ROWCHUNKS = 4, CPT = 16 / Q /*children per tile: 4, 2 or 1*/, TH = 8 / CPT, T = 2 * TH, KS = 4;
-    static_assert(HZ < 0 || CPT == 1, "half units exist for one-child tiles only");
+    static_assert(HZ < 0 || CPT <= 2, "half units: tiles of one or two children (a z-half tile holds both halves' columns)");
     static constexpr int Z_HALF = HZ;
     static constexpr bool HALF = false;
     static constexpr int kfirst(int) { return 0; }
@@ -133,6 +135,7 @@ struct PassA {
             return ((cell_reach(c) >> (t - TH)) & 1) && cell_k(c, t - TH) == 13;
         }
         const int kz = cz_of(c) - tz(t);
+        if (HZ >= 0 && tz(t) != HZ) return false;               // (CPT == 2: tile = (jz, jy) quarter)
         if (CPT == 4) {
             if (t < TH) return in02(kz);
             return kz == 1 && (cy_of(c) == 1 || cy_of(c) == 2) && (cx_of(c) == 1 || cx_of(c) == 2);
@@ -157,13 +160,17 @@ struct PassA {
 // InceptionResNet pass B: the gathered rows are t = [relu(conv0_0) | relu(conv1_0)] (2Q wide).  conv0_1 (k3 Q -> 2Q) reads the
 // first Q channels, conv1_1 (k3 Q -> Q) the last Q: with Q = 8 (C = 32) those are K-steps {0,1} / {2,3} of the one 16-channel
 // block, with Q = 4 (C = 16) K-step 0 / 1 of a half-width block.
-template <int C>
+template <int C, int HZ = -1>
 struct PassB {
     static constexpr int Q = C / 4, NB = 1, ROWCHUNKS = Q / 2 /*2Q floats = Q/2 chunks*/, KS = Q / 4;
     static constexpr int CPT0 = 16 / (2 * Q) /*children per conv0_1 tile: 1 or 2*/, T0 = 8 / CPT0, CPT1 = 16 / Q, T1 = 8 / CPT1, T = T0 + T1;
+    static constexpr int Z_HALF = HZ;
+    static_assert(HZ < 0 || CPT1 <= 2, "half units: no tile may hold children of both z halves");
     static constexpr bool HALF = false;
     static constexpr int kfirst(int t) { return t < T0 ? 0 : KS; }
+    static constexpr int tile_z(int t) { return t < T0 ? ((t * CPT0) >> 2) & 1 : (((t - T0) * CPT1) >> 2) & 1; }   // z bit of the tile's children
     static constexpr bool active(int c, int t) {
+        if (HZ >= 0 && tile_z(t) != HZ) return false;
         if (t < T0) {
             if (CPT0 == 1) return (cell_reach(c) >> t) & 1;
             return in02(cz_of(c) - (t >> 1)) && in02(cy_of(c) - (t & 1));           // (jz, jy) quarters
@@ -523,20 +530,19 @@ __device__ __forceinline__ void child_flush(const float* scratch, int rows, int6
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(8 * n_p * in_ld * 4), 0x00020000); \
     const int64_t ntiles = (n_p + 15) >> 4;
 
-// plain conv:  acc[t][r] = out[8 (p0 + 4 mq + r) + j][16 n + mi],  t = j * NT + n
-template <int NB, int NT, int NW, int D>
+template <class T_> struct child_type_tag { using type = T_; };
+// plain conv:  acc[t][r] = out[8 (p0 + 4 mq + r) + j][16 n + mi],  t = j * NT + n.   SPLIT: half units (see k_child_irn_a)
+template <int NB, int NT, int NW, int D, bool SPLIT = false>
 __global__ void __launch_bounds__(NW * 64)
 k_child_conv(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in, int in_ld,
              const float* __restrict__ table, int table_bytes, ChildEpi ep) {
     using V = PlainConv<NB, NT>;
     CHILD_KERNEL_PROLOGUE(V, NW, D, D * NB * 64)
-    for (int i = 0;; ++i) {
-        const int64_t tile = child_tile<NW>(i, wave, ntiles);
-        if (tile < 0) break;
-        const int64_t p0 = tile * 16;
-        CHILD_T(t_it0);
-        f32x4 acc[V::T];
-        child_tile_mainloop<V, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
+    auto unit = [&](auto tag, const int64_t p0) {
+        using VV = typename decltype(tag)::type;
+        constexpr int HZ = VV::Z_HALF;
+        f32x4 acc[VV::T];
+        child_tile_mainloop<VV, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
         // staged epilogue: CH rows (CH / 8 parents) at a time through the ring's LDS
         constexpr int W = 16 * NT, CH = (64 * W * 4 <= D * NB * 1024) ? 64 : 32, PPC = CH / 8, MQC = PPC / 4;   // MQC: lane quarters per chunk
         float* scratch = (float*)ring;
@@ -544,8 +550,9 @@ k_child_conv(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restr
         for (int h = 0; h < 128 / CH; ++h) {
             if (mq / MQC == h) {
 #pragma unroll
-                for (int t = 0; t < V::T; ++t) {
+                for (int t = 0; t < VV::T; ++t) {
                     const int j = t / NT, n = t % NT;
+                    if (HZ >= 0 && ((j >> 2) & 1) != HZ) continue;
                     const float bv = ep.bias ? ep.bias[16 * n + mi] : 0.0f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -556,8 +563,20 @@ k_child_conv(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restr
                 }
             }
             wave_lds_sync();
-            child_flush<W>(scratch, CH, 8 * p0 + h * CH, 8 * n_p, ep.out, ep.out_ld, ep.res, ep.res_ld, ep.relu, lane);
+            child_flush<W>(scratch, CH, 8 * p0 + h * CH, 8 * n_p, ep.out, ep.out_ld, ep.res, ep.res_ld, ep.relu, lane, HZ);
             wave_lds_sync();
+        }
+    };
+    const int64_t nunits = SPLIT ? 2 * ntiles : ntiles;
+    for (int i = 0;; ++i) {
+        const int64_t u = child_tile<NW>(i, wave, nunits);
+        if (u < 0) break;
+        CHILD_T(t_it0);
+        if constexpr (SPLIT) {
+            if (u & 1) unit(child_type_tag<PlainConv<NB, NT, 1>>{}, (u >> 1) * 16);
+            else unit(child_type_tag<PlainConv<NB, NT, 0>>{}, (u >> 1) * 16);
+        } else {
+            unit(child_type_tag<V>{}, u * 16);
         }
 #ifdef PCGC_CHILD_TIMING
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -604,14 +623,13 @@ k_child_cls(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restri
 // SPLIT (C = 64): the level is ~1.14 tiles per SIMD, and a tile is 48 us of one SIMD's MFMA pipe — whole tiles quantise to TWO tile times
 // per launch.  Half units (the four children with z bit 0 / 1 of 16 parents: half the MFMAs, 48 of the 64 cells) quantise to three
 // half-tile times.  Both halves are separate instantiations of the statically unrolled body; a wave picks one per unit.
-template <class T_> struct child_type_tag { using type = T_; };
 template <int C, int NW, int D, bool SPLIT = false>
 __global__ void __launch_bounds__(NW * 64)
 k_child_irn_a(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in, int in_ld,
               const float* __restrict__ table, int table_bytes, IrnEpi ep) {
     using V = PassA<C>;
     constexpr int Q = V::Q, CPT = V::CPT, TH = V::TH;
-    static_assert(!SPLIT || CPT == 1, "half units exist for one-child tiles only");
+    static_assert(!SPLIT || CPT <= 2, "half units: tiles of one or two children");
     CHILD_KERNEL_PROLOGUE(V, NW, D, D * V::NB * 64)
     const int co = mi % Q, sub = mi / Q;                       // column -> (child within the tile, output channel)
     const float b00 = ep.b0[co], b10 = ep.b1[co];
@@ -627,7 +645,7 @@ k_child_irn_a(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
             if (mq / MQC == h) {
 #pragma unroll
                 for (int t = 0; t < TH; ++t) {
-                    if (HZ >= 0 && ((t >> 2) & 1) != HZ) continue;             // (one-child tiles: t is the child)
+                    if (HZ >= 0 && (((t * CPT) >> 2) & 1) != HZ) continue;     // (tile t holds children t CPT ...)
                     const int j = t * CPT + sub;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -664,7 +682,7 @@ k_child_irn_a(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
 //          out[row][2Q:4Q] = (conv1_2(relu(conv1_1(t[:, Q:]) + b11)) + b12) + x[row][2Q:4Q]
 // conv1_2 (k1, Q -> 2Q) is a second, tiny MFMA product: u = relu(conv1_1 + b11) goes through a per-wave LDS scratch (the gather
 // ring, idle by then) from the accumulator layout (lane = column) into A fragments (lane = row), 16 output rows per product.
-template <int C, int NW, int D>
+template <int C, int NW, int D, bool SPLIT = false>
 __global__ void __launch_bounds__(NW * 64)
 k_child_irn_b(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in /* t */, int in_ld,
               const float* __restrict__ table, int table_bytes, IrnEpi ep) {
@@ -681,21 +699,23 @@ k_child_irn_b(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
     float w12[KQ];
 #pragma unroll
     for (int jj = 0; jj < KQ; ++jj) w12[jj] = ((const float*)lds_raw)[V::FRAG_W12 * frag_floats<V>() + lane * KQ + jj];
-    for (int i = 0;; ++i) {
-        const int64_t tile = child_tile<NW>(i, wave, ntiles);
-        if (tile < 0) break;
-        const int64_t p0 = tile * 16;
-        CHILD_T(t_it0);
-        f32x4 acc[V::T];
-        child_tile_mainloop<V, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
+    // one unit: a whole tile, or (SPLIT) the four children with one z bit of its 16 parents — see k_child_irn_a.  In a half unit the other
+    // half's rows of the scratch hold stale values: they go through conv1_2 like the rest and are never stored.
+    auto unit = [&](auto tag, const int64_t p0) {
+        using VV = typename decltype(tag)::type;
+        constexpr int HZ = VV::Z_HALF;
+        f32x4 acc[VV::T];
+        child_tile_mainloop<VV, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
         // ---- u = relu(conv1_1 + b11) -> scratch us [local row = 8 (4 mq + r) + child][Q]
         {
             const int c1 = mi % Q, sub1 = mi / Q;
             const float b11 = ep.b1[c1];
 #pragma unroll
-            for (int u = 0; u < T1; ++u)
+            for (int u = 0; u < T1; ++u) {
+                if (HZ >= 0 && VV::tile_z(T0 + u) != HZ) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) us[(8 * (4 * mq + r) + u * CPT1 + sub1) * Q + c1] = fmaxf(acc[T0 + u][r] + b11, 0.0f);
+            }
         }
         wave_lds_sync();
         // ---- CH rows at a time: [conv0_1 + b01 | conv1_2(u) + b12] staged row-major, then flushed with the residual x
@@ -708,6 +728,7 @@ k_child_irn_b(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
                 if (mq / MQC == h) {
 #pragma unroll
                     for (int t = 0; t < T0; ++t) {
+                        if (HZ >= 0 && VV::tile_z(t) != HZ) continue;
                         const int j = t * CPT0 + sub0;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) stage[(8 * (4 * (mq % MQC) + r) + j) * C + c0] = acc[t][r] + b01;
@@ -725,9 +746,21 @@ k_child_irn_b(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
                     }
                 }
                 wave_lds_sync();
-                child_flush<C>(stage, CH, 8 * p0 + h * CH, 8 * n_p, ep.out, ep.out_ld, ep.x, ep.x_ld, 0, lane);
+                child_flush<C>(stage, CH, 8 * p0 + h * CH, 8 * n_p, ep.out, ep.out_ld, ep.x, ep.x_ld, 0, lane, HZ);
                 wave_lds_sync();
             }
+        }
+    };
+    const int64_t nunits = SPLIT ? 2 * ntiles : ntiles;
+    for (int i = 0;; ++i) {
+        const int64_t u = child_tile<NW>(i, wave, nunits);
+        if (u < 0) break;
+        CHILD_T(t_it0);
+        if constexpr (SPLIT) {
+            if (u & 1) unit(child_type_tag<PassB<C, 1>>{}, (u >> 1) * 16);
+            else unit(child_type_tag<PassB<C, 0>>{}, (u >> 1) * 16);
+        } else {
+            unit(child_type_tag<V>{}, u * 16);
         }
 #ifdef PCGC_CHILD_TIMING
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -850,6 +883,21 @@ int launch_child_conv(const int32_t* pnbr, int64_t n_p, const float* in, int in_
                       const ChildEpi& ep, hipStream_t s) {
     CHILD_LAUNCH((k_child_conv<NB, NT, NW, D>), NW, D * NB * 1024, ep);
 }
+// half units: twice the work items per tile
+#define CHILD_LAUNCH_SPLIT(KERN, NW, RINGBYTES, EP)                                                                            \
+    do {                                                                                                                       \
+        const size_t lds = (size_t)table_bytes + (size_t)(NW) * (RINGBYTES);                                                   \
+        auto kern = KERN;                                                                                                      \
+        static ChildLdsGrant granted;                                                                                          \
+        if (int rc = child_lds_limit(kern, lds, granted)) return rc;                                                           \
+        hipLaunchKernelGGL(kern, dim3(child_grid(n_p, NW, lds, 2)), dim3((NW) * 64), lds, s, pnbr, n_p, in, in_ld, table, table_bytes, EP); \
+        return 0;                                                                                                              \
+    } while (0)
+template <int NB, int NT, int NW, int D>
+int launch_child_conv_split(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
+                            const ChildEpi& ep, hipStream_t s) {
+    CHILD_LAUNCH_SPLIT((k_child_conv<NB, NT, NW, D, true>), NW, D * NB * 1024, ep);
+}
 template <int NB, int NW, int D>
 int launch_child_cls(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
                      const ChildEpi& ep, hipStream_t s) {
@@ -877,6 +925,14 @@ int launch_child_irn_b(const int32_t* pnbr, int64_t n_p, const float* in, int in
     constexpr int need = (128 * Q + CH * C) * 4;
     constexpr int ringb = (D * 1024 > need) ? D * 1024 : need;
     CHILD_LAUNCH((k_child_irn_b<C, NW, D>), NW, ringb, ep);
+}
+template <int C, int NW, int D>
+int launch_child_irn_b_split(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
+                             const IrnEpi& ep, hipStream_t s) {
+    constexpr int Q = C / 4, CH = ((128 * Q + 64 * C) * 4 <= D * 1024) ? 64 : 32;
+    constexpr int need = (128 * Q + CH * C) * 4;
+    constexpr int ringb = (D * 1024 > need) ? D * 1024 : need;
+    CHILD_LAUNCH_SPLIT((k_child_irn_b<C, NW, D, true>), NW, ringb, ep);
 }
 
 template <int NW, int D>
