@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Serving throughput (4 frames in flight, shard.code_units) under different host / kernel settings, several repetitions each."""
+"""Serving throughput (4 frames in flight, shard.code_units) for different sizes of the entropy-decoder pools, five repetitions each."""
 import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,11 +24,7 @@ def run():
     t = time.perf_counter(); shard.code_units(coder, units, in_flight=4); torch.cuda.synchronize()
     return n / (time.perf_counter() - t) / 1e6
 run()
-orig = ops.set_child_units
-for label, rc_threads, force_half in (('pools 8 threads, whole tiles', 8, False), ('pools 8 threads, half units', 8, True), ('pools 1 thread, whole tiles', 1, False),
-                                      ('pools 3 threads, whole tiles', 3, False)):
+for rc_threads in (8, 3, 1):
     ops.set_rc_threads(rc_threads)
-    ops.set_child_units = (lambda whole: orig(False)) if force_half else orig
     vals = [run() for _ in range(5)]
-    print(f'{label:34s}: ' + ' '.join(f'{v:6.1f}' for v in vals) + f'   median {sorted(vals)[2]:.1f} Mpoints/s')
-ops.set_child_units = orig
+    print(f'entropy pools of {rc_threads} thread(s): ' + ' '.join(f'{v:6.1f}' for v in vals) + f'   median {sorted(vals)[2]:.1f} Mpoints/s')
