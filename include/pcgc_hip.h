@@ -150,6 +150,10 @@ int pcgc_set_irn_split(int on);
 /* C = 32 pass A gathers 16 instead of 32 channels per sub-step on levels of at least `min_rows` rows (default 400 000; 0 =
  * always, negative = default).  Bit-identical; a speed/occupancy trade measured per level size. */
 int pcgc_set_irn_cb16_rows(int64_t min_rows);
+/* The LDS-shared-weight MFMA gather conv (k3 64->64 / 32->32, autoencoder.py:109-115,162-168) runs four 16-row M tiles per
+ * wave on levels of at least `min_rows` rows (default 400 000: the vox11 / vox12 levels of configs 4 and 5), two below
+ * (0 = always four, negative = default).  Bit-identical; the switch lets tests reach the large-level instantiation on small clouds. */
+int pcgc_set_wlds_mt4_rows(int64_t min_rows);
 /* Fused InceptionResNet block (autoencoder.py:7-57):  out = cat(conv0_1(relu(conv0_0 x)), conv1_2(relu(conv1_1(relu(conv1_0 x))))) + x
  * in two gather passes.  params[10] = {conv0_0.kernel, .bias, conv0_1.kernel, .bias, conv1_0.kernel, .bias, conv1_1.kernel,
  * .bias, conv1_2.kernel, .bias} (ME layouts).  t_scratch: [n, C/2] fp32 workspace.  Bit-identical to the five

@@ -48,6 +48,7 @@ SIGNATURES = {
     'pcgc_set_irn_rows': (ci, [ci]),
     'pcgc_set_irn_split': (ci, [ci]),
     'pcgc_set_irn_cb16_rows': (ci, [i64]),
+    'pcgc_set_wlds_mt4_rows': (ci, [i64]),
     'pcgc_irn_block': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, ci, vp]),
     'pcgc_conv_gather_masked': (ci, [vp, i64, vp, i64, ci, ci, vp, ci, vp, vp, ci, vp, ci, vp]),
     'pcgc_irn_tail': (ci, [vp, vp, ci, ci, vp, vp, vp, ci, i64, vp]),

@@ -41,35 +41,50 @@ def _slurp(path):
         return fh.read()
 
 
-# ---- decoding index of `_F.bin` (not part of the reference's format; see FeatureCoder) -------------------------------------------
-# A range-coded stream is sequential only because the decoder state at a later symbol is unknown.  The encoder knows it: next to
-# `_F.bin` (bit-identical to the reference's stream, decodable by torchac and by this package without the sidecar) it writes
-# `_F.idx` — the decoder state at INDEX_SEGMENTS row boundaries, 24 bytes each — and the decoder decodes the segments on several
-# threads (1.4 ms -> ~0.3 ms for the 150 k latent symbols of a vox10 frame).  The sidecar names the stream it belongs to by length and
-# CRC-32; one that does not match (or is absent: a reference-made stream) is ignored and the stream is decoded serially.
-INDEX_SEGMENTS = 8                               # 0 = never write or read the sidecar
+# ---- sidecar of `_F.bin` (not part of the reference's format; see FeatureCoder) ---------------------------------------------------
+# (1) Decoding index.  A range-coded stream is sequential only because the decoder state at a later symbol is unknown.  The
+# encoder knows it: next to `_F.bin` (bit-identical to the reference's stream, decodable by torchac and by this package without
+# the sidecar) it writes `_F.idx` — the decoder state at INDEX_SEGMENTS row boundaries, 24 bytes each — and the decoder decodes
+# the segments on several threads (1.4 ms -> ~0.3 ms for the 150 k latent symbols of a vox10 frame).
+# (2) Table guard.  The uint16 CDF table is evaluated with torch's CPU kernels (the reference's arithmetic, entropy_model.py
+# docstring), which are not bit-reproducible across CPU kinds / torch builds: a stream coded on one host can meet a table that
+# differs by one count on another and decode to garbage without any error.  The sidecar carries the CRC-32 of the encoder's
+# table; a decoder that derives a different table REFUSES the stream instead of returning noise.
+# The sidecar names the stream it belongs to by length and CRC-32 and carries a CRC over itself; one that does not match (or is
+# absent: a reference-made stream) is ignored and the stream is decoded serially, unguarded — exactly what the reference does.
+INDEX_SEGMENTS = 8                               # checkpoints per stream; 0 = never write or read the sidecar
 INDEX_SUFFIX = '_F.idx'
-_INDEX_HEAD = struct.Struct('<4sIII')            # magic, stream bytes, stream CRC-32, checkpoints
+_INDEX_HEAD = struct.Struct('<4sIIIII')          # magic, stream bytes, stream CRC-32, checkpoints, table CRC-32, CRC-32 of (head so far + body)
 
 
-def _pack_index(payload, index):
+def _pack_index(payload, index, table_crc=0):
     import zlib
-    idx = np.ascontiguousarray(index, dtype='<u4')
-    return _INDEX_HEAD.pack(b'PCGI', len(payload), zlib.crc32(payload), idx.shape[0]) + idx.tobytes()
+    idx = np.ascontiguousarray(np.zeros((0, ops.RC_CKPT_WORDS)) if index is None else index, dtype='<u4')
+    head = struct.pack('<4sIIII', b'PCG2', len(payload), zlib.crc32(payload), idx.shape[0], int(table_crc) & 0xFFFFFFFF)
+    body = idx.tobytes()
+    return head + struct.pack('<I', zlib.crc32(head + body)) + body
 
 
-def _load_index(path, payload):
+def _load_sidecar(path, payload):
+    """-> (index uint32 [k, RC_CKPT_WORDS] or None, table CRC-32 or None); (None, None) unless the file is intact AND belongs to
+    `payload`."""
     import zlib
     try:
         blob = _slurp(path)
     except OSError:
-        return None
+        return None, None
     if len(blob) < _INDEX_HEAD.size:
-        return None
-    magic, nbytes, crc, count = _INDEX_HEAD.unpack(blob[:_INDEX_HEAD.size])
-    if magic != b'PCGI' or nbytes != len(payload) or len(blob) != _INDEX_HEAD.size + count * 4 * ops.RC_CKPT_WORDS or crc != zlib.crc32(payload):
-        return None
-    return np.frombuffer(blob, dtype='<u4', offset=_INDEX_HEAD.size).reshape(count, ops.RC_CKPT_WORDS)
+        return None, None
+    magic, nbytes, crc, count, table_crc, self_crc = _INDEX_HEAD.unpack(blob[:_INDEX_HEAD.size])
+    if (magic != b'PCG2' or nbytes != len(payload) or len(blob) != _INDEX_HEAD.size + count * 4 * ops.RC_CKPT_WORDS
+            or self_crc != zlib.crc32(blob[:_INDEX_HEAD.size - 4] + blob[_INDEX_HEAD.size:]) or crc != zlib.crc32(payload)):
+        return None, None
+    index = np.frombuffer(blob, dtype='<u4', offset=_INDEX_HEAD.size).reshape(count, ops.RC_CKPT_WORDS) if count >= 2 else None
+    return index, table_crc
+
+
+def _load_index(path, payload):
+    return _load_sidecar(path, payload)[0]
 
 
 def index_bits(prefix, postfix=''):
@@ -139,13 +154,16 @@ class FeatureCoder():
         n, c = feats.shape
         segments = min(int(INDEX_SEGMENTS), n // 2048)           # (a segment shorter than ~16 k symbols is not worth a thread)
         index_path = self.filename + postfix + INDEX_SUFFIX
+        info = {}
         if segments >= 2:
-            payload, min_v, max_v, index = self.entropy_model.compress(feats, checkpoints=segments)
-            _dump(index_path, _pack_index(payload, index))
+            payload, min_v, max_v, index = self.entropy_model.compress(feats, checkpoints=segments, info=info)
         else:
-            payload, min_v, max_v = self.entropy_model.compress(feats)
-            if os.path.exists(index_path):
-                os.remove(index_path)                                 # never leave an index of an older stream behind
+            payload, min_v, max_v = self.entropy_model.compress(feats, info=info)
+            index = None
+        if INDEX_SEGMENTS:
+            _dump(index_path, _pack_index(payload, index, info['table_crc']))
+        elif os.path.exists(index_path):
+            os.remove(index_path)                                     # never leave a sidecar of an older stream behind
         _dump(self.filename + postfix + '_F.bin', payload)
         _dump(self.filename + postfix + '_H.bin', _HEADER.pack(n, c, len(min_v), float(min_v[0]), float(max_v[0])))
 
@@ -154,9 +172,9 @@ class FeatureCoder():
         if n_minv != 1:
             raise ValueError('unsupported _H.bin: expected one (min_v, max_v) pair')
         payload = _slurp(self.filename + postfix + '_F.bin')
-        index = _load_index(self.filename + postfix + INDEX_SUFFIX, payload) if INDEX_SEGMENTS else None
+        index, table_crc = _load_sidecar(self.filename + postfix + INDEX_SUFFIX, payload) if INDEX_SEGMENTS else (None, None)
         return self.entropy_model.decompress(payload, np.float32(min_v), np.float32(max_v), (n, c), channels=c, device=device,
-                                             on_table_launched=on_table_launched, index=index)
+                                             on_table_launched=on_table_launched, index=index, expect_table_crc=table_crc)
 
 
 class Coder():

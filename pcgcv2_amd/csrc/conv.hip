@@ -1426,6 +1426,8 @@ static int g_auto_wlds = 1;         // auto: LDS-shared-weight MFMA kernel for 6
                                     // bank-conflict free, 32->32 (181 -> 168 us at 256 k rows, 400 -> 374 at 570 k)
 static int g_auto_mfma = 1;         // auto mode uses the MFMA kernel for its eligible shapes once A/B says so
 extern "C" int pcgc_set_conv_impl(int impl) { g_conv_impl = impl; return 0; }
+static int64_t g_wlds_mt4_rows = 400000;   // the LDS-shared-weight MFMA kernel runs 4 M-tiles per wave (MT = 4) from this many rows on, 2 below
+extern "C" int pcgc_set_wlds_mt4_rows(int64_t min_rows) { g_wlds_mt4_rows = min_rows < 0 ? 400000 : min_rows; return 0; }
 
 extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int Cin, int in_ld,
                                 int in_coff, const float* W, const float* bias, const float* residual, int res_ld, int res_coff,
@@ -1447,12 +1449,12 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
         const bool pipe = g_mfma_pipe > 0 || (g_mfma_pipe < 0 && n_out < 110000);        // 64->64: 248 -> 220 us at 71 k rows, 381 -> 395 at 150 k
         if (Cin == 64 && pipe) launch_mfma_pipe<64, 64, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         else if (Cin == 64) {
-            if (n_out < 400000) launch_mfma_wlds<64, 64, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+            if (n_out < g_wlds_mt4_rows) launch_mfma_wlds<64, 64, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
             else launch_mfma_wlds<64, 64, 4>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         } else if (g_mfma_pipe > 0) {
             launch_mfma_pipe<32, 32, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         } else {
-            if (n_out < 400000) launch_mfma_wlds<32, 32, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+            if (n_out < g_wlds_mt4_rows) launch_mfma_wlds<32, 32, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
             else launch_mfma_wlds<32, 32, 4>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         }
         PCGC_CHECK_LAUNCH("conv_gather_mfma_wlds");

@@ -448,6 +448,11 @@ def set_irn_cb16_rows(min_rows):
     check(lib().pcgc_set_irn_cb16_rows(int(min_rows)), 'set_irn_cb16_rows')
 
 
+def set_wlds_mt4_rows(min_rows):
+    """k3 64->64 / 32->32 gather conv: 4 M-tiles per wave on levels of at least `min_rows` rows (negative = default 400 000, 0 = always)."""
+    check(lib().pcgc_set_wlds_mt4_rows(int(min_rows)), 'set_wlds_mt4_rows')
+
+
 def _irn_config(C, n):
     """(rows per wave tile, pass-A channels per sub-step) the library picks for this level: asked, not re-derived."""
     import ctypes

@@ -158,19 +158,32 @@ def test_entropy_pools_under_concurrent_callers():
 
 
 def test_feature_index_sidecar_is_tied_to_its_stream(tmp_path):
-    """coder._pack_index / _load_index: the sidecar is used only for the stream it was written with."""
+    """coder._pack_index / _load_sidecar: the sidecar is used only for the stream it was written with, and only if it is intact —
+    a damaged checkpoint word (header untouched) must not reach the decoder (the body is covered by a CRC)."""
     from pcgcv2_amd import coder
     index = np.arange(2 * ops.RC_CKPT_WORDS, dtype=np.uint32).reshape(2, -1)
     path = str(tmp_path / 'x_F.idx')
+    blob = coder._pack_index(b'stream-bytes', index, table_crc=0xDEADBEEF)
     with open(path, 'wb') as fh:
-        fh.write(coder._pack_index(b'stream-bytes', index))
-    np.testing.assert_array_equal(coder._load_index(path, b'stream-bytes'), index)
+        fh.write(blob)
+    got, crc = coder._load_sidecar(path, b'stream-bytes')
+    np.testing.assert_array_equal(got, index)
+    assert crc == 0xDEADBEEF
     assert coder._load_index(path, b'stream-bytez') is None          # same length, other content
     assert coder._load_index(path, b'stream-bytes+') is None
     assert coder._load_index(str(tmp_path / 'missing.idx'), b'stream-bytes') is None
+    for pos in (len(blob) - 3, 17):                                   # a flipped bit in a checkpoint word / in the table-CRC field
+        bad = bytearray(blob); bad[pos] ^= 0x10
+        with open(path, 'wb') as fh:
+            fh.write(bytes(bad))
+        assert coder._load_sidecar(path, b'stream-bytes') == (None, None)
     with open(path, 'wb') as fh:
-        fh.write(b'PCGI')                                             # truncated
+        fh.write(b'PCG2')                                             # truncated
     assert coder._load_index(path, b'stream-bytes') is None
+    # a sidecar without checkpoints (short streams) still carries the table guard
+    with open(path, 'wb') as fh:
+        fh.write(coder._pack_index(b'stream-bytes', None, table_crc=7))
+    assert coder._load_sidecar(path, b'stream-bytes') == (None, 7)
 
 
 def test_range_coder_rejects_out_of_table_symbol():
