@@ -77,9 +77,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     backend = os.environ.get('PCGC_DIST_BACKEND', 'nccl')      # 'nccl' = RCCL over xGMI; 'gloo' only to test the path on 1 GPU
-    if world > 1:
+    # PCGC_DIST_FORCE=1: create the process group and issue every collective even with ONE rank, so that the RCCL path (communicator
+    # set-up, the two all-reduces, the padded all-gather of decoded coordinates) executes on the device where only one GPU exists
+    dist_on = world > 1 or os.environ.get('PCGC_DIST_FORCE', '0') == '1'
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
@@ -88,8 +92,10 @@ def main():
     red_dev = dev if backend == 'nccl' else torch.device('cpu')
 
     import pcgcv2_amd
-    pcgcv2_amd.configure_host_threads(local_world=world)          # one node: the ranks share its CPUs (quota-aware pool sizes)
+    # one node: the ranks share its CPUs (quota-aware pool sizes); with several ranks each is pinned to its GPU's NUMA-local CPUs
+    host_threads = pcgcv2_amd.configure_host_threads(local_world=world, pin_device=local if world > 1 else None)
     from pcgcv2_amd import synthetic, ops, shard
+    shard.FORCE_COLLECTIVES = dist_on and world == 1
     from pcgcv2_amd.pcc_model import PCCModel
     from pcgcv2_amd.coder import Coder, STREAMS
     from pcgcv2_amd.data_utils import scale_sparse_tensor
@@ -136,6 +142,7 @@ def main():
         scaling = 'strong'
         desc = (f'{base}: vox12 cloud ({len(whole)} points) scaled by 0.375 -> {len(x_in)} points, {len(blocks)} octant blocks '
                 f'round-robin over {world} GPU(s)')
+        whole_C = whole.C
         del whole
     n_points = sum(len(u) for _, u in units)
     tmp = tempfile.mkdtemp(prefix=f'pcgc_bench_r{rank}_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
@@ -166,7 +173,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -235,9 +242,31 @@ def main():
     # serving mode (reported beside the headline, never as `value`): several frames in flight per GPU — each on its own host
     # thread + HIP stream (shard.code_units(in_flight=F)) — so one frame's sequential host stages and small-level kernels
     # overlap with the other frames' GPU work.  Results are byte-identical to sequential coding (tests/test_gpu_parity.py).
+    # the same K steps on the reference's four files alone (no `_F.idx` sidecar: the feature stream is decoded serially, exactly as a
+    # reference-made stream would be) — reported beside `value`, so rate and speed of BOTH configurations are on the line
+    plain = None
+    if cfg == 'frame':
+        from pcgcv2_amd import coder as coder_mod
+        keep_segments, coder_mod.INDEX_SEGMENTS = coder_mod.INDEX_SEGMENTS, 0
+        try:
+            step()
+            barrier()
+            t_p = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            dt_p = time.perf_counter() - t_p
+        finally:
+            coder_mod.INDEX_SEGMENTS = keep_segments
+        plain = {'value': round(n_coded * args.steps / dt_p / 1e6, 4), 'unit': 'Mpoints/s', 'ms_per_step': round(dt_p / args.steps * 1e3, 3),
+                 'note': 'this rank, the reference format only (INDEX_SEGMENTS = 0: no sidecar written or read, `_F.bin` decoded by one thread)'}
+        step()                                           # leave the files of the default configuration behind
+
     serving = None
     if cfg == 'frame' and world == 1 and args.serving_frames > 0:
         model.load_state_dict(sd)
+        # thread budget of the serving mode: frames x (launcher + coordinate helper + range-decoder helpers + ATen) <= CPU quota
+        serving_threads = pcgcv2_amd.configure_host_threads(local_world=world, frames_in_flight=args.serving_in_flight)
         s_units = [(f's{i}', cloud(variants[i % len(variants)])) for i in range(args.serving_frames)]
 
         def fresh(us):
@@ -247,17 +276,20 @@ def main():
         shard.code_units(coder, fresh(s_units[:args.serving_in_flight]), in_flight=args.serving_in_flight)       # warm the worker path
         torch.cuda.synchronize()
         n_s = sum(len(u) for _, u in s_units)
-        dt_s = float('inf')
-        for _ in range(2):                           # best of two passes: the figure is auxiliary
+        dts = []
+        for _ in range(3):                           # best of three passes (all reported): the figure is auxiliary
             fresh(s_units)
             t_s = time.perf_counter()
             shard.code_units(coder, s_units, in_flight=args.serving_in_flight)
             torch.cuda.synchronize()
-            dt_s = min(dt_s, time.perf_counter() - t_s)
+            dts.append(time.perf_counter() - t_s)
+        dt_s = min(dts)
         serving = {'frames_in_flight': args.serving_in_flight, 'frames': len(s_units), 'value': round(n_s / dt_s / 1e6, 3), 'unit': 'Mpoints/s',
-                   'note': 'independent vox10 frames coded concurrently on one GPU (own thread + HIP stream each), best of 2 passes; '
+                   'passes_Mpoints_s': [round(n_s / d / 1e6, 1) for d in dts], 'host_threads': serving_threads,
+                   'note': 'independent vox10 frames coded concurrently on one GPU (own thread + HIP stream each), best of 3 passes; '
                            'the headline `value` is the single-frame-at-a-time rate'}
         del s_units
+        pcgcv2_amd.configure_host_threads(local_world=world)
     elif cfg in ('batch4', 'blocks') and args.serving_in_flight > 1 and len(units) > 1:
         # the same units of this rank, several in flight (blocks / frames are independent; only the single-unit latency needs them one by one)
         for _, u in units:
@@ -289,21 +321,32 @@ def main():
                     'note': 'host octree coder alone (one unit); overlapped with GPU work inside a step'}
 
     enc_t, dec_t = timers
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed, enc_t, dec_t], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, enc_t, dec_t = [float(v) for v in t.tolist()]
-        tot = torch.tensor([float(n_coded), float(n_out), float(bits), float(n_points)], dtype=torch.float64, device=red_dev)
+        tot = torch.tensor([float(n_coded), float(n_out), float(bits), float(n_points), float(index_bits)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_coded, total_out, total_bits, total_points = [float(v) for v in tot.tolist()]
+        total_coded, total_out, total_bits, total_points, total_index_bits = [float(v) for v in tot.tolist()]
     else:
-        total_coded, total_out, total_bits, total_points = float(n_coded), float(n_out), float(bits), float(n_points)
+        total_coded, total_out, total_bits, total_points, total_index_bits = float(n_coded), float(n_out), float(bits), float(n_points), float(index_bits)
 
     # quality of this rank's first unit (outside the timed region, as coder.py:180-182): D1 on the GPU
     d1 = None
     if units and cfg != 'blocks':
         from pcgcv2_amd.pc_error import d1_psnr_device
         d1 = d1_psnr_device(units[0][1].C, outs[0].C, {'shell11': 2048, 'shell12': 4096}.get(base, 1024))
+    elif cfg == 'blocks':
+        # exact GLOBAL D1 of the blocked cloud (SURVEY 8e caveat b: a per-block D1 misses nearest neighbours across block borders):
+        # every rank's decoded blocks travel to rank 0 in one padded all-gather (shard.gather_varlen: RCCL over xGMI), are scaled back
+        # (coder.py:166) and compared with the original cloud there
+        from pcgcv2_amd.pc_error import d1_psnr_device
+        mine_dec = torch.cat([o.C for o in outs], 0) if outs else torch.zeros((0, 4), dtype=torch.int32, device=dev)
+        all_dec = shard.gather_varlen(mine_dec.contiguous(), dst=0)
+        if rank == 0:
+            dec = SparseTensor(torch.ones((len(all_dec), 1), device=dev), coordinates=all_dec, tensor_stride=1, device=dev)
+            back = scale_sparse_tensor(dec, 1.0 / 0.375)
+            d1 = d1_psnr_device(whole_C, back.C, 4096)
     if rank == 0:
         value = total_coded * args.steps / elapsed / 1e6
         nbar = None
@@ -319,14 +362,20 @@ def main():
                        'points_in_per_step_all_gpus': int(total_points), 'points_coded_per_step_all_gpus': int(total_coded),
                        'enc_ms': round(enc_t / args.steps * 1e3, 3), 'dec_ms': round(dec_t / args.steps * 1e3, 3),
                        'enc_plus_dec_s_per_step': round((enc_t + dec_t) / args.steps, 4),
-                       'bpp': round(total_bits / max(total_coded, 1), 5), 'points_out': int(total_out),
-                       'bpp_incl_decoding_index_rank0': round((bits + index_bits) / max(n_coded, 1), 5),
+                       'bpp': round((total_bits + total_index_bits) / max(total_coded, 1), 5), 'points_out': int(total_out),
+                       'bpp_note': '`bpp` counts everything the timed configuration writes: the reference\'s four files AND the `_F.idx` sidecar '
+                                   '(decoding index + table guard); `bpp_reference_files_only` is the four files, the rate `reference_format_only` codes at',
+                       'bpp_reference_files_only': round(total_bits / max(total_coded, 1), 5),
+                       'reference_format_only': plain, 'host_threads': host_threads,
                        'entropy_decode': '`_F.bin` (bit-identical to the reference-format stream, decodable without it) comes with a sidecar '
                                          '`_F.idx` of decoder states at 8 row boundaries: its segments are decoded on 8 threads; `_C.bin` '
                                          '(native octree, tmc3 absent) is coded as up to 8 independent groups of subtrees',
                        'coord_codec': 'native-octree (tmc3 absent)', 'coord_coder_ms': coord_ms, 'serving_throughput': serving,
                        'step_ms_rank0': step_ms,
                        'd1_psnr_rank0_db': None if d1 is None else round(d1['mseF,PSNR (p2point)'], 4),
+                       'd1_scope': 'whole blocked cloud, decoded blocks gathered to rank 0 (shard.gather_varlen)' if cfg == 'blocks' else "this rank's first unit",
+                       'rccl_loaded': any('librccl' in l for l in open('/proc/self/maps')),
+                       'collectives': ('RCCL' if backend == 'nccl' else backend) + (' (forced with one rank)' if dist_on and world == 1 else '') if dist_on else 'none (single process)',
                        'caveats': 'synthetic random weights: the decoder keeps the wrong voxels, so D1 only shows that the metric path runs, and bpp '
                                   '(~1.0) is ~11x the 0.093 of the real r3 checkpoint; the mean kernel-map occupancy of the dominant level is '
                                   f'{nbar} neighbours per row here against 18.7 probed for true geometry (SURVEY 8d) — a real checkpoint would see '
@@ -341,7 +390,7 @@ def main():
             with open(args.detail, 'w') as f:
                 json.dump(warm_detail, f, indent=1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -26,16 +26,72 @@ def effective_cpus():
     return n
 
 
-def configure_host_threads(max_threads=4, local_world=None):
+def _parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]"""
+    cpus = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus += list(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def numa_cpus_of_gpu(pci_bus_id, sysfs='/sys'):
+    """CPUs of the NUMA node a GPU hangs off, from sysfs (`<sysfs>/bus/pci/devices/<domain:bus:dev.fn>/numa_node` ->
+    `<sysfs>/devices/system/node/node<N>/cpulist`); None if the platform does not say (single node, or numa_node = -1)."""
+    import os
+    try:
+        node = int(open(os.path.join(sysfs, 'bus/pci/devices', pci_bus_id.lower(), 'numa_node')).read())
+        if node < 0:
+            return None
+        return _parse_cpulist(open(os.path.join(sysfs, f'devices/system/node/node{node}/cpulist')).read()) or None
+    except (OSError, ValueError):
+        return None
+
+
+def pin_to_gpu_numa_node(device_index):
+    """Restrict this process (one rank per GPU) to the CPUs of its GPU's NUMA node: the host stages of the codec — range coder,
+    octree coder, table evaluation, pinned staging copies — then run next to the memory and the PCIe root port they use, and
+    the eight ranks of a node do not migrate across sockets.  -> the CPU list applied, or None if nothing was changed (unknown
+    topology, or the intersection with the current affinity mask is empty)."""
+    import os
+    import torch
+    if not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bus = f'{getattr(p, "pci_domain_id", 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0'
+    except (AttributeError, RuntimeError, AssertionError):
+        return None
+    cpus = numa_cpus_of_gpu(bus)
+    if not cpus:
+        return None
+    allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+    if not allowed:
+        return None
+    os.sched_setaffinity(0, allowed)
+    return allowed
+
+
+def configure_host_threads(max_threads=4, local_world=None, frames_in_flight=1, pin_device=None):
     """The host side of the codec is a single-threaded launcher + sequential entropy coder (+ a few short-lived helper threads for the
     indexed entropy decoders); keep torch's CPU thread pool small so its workers do not spin away the container's CPU quota, and size
     the decoder pools from this process's SHARE of the CPUs: `local_world` = processes on this node that share them (one rank per GPU;
-    default: LOCAL_WORLD_SIZE or 1)."""
+    default: LOCAL_WORLD_SIZE or 1), `frames_in_flight` = frames this process codes concurrently (shard.code_units(in_flight=F)):
+    the budget is   frames x (1 launcher + 1 coordinate helper + range-decoder helpers + ATen threads)  <=  this process's CPUs.
+    `pin_device` (GPU index): also pin the process to that GPU's NUMA-local CPUs (multi-rank nodes).
+    -> dict of what was applied."""
     import os
     import torch
     if local_world is None:
         local_world = int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1)
+    pinned = pin_to_gpu_numa_node(pin_device) if pin_device is not None else None
     cpus = max(1, effective_cpus() // max(1, int(local_world)))
-    torch.set_num_threads(max(1, min(max_threads, cpus)))
+    per_frame = max(1, cpus // max(1, int(frames_in_flight)))
+    aten = max(1, min(max_threads, per_frame - 2)) if frames_in_flight > 1 else max(1, min(max_threads, cpus))
+    rc = max(1, min(8, per_frame - 2))
+    torch.set_num_threads(aten)
     from . import ops
-    ops.set_rc_threads(max(1, min(8, cpus - 2)))                 # segments of an indexed `_F.bin` / groups of `_C.bin` decoded side by side
+    ops.set_rc_threads(rc)                                       # segments of an indexed `_F.bin` / groups of `_C.bin` decoded side by side
+    return {'cpus': cpus, 'frames_in_flight': int(frames_in_flight), 'aten_threads': aten, 'rc_threads': rc, 'pinned_cpus': pinned}

@@ -8,7 +8,10 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <sched.h>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -263,6 +266,7 @@ class SegmentPool {
     std::vector<std::thread> workers; std::mutex m; std::condition_variable work, done;
     std::mutex serial;                                 // one run() at a time per pool
     const std::function<void(int)>* job = nullptr; int n_tasks = 0; std::atomic<int> next{0}; int active = 0; uint64_t gen = 0; bool stop = false;
+    int wanted = 0, joined = 0;                        // helpers this run asked for / workers that have joined it (tickets)
     static void drain(const std::function<void(int)>& fn, std::atomic<int>& next, int n) { for (int i; (i = next.fetch_add(1)) < n;) fn(i); }
     void loop() {
         uint64_t seen = 0;
@@ -273,6 +277,8 @@ class SegmentPool {
             seen = gen;
             const std::function<void(int)>* fn = job;  // null once run() has finished: a worker that wakes late has nothing to do,
             if (!fn) continue;                         // and run() does not wait for it
+            if (joined >= wanted) continue;            // the run asked for fewer helpers than the pool has grown to (pcgc_set_rc_threads)
+            ++joined;
             const int n = n_tasks;
             ++active;
             lk.unlock();
@@ -289,7 +295,7 @@ public:
         {
             std::lock_guard<std::mutex> lk(m);
             while ((int)workers.size() < helpers) workers.emplace_back([this] { loop(); });
-            job = &fn; n_tasks = tasks; next.store(0); ++gen;
+            job = &fn; n_tasks = tasks; next.store(0); wanted = helpers; joined = 0; ++gen;
         }
         work.notify_all();
         drain(fn, next, tasks);                        // returns once every task has been taken
@@ -301,10 +307,31 @@ public:
 SegmentPool& segment_pool() { static SegmentPool p; return p; }     // range decoder
 SegmentPool& octree_pool() { static SegmentPool p; return p; }      // coordinate codec: its own threads, the two decode side by side
 int g_rc_threads = 0;                                  // 0 = automatic: min(8, hardware threads)
+// CPUs this process may really use: the cgroup CPU quota (v2 cpu.max, v1 cfs_quota/period) and the affinity mask, not the
+// advertised core count (a 16-CPU container on a 256-thread host)
+int effective_cpus() {
+    static int cached = 0;
+    if (cached) return cached;
+    unsigned hw = std::thread::hardware_concurrency();
+    long n = hw ? (long)hw : 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0 && a < n) n = a; }
+    long quota = -1, period = -1;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        if (std::fscanf(f, "%63s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atol(q);
+        std::fclose(f);
+    } else {
+        if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(g, "%ld", &quota) != 1) quota = -1; std::fclose(g); }
+        if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(g, "%ld", &period) != 1) period = -1; std::fclose(g); }
+    }
+    if (quota > 0 && period > 0) { const long c = (quota + period - 1) / period; if (c >= 1 && c < n) n = c; }
+    cached = (int)(n < 1 ? 1 : n);
+    return cached;
+}
 int rc_threads() {
     if (g_rc_threads > 0) return g_rc_threads;
-    const unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::min(8u, hw ? hw : 1u);
+    return std::min(8, effective_cpus());
 }
 bool rc_use_avx512(int Lp) {
     return g_rc_impl == 0 && Lp <= 64 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq") &&
@@ -580,7 +607,8 @@ int kOctGroups = 8;
 #endif
 int g_oct_tiled = 1;                                   // 0 = always one stream (A/B tests)
 }  // namespace
-extern "C" int pcgc_set_oct_tiled(int on) { g_oct_tiled = on ? 1 : 0; if (on > 1) kOctGroups = on; return 0; }
+// 0 = one stream, 1 = the default 8 groups, n > 1 = n groups (clamped to the 255 the one-byte group count of the stream can hold)
+extern "C" int pcgc_set_oct_tiled(int on) { g_oct_tiled = on ? 1 : 0; kOctGroups = on > 1 ? (on > 255 ? 255 : on) : 8; return 0; }
 
 // stream, version 2: "PCGO" | 2 | depth u8 | n u32 | range-coded occupancy bits of the whole tree
 // stream, version 3 (clouds of >= 8192 points): "PCGO" | 3 | depth u8 | n u32 | split level d u8 | groups G u8 | top bytes u32 |
@@ -677,29 +705,29 @@ extern "C" int64_t pcgc_oct_decode_count(const uint8_t* in, int64_t nbytes) {
 }
 
 extern "C" int pcgc_oct_decode(const uint8_t* in, int64_t nbytes, int32_t* xyz, int64_t n) {
-    if (pcgc_oct_decode_count(in, nbytes) != n) return -1;
+    if (pcgc_oct_decode_count(in, nbytes) != n) { pcgc_set_error("oct_decode: not a PCGO stream of %lld points", (long long)n); return -1; }
     const int depth = in[5];
-    if (depth < 1 || depth > 21) return -1;
+    if (depth < 1 || depth > 21) { pcgc_set_error("oct_decode: bad depth %d", depth); return -1; }
     std::vector<uint64_t> leaves;
     if (in[4] == kOctVersion) {
         std::vector<uint64_t> root; if (n > 0) root.push_back(0);
-        if (oct_decode_part(in + 10, nbytes - 10, root, 0, depth, depth, n, leaves)) return -2;
+        if (oct_decode_part(in + 10, nbytes - 10, root, 0, depth, depth, n, leaves)) { pcgc_set_error("oct_decode: corrupt or truncated stream (line %d)", __LINE__); return -2; }
     } else {
-        if (nbytes < 16) return -2;
+        if (nbytes < 16) { pcgc_set_error("oct_decode: corrupt or truncated stream (line %d)", __LINE__); return -2; }
         const int d = in[10], G = in[11];
         uint32_t top_bytes; std::memcpy(&top_bytes, in + 12, 4);
         const int64_t table = 16, payload = table + 12 * (int64_t)G;
-        if (d < 1 || d >= depth || G < 1 || payload + (int64_t)top_bytes > nbytes) return -2;
+        if (d < 1 || d >= depth || G < 1 || payload + (int64_t)top_bytes > nbytes) { pcgc_set_error("oct_decode: corrupt or truncated stream (line %d)", __LINE__); return -2; }
         std::vector<uint64_t> split_nodes, root(1, 0);
         const std::vector<uint16_t>& prior = oct_prior();
-        if (oct_decode_part(in + payload, top_bytes, root, 0, d, d, n, split_nodes, &prior)) return -2;      // (the top is a tree of depth d of its own)
+        if (oct_decode_part(in + payload, top_bytes, root, 0, d, d, n, split_nodes, &prior)) { pcgc_set_error("oct_decode: corrupt or truncated stream (line %d)", __LINE__); return -2; }      // (the top is a tree of depth d of its own)
         std::vector<int64_t> root_at((size_t)G + 1, 0), leaf_at((size_t)G + 1, 0), byte_at((size_t)G + 1, payload + top_bytes);
         for (int g = 0; g < G; ++g) {
             uint32_t rec[3]; std::memcpy(rec, in + table + 12 * g, 12);
             root_at[(size_t)g + 1] = root_at[(size_t)g] + rec[0]; leaf_at[(size_t)g + 1] = leaf_at[(size_t)g] + rec[1]; byte_at[(size_t)g + 1] = byte_at[(size_t)g] + rec[2];
-            if (rec[0] == 0) return -2;
+            if (rec[0] == 0) { pcgc_set_error("oct_decode: corrupt or truncated stream (line %d)", __LINE__); return -2; }
         }
-        if (root_at[(size_t)G] != (int64_t)split_nodes.size() || leaf_at[(size_t)G] != n || byte_at[(size_t)G] > nbytes) return -2;
+        if (root_at[(size_t)G] != (int64_t)split_nodes.size() || leaf_at[(size_t)G] != n || byte_at[(size_t)G] > nbytes) { pcgc_set_error("oct_decode: corrupt or truncated stream (line %d)", __LINE__); return -2; }
         leaves.assign((size_t)n, 0);
         std::vector<int> status((size_t)G, 0);
         const std::function<void(int)> one = [&](int g) {
@@ -711,9 +739,9 @@ extern "C" int pcgc_oct_decode(const uint8_t* in, int64_t nbytes, int32_t* xyz, 
         };
         const int threads = rc_threads();
         if (threads <= 1) { for (int g = 0; g < G; ++g) one(g); } else octree_pool().run(G, std::min(threads, G) - 1, one);
-        for (int g = 0; g < G; ++g) if (status[(size_t)g]) return -2;
+        for (int g = 0; g < G; ++g) if (status[(size_t)g]) { pcgc_set_error("oct_decode: corrupt or truncated stream (line %d)", __LINE__); return -2; }
     }
-    if ((int64_t)leaves.size() != n) return -2;
+    if ((int64_t)leaves.size() != n) { pcgc_set_error("oct_decode: corrupt or truncated stream (line %d)", __LINE__); return -2; }
     for (int64_t i = 0; i < n; ++i) demorton3(leaves[(size_t)i], xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
     return 0;
 }

@@ -13,10 +13,17 @@ import torch
 import torch.distributed as dist
 
 
+FORCE_COLLECTIVES = False      # True: issue the collectives even in a one-rank group (tests: RCCL with world_size 1 on one GPU)
+
+
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def _collectives_on():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
 
 
 def shard_units(n_units, rank=None, world_size=None):
@@ -65,7 +72,7 @@ class Stats:
         return self
 
     def reduce(self):
-        if world()[1] > 1:
+        if _collectives_on():
             dist.all_reduce(self.v, op=dist.ReduceOp.SUM)
         return self
 
@@ -81,7 +88,7 @@ def gather_varlen(rows, dst=0):
     """All ranks contribute an int32 [n_i, C] tensor; rank `dst` gets the concatenation (others get None).
     Sizes are exchanged first, then one padded all-gather (xGMI: a single large transfer beats many small ones)."""
     rank, w = world()
-    if w == 1:
+    if not _collectives_on():
         return rows
     n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
     sizes = [torch.zeros_like(n) for _ in range(w)]

@@ -848,6 +848,22 @@ def test_bench_two_ranks_over_gloo_on_one_gpu():
     assert 'cpu_baseline' not in line                                            # rank 0 at N=1 only
 
 
+def test_bench_runs_its_collectives_over_rccl_with_one_rank():
+    """No multi-GPU node is available to the builder, so the RCCL path runs with world_size 1 on this box's GPU: PCGC_DIST_FORCE=1
+    makes bench.py create the `nccl` process group (RCCL communicator on the device), issue the barrier, both all-reduces and —
+    in the blocks configuration — the padded all-gather of decoded coordinates (shard.gather_varlen) that feeds the global D1.
+    Done = the run succeeds, librccl is mapped into the process, and the reduced figures equal the single-process ones."""
+    args = ['--config', 'blocks', '--steps', '1', '--warmup', '1', '--workload', 'shell10', '--no-cpu-baseline', '--no-events']
+    r, line = _run_bench(args, {'PCGC_DIST_FORCE': '1'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line['config']['collectives'].startswith('RCCL') and line['config']['rccl_loaded'] is True
+    r0, plain = _run_bench(args)
+    assert r0.returncode == 0 and plain['config']['collectives'].startswith('none')
+    for k in ('points_in_per_step_all_gpus', 'points_out', 'bpp', 'd1_psnr_rank0_db'):
+        assert line['config'][k] == plain['config'][k], k
+    assert line['config']['d1_scope'].startswith('whole blocked cloud') and line['config']['d1_psnr_rank0_db'] > 20
+
+
 def test_bench_refuses_a_world_size_mismatch():
     r, line = _run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0'])
     assert r.returncode == 2 and line is None and 'WORLD_SIZE' in r.stderr

@@ -451,3 +451,30 @@ def test_tmc3_failure_is_reported(tmp_path, monkeypatch):
     with pytest.raises(RuntimeError, match='tmc3 encode failed'):
         CoordinateCoder(str(tmp_path / 'x')).encode(np.zeros((3, 3), np.int32))
     assert not [p for p in tmp_path.iterdir() if p.suffix == '.ply']
+
+
+def test_numa_cpu_lookup_and_thread_budget(tmp_path):
+    """pcgcv2_amd.numa_cpus_of_gpu reads the GPU's NUMA node and that node's CPU list from sysfs (faked here);
+    configure_host_threads budgets frames x (launcher + helper + range-decoder threads + ATen threads) within the CPU quota."""
+    import pcgcv2_amd
+    assert pcgcv2_amd._parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+    dev = tmp_path / 'bus/pci/devices/0000:c1:00.0'
+    dev.mkdir(parents=True)
+    (dev / 'numa_node').write_text('1\n')
+    node = tmp_path / 'devices/system/node/node1'
+    node.mkdir(parents=True)
+    (node / 'cpulist').write_text('16-31,144-159\n')
+    cpus = pcgcv2_amd.numa_cpus_of_gpu('0000:C1:00.0', sysfs=str(tmp_path))
+    assert cpus == list(range(16, 32)) + list(range(144, 160))
+    (dev / 'numa_node').write_text('-1\n')
+    assert pcgcv2_amd.numa_cpus_of_gpu('0000:c1:00.0', sysfs=str(tmp_path)) is None
+    assert pcgcv2_amd.numa_cpus_of_gpu('0000:ff:00.0', sysfs=str(tmp_path)) is None
+    try:
+        quota = pcgcv2_amd.effective_cpus()
+        for frames in (1, 2, 4, 8):
+            cfg = pcgcv2_amd.configure_host_threads(frames_in_flight=frames)
+            assert cfg['rc_threads'] >= 1 and cfg['aten_threads'] >= 1
+            if frames > 1 and quota >= 4 * frames:
+                assert frames * (2 + (cfg['rc_threads'] - 1) + cfg['aten_threads']) <= quota + frames     # (the decoding thread is one of rc_threads)
+    finally:
+        pcgcv2_amd.configure_host_threads()
