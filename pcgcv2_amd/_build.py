@@ -33,9 +33,14 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
-    for src in SOURCES:
+    only = [t for t in os.environ.get('PCGC_BUILD_ONLY', '').split(',') if t]      # (kernel experiments: rebuild just these units,
+    for src in SOURCES:                                                             #  e.g. PCGC_BUILD_ONLY=child_irn_a16 — seconds instead of minutes)
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.rsplit('.', 1)[0] + '.o')
+        if only and os.path.exists(o):
+            if src.rsplit('.', 1)[0] in only:
+                jobs.append((o, [hipcc] + FLAGS + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', s, '-o', o]))
+            continue
         if force or _stale(o, [s] + HEADERS):
             lang = ['-x', 'hip'] if src.endswith('.hip') else []
             jobs.append((o, [hipcc] + FLAGS + lang + ['-c', s, '-o', o]))

@@ -491,12 +491,24 @@ def test_full_size_frame_properties(sd, tmp_path):
     # stream), with a sidecar of another stream (ignored), and `_F.bin` is the same when no index is written at all
     from pcgcv2_amd import coder as coder_mod
     idx = tmp_path / 'full_F.idx'
-    assert idx.exists() and coder_mod.index_bits(str(tmp_path / 'full')) == 8 * (16 + 8 * 4 * ops.RC_CKPT_WORDS)
+    assert idx.exists() and coder_mod.index_bits(str(tmp_path / 'full')) == 8 * (coder_mod._INDEX_HEAD.size + 8 * 4 * ops.RC_CKPT_WORDS)
     blob = idx.read_bytes()
     idx.unlink()
     np.testing.assert_array_equal(coder.decode().C.cpu().numpy(), oc)
-    idx.write_bytes(blob[:12] + bytes([blob[12] ^ 1]) + blob[13:])            # CRC of a different stream
+    idx.write_bytes(blob[:8] + bytes([blob[8] ^ 1]) + blob[9:])               # CRC of a different stream
     np.testing.assert_array_equal(coder.decode().C.cpu().numpy(), oc)
+    idx.write_bytes(blob[:-5] + bytes([blob[-5] ^ 0x40]) + blob[-4:])         # a damaged checkpoint word: the sidecar's own CRC refuses it
+    np.testing.assert_array_equal(coder.decode().C.cpu().numpy(), oc)
+    # table guard: an intact sidecar whose table CRC is not the one this host derives (a stream coded where torch's CPU kernels give
+    # another table) must be REFUSED, not decoded to noise
+    import struct, zlib
+    head = bytearray(blob[:coder_mod._INDEX_HEAD.size - 4])
+    head[16] ^= 0xFF
+    body = blob[coder_mod._INDEX_HEAD.size:]
+    idx.write_bytes(bytes(head) + struct.pack('<I', zlib.crc32(bytes(head) + body)) + body)
+    with pytest.raises(Exception, match='CDF table'):
+        coder.decode()
+    idx.write_bytes(blob)
     coder_mod.INDEX_SEGMENTS = 0
     try:
         coder3 = Coder(m, str(tmp_path / 'plain'))
