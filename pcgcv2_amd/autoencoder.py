@@ -35,7 +35,7 @@ class InceptionResNet(torch.nn.Module):
                 if c == 64:
                     return SparseTensor(ops.irn_block_child64(x.cmap.origin[1].k3, x.F, params, self._child_tables), coordinate_map=x.cmap)
                 return SparseTensor(ops.irn_block_child(x.cmap.origin[1].k3, x.F, params, self._child_tables), coordinate_map=x.cmap)
-            if c == 64 and ops.MFMA_IRN and x.F.shape[0] >= 30000:
+            if c == 64 and ops.MFMA_IRN and x.F.shape[0] >= 512:       # (1-18 k rows: 117-123 us per block against 177-220 on the VALU passes)
                 # block-sparse MFMA path; the fused weights are rebuilt whenever a parameter tensor was replaced or modified
                 stamp = tuple((p.data_ptr(), p._version) for p in params)
                 if getattr(self, '_fused_stamp', None) != stamp:

@@ -857,7 +857,7 @@ extern "C" int pcgc_set_irn_cb16_rows(int64_t min_rows) { g_irn_cb16_rows = min_
 extern "C" int pcgc_set_irn_rows(int rows) { g_irn_rows = rows; return 0; }
 static int g_irn_split = 1;         // 16-row tiles at C <= 32: row-split kernels (1, default) or the lane = row kernels (0; A/B tests)
 extern "C" int pcgc_set_irn_split(int on) { g_irn_split = on ? 1 : 0; return 0; }
-static int irn_rows_for(int64_t n) { return g_irn_rows > 0 ? g_irn_rows : (n < 40000 ? 16 : 64); }   // (measurements: launch_irn_rows)
+static int irn_rows_for(int64_t n) { return g_irn_rows > 0 ? g_irn_rows : (n < 40000 ? 16 : (n < 120000 ? 32 : 64)); }   // (measurements: launch_irn_rows; 64-71 k rows at C = 32: 32-row tiles 62-72 us, 64-row 74-84)
 
 // kernel offsets gathered per wait (27 = 9 x 3): more gathers in flight per wave.  Pays only while the extra row buffers do
 // not cut occupancy: measured irn_b<16> 194 -> 167 us, but irn_b<32> 127 -> 160 us and irn_b<64> 196 -> 433 us with 3.
@@ -1443,7 +1443,15 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
     const bool v1_eligible = nbr != nullptr && K <= 27 && aligned && small && (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64);
     const bool v1_wanted = g_conv_impl == 1 || (g_conv_impl < 0 && n_out >= 30000);
     const bool wlds_shape = (Cin == 64 && Cout == 64) || (Cin == 32 && Cout == 32);
-    if (v1_eligible && wlds_shape && (((uintptr_t)W) & 15) == 0 && (g_conv_impl == 3 || (g_conv_impl < 0 && g_auto_wlds && n_out >= 30000))) {
+    // Size policy of the two wide k3 shapes (tools/gate_ab.py, us per launch; every family is a chain of barrier-separated steps whose
+    // length barely depends on the row count below ~20 k rows):
+    //   64 -> 64   rows 1-18 k: v0 367-480, v2 81-118, v2b 137-141, v2c 109-112;  64 k: v2 198, v2b 196, v2c 161;  71 k: 233 / 231 / 208;  150 k: v2b 378
+    //              -> v2 (MFMA, weights from L2) below 8 k rows, v2c up to 110 k, v2b above
+    //   32 -> 32   rows 1-18 k: v0 96, v2 45, v2b 52, v2c 41;  64-71 k: v2 69-86, v2b 64-77, v2c 56-70;  256 k: v2b 171 (v2c 178)
+    //              -> v2c up to 110 k rows, v2b above
+    // (round 2 sent everything below 30 k rows to the one-thread-per-row v0 kernel: 334 us for the 64 -> 64 conv of a 117 k-point block)
+    const bool wide_auto = g_conv_impl < 0 && g_auto_wlds && K == 27 && (Cin == 32 || n_out >= 8192);
+    if (v1_eligible && wlds_shape && (((uintptr_t)W) & 15) == 0 && (g_conv_impl == 3 || wide_auto)) {
         const float* res0 = residual ? residual + res_coff : nullptr;
         float* out0 = out + out_coff;
         const bool pipe = g_mfma_pipe > 0 || (g_mfma_pipe < 0 && n_out < 110000);        // 64->64: 248 -> 220 us at 71 k rows, 381 -> 395 at 150 k
@@ -1451,6 +1459,8 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
         else if (Cin == 64) {
             if (n_out < g_wlds_mt4_rows) launch_mfma_wlds<64, 64, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
             else launch_mfma_wlds<64, 64, 4>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        } else if (pipe && g_conv_impl < 0) {
+            launch_mfma_pipe<32, 32, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         } else if (g_mfma_pipe > 0) {
             launch_mfma_pipe<32, 32, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         } else {
@@ -1461,7 +1471,12 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
         return 0;
     }
     const bool mfma_eligible = v1_eligible && (Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 16 || Cout == 32 || Cout == 64);
-    if (mfma_eligible && (g_conv_impl == 2 || (g_conv_impl < 0 && g_auto_mfma && n_out >= 8192))) {      // (down2 64->32 at 18.7 k rows: 58 -> 38 us)
+    // narrow outputs on small levels: the row-split kernel (16 -> 16 at 1-18 k rows: 12-16 us against 27 on v2; 32 -> 8: 16-20 against 40;
+    // 32 -> 8 at 64-71 k rows: 38-49 against 68-73)
+    const bool split_first = g_conv_impl < 0 && K == 27 && Cin <= 32 && Cout <= 16 && n_out < (Cout <= 8 ? 150000 : 40000);
+    // everything else with MFMA-sized channels: v2 from 512 rows on (64 -> 32 at 1-18 k rows: v0 178-220 us, v2 81; the k2 s2 down convs
+    // 64 -> 32 / 32 -> 64 on an octant block's 3-10 k rows: v0 93 us)
+    if (mfma_eligible && !split_first && (g_conv_impl == 2 || (g_conv_impl < 0 && g_auto_mfma && n_out >= 512))) {      // (down2 64->32 at 18.7 k rows: 58 -> 38 us)
         const float* res0 = residual ? residual + res_coff : nullptr;
         float* out0 = out + out_coff;
         bool ok = false;
@@ -1470,7 +1485,7 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
         else ok = dispatch_mfma<64>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         if (ok) { PCGC_CHECK_LAUNCH("conv_gather_mfma"); return 0; }
     }
-    if (v1_eligible && K == 27 && Cin <= 32 && Cout <= 16 && (Cout & 3) == 0 && (g_conv_impl == 6 || (g_conv_impl < 0 && n_out < 40000))) {
+    if (v1_eligible && K == 27 && Cin <= 32 && Cout <= 16 && (Cout & 3) == 0 && (g_conv_impl == 6 || split_first)) {
         const float* res0 = residual ? residual + res_coff : nullptr;       // (conv3 32->8 at 18.7 k rows: 71 us on v0, 42 us on the burst form)
         float* out0 = out + out_coff;
         int rc = 1;
