@@ -56,6 +56,7 @@ def parse():
     ap.add_argument('--no-events', action='store_true', help='do not bracket the dominant kernel with HIP events')
     ap.add_argument('--irn-rows', type=int, default=0, help='force the fused-IRN tile height (A/B); 0 = automatic')
     ap.add_argument('--detail', default='', help='optional path for a per-kernel-shape JSON breakdown')
+    ap.add_argument('--no-batch', action='store_true', help='blocks config: code the blocks one by one instead of as ONE collated batch')
     ap.add_argument('--serving-frames', type=int, default=16, help='frames of the extra serving-throughput measurement (0 = skip; frame config only)')
     ap.add_argument('--serving-in-flight', type=int, default=4, help='frames in flight per GPU in that measurement')
     return ap.parse_args()
@@ -141,16 +142,39 @@ def main():
             units.append((f'b{i}', SparseTensor(torch.ones((len(c), 1), device=dev), coordinates=c, tensor_stride=1, device=dev, assume_unique=True)))
         scaling = 'strong'
         desc = (f'{base}: vox12 cloud ({len(whole)} points) scaled by 0.375 -> {len(x_in)} points, {len(blocks)} octant blocks '
-                f'round-robin over {world} GPU(s)')
+                f'round-robin over {world} GPU(s), this rank\'s blocks collated into ONE batch per step (Coder.encode_batch / decode_batch: '
+                'files and decoded voxels identical to coding them one by one)' if not args.no_batch else
+                f'{base}: vox12 cloud ({len(whole)} points) scaled by 0.375 -> {len(x_in)} points, {len(blocks)} octant blocks round-robin over {world} GPU(s), coded one by one')
         whole_C = whole.C
         del whole
     n_points = sum(len(u) for _, u in units)
+    # blocks: the rank's blocks as one collated batch (item index in column 0), resident in HBM like the single units
+    batch = None
+    if cfg == 'blocks' and len(units) > 1 and not args.no_batch:
+        cb = torch.cat([torch.cat([torch.full((len(u), 1), i, dtype=torch.int32, device=dev), u.C[:, 1:]], 1) for i, (_, u) in enumerate(units)], 0).contiguous()
+        batch = (SparseTensor(torch.ones((len(cb), 1), device=dev), coordinates=cb, tensor_stride=1, device=dev, assume_unique=True),
+                 [f'_{name}' for name, _ in units])
     tmp = tempfile.mkdtemp(prefix=f'pcgc_bench_r{rank}_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
     coder = Coder(model, os.path.join(tmp, 'u'))
 
-    def step(timers=None):
+    def step(timers=None, one_by_one=False):
         """one pass over this rank's units -> (decoded tensors); timers = [enc_s, dec_s] accumulators"""
         outs = []
+        if batch is not None and not one_by_one:
+            xb, posts = batch
+            xb.cmap.drop_caches()
+            a = time.perf_counter()
+            coder.encode_batch(xb, posts)
+            if timers is not None:
+                torch.cuda.synchronize()
+            b = time.perf_counter()
+            outs = coder.decode_batch(posts)
+            if timers is not None:
+                torch.cuda.synchronize()
+                c = time.perf_counter()
+                timers[0] += b - a
+                timers[1] += c - b
+            return outs
         for name, x in units:
             x.cmap.drop_caches()
             rates = rate_sds if rate_sds is not None else [None]
@@ -262,6 +286,19 @@ def main():
                  'note': 'this rank, the reference format only (INDEX_SEGMENTS = 0: no sidecar written or read, `_F.bin` decoded by one thread)'}
         step()                                           # leave the files of the default configuration behind
 
+    one_by_one = None
+    if batch is not None:
+        step(one_by_one=True)
+        barrier()
+        t_p = time.perf_counter()
+        for _ in range(args.steps):
+            step(one_by_one=True)
+        barrier()
+        dt_p = time.perf_counter() - t_p
+        one_by_one = {'value': round(n_coded * args.steps / dt_p / 1e6, 4), 'unit': 'Mpoints/s', 'ms_per_step': round(dt_p / args.steps * 1e3, 3),
+                      'note': "this rank's blocks coded one after the other (one Coder.encode + decode per block): the latency-bound form"}
+        step()
+
     serving = None
     if cfg == 'frame' and world == 1 and args.serving_frames > 0:
         model.load_state_dict(sd)
@@ -290,7 +327,7 @@ def main():
                            'the headline `value` is the single-frame-at-a-time rate'}
         del s_units
         pcgcv2_amd.configure_host_threads(local_world=world)
-    elif cfg in ('batch4', 'blocks') and args.serving_in_flight > 1 and len(units) > 1:
+    elif cfg in ('batch4', 'blocks') and args.serving_in_flight > 1 and len(units) > 1 and batch is None:
         # the same units of this rank, several in flight (blocks / frames are independent; only the single-unit latency needs them one by one)
         for _, u in units:
             u.cmap.drop_caches()
@@ -366,7 +403,7 @@ def main():
                        'bpp_note': '`bpp` counts everything the timed configuration writes: the reference\'s four files AND the `_F.idx` sidecar '
                                    '(decoding index + table guard); `bpp_reference_files_only` is the four files, the rate `reference_format_only` codes at',
                        'bpp_reference_files_only': round(total_bits / max(total_coded, 1), 5),
-                       'reference_format_only': plain, 'host_threads': host_threads,
+                       'reference_format_only': plain, 'units_one_by_one': one_by_one, 'host_threads': host_threads,
                        'entropy_decode': '`_F.bin` (bit-identical to the reference-format stream, decodable without it) comes with a sidecar '
                                          '`_F.idx` of decoder states at 8 row boundaries: its segments are decoded on 8 threads; `_C.bin` '
                                          '(native octree, tmc3 absent) is coded as up to 8 independent groups of subtrees',

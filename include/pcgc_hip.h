@@ -208,12 +208,22 @@ int pcgc_set_convention(int what, int value);
 size_t pcgc_topk_workspace_bytes(int64_t n);
 int pcgc_topk_mask(const float* logits /*[dev n], stride ld*/, int ld, int64_t n, int64_t k, uint8_t* mask /*[dev n]*/,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* ---- batches (ME.utils.sparse_collate, data_utils.py:107: batch index in column 0; istopk loops over the items, :80-87).  Every
+ *      level of a collated batch is the concatenation of its items' levels, so the per-item operators work on contiguous row
+ *      segments: seg_rows[b] rows for item b (HOST arrays; workspace as for the largest segment). ---- */
+int pcgc_topk_mask_segments(const float* logits, int ld, int nseg, const int64_t* seg_rows, const int64_t* seg_k, uint8_t* mask,
+                            void* workspace, size_t workspace_bytes, void* stream);
+/* rows per batch item: counts[16] (device) <- histogram of coords[:, 0]. */
+int pcgc_batch_counts(const int32_t* coords /*[dev n,4]*/, int64_t n, int32_t* counts /*[dev 16]*/, void* stream);
 
 /* ---- canonical ordering: sort_spare_tensor / array2vector (data_utils.py:55-61,91-101; coder.py:97-99):
  *      perm = argsort of (z, y, x, batch) most-significant first. ---- */
 size_t pcgc_sort_workspace_bytes(int64_t n);
 int pcgc_sort_zyx(const int32_t* coords, int64_t n, int32_t* perm /*[dev n]*/, void* workspace, size_t workspace_bytes,
                   void* stream);
+/* the same with the batch index MOST significant: the items of a batch stay contiguous, each in the (z, y, x) order it has when
+ * coded alone */
+int pcgc_sort_bzyx(const int32_t* coords, int64_t n, int32_t* perm /*[dev n]*/, void* workspace, size_t workspace_bytes, void* stream);
 int pcgc_gather_rows_i32x4(const int32_t* in, const int32_t* perm, int64_t n, int32_t* out, void* stream);
 int pcgc_gather_rows_f32(const float* in, int C, const int32_t* perm, int64_t n, float* out, void* stream);
 
@@ -228,6 +238,8 @@ int pcgc_desymbolize(const int16_t* sym, int64_t count, float min_v, float* feat
  * The host fetches both with one copy and evaluates the CDF table itself (reference arithmetic, see
  * pcgcv2_amd/entropy_model.py:reference_table). */
 int pcgc_quantize_symbols(const float* feats, int64_t count, float* minmax /*[dev 2]*/, int16_t* sym /*[dev count]*/, void* stream);
+/* per batch item (its own header range, coder.py:51-55): minmax [dev nseg,2], seg_rows [host nseg] rows of C channels each. */
+int pcgc_quantize_symbols_segments(const float* feats, int C, int nseg, const int64_t* seg_rows, float* minmax, int16_t* sym, void* stream);
 /* fused CDF table: _likelihood -> clamp(1e-9) -> cumsum -> clamp(1) -> torchac 16-bit normalisation
  * (entropy_model.py:112-149,165-170 + torchac ‡).  params: 352 fp32 packed matrices|biases|factors.
  * cdf_u16 [C, L+1], L = max_v-min_v+1.  cdf_f32 (optional, may be NULL) receives the fp32 cdf [C, L+1]. */

@@ -60,6 +60,10 @@ SIGNATURES = {
     'pcgc_conv_up2': (ci, [i64, vp, ci, ci, vp, vp, ci, vp, ci, vp]),
     'pcgc_topk_workspace_bytes': (sz, [i64]),
     'pcgc_topk_mask': (ci, [vp, ci, i64, i64, vp, vp, sz, vp]),
+    'pcgc_topk_mask_segments': (ci, [vp, ci, ci, vp, vp, vp, vp, sz, vp]),
+    'pcgc_batch_counts': (ci, [vp, i64, vp, vp]),
+    'pcgc_sort_bzyx': (ci, [vp, i64, vp, vp, sz, vp]),
+    'pcgc_quantize_symbols_segments': (ci, [vp, ci, ci, vp, vp, vp, vp]),
     'pcgc_sort_workspace_bytes': (sz, [i64]),
     'pcgc_sort_zyx': (ci, [vp, i64, vp, vp, sz, vp]),
     'pcgc_gather_rows_i32x4': (ci, [vp, vp, i64, vp, vp]),

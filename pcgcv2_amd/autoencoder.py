@@ -93,12 +93,20 @@ class Decoder(torch.nn.Module):
         self.pruning = MinkowskiPruning()
 
     def prune_voxel(self, data, data_cls, nums, ground_truth=None, training=False):
-        """autoencoder.py:239-249 with istopk (data_utils.py:77-89) on device; batch size 1."""
+        """autoencoder.py:239-249 with istopk (data_utils.py:77-89) on device: per batch item b the nums[b] largest logits among
+        the item's own rows (contiguous segments, sparse.CoordMap.batch_rows)."""
         if training:
             raise NotImplementedError('training-time pruning (top-k ∪ ground truth) is outside the encode/decode path')
-        k = int(min(len(data_cls), nums[0]))
-        mask = ops.topk_mask(data_cls.F, k)
-        return self.pruning(data, mask, n_keep=k)
+        if len(nums) == 1:
+            k = int(min(len(data_cls), nums[0]))
+            mask = ops.topk_mask(data_cls.F, k)
+            return self.pruning(data, mask, n_keep=k)
+        rows = data.cmap.batch_rows
+        if len(rows) != len(nums):
+            raise ValueError(f'prune_voxel: {len(nums)} budgets for a batch of {len(rows)} items')
+        keep = [int(min(r, n)) for r, n in zip(rows, nums)]
+        mask = ops.topk_mask_segments(data_cls.F, rows, keep)
+        return self.pruning(data, mask, n_keep=sum(keep), keep_per_item=keep)
 
     def forward(self, x, nums_list, ground_truth_list=(None, None, None), training=False):
         out, cls_list = x, []

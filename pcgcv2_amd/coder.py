@@ -153,28 +153,53 @@ class FeatureCoder():
     def encode(self, feats, postfix=''):
         n, c = feats.shape
         segments = min(int(INDEX_SEGMENTS), n // 2048)           # (a segment shorter than ~16 k symbols is not worth a thread)
-        index_path = self.filename + postfix + INDEX_SUFFIX
         info = {}
         if segments >= 2:
             payload, min_v, max_v, index = self.entropy_model.compress(feats, checkpoints=segments, info=info)
         else:
             payload, min_v, max_v = self.entropy_model.compress(feats, info=info)
             index = None
+        self._write(postfix, n, c, payload, min_v, max_v, index, info['table_crc'])
+
+    def encode_symbols(self, sym_h, min_v, max_v, postfix='', device=None):
+        """encode() from the host side on: int16 symbols [n, c] and their range (one item of a batch, coder.Coder.encode_batch)."""
+        n, c = sym_h.shape
+        segments = min(int(INDEX_SEGMENTS), n // 2048)
+        info = {}
+        if segments >= 2:
+            payload, min_v, max_v, index = self.entropy_model.compress_symbols(sym_h, min_v, max_v, checkpoints=segments, info=info, device=device)
+        else:
+            payload, min_v, max_v = self.entropy_model.compress_symbols(sym_h, min_v, max_v, info=info, device=device)
+            index = None
+        self._write(postfix, n, c, payload, min_v, max_v, index, info['table_crc'])
+
+    def _write(self, postfix, n, c, payload, min_v, max_v, index, table_crc):
+        index_path = self.filename + postfix + INDEX_SUFFIX
         if INDEX_SEGMENTS:
-            _dump(index_path, _pack_index(payload, index, info['table_crc']))
+            _dump(index_path, _pack_index(payload, index, table_crc))
         elif os.path.exists(index_path):
             os.remove(index_path)                                     # never leave a sidecar of an older stream behind
         _dump(self.filename + postfix + '_F.bin', payload)
         _dump(self.filename + postfix + '_H.bin', _HEADER.pack(n, c, len(min_v), float(min_v[0]), float(max_v[0])))
 
-    def decode(self, postfix='', device=None, on_table_launched=None):
+    def _read(self, postfix):
         n, c, n_minv, min_v, max_v = _HEADER.unpack(_slurp(self.filename + postfix + '_H.bin')[:_HEADER.size])
         if n_minv != 1:
             raise ValueError('unsupported _H.bin: expected one (min_v, max_v) pair')
         payload = _slurp(self.filename + postfix + '_F.bin')
         index, table_crc = _load_sidecar(self.filename + postfix + INDEX_SUFFIX, payload) if INDEX_SEGMENTS else (None, None)
+        return n, c, min_v, max_v, payload, index, table_crc
+
+    def decode(self, postfix='', device=None, on_table_launched=None):
+        n, c, min_v, max_v, payload, index, table_crc = self._read(postfix)
         return self.entropy_model.decompress(payload, np.float32(min_v), np.float32(max_v), (n, c), channels=c, device=device,
                                              on_table_launched=on_table_launched, index=index, expect_table_crc=table_crc)
+
+    def decode_symbols(self, postfix='', device=None):
+        """decode() up to the host symbols -> (int16 ndarray [n, c], min_v) (one item of a batch, coder.Coder.decode_batch)."""
+        n, c, min_v, max_v, payload, index, table_crc = self._read(postfix)
+        return self.entropy_model.decompress_symbols(payload, np.float32(min_v), np.float32(max_v), (n, c), channels=c, device=device,
+                                                     index=index, expect_table_crc=table_crc)
 
 
 class Coder():
@@ -277,6 +302,114 @@ class Coder():
         budgets = [[n4], [n2], [int(rho * n1)]]                  # coder.py:105-108
         _, out = self.model.decoder(y, nums_list=budgets, ground_truth_list=[None] * 3, training=False)
         return out
+
+
+    # ---- collated batches: several clouds through ONE encoder / decoder pass ------------------------------------------------------
+    # The reference codes one cloud per call (coder.py:80-112); its network code is batched all the same (sparse_collate,
+    # data_utils.py:107; istopk per batch item, :77-89).  Small clouds — the octant blocks of BASELINE config 5, ~117 k points each —
+    # leave the GPU to launch latency: ~140 kernels per block on levels of 3-40 k rows.  Collated, B clouds are one launch sequence on
+    # B-times larger levels.  Results per item are IDENTICAL to coding it alone: the batch index is part of every coordinate key (no
+    # kernel-map entry crosses items), every level of the batch is the concatenation of the items' levels (canonical orders are
+    # first-occurrence orders of an item-contiguous input), and each output row's arithmetic chain depends on its own neighbours only.
+    @torch.no_grad()
+    def encode_batch(self, x, postfixes):
+        """x: collated sparse tensor (item index in column 0, items contiguous); postfixes[b]: file postfix of item b.  Writes the
+        four files (+ sidecar) of every item, byte-identical to encode() of the item alone; returns the sorted latent of the batch
+        (items contiguous, each in (z, y, x) order)."""
+        with torch.cuda.device(x.device):
+            return self._encode_batch(x, list(postfixes))
+
+    def _encode_batch(self, x, postfixes):
+        B = len(postfixes)
+        lvl8 = x.cmap.build_pyramid(3)
+        l2 = x.cmap._down[0]
+        l4 = l2._down[0]
+        rows1, rows2, rows4, rows8 = x.cmap.batch_rows, l2.batch_rows, l4.batch_rows, lvl8.batch_rows
+        if not (len(rows1) == len(rows2) == len(rows4) == len(rows8) == B):
+            raise ValueError(f'encode_batch: {B} postfixes for a batch of {len(rows1)} items')
+        y_list = self.model.encoder(x)
+        order = ops.sort_zyx(lvl8.C, batch_major=True)
+        y_C = ops.gather_coords(lvl8.C, order)
+        y_F = ops.gather_feats(y_list[0].F, order)
+        ranges, sym_h = ops.quantize_symbols_segments(y_F, rows8)             # one synchronising copy: every item's range + symbols
+        host_C = y_C.cpu().numpy()
+        dev = x.device
+        offs = np.concatenate([[0], np.cumsum(rows8)])
+
+        def one(b):
+            a, e = int(offs[b]), int(offs[b + 1])
+            _dump(self.filename + postfixes[b] + '_num_points.bin', _COUNTS.pack(rows4[b], rows2[b], rows1[b]))
+            self.feature_coder.encode_symbols(sym_h[a:e], ranges[b][0], ranges[b][1], postfix=postfixes[b], device=dev)
+            self.coordinate_coder.encode(host_C[a:e, 1:] // lvl8.stride, postfix=postfixes[b])
+        list(_batch_pool().map(one, range(B)))
+        cmap = CoordMap(y_C, lvl8.stride, unique=True)
+        cmap._batch_rows = list(rows8)
+        return SparseTensor(y_F, coordinate_map=cmap)
+
+    @torch.no_grad()
+    def decode_batch(self, postfixes, rho=1):
+        """Reads the files of every item and decodes them in ONE decoder pass -> list of sparse tensors (batch column 0 each), equal
+        to decode() of the item alone."""
+        dev = require_gpu(next(self.model.decoder.parameters()).device)
+        with torch.cuda.device(dev):
+            return self._decode_batch(list(postfixes), rho, dev)
+
+    def _decode_batch(self, postfixes, rho, dev):
+        B = len(postfixes)
+
+        def one(b):
+            xyz8 = np.asarray(self.coordinate_coder.decode(postfixes[b]), dtype=np.int32)
+            counts = _COUNTS.unpack(_slurp(self.filename + postfixes[b] + '_num_points.bin')[:_COUNTS.size])
+            sym_h, min_v = self.feature_coder.decode_symbols(postfix=postfixes[b], device=dev)
+            if len(sym_h) != len(xyz8):
+                raise ValueError(f'item {b}: {len(xyz8)} coordinates but {len(sym_h)} latent rows')
+            return xyz8, counts, sym_h, min_v
+        items = list(_batch_pool().map(one, range(B)))
+        rows8 = [len(it[0]) for it in items]
+        C4 = np.zeros((sum(rows8), 4), dtype=np.int32)
+        off = 0
+        for b, (xyz8, _, _, _) in enumerate(items):
+            C4[off:off + rows8[b], 0] = b
+            C4[off:off + rows8[b], 1:] = xyz8 * 8
+            off += rows8[b]
+        y_C = torch.from_numpy(C4).to(dev)
+        y_C = ops.gather_coords(y_C, ops.sort_zyx(y_C, batch_major=True))      # items stay contiguous, each in its coded (z, y, x) order
+        sym = torch.from_numpy(np.concatenate([it[2] for it in items], 0)).to(dev)
+        y_F = torch.empty(sym.shape, dtype=torch.float32, device=dev)
+        off = 0
+        for b, (_, _, _, min_v) in enumerate(items):                           # every item has its own symbol offset
+            y_F[off:off + rows8[b]] = ops.desymbolize(sym[off:off + rows8[b]], min_v)
+            off += rows8[b]
+        lvl8 = CoordMap(y_C, 8, unique=True)
+        lvl8._batch_rows = rows8
+        y = SparseTensor(features=y_F, coordinate_map=lvl8)
+        budgets = [[it[1][0] for it in items], [it[1][1] for it in items], [int(rho * it[1][2]) for it in items]]     # coder.py:105-108
+        _, out = self.model.decoder(y, nums_list=budgets, ground_truth_list=[None] * 3, training=False)
+        outs, off = [], 0
+        for b, r in enumerate(out.cmap.batch_rows):
+            c = out.C[off:off + r].clone()
+            c[:, 0] = 0                                                        # coded alone, the item is batch 0
+            outs.append(_coords_only(c, out.cmap.stride))
+            off += r
+        return outs
+
+
+def _coords_only(coords, stride):
+    """decoded cloud: coordinates with unit features (what decode() of a single cloud hands on: its features are never read)"""
+    return SparseTensor(lambda: torch.ones((coords.shape[0], 1), dtype=torch.float32, device=coords.device),
+                        coordinate_map=CoordMap(coords, stride, unique=True))
+
+
+_BATCH_POOL = None
+
+
+def _batch_pool():
+    """host threads for the per-item entropy / coordinate coding of a batch (native calls: they release the GIL)"""
+    global _BATCH_POOL
+    if _BATCH_POOL is None:
+        import pcgcv2_amd
+        _BATCH_POOL = ThreadPoolExecutor(max_workers=max(2, min(16, pcgcv2_amd.effective_cpus())), thread_name_prefix='pcgc-item')
+    return _BATCH_POOL
 
 
 # ------------------------------------------------------------------------------------------------ CLI (coder.py:114-184)

@@ -166,6 +166,20 @@ extern "C" int pcgc_quantize_symbols(const float* feats, int64_t count, float* m
     PCGC_CHECK_LAUNCH("quantize_symbols");
     return 0;
 }
+// Batched form: segment b = the rows of batch item b (contiguous), each with its OWN symbol range — the reference codes every cloud
+// with its own (min_v, max_v) header.  minmax: [nseg][2] on the device; seg_rows: host array.
+extern "C" int pcgc_quantize_symbols_segments(const float* feats, int C, int nseg, const int64_t* seg_rows, float* minmax, int16_t* sym,
+                                              void* stream) {
+    PCGC_REQUIRE(nseg >= 1 && seg_rows && C >= 1, "bad segments");
+    int64_t off = 0;
+    for (int b = 0; b < nseg; ++b) {
+        PCGC_REQUIRE(seg_rows[b] > 0, "empty latent in a batch item");
+        const int rc = pcgc_quantize_symbols(feats + off * C, seg_rows[b] * C, minmax + 2 * b, sym + off * C, stream);
+        if (rc) return rc;
+        off += seg_rows[b];
+    }
+    return 0;
+}
 __global__ void k_cdf_likelihood_dev(const float* __restrict__ P, int C, const float* __restrict__ minmax, int max_L,
                                      float* __restrict__ cdf_f32, int32_t* __restrict__ info) {
     __shared__ EbShared sh;

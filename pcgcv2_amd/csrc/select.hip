@@ -301,14 +301,59 @@ extern "C" int pcgc_topk_mask(const float* logits, int ld, int64_t n, int64_t k,
     return 0;
 }
 
+// Batched form (data_utils.py:77-89: `istopk` loops over the batch items, each with its own budget nums[b]): the rows of item b
+// are the contiguous range [sum(seg_rows[:b]), +seg_rows[b]) — every level of a collated batch is the concatenation of its
+// items' levels (canonical row orders are first-occurrence orders of item-contiguous inputs) — so the mask of a batch is the
+// single-cloud sequence run per segment on a sub-range.  One workspace serves all segments (same stream: segment b + 1 starts
+// after segment b).  seg_rows / seg_k are HOST arrays.
+extern "C" int pcgc_topk_mask_segments(const float* logits, int ld, int nseg, const int64_t* seg_rows, const int64_t* seg_k,
+                                       uint8_t* mask, void* workspace, size_t workspace_bytes, void* stream) {
+    PCGC_REQUIRE(nseg >= 0 && (nseg == 0 || (seg_rows && seg_k)), "bad segments");
+    int64_t off = 0, nmax = 0;
+    for (int b = 0; b < nseg; ++b) { PCGC_REQUIRE(seg_rows[b] >= 0, "negative segment"); if (seg_rows[b] > nmax) nmax = seg_rows[b]; }
+    PCGC_REQUIRE(workspace_bytes >= pcgc_topk_workspace_bytes(nmax), "workspace too small");
+    for (int b = 0; b < nseg; ++b) {
+        const int rc = pcgc_topk_mask(logits + off * ld, ld, seg_rows[b], seg_k[b], mask + off, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+        off += seg_rows[b];
+    }
+    return 0;
+}
+
+// rows per batch item (column 0 of the coordinates): counts[b] for b < 16 (the coordinate key holds 4 batch bits)
+__global__ void k_batch_counts(const int4* __restrict__ coords, int64_t n, int32_t* __restrict__ counts) {
+    __shared__ int h[16];
+    if (threadIdx.x < 16) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = coords[i].x;
+        if ((unsigned)b < 16u) atomicAdd(&h[b], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
+}
+extern "C" int pcgc_batch_counts(const int32_t* coords, int64_t n, int32_t* counts, void* stream) {
+    PCGC_REQUIRE(counts != nullptr, "null argument");
+    hipError_t e = hipMemsetAsync(counts, 0, 16 * sizeof(int32_t), S(stream));
+    if (e != hipSuccess) { pcgc_set_error("batch_counts: %s", hipGetErrorString(e)); return -1; }
+    if (n == 0) return 0;
+    unsigned g = grid_for(n, 256 * 16); if (g > 512) g = 512; if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_batch_counts, dim3(g), dim3(256), 0, S(stream), (const int4*)coords, n, counts);
+    PCGC_CHECK_LAUNCH("batch_counts");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------- z-major sort
 // array2vector(C, C.max()+1) orders rows by (z, y, x, batch), z most significant (data_utils.py:55-61); every field
 // is < step, so sorting the packed 64-bit key (z<<44 | y<<24 | x<<4 | batch) gives the same permutation.
-__global__ void k_zyx_keys(const int4* __restrict__ coords, int64_t n, uint64_t* keys, int32_t* idx) {
+// batch_major: (batch, z, y, x) instead — the items of a collated batch stay contiguous, each in its own (z, y, x) order: the order
+// sort_spare_tensor gives every item when the clouds are coded one by one
+__global__ void k_zyx_keys(const int4* __restrict__ coords, int64_t n, uint64_t* keys, int32_t* idx, int batch_major) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int4 c = coords[i];
-    keys[i] = ((uint64_t)(uint32_t)c.w << 44) | ((uint64_t)(uint32_t)c.z << 24) | ((uint64_t)(uint32_t)c.y << 4) | (uint64_t)(uint32_t)c.x;
+    keys[i] = batch_major ? (((uint64_t)(uint32_t)c.x << 60) | ((uint64_t)(uint32_t)c.w << 40) | ((uint64_t)(uint32_t)c.z << 20) | (uint64_t)(uint32_t)c.y)
+                          : (((uint64_t)(uint32_t)c.w << 44) | ((uint64_t)(uint32_t)c.z << 24) | ((uint64_t)(uint32_t)c.y << 4) | (uint64_t)(uint32_t)c.x);
     idx[i] = (int32_t)i;
 }
 static size_t sort_temp_bytes(int64_t n) {
@@ -321,8 +366,16 @@ extern "C" size_t pcgc_sort_workspace_bytes(int64_t n) {
     if (n < 1) n = 1;
     return align256((size_t)n * 8) * 2 + align256((size_t)n * 4) + align256(sort_temp_bytes(n));
 }
+static int sort_coords(const int32_t* coords, int64_t n, int32_t* perm, void* workspace, size_t workspace_bytes, void* stream, int batch_major);
 extern "C" int pcgc_sort_zyx(const int32_t* coords, int64_t n, int32_t* perm, void* workspace, size_t workspace_bytes,
                              void* stream) {
+    return sort_coords(coords, n, perm, workspace, workspace_bytes, stream, 0);
+}
+extern "C" int pcgc_sort_bzyx(const int32_t* coords, int64_t n, int32_t* perm, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+    return sort_coords(coords, n, perm, workspace, workspace_bytes, stream, 1);
+}
+static int sort_coords(const int32_t* coords, int64_t n, int32_t* perm, void* workspace, size_t workspace_bytes, void* stream, int batch_major) {
     PCGC_REQUIRE(workspace_bytes >= pcgc_sort_workspace_bytes(n), "workspace too small");
     if (n == 0) return 0;
     char* ws = (char*)workspace;
@@ -330,7 +383,7 @@ extern "C" int pcgc_sort_zyx(const int32_t* coords, int64_t n, int32_t* perm, vo
     uint64_t* kout = (uint64_t*)ws; ws += align256((size_t)n * 8);
     int32_t* idx = (int32_t*)ws; ws += align256((size_t)n * 4);
     size_t tmp = sort_temp_bytes(n);
-    hipLaunchKernelGGL(k_zyx_keys, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n, kin, idx);
+    hipLaunchKernelGGL(k_zyx_keys, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n, kin, idx, batch_major);
     hipError_t e = rocprim::radix_sort_pairs((void*)ws, tmp, kin, kout, idx, perm, (size_t)n, 0, 64, S(stream));
     if (e != hipSuccess) { pcgc_set_error("sort_zyx: %s", hipGetErrorString(e)); return -1; }
     PCGC_CHECK_LAUNCH("sort_zyx");

@@ -39,9 +39,14 @@ def array2vector(array, step):
 
 
 def istopk(data, nums, rho=1.0):
-    """data_utils.py:77-89 for batch size 1, on device."""
-    k = int(min(len(data), nums[0] * rho))
-    return ops.topk_mask(data.F, k).bool()
+    """data_utils.py:77-89 on device: per batch item b, mask of its int(min(rows_b, nums[b] * rho)) largest values (the reference
+    loops over the items on the host; here the items are contiguous row segments of one tensor)."""
+    if len(nums) == 1:
+        k = int(min(len(data), nums[0] * rho))
+        return ops.topk_mask(data.F, k).bool()
+    rows = data.cmap.batch_rows
+    keep = [int(min(r, n * rho)) for r, n in zip(rows, nums)]
+    return ops.topk_mask_segments(data.F, rows, keep).bool()
 
 
 def sort_spare_tensor(sparse_tensor):

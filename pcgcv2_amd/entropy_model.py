@@ -198,7 +198,12 @@ class EntropyBottleneck(nn.Module):
         # symbol range + symbols in one enqueue and ONE synchronising copy; the table is then evaluated (or found in the cache) on
         # the host, where the range coder consumes it
         min_v, max_v, sym_h = ops.quantize_symbols(inputs)
-        table_h, crc = self.host_table(min_v, max_v, inputs.device, want_crc=True)
+        return self.compress_symbols(sym_h, min_v, max_v, checkpoints=checkpoints, info=info, device=inputs.device)
+
+    def compress_symbols(self, sym_h, min_v, max_v, checkpoints=0, info=None, device=None):
+        """The host half of compress(): int16 symbols [N, C] (= round(x) - min_v) + their range -> the same tuple compress returns.
+        Thread-safe: the items of a batch are range-coded side by side (coder.Coder.encode_batch)."""
+        table_h, crc = self.host_table(min_v, max_v, device, want_crc=True)
         if info is not None:
             info['table_crc'] = crc
         if checkpoints > 0:
@@ -215,6 +220,14 @@ class EntropyBottleneck(nn.Module):
         `expect_table_crc` (optional): CRC-32 of the ENCODER's table; if this host derives another table (torch-CPU kernels differ
         between CPU kinds and torch builds by a count here and there) the stream would decode to garbage — raise instead."""
         device = torch.device('cuda') if device is None else device
+        sym_h, min_v = self.decompress_symbols(strings, min_v, max_v, shape, channels, device=device, on_table_launched=on_table_launched,
+                                               index=index, expect_table_crc=expect_table_crc)
+        sym = torch.from_numpy(sym_h).to(device)
+        return ops.desymbolize(sym, min_v)
+
+    def decompress_symbols(self, strings, min_v, max_v, shape, channels, device=None, on_table_launched=None, index=None, expect_table_crc=None):
+        """The host half of decompress(): -> (int16 symbols ndarray [shape[0], channels], min_v); values = symbols + min_v.
+        Thread-safe (coder.Coder.decode_batch decodes the items of a batch side by side)."""
         min_v, max_v = np.float32(np.asarray(min_v).reshape(-1)[0]), np.float32(np.asarray(max_v).reshape(-1)[0])
         if on_table_launched is not None:
             on_table_launched()
@@ -225,5 +238,4 @@ class EntropyBottleneck(nn.Module):
                             'Decoding would return noise; decode where the stream was encoded, or re-encode with table_mode="device".')
         n = int(shape[0]) * int(channels)
         sym_h = ops.rc_decode(table_h, strings, n, index=index)
-        sym = torch.from_numpy(sym_h.reshape(int(shape[0]), int(channels))).to(device)
-        return ops.desymbolize(sym, min_v)
+        return sym_h.reshape(int(shape[0]), int(channels)), min_v

@@ -65,7 +65,7 @@ class MinkowskiPruning(torch.nn.Module):
     """Keep rows where mask is set, order preserved (autoencoder.py:237,247).  n_keep, when the caller knows it
     (top-k), avoids a device->host sync."""
 
-    def forward(self, x, mask, n_keep=None):
+    def forward(self, x, mask, n_keep=None, keep_per_item=None):
         from .sparse import CoordMap
         prefix, total = ops.mask_scan(mask)
         n = int(total.item()) if n_keep is None else int(n_keep)
@@ -73,5 +73,7 @@ class MinkowskiPruning(torch.nn.Module):
         # the surviving feature rows are compacted on first use: the last decoder stage only hands on coordinates
         src = x.F
         feats = lambda: ops.compact_feats(src, mask, prefix, n)
-        return SparseTensor(feats, coordinate_map=CoordMap(coords, x.cmap.stride, unique=True,
-                                                           origin=('pruned', x.cmap, mask, prefix)))
+        cmap = CoordMap(coords, x.cmap.stride, unique=True, origin=('pruned', x.cmap, mask, prefix))
+        if keep_per_item is not None:
+            cmap._batch_rows = [int(k) for k in keep_per_item]
+        return SparseTensor(feats, coordinate_map=cmap)

@@ -884,13 +884,45 @@ def topk_mask(logits, k):
     return mask
 
 
-def sort_zyx(coords):
+def sort_zyx(coords, batch_major=False):
+    """argsort by (z, y, x, batch) — array2vector's order — or, batch_major, by (batch, z, y, x): the items of a collated batch stay
+    contiguous, each in the order it has when coded alone."""
     n = coords.shape[0]
     perm = torch.empty(n, dtype=torch.int32, device=coords.device)
     ws_bytes = int(lib().pcgc_sort_workspace_bytes(n))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=coords.device)
-    check(lib().pcgc_sort_zyx(_p(_i32(coords)), n, _p(perm), _p(ws), ws_bytes, _stream(coords)), 'sort_zyx')
+    fn = lib().pcgc_sort_bzyx if batch_major else lib().pcgc_sort_zyx
+    check(fn(_p(_i32(coords)), n, _p(perm), _p(ws), ws_bytes, _stream(coords)), 'sort_zyx')
     return perm
+
+
+def batch_counts(coords):
+    """rows per batch item (column 0), trailing empty items dropped -> list of ints (one device histogram + read-back)."""
+    counts = torch.empty(16, dtype=torch.int32, device=coords.device)
+    check(lib().pcgc_batch_counts(_p(_i32(coords)), coords.shape[0], _p(counts), _stream(coords)), 'batch_counts')
+    c = counts.cpu().tolist()
+    while len(c) > 1 and c[-1] == 0:
+        c.pop()
+    return c
+
+
+def _i64_array(values):
+    import ctypes
+    return (ctypes.c_int64 * len(values))(*[int(v) for v in values])
+
+
+def topk_mask_segments(logits, seg_rows, seg_k):
+    """istopk per batch item (data_utils.py:77-89): item b = the next seg_rows[b] rows, keeps its seg_k[b] largest logits."""
+    _f32(logits, 'logits')
+    n = logits.shape[0]
+    if sum(seg_rows) != n:
+        raise PcgcError(f'topk_mask_segments: segments cover {sum(seg_rows)} of {n} rows')
+    mask = torch.empty(n, dtype=torch.uint8, device=logits.device)
+    ws_bytes = int(lib().pcgc_topk_workspace_bytes(max(seg_rows) if seg_rows else 0))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=logits.device)
+    check(lib().pcgc_topk_mask_segments(_p(logits), logits.stride(0), len(seg_rows), _i64_array(seg_rows), _i64_array(seg_k), _p(mask), _p(ws),
+                                        ws_bytes, _stream(logits)), 'topk_mask_segments')
+    return mask
 
 
 def gather_coords(coords, perm):
@@ -937,6 +969,22 @@ def quantize_symbols(feats):
     host = buf.cpu().numpy()
     mm = host[:4].view(np.float32)
     return np.float32(mm[0]), np.float32(mm[1]), host[4:].reshape(feats.shape)
+
+
+def quantize_symbols_segments(feats, seg_rows):
+    """quantize_symbols per batch item (contiguous row segments), ONE synchronising copy
+    -> ([(min_v, max_v)] per item as np.float32, sym int16 ndarray of feats.shape)."""
+    feats = _f32(feats).contiguous()
+    n, C = feats.shape
+    B = len(seg_rows)
+    if sum(seg_rows) != n:
+        raise PcgcError(f'quantize_symbols_segments: segments cover {sum(seg_rows)} of {n} rows')
+    buf = torch.empty(4 * B + n * C, dtype=torch.int16, device=feats.device)          # [B x (min, max) fp32 | symbols]
+    check(lib().pcgc_quantize_symbols_segments(_p(feats), C, B, _i64_array(seg_rows), _p(buf), buf.data_ptr() + 8 * B, _stream(feats)),
+          'quantize_symbols_segments')
+    host = buf.cpu().numpy()
+    mm = host[:4 * B].view(np.float32).reshape(B, 2)
+    return [(np.float32(a), np.float32(b)) for a, b in mm], host[4 * B:].reshape(n, C)
 
 
 def compress_prepare(feats, params, C, max_L=1024):

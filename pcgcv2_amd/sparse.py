@@ -39,9 +39,19 @@ class CoordMap:
         self._parent_of = None
         self._unique = unique
         self._prepared_up = None
+        self._batch_rows = None
 
     def __len__(self):
         return self.C.shape[0]
+
+    @property
+    def batch_rows(self):
+        """Rows per batch item, in item order (ME.utils.sparse_collate puts the item index in column 0; the rows of an item are
+        contiguous on every level: canonical orders are first-occurrence orders of an item-contiguous input).  Levels produced by
+        up() / pruning inherit theirs; otherwise one device histogram + read-back, cached."""
+        if self._batch_rows is None:
+            self._batch_rows = ops.batch_counts(self.C) if len(self) else [0]
+        return self._batch_rows
 
     @property
     def table(self):
@@ -104,7 +114,10 @@ class CoordMap:
         if self._prepared_up is not None:
             child, self._prepared_up = self._prepared_up, None
             return child
-        return CoordMap(ops.coords_children(self.C, self.stride), self.stride // 2, unique=True, origin=('children', self))
+        child = CoordMap(ops.coords_children(self.C, self.stride), self.stride // 2, unique=True, origin=('children', self))
+        if self._batch_rows is not None:
+            child._batch_rows = [8 * r for r in self._batch_rows]
+        return child
 
     def prepare_up(self):
         """Build the children level and its k3 kernel map ahead of time (the decoder's first stage needs both); used to

@@ -520,6 +520,68 @@ def test_full_size_frame_properties(sd, tmp_path):
         coder_mod.INDEX_SEGMENTS = 8
 
 
+def test_batch_coding_identical_to_one_by_one(sd, sd_np, tmp_path):
+    """Coder.encode_batch / decode_batch: several clouds collated into ONE sparse tensor (item index in column 0, as
+    ME.utils.sparse_collate does, data_utils.py:107) go through one encoder pass and one decoder pass; every item's four files and
+    its decoded cloud must equal what coding the item ALONE gives (and the oracle).  The items overlap in space on purpose —
+    the same cloud twice, clouds inside each other: only the batch index keeps their kernel maps apart."""
+    from pcgcv2_amd.coder import Coder, STREAMS
+    from pcgcv2_amd.sparse import sparse_collate
+    m = _model(sd)
+    names = ['shell7', 'shell8', 'shell7', 'shell6', 'shell8']
+    clouds = [_coords(nm)[:, 1:] + (3 * i if i == 2 else 0) for i, nm in enumerate(names)]       # item 2 = item 0 shifted by 3 voxels
+    coords, feats = sparse_collate([torch.from_numpy(c) for c in clouds], [torch.ones((len(c), 1)) for c in clouds])
+    xb = SparseTensor(feats, coordinates=coords, tensor_stride=1, device=DEV)
+    assert xb.cmap.batch_rows == [len(c) for c in clouds]
+    posts = [f'_i{i}' for i in range(len(clouds))]
+    bdir, sdir = tmp_path / 'batch', tmp_path / 'single'
+    bdir.mkdir(); sdir.mkdir()
+    cb, cs = Coder(m, str(bdir / 'c')), Coder(m, str(sdir / 'c'))
+    yb = cb.encode_batch(xb, posts)
+    outs_b = cb.decode_batch(posts)
+    off = 0
+    for i, c in enumerate(clouds):
+        c4 = np.concatenate([np.zeros((len(c), 1), np.int32), c.astype(np.int32)], 1)
+        xi = SparseTensor(torch.ones((len(c4), 1)), coordinates=_t(c4), tensor_stride=1, device=DEV)
+        yi = cs.encode(xi, postfix=posts[i])
+        oi = cs.decode(postfix=posts[i])
+        for suffix in STREAMS + ('_F.idx',):
+            a, b = bdir / f'c{posts[i]}{suffix}', sdir / f'c{posts[i]}{suffix}'
+            assert a.exists() == b.exists() and (not a.exists() or a.read_bytes() == b.read_bytes()), (i, suffix)
+        np.testing.assert_array_equal(outs_b[i].C.cpu().numpy(), oi.C.cpu().numpy())
+        n8 = len(yi)
+        np.testing.assert_array_equal(yb.F[off:off + n8].cpu().numpy(), yi.F.cpu().numpy())           # the item's sorted latent
+        np.testing.assert_array_equal(yb.C[off:off + n8, 1:].cpu().numpy(), yi.C[:, 1:].cpu().numpy())
+        off += n8
+        if i in (0, 3):                                                                                # and the oracle, for two of them
+            ref = orc.encode(sd_np, c4)
+            for k in ('F', 'H', 'num_points'):
+                assert (bdir / f'c{posts[i]}_{k}.bin').read_bytes() == ref[k], (i, k)
+            np.testing.assert_array_equal(outs_b[i].C.cpu().numpy(), orc.decode(sd_np, ref['coords8'], ref['F'], ref['H'], ref['num_points']))
+    assert off == len(yb)
+    # rho != 1 goes through the per-item budgets too
+    outs_r = cb.decode_batch(posts, rho=0.7)
+    for i in (1, 4):
+        np.testing.assert_array_equal(outs_r[i].C.cpu().numpy(), cs.decode(rho=0.7, postfix=posts[i]).C.cpu().numpy())
+
+
+def test_topk_segments_and_batch_counts():
+    """pcgc_topk_mask_segments == the single-cloud mask per segment (ties included); pcgc_batch_counts == bincount."""
+    rng = np.random.default_rng(3)
+    rows = [1000, 1, 4097, 300, 65000]
+    ks = [391, 1, 4097, 0, 20000]
+    v = rng.standard_normal(sum(rows)).astype(np.float32)
+    v[1100:1400] = 0.25                                                        # ties inside segment 2
+    got = ops.topk_mask_segments(_t(v).reshape(-1, 1), rows, ks).cpu().numpy().astype(bool)
+    off = 0
+    for r, k in zip(rows, ks):
+        np.testing.assert_array_equal(got[off:off + r], orc.topk_mask(v[off:off + r], k))
+        off += r
+    b = np.repeat(np.arange(5), [7, 0, 1000, 33, 5]).astype(np.int32)
+    c4 = np.concatenate([b[:, None], rng.integers(0, 100, size=(len(b), 3)).astype(np.int32)], 1)
+    assert ops.batch_counts(_t(c4)) == [7, 0, 1000, 33, 5]
+
+
 @pytest.mark.parametrize('in_flight', [2, 4])
 def test_frames_in_flight_identical_to_sequential(in_flight, sd, sd_np, tmp_path):
     """Serving mode (shard.code_units(in_flight=F)): F host threads with their own Coder + HIP stream code different frames
