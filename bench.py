@@ -150,7 +150,7 @@ def main():
     n_points = sum(len(u) for _, u in units)
     # blocks: the rank's blocks as one collated batch (item index in column 0), resident in HBM like the single units
     batch = None
-    if cfg == 'blocks' and len(units) > 1 and not args.no_batch:
+    if cfg in ('blocks', 'batch4') and len(units) > 1 and not args.no_batch:
         cb = torch.cat([torch.cat([torch.full((len(u), 1), i, dtype=torch.int32, device=dev), u.C[:, 1:]], 1) for i, (_, u) in enumerate(units)], 0).contiguous()
         batch = (SparseTensor(torch.ones((len(cb), 1), device=dev), coordinates=cb, tensor_stride=1, device=dev, assume_unique=True),
                  [f'_{name}' for name, _ in units])
@@ -263,9 +263,6 @@ def main():
     if roof is not None and warm_all is not None:
         roof['all_launches'] = dict(warm_all['all_launches'], measured='untimed analysis step before the timed region, every sparse-conv launch bracketed')
 
-    # serving mode (reported beside the headline, never as `value`): several frames in flight per GPU — each on its own host
-    # thread + HIP stream (shard.code_units(in_flight=F)) — so one frame's sequential host stages and small-level kernels
-    # overlap with the other frames' GPU work.  Results are byte-identical to sequential coding (tests/test_gpu_parity.py).
     # the same K steps on the reference's four files alone (no `_F.idx` sidecar: the feature stream is decoded serially, exactly as a
     # reference-made stream would be) — reported beside `value`, so rate and speed of BOTH configurations are on the line
     plain = None
@@ -301,32 +298,42 @@ def main():
 
     serving = None
     if cfg == 'frame' and world == 1 and args.serving_frames > 0:
+        # serving mode (reported beside the headline, never as `value`): independent frames collated into batches of F and coded by ONE
+        # encoder / decoder pass per batch (Coder.encode_batch / decode_batch) — one frame's sequential host stages (range coder, octree
+        # coder, files) run beside the other frames' on a thread pool inside the call, the small-level kernels work on F-times larger
+        # levels.  Bitstreams and decoded clouds are byte-identical to frame-by-frame coding (tests/test_gpu_parity.py).  (Round 2 ran F
+        # host threads with a Coder and a HIP stream each: 34-165 Mpoints/s depending on how the box scheduled them; this form has no
+        # thread race in it.)
         model.load_state_dict(sd)
-        # thread budget of the serving mode: frames x (launcher + coordinate helper + range-decoder helpers + ATen) <= CPU quota
-        serving_threads = pcgcv2_amd.configure_host_threads(local_world=world, frames_in_flight=args.serving_in_flight)
-        s_units = [(f's{i}', cloud(variants[i % len(variants)])) for i in range(args.serving_frames)]
+        F = max(1, args.serving_in_flight)
+        n_batches = max(1, args.serving_frames // F)
+        batches = []
+        for bi in range(n_batches):
+            cs = [cloud(variants[(bi * F + i) % len(variants)]).C for i in range(F)]
+            cbat = torch.cat([torch.cat([torch.full((len(c), 1), i, dtype=torch.int32, device=dev), c[:, 1:]], 1) for i, c in enumerate(cs)], 0).contiguous()
+            batches.append((SparseTensor(torch.ones((len(cbat), 1), device=dev), coordinates=cbat, tensor_stride=1, device=dev, assume_unique=True),
+                            [f'_s{bi}_{i}' for i in range(F)]))
+        n_s = sum(len(xb) for xb, _ in batches)
 
-        def fresh(us):
-            for _, u in us:
-                u.cmap.drop_caches()                 # no geometry survives between frames here either
-            return us
-        shard.code_units(coder, fresh(s_units[:args.serving_in_flight]), in_flight=args.serving_in_flight)       # warm the worker path
+        def serve():
+            for xb, posts in batches:
+                xb.cmap.drop_caches()                # no geometry survives between batches either
+                coder.encode_batch(xb, posts)
+                coder.decode_batch(posts)
+        serve()
         torch.cuda.synchronize()
-        n_s = sum(len(u) for _, u in s_units)
         dts = []
         for _ in range(3):                           # best of three passes (all reported): the figure is auxiliary
-            fresh(s_units)
             t_s = time.perf_counter()
-            shard.code_units(coder, s_units, in_flight=args.serving_in_flight)
+            serve()
             torch.cuda.synchronize()
             dts.append(time.perf_counter() - t_s)
         dt_s = min(dts)
-        serving = {'frames_in_flight': args.serving_in_flight, 'frames': len(s_units), 'value': round(n_s / dt_s / 1e6, 3), 'unit': 'Mpoints/s',
-                   'passes_Mpoints_s': [round(n_s / d / 1e6, 1) for d in dts], 'host_threads': serving_threads,
-                   'note': 'independent vox10 frames coded concurrently on one GPU (own thread + HIP stream each), best of 3 passes; '
-                           'the headline `value` is the single-frame-at-a-time rate'}
-        del s_units
-        pcgcv2_amd.configure_host_threads(local_world=world)
+        serving = {'frames_per_batch': F, 'frames': n_batches * F, 'value': round(n_s / dt_s / 1e6, 3), 'unit': 'Mpoints/s',
+                   'passes_Mpoints_s': [round(n_s / d / 1e6, 1) for d in dts],
+                   'note': 'independent vox10 frames collated F at a time and coded by one encoder / decoder pass per batch (Coder.encode_batch / '
+                           'decode_batch), best of 3 passes; the headline `value` is the single-frame-at-a-time rate'}
+        del batches
     elif cfg in ('batch4', 'blocks') and args.serving_in_flight > 1 and len(units) > 1 and batch is None:
         # the same units of this rank, several in flight (blocks / frames are independent; only the single-unit latency needs them one by one)
         for _, u in units:

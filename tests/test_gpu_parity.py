@@ -565,6 +565,38 @@ def test_batch_coding_identical_to_one_by_one(sd, sd_np, tmp_path):
         np.testing.assert_array_equal(outs_r[i].C.cpu().numpy(), cs.decode(rho=0.7, postfix=posts[i]).C.cpu().numpy())
 
 
+def test_batched_serving_is_not_slower_than_frame_by_frame(sd, tmp_path):
+    """Four shell9 frames collated into one batch must code at least as fast as the same four one after the other (VERDICT r2 #6:
+    the serving figure has to be a reproducible property of the code, not of how a box schedules host threads).  Median of 5."""
+    import time
+    from pcgcv2_amd.coder import Coder
+    from pcgcv2_amd.sparse import sparse_collate
+    m = _model(sd)
+    c = _coords('shell9')[:, 1:]
+    coords, feats = sparse_collate([torch.from_numpy(c)] * 4, [torch.ones((len(c), 1))] * 4)
+    xb = SparseTensor(feats, coordinates=coords, tensor_stride=1, device=DEV, assume_unique=True)
+    c4 = np.concatenate([np.zeros((len(c), 1), np.int32), c], 1)
+    xs = [SparseTensor(torch.ones((len(c4), 1)), coordinates=_t(c4), tensor_stride=1, device=DEV, assume_unique=True) for _ in range(4)]
+    coder = Coder(m, str(tmp_path / 's'))
+    posts = [f'_{i}' for i in range(4)]
+
+    def batched():
+        xb.cmap.drop_caches(); coder.encode_batch(xb, posts); coder.decode_batch(posts); torch.cuda.synchronize()
+
+    def single():
+        for x, p in zip(xs, posts):
+            x.cmap.drop_caches(); coder.encode(x, postfix=p); coder.decode(postfix=p)
+        torch.cuda.synchronize()
+    times = {}
+    for name, f in (('batched', batched), ('single', single)):
+        f(); f()
+        t = []
+        for _ in range(5):
+            a = time.perf_counter(); f(); t.append(time.perf_counter() - a)
+        times[name] = sorted(t)[2]
+    assert times['batched'] <= 1.05 * times['single'], times
+
+
 def test_topk_segments_and_batch_counts():
     """pcgc_topk_mask_segments == the single-cloud mask per segment (ties included); pcgc_batch_counts == bincount."""
     rng = np.random.default_rng(3)
