@@ -56,6 +56,7 @@ def parse():
     ap.add_argument('--no-events', action='store_true', help='do not bracket the dominant kernel with HIP events')
     ap.add_argument('--irn-rows', type=int, default=0, help='force the fused-IRN tile height (A/B); 0 = automatic')
     ap.add_argument('--detail', default='', help='optional path for a per-kernel-shape JSON breakdown')
+    ap.add_argument('--no-extra', action='store_true', help='skip the auxiliary measurements after the timed region (reference-format-only / one-by-one / serving): profiler runs')
     ap.add_argument('--no-batch', action='store_true', help='blocks config: code the blocks one by one instead of as ONE collated batch')
     ap.add_argument('--serving-frames', type=int, default=16, help='frames of the extra serving-throughput measurement (0 = skip; frame config only)')
     ap.add_argument('--serving-in-flight', type=int, default=4, help='frames in flight per GPU in that measurement')
@@ -266,7 +267,7 @@ def main():
     # the same K steps on the reference's four files alone (no `_F.idx` sidecar: the feature stream is decoded serially, exactly as a
     # reference-made stream would be) — reported beside `value`, so rate and speed of BOTH configurations are on the line
     plain = None
-    if cfg == 'frame':
+    if cfg == 'frame' and not args.no_extra:
         from pcgcv2_amd import coder as coder_mod
         keep_segments, coder_mod.INDEX_SEGMENTS = coder_mod.INDEX_SEGMENTS, 0
         try:
@@ -284,7 +285,7 @@ def main():
         step()                                           # leave the files of the default configuration behind
 
     one_by_one = None
-    if batch is not None:
+    if batch is not None and not args.no_extra:
         step(one_by_one=True)
         barrier()
         t_p = time.perf_counter()
@@ -297,7 +298,7 @@ def main():
         step()
 
     serving = None
-    if cfg == 'frame' and world == 1 and args.serving_frames > 0:
+    if cfg == 'frame' and world == 1 and args.serving_frames > 0 and not args.no_extra:
         # serving mode (reported beside the headline, never as `value`): independent frames collated into batches of F and coded by ONE
         # encoder / decoder pass per batch (Coder.encode_batch / decode_batch) — one frame's sequential host stages (range coder, octree
         # coder, files) run beside the other frames' on a thread pool inside the call, the small-level kernels work on F-times larger

@@ -227,6 +227,11 @@ int pcgc_sort_bzyx(const int32_t* coords, int64_t n, int32_t* perm /*[dev n]*/, 
 int pcgc_gather_rows_i32x4(const int32_t* in, const int32_t* perm, int64_t n, int32_t* out, void* stream);
 int pcgc_gather_rows_f32(const float* in, int C, const int32_t* perm, int64_t n, float* out, void* stream);
 
+/* ---- pointwise operators of the unfused ME-style graph: ME.MinkowskiReLU (autoencoder.py:50) and SparseTensor.__add__ (:55) on
+ *      contiguous feature buffers (in place allowed: out == in / out == a).  The fused forward passes do not call them. ---- */
+int pcgc_relu(const float* in, int64_t count, float* out, void* stream);
+int pcgc_add(const float* a, const float* b, int64_t count, float* out, void* stream);
+
 /* ---- factorized entropy bottleneck (entropy_model.py:82-196) ---- */
 /* values = round_half_even(feats); minmax[0]=min, minmax[1]=max (fp32, -0 canonicalised to +0). */
 int pcgc_round_minmax(const float* feats, int64_t count, float* minmax /*[dev 2]*/, void* stream);

@@ -68,6 +68,8 @@ SIGNATURES = {
     'pcgc_sort_zyx': (ci, [vp, i64, vp, vp, sz, vp]),
     'pcgc_gather_rows_i32x4': (ci, [vp, vp, i64, vp, vp]),
     'pcgc_gather_rows_f32': (ci, [vp, ci, vp, i64, vp, vp]),
+    'pcgc_relu': (ci, [vp, i64, vp, vp]),
+    'pcgc_add': (ci, [vp, vp, i64, vp, vp]),
     'pcgc_round_minmax': (ci, [vp, i64, vp, vp]),
     'pcgc_symbolize': (ci, [vp, i64, f32, vp, vp]),
     'pcgc_desymbolize': (ci, [vp, i64, f32, vp, vp]),

@@ -56,6 +56,30 @@ extern "C" int pcgc_desymbolize(const int16_t* sym, int64_t count, float min_v, 
     return 0;
 }
 
+// ---- pointwise operators of the unfused ME-style graph (MinkowskiReLU, SparseTensor.__add__: autoencoder.py:50,55).  The product's
+//      own forward passes fuse both into the producing conv's epilogue; these exist for code written against the ME operator surface
+//      (pcgcv2_amd/ME.py).  Same arithmetic as the fused epilogues: max(v, 0) and one fp32 add.
+__global__ void k_relu(const float* __restrict__ in, int64_t count, float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = fmaxf(in[i], 0.0f);
+}
+__global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, int64_t count, float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = a[i] + b[i];
+}
+extern "C" int pcgc_relu(const float* in, int64_t count, float* out, void* stream) {
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(k_relu, dim3(grid_for(count, 256)), dim3(256), 0, S(stream), in, count, out);
+    PCGC_CHECK_LAUNCH("relu");
+    return 0;
+}
+extern "C" int pcgc_add(const float* a, const float* b, int64_t count, float* out, void* stream) {
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(k_add, dim3(grid_for(count, 256)), dim3(256), 0, S(stream), a, b, count, out);
+    PCGC_CHECK_LAUNCH("add");
+    return 0;
+}
+
 // ---- fused CDF table ----------------------------------------------------------------------------------------
 // params packing (352 floats for C=8): matrices 0..3 [C,fo,fi] | biases 0..3 [C,fo,1] | factors 0..3 [C,fo,1],
 // filters (1,3,3,3,1).  Evaluated in fp64 from the fp32 parameters; rounded to fp32 where the reference holds fp32

@@ -38,6 +38,16 @@ def array2vector(array, step):
     return sum(array[:, i] * (step ** i) for i in range(array.shape[-1]))
 
 
+def isin(data, ground_truth):
+    """data_utils.py:63-75: boolean vector, True where a row of `data` (int coordinates [N, D]) occurs in `ground_truth`.  Training-time
+    helper of the reference's Decoder.prune_voxel (autoencoder.py:241-243); provided so that `from data_utils import isin, istopk`
+    binds — host implementation, as in the reference."""
+    dev = data.device
+    a, b = torch.as_tensor(data).long().cpu(), torch.as_tensor(ground_truth).long().cpu()
+    step = int(max(a.max(), b.max())) + 1
+    return torch.isin(array2vector(a, step), array2vector(b, step)).to(dev)
+
+
 def istopk(data, nums, rho=1.0):
     """data_utils.py:77-89 on device: per batch item b, mask of its int(min(rows_b, nums[b] * rho)) largest values (the reference
     loops over the items on the host; here the items are contiguous row segments of one tensor)."""

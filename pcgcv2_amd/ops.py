@@ -938,6 +938,23 @@ def gather_feats(feats, perm):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ pointwise (ME-style graphs)
+def relu(x, inplace=False):
+    x = _f32(x).contiguous()
+    out = x if inplace else torch.empty_like(x)
+    check(lib().pcgc_relu(_p(x), x.numel(), _p(out), _stream(x)), 'relu')
+    return out
+
+
+def add(a, b):
+    a, b = _f32(a).contiguous(), _f32(b).contiguous()
+    if a.shape != b.shape:
+        raise PcgcError(f'add: shapes {tuple(a.shape)} and {tuple(b.shape)} differ')
+    out = torch.empty_like(a)
+    check(lib().pcgc_add(_p(a), _p(b), a.numel(), _p(out), _stream(a)), 'add')
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ entropy
 def round_minmax(feats):
     feats = _f32(feats).contiguous()

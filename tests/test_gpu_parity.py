@@ -1102,3 +1102,54 @@ def test_hip_replays_a_self_made_third_party_file(tmp_path, monkeypatch):
     monkeypatch.setattr(tp, 'PATH', str(path))
     report = tp.run(_HipBackend())
     assert len(report) >= 12 and all(v == 1.0 for v in report.values())
+
+
+def test_me_facade_unfused_graph_equals_fused(sd, sd_np):
+    """Code written against the MinkowskiEngine operator surface (pcgcv2_amd.ME: conv -> MinkowskiReLU -> ME.cat -> `+`,
+    MinkowskiPruning with a boolean mask, istopk) gives the product's fused network bit for bit — and therefore the oracle's."""
+    import pcgcv2_amd.ME as ME
+    from pcgcv2_amd.data_utils import istopk
+    m = _model(sd)
+    enc, dec = m.encoder, m.decoder
+    relu = ME.MinkowskiReLU(inplace=True)
+
+    def conv(mod, x):                                            # an ME-style layer holding the same parameters
+        cls = ME.MinkowskiGenerativeConvolutionTranspose if type(mod).__name__.startswith('MinkowskiGenerative') else ME.MinkowskiConvolution
+        layer = cls(in_channels=mod.in_channels, out_channels=mod.out_channels, kernel_size=mod.kernel_size, stride=mod.stride, bias=True, dimension=3).to(DEV)
+        layer.load_state_dict(mod.state_dict())
+        return layer(x)
+
+    def block(b, x):                                             # autoencoder.py:52-57, unfused
+        out0 = conv(b.conv0_1, relu(conv(b.conv0_0, x)))
+        out1 = conv(b.conv1_2, relu(conv(b.conv1_1, relu(conv(b.conv1_0, x)))))
+        return ME.cat(out0, out1) + x
+
+    c4 = _coords('shell7')
+    x = ME.SparseTensor(features=torch.ones((len(c4), 1)), coordinates=_t(c4), tensor_stride=1, device=DEV)
+    ops.CHILD_MFMA, old = False, ops.CHILD_MFMA                 # the facade's layers are plain per-level convs
+    try:
+        with torch.no_grad():
+            out0 = relu(conv(enc.down0, relu(conv(enc.conv0, x))))
+            for b in enc.block0: out0 = block(b, out0)
+            out1 = relu(conv(enc.down1, relu(conv(enc.conv1, out0))))
+            for b in enc.block1: out1 = block(b, out1)
+            out2 = relu(conv(enc.down2, relu(conv(enc.conv2, out1))))
+            for b in enc.block2: out2 = block(b, out2)
+            out2 = conv(enc.conv3, out2)
+            nums = [[len(out1)], [len(out0)], [len(x)]]
+            out, cls_list = out2, []
+            pruning = ME.MinkowskiPruning()
+            for l in range(3):
+                out = relu(conv(getattr(dec, f'conv{l}'), relu(conv(getattr(dec, f'up{l}'), out))))
+                for b in getattr(dec, f'block{l}'): out = block(b, out)
+                cls = conv(getattr(dec, f'conv{l}_cls'), out)
+                cls_list.append(cls)
+                out = pruning(out, istopk(cls, nums[l]))
+    finally:
+        ops.CHILD_MFMA = old
+    with torch.no_grad():
+        ys = m.encoder(SparseTensor(torch.ones((len(c4), 1)), coordinates=_t(c4), tensor_stride=1, device=DEV))
+        f_cls, f_out = m.decoder(ys[0], [[n[0]] for n in nums])
+    for got, want in ((out2, ys[0]), (out1, ys[1]), (out0, ys[2]), (out, f_out)) + tuple(zip(cls_list, f_cls)):
+        np.testing.assert_array_equal(got.C.cpu().numpy(), want.C.cpu().numpy())
+        np.testing.assert_array_equal(got.F.cpu().numpy(), want.F.cpu().numpy())

@@ -478,3 +478,35 @@ def test_numa_cpu_lookup_and_thread_budget(tmp_path):
                 assert frames * (2 + (cfg['rc_threads'] - 1) + cfg['aten_threads']) <= quota + frames     # (the decoding thread is one of rc_threads)
     finally:
         pcgcv2_amd.configure_host_threads()
+
+
+def test_reference_autoencoder_binds_to_the_me_facade(golden_dir):
+    """`pcgcv2_amd.ME` stands in for MinkowskiEngine: the REFERENCE's autoencoder.py, loaded as it is (this container only; the GPU
+    box has no /root/reference), must construct its Encoder / Decoder from the facade's layers, and their parameters must be exactly
+    the product's checkpoint keys and shapes — i.e. a reference checkpoint loads into the reference's own module tree built on these
+    operators."""
+    import importlib.util, sys, types
+    ref = '/root/reference/autoencoder.py'
+    if not os.path.exists(ref):
+        pytest.skip('reference sources are not available here')
+    import pcgcv2_amd.ME as ME
+    import pcgcv2_amd.data_utils as du
+    saved = {k: sys.modules.get(k) for k in ('MinkowskiEngine', 'data_utils')}
+    sys.modules['MinkowskiEngine'], sys.modules['data_utils'] = ME, du
+    try:
+        spec = importlib.util.spec_from_file_location('_ref_autoencoder', ref)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        enc, dec = mod.Encoder(channels=[1, 16, 32, 64, 32, 8]), mod.Decoder(channels=[8, 64, 32, 16])
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    from pcgcv2_amd.pcc_model import PCCModel
+    got = {('encoder.' + k): tuple(v.shape) for k, v in enc.state_dict().items()}
+    got.update({('decoder.' + k): tuple(v.shape) for k, v in dec.state_dict().items()})
+    want = {k: tuple(v.shape) for k, v in PCCModel().state_dict().items() if k.split('.')[0] in ('encoder', 'decoder')}
+    assert got == want and len(got) == 212                        # the 227 checkpoint keys minus the 15 entropy-bottleneck ones (golden G5)
+    assert got['encoder.conv0.kernel'] == (27, 1, 16) and got['encoder.down0.kernel'] == (8, 16, 32) and got['encoder.block0.0.conv1_0.kernel'] == (32, 8)

@@ -6,11 +6,17 @@ mkdir -p $R/gpurun_out/final
 timeout 600 bash $R/tools/pmc_traffic.sh > $R/gpurun_out/final/pmc.log 2>&1
 cp $R/profiles/pmc_traffic.json $R/gpurun_out/final/pmc_traffic.json
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/kt -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-events --serving-frames 0 > $R/gpurun_out/final/kt.log 2>&1
-cd $R
-python tools/rocprof_summary.py gpurun_out/final/kt/*/*kernel_stats.csv at::native > gpurun_out/final/kernel_trace.txt 2>&1 || true
-find gpurun_out/final/kt -name '*kernel_trace.csv' -delete
-bash tools/fetch_calib.sh > /dev/null 2>&1; cp gpurun_out/r02_fetch_calibration.txt gpurun_out/final/
+# kernel traces of the three bench configurations: summaries of the TIMED steps by timestamp window (at::native / rocclr kernels inside a step included)
+for cfg in frame:10:1 sweep:2:7 blocks:3:8; do
+  c=${cfg%%:*}; rest=${cfg#*:}; st=${rest%%:*}; per=${rest##*:}
+  cd /tmp
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/kt_$c -- python $R/bench.py --config $c --steps $st --warmup 2 --no-cpu-baseline --no-events --serving-frames 0 --no-extra > $R/gpurun_out/final/kt_$c.log 2>&1
+  cd $R
+  python tools/trace_window_summary.py gpurun_out/final/kt_$c/*/*kernel_trace.csv $st $per > gpurun_out/final/kernel_trace_$c.txt 2>&1 || true
+  python tools/rocprof_summary.py gpurun_out/final/kt_$c/*/*kernel_stats.csv > gpurun_out/final/kernel_stats_$c.txt 2>&1 || true
+  find gpurun_out/final/kt_$c -name '*kernel_trace.csv' -delete
+done
+bash tools/fetch_calib.sh > /dev/null 2>&1; cp gpurun_out/r02_fetch_calibration.txt gpurun_out/final/fetch_calibration.txt
 for cfg in 16:irn 16:conv 32:irn; do
   bash tools/child_pmc.sh ${cfg%%:*} 0 0 ${cfg##*:} > /dev/null 2>&1; cp gpurun_out/child_pmc/summary.txt gpurun_out/final/child_pmc_${cfg%%:*}_${cfg##*:}.txt
 done
