@@ -129,7 +129,9 @@ def main():
         desc = f'{"+".join(variants)}: 4-frame vox10 batch, frames round-robin over {world} GPU(s)'
     elif cfg == 'sweep':
         units = [(base, cloud(base))]                  # every rank sweeps its own copy of the frame (weak scaling)
-        rate_sds = [synthetic.synthetic_state_dict(gain=g) for g in SWEEP_GAINS]
+        # one checkpoint per rate, staged on the device before the clock starts (test.py loads its .pth files outside the timers too):
+        # inside a step a rate change is 227 device-to-device parameter copies, not 227 host-to-device ones
+        rate_sds = [{k: v.to(dev) for k, v in synthetic.synthetic_state_dict(gain=g).items()} for g in SWEEP_GAINS]
         scaling = 'weak'
         desc = f'{base}: vox11 frame through {len(SWEEP_GAINS)} synthetic rates (latent gains {SWEEP_GAINS}), geometry maps shared by the rates'
     else:

@@ -1,5 +1,6 @@
 // Stream compaction (MinkowskiPruning, autoencoder.py:237,247), top-k mask (istopk, data_utils.py:77-89) and the
 // canonical z-major ordering (sort_spare_tensor / array2vector, data_utils.py:55-61,91-101; coder.py:97-99).
+#include <algorithm>
 #include <cstring>
 #include "pcgc_common.h"
 #include <rocprim/rocprim.hpp>
@@ -166,28 +167,40 @@ extern "C" int pcgc_compact_feats(const float* in, int C, int in_ld, const uint8
 // mask = key > T, plus the first `need` rows (by index) among key == T (canonical tie rule: lower row wins).  The final
 // pick knows how many keys equal T: unless fewer than all of them are needed (a genuine tie at the threshold) every one is
 // kept and the ranking launches (equality flags scanned, mask fixed up) return at once.
-struct TopkState { uint32_t prefix; uint32_t tie; int64_t k_remaining; uint32_t done; uint32_t count_eq; };   // lives at workspace[0]
+struct TopkState { uint32_t prefix; uint32_t tie; int64_t k_remaining; uint32_t done; uint32_t count_eq; };   // one per segment, at workspace[0]
+// Row segments of a collated batch (data_utils.py:77-89: istopk loops over the batch items, each with its own budget): item b =
+// rows [off[b], off[b + 1]).  A single cloud is one segment.  Passed by value: up to 16 items (the coordinate key's 4 batch bits).
+constexpr int TOPK_MAX_SEGS = 16;
+struct TopkSegs { int n; long long off[TOPK_MAX_SEGS + 1]; long long k[TOPK_MAX_SEGS]; };
 
 __device__ static inline uint32_t order_key(float f) {
     f = f + 0.0f;                                      // -0.0 -> +0.0
     uint32_t b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u); // ascending in float order
 }
-// zeroes the state, the histogram and the tie path's scan workspace
-__global__ void k_topk_init(TopkState* st, uint32_t* hist, int64_t k, unsigned long long* scan_ws, int64_t scan_words) {
-    if (threadIdx.x == 0) { st->prefix = 0; st->tie = 0; st->k_remaining = k; st->done = 0; st->count_eq = 0; }
-    hist[threadIdx.x] = 0;
-    for (int64_t i = threadIdx.x; i < scan_words; i += blockDim.x) scan_ws[i] = 0;
+// one block per segment: zeroes its state and histogram; block 0 also the tie path's scan workspace and the any-tie flag
+__global__ void k_topk_init(TopkState* st, uint32_t* hist, TopkSegs segs, unsigned long long* scan_ws, int64_t scan_words, uint32_t* any_tie) {
+    const int y = blockIdx.x;
+    if (threadIdx.x == 0) { st[y].prefix = 0; st[y].tie = 0; st[y].k_remaining = segs.k[y]; st[y].done = 0; st[y].count_eq = 0; }
+    hist[256 * y + threadIdx.x] = 0;
+    if (y == 0) {
+        if (threadIdx.x == 0) *any_tie = 0;
+        for (int64_t i = threadIdx.x; i < scan_words; i += blockDim.x) scan_ws[i] = 0;
+    }
 }
-// Block-local LDS histogram, flushed with one global atomic per non-empty bin.  The grid is kept SMALL (<= 256 blocks):
+// Block-local LDS histogram, flushed with one global atomic per non-empty bin.  The grid is kept SMALL (<= 256 blocks per segment):
 // the flush is up to 256 same-address atomics per block, and with 2048 blocks those serialised in L2 for ~30 us per pass
-// on the 2 M-candidate level (the element loop itself is ~3 us).
-__global__ void __launch_bounds__(256) k_topk_hist(const float* __restrict__ v, int ld, int64_t n, TopkState* st,
-                                                   int pass, uint32_t* hist) {
+// on the 2 M-candidate level (the element loop itself is ~3 us).  blockIdx.y = segment.
+__global__ void __launch_bounds__(256) k_topk_hist(const float* __restrict__ v_all, int ld, TopkSegs segs, TopkState* st_all,
+                                                   int pass, uint32_t* hist_all, uint32_t* any_tie) {
     __shared__ uint32_t h[256];
     __shared__ int64_t S[257];
     __shared__ bool last_s;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, y = blockIdx.y;
+    const float* __restrict__ v = v_all + segs.off[y] * ld;
+    const int64_t n = segs.off[y + 1] - segs.off[y];
+    TopkState* st = st_all + y;
+    uint32_t* hist = hist_all + 256 * y;
     h[t] = 0;
     __syncthreads();
     int shift = 24 - 8 * pass;
@@ -208,8 +221,8 @@ __global__ void __launch_bounds__(256) k_topk_hist(const float* __restrict__ v, 
         if ((key & pmask) == prefix) atomicAdd(&h[(key >> shift) & 0xff], 1u);
     }
     __syncthreads();
-    // the last block to arrive picks the digit.  No fences (a device-scope release is a whole-L2 write-back here): the bin
-    // updates are device-scope atomics, i.e. performed at the memory side; each thread waits for the RETURN of its own update
+    // the last block of the segment to arrive picks the digit.  No fences (a device-scope release is a whole-L2 write-back here): the
+    // bin updates are device-scope atomics, i.e. performed at the memory side; each thread waits for the RETURN of its own update
     // before the block's arrival is counted, and the last block reads the bins with device-scope atomic loads.
     uint32_t seen = 0;
     if (h[t]) seen = atomicAdd(&hist[t], h[t]);
@@ -238,86 +251,104 @@ __global__ void __launch_bounds__(256) k_topk_hist(const float* __restrict__ v, 
         st->prefix = prefix | ((uint32_t)t << shift);
         st->k_remaining = rem;
         st->done = 0;
-        if (pass == 3) { st->count_eq = (uint32_t)mine; st->tie = rem < mine ? 1u : 0u; }
+        if (pass == 3) {
+            st->count_eq = (uint32_t)mine;
+            st->tie = rem < mine ? 1u : 0u;
+            if (rem < mine) atomicOr(any_tie, 1u);     // some segment needs the ranking launches below
+        }
     }
     hist[t] = 0;                                       // ready for the next pass
 }
 // mask = key > T, or key == T when every such row is kept; on a genuine tie the equal rows are flagged for the ranking below
-__global__ void k_topk_mask(const float* __restrict__ v, int ld, int64_t n, const TopkState* st, uint8_t* mask, uint8_t* eq) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// (eq is written for every row: the ranking scans the flags of ALL segments in one pass)
+__global__ void k_topk_mask(const float* __restrict__ v, int ld, TopkSegs segs, const TopkState* st_all, uint8_t* mask, uint8_t* eq) {
+    const int y = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, n = segs.off[y + 1] - segs.off[y];
     if (i >= n) return;
-    const uint32_t key = order_key(v[i * ld]), T = st->prefix;
+    const int64_t g = segs.off[y] + i;
+    const TopkState* st = st_all + y;
+    const uint32_t key = order_key(v[g * ld]), T = st->prefix;
     const bool tie = st->tie != 0;
-    mask[i] = (key > T) || (key == T && !tie);
-    if (tie) eq[i] = key == T;
+    mask[g] = (key > T) || (key == T && !tie);
+    eq[g] = tie && key == T;
 }
-// tie_high = 0: among logits equal to the threshold the LOWER row indices are kept (canonical); 1: the HIGHER ones
-__global__ void k_topk_tie_fix(const TopkState* st, const uint8_t* __restrict__ eq, const int32_t* __restrict__ eq_rank, int64_t n,
+// tie_high = 0: among logits equal to the threshold the LOWER row indices are kept (canonical); 1: the HIGHER ones.
+// eq_rank = exclusive count of flagged rows over the whole batch: the rank inside the segment subtracts the count at its first row
+__global__ void k_topk_tie_fix(const TopkState* st_all, TopkSegs segs, const uint8_t* __restrict__ eq, const int32_t* __restrict__ eq_rank,
                                int tie_high, uint8_t* mask) {
+    const int y = blockIdx.y;
+    const TopkState* st = st_all + y;
     if (st->tie == 0) return;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !eq[i]) return;
-    const int64_t need = st->k_remaining, r = eq_rank[i];
-    mask[i] = tie_high ? r >= (int64_t)st->count_eq - need : r < need;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, n = segs.off[y + 1] - segs.off[y];
+    if (i >= n) return;
+    const int64_t g = segs.off[y] + i;
+    if (!eq[g]) return;
+    const int64_t need = st->k_remaining, r = (int64_t)eq_rank[g] - (int64_t)eq_rank[segs.off[y]];
+    mask[g] = tie_high ? r >= (int64_t)st->count_eq - need : r < need;
 }
-
 static int g_topk_tie_high = 0;
-// ‡ conventions of the un-vendored dependencies that the reference's results depend on but its sources do not pin:
-//   what = 0  top-k tie rule (data_utils.py:85-87, torch.topk on ME's row order): value 0 = lower row wins (default), 1 = higher row wins
-// (the dedup policy is an argument of pcgc_hash_insert_policy; the kernel-offset order is a weight permutation done by the host).
+// result-changing ‡ conventions (see include/pcgc_hip.h); 0 = top-k tie rule
 extern "C" int pcgc_set_convention(int what, int value) {
     if (what == 0) { g_topk_tie_high = value ? 1 : 0; return 0; }
     pcgc_set_error("set_convention: unknown convention %d", what);
     return -2;
 }
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+// workspace: states (16 x 32 B) | any-tie flag | histograms (16 x 256 x 4 B) | eq flags | ranks | total | scan workspace
 extern "C" size_t pcgc_topk_workspace_bytes(int64_t n) {
-    return 256 + 1024 + align256((size_t)n) + align256((size_t)n * 4) + 256 + align256(pcgc_scan_workspace_bytes(n));
+    return 1024 + (size_t)TOPK_MAX_SEGS * 1024 + align256((size_t)n) + align256((size_t)n * 4) + 256 + align256(pcgc_scan_workspace_bytes(n));
 }
-extern "C" int pcgc_topk_mask(const float* logits, int ld, int64_t n, int64_t k, uint8_t* mask, void* workspace,
-                              size_t workspace_bytes, void* stream) {
+static int topk_segments(const float* logits, int ld, const TopkSegs& segs, uint8_t* mask, void* workspace, size_t workspace_bytes, void* stream) {
+    const int64_t n = segs.off[segs.n];
     PCGC_REQUIRE(workspace_bytes >= pcgc_topk_workspace_bytes(n), "workspace too small");
     PCGC_REQUIRE(((uintptr_t)workspace & 7) == 0, "workspace must be 8-byte aligned");
     if (n == 0) return 0;
-    if (k >= n) { (void)hipMemsetAsync(mask, 1, (size_t)n, S(stream)); return 0; }
-    if (k <= 0) { (void)hipMemsetAsync(mask, 0, (size_t)n, S(stream)); return 0; }
     char* ws = (char*)workspace;
-    TopkState* st = (TopkState*)ws; ws += 256;
-    uint32_t* hist = (uint32_t*)ws; ws += 1024;
+    TopkState* st = (TopkState*)ws;
+    uint32_t* any_tie = (uint32_t*)(ws + 768); ws += 1024;
+    uint32_t* hist = (uint32_t*)ws; ws += (size_t)TOPK_MAX_SEGS * 1024;
     uint8_t* eq = (uint8_t*)ws; ws += align256((size_t)n);
     int32_t* rank = (int32_t*)ws; ws += align256((size_t)n * 4);
     int32_t* total = (int32_t*)ws; ws += 256;
     void* scan_ws = ws;
-    unsigned g = grid_for(n, 256 * 8); if (g > 256) g = 256; if (g < 1) g = 1;
-    hipLaunchKernelGGL(k_topk_init, dim3(1), dim3(256), 0, S(stream), st, hist, k, (unsigned long long*)scan_ws,
-                       (int64_t)(pcgc_scan_workspace_bytes(n) / 8));
+    int64_t nmax = 0;
+    for (int b = 0; b < segs.n; ++b) nmax = std::max<int64_t>(nmax, segs.off[b + 1] - segs.off[b]);
+    unsigned g = grid_for(nmax, 256 * 8); if (g > 256) g = 256; if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_topk_init, dim3(segs.n), dim3(256), 0, S(stream), st, hist, segs, (unsigned long long*)scan_ws,
+                       (int64_t)(pcgc_scan_workspace_bytes(n) / 8), any_tie);
     for (int pass = 0; pass < 4; ++pass)
-        hipLaunchKernelGGL(k_topk_hist, dim3(g), dim3(256), 0, S(stream), logits, ld, n, st, pass, hist);
-    hipLaunchKernelGGL(k_topk_mask, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), logits, ld, n, st, mask, eq);
-    // genuine tie at the threshold only (st->tie): rank the equal rows and keep `need` of them
-    launch_scan(eq, n, rank, total, scan_ws, &st->tie, S(stream));
-    hipLaunchKernelGGL(k_topk_tie_fix, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), st, eq, rank, n, g_topk_tie_high, mask);
+        hipLaunchKernelGGL(k_topk_hist, dim3(g, segs.n), dim3(256), 0, S(stream), logits, ld, segs, st, pass, hist, any_tie);
+    hipLaunchKernelGGL(k_topk_mask, dim3(grid_for(nmax, 256), segs.n), dim3(256), 0, S(stream), logits, ld, segs, st, mask, eq);
+    // genuine tie at a segment's threshold only (any_tie): rank the equal rows and keep `need` of them per segment
+    launch_scan(eq, n, rank, total, scan_ws, any_tie, S(stream));
+    hipLaunchKernelGGL(k_topk_tie_fix, dim3(grid_for(nmax, 256), segs.n), dim3(256), 0, S(stream), st, segs, eq, rank, g_topk_tie_high, mask);
     PCGC_CHECK_LAUNCH("topk_mask");
     return 0;
 }
+extern "C" int pcgc_topk_mask(const float* logits, int ld, int64_t n, int64_t k, uint8_t* mask, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    if (n == 0) return 0;
+    if (k >= n) { (void)hipMemsetAsync(mask, 1, (size_t)n, S(stream)); return 0; }
+    if (k <= 0) { (void)hipMemsetAsync(mask, 0, (size_t)n, S(stream)); return 0; }
+    TopkSegs segs{};
+    segs.n = 1; segs.off[0] = 0; segs.off[1] = n; segs.k[0] = k;
+    return topk_segments(logits, ld, segs, mask, workspace, workspace_bytes, stream);
+}
 
-// Batched form (data_utils.py:77-89: `istopk` loops over the batch items, each with its own budget nums[b]): the rows of item b
-// are the contiguous range [sum(seg_rows[:b]), +seg_rows[b]) — every level of a collated batch is the concatenation of its
-// items' levels (canonical row orders are first-occurrence orders of item-contiguous inputs) — so the mask of a batch is the
-// single-cloud sequence run per segment on a sub-range.  One workspace serves all segments (same stream: segment b + 1 starts
-// after segment b).  seg_rows / seg_k are HOST arrays.
+// Batched form: ONE launch sequence for all items (blockIdx.y = item).  seg_rows / seg_k are HOST arrays; the workspace is sized for
+// the TOTAL row count (pcgc_topk_workspace_bytes(sum of seg_rows)).  k is clamped to [0, rows] per item.
 extern "C" int pcgc_topk_mask_segments(const float* logits, int ld, int nseg, const int64_t* seg_rows, const int64_t* seg_k,
                                        uint8_t* mask, void* workspace, size_t workspace_bytes, void* stream) {
-    PCGC_REQUIRE(nseg >= 0 && (nseg == 0 || (seg_rows && seg_k)), "bad segments");
-    int64_t off = 0, nmax = 0;
-    for (int b = 0; b < nseg; ++b) { PCGC_REQUIRE(seg_rows[b] >= 0, "negative segment"); if (seg_rows[b] > nmax) nmax = seg_rows[b]; }
-    PCGC_REQUIRE(workspace_bytes >= pcgc_topk_workspace_bytes(nmax), "workspace too small");
+    PCGC_REQUIRE(nseg >= 0 && nseg <= TOPK_MAX_SEGS && (nseg == 0 || (seg_rows && seg_k)), "at most 16 segments");
+    if (nseg == 0) return 0;
+    TopkSegs segs{};
+    segs.n = nseg; segs.off[0] = 0;
     for (int b = 0; b < nseg; ++b) {
-        const int rc = pcgc_topk_mask(logits + off * ld, ld, seg_rows[b], seg_k[b], mask + off, workspace, workspace_bytes, stream);
-        if (rc) return rc;
-        off += seg_rows[b];
+        PCGC_REQUIRE(seg_rows[b] >= 0, "negative segment");
+        segs.off[b + 1] = segs.off[b] + seg_rows[b];
+        segs.k[b] = seg_k[b] < 0 ? 0 : (seg_k[b] > seg_rows[b] ? seg_rows[b] : seg_k[b]);
     }
-    return 0;
+    return topk_segments(logits, ld, segs, mask, workspace, workspace_bytes, stream);
 }
 
 // rows per batch item (column 0 of the coordinates): counts[b] for b < 16 (the coordinate key holds 4 batch bits)

@@ -918,7 +918,7 @@ def topk_mask_segments(logits, seg_rows, seg_k):
     if sum(seg_rows) != n:
         raise PcgcError(f'topk_mask_segments: segments cover {sum(seg_rows)} of {n} rows')
     mask = torch.empty(n, dtype=torch.uint8, device=logits.device)
-    ws_bytes = int(lib().pcgc_topk_workspace_bytes(max(seg_rows) if seg_rows else 0))
+    ws_bytes = int(lib().pcgc_topk_workspace_bytes(n))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=logits.device)
     check(lib().pcgc_topk_mask_segments(_p(logits), logits.stride(0), len(seg_rows), _i64_array(seg_rows), _i64_array(seg_k), _p(mask), _p(ws),
                                         ws_bytes, _stream(logits)), 'topk_mask_segments')
