@@ -136,6 +136,11 @@ int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const float* in, 
 /* kernel selection for the gather conv: -1 auto (default), 0 = v0 direct-load kernel, 1 = v1 LDS-DMA kernel, 2 / 3 = the fp32-MFMA
  * kernels, 5 / 6 = the 16-row "burst" and row-split forms that small levels get (each where eligible).  All produce bit-identical results; the
  * switch exists for A/B measurements and tests. */
+/* The codec's first layer (Encoder.conv0, autoencoder.py:71-77) on its actual input, the all-ones single-channel occupancy indicator
+ * (data_utils.py:104,114): out = relu?(sum over PRESENT offsets k, ascending, of W[k][0][:] + bias).  fmaf(1, w, acc) = acc + w exactly,
+ * so this IS pcgc_conv_gather's chain on that input, without the 27 feature gathers per row.  W: [K, 1, Cout]. */
+int pcgc_conv_gather_unit(const int32_t* nbr /*[dev K,n_out]*/, int K, int64_t n_out, const float* W, const float* bias, int relu,
+                          float* out, int Cout, int out_ld, void* stream);
 int pcgc_set_conv_impl(int impl);
 /* the LDS-shared-weight MFMA kernels come in two schedules (v2b: 16-channel sub-steps; v2c: 32-channel steps with the next
  * step's loads in flight): -1 choose by level size (default), 0 always v2b, 1 always v2c.  Bit-identical. */

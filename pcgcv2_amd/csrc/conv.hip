@@ -72,6 +72,51 @@ static void launch_valu(const int32_t* nbr, int K, int64_t n_out, const float* i
 }
 
 
+// The first layer of the codec sees the occupancy indicator: one input channel that is 1.0 on every occupied voxel
+// (data_utils.py:104 `feats = torch.ones(...)`, :114 after a rescale).  fmaf(1.0f, w, acc) is exactly acc + w, so the layer is a sum
+// of the kernel slices of the PRESENT offsets, in ascending offset order — the canonical chain — and the 27 four-byte feature
+// gathers per row (8.1 M of them on a vox10 frame: the texture-addresser bound of k_conv_gather_valu<16>, 88-105 us) are not needed:
+// the kernel map says which offsets are present.  One thread per output row; the map is read coalesced, the weights are wave-uniform.
+template <int COUT>
+__global__ void __launch_bounds__(256)
+k_conv_unit(const int32_t* __restrict__ nbr, int K, int64_t n_out, const float* __restrict__ W, const float* __restrict__ bias,
+            int relu, float* __restrict__ out, int out_ld) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_out) return;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        if (nbr[(int64_t)k * n_out + o] < 0) continue;
+        const float* w = W + (int64_t)k * COUT;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = fmaf(1.0f, w[co], acc[co]);
+    }
+    float* y = out + o * out_ld;
+#pragma unroll
+    for (int co = 0; co < COUT; co += 4) {
+        float4 v;
+        v.x = acc[co] + (bias ? bias[co] : 0.0f); v.y = acc[co + 1] + (bias ? bias[co + 1] : 0.0f);
+        v.z = acc[co + 2] + (bias ? bias[co + 2] : 0.0f); v.w = acc[co + 3] + (bias ? bias[co + 3] : 0.0f);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *(float4*)(y + co) = v;
+    }
+}
+extern "C" int pcgc_conv_gather_unit(const int32_t* nbr, int K, int64_t n_out, const float* W, const float* bias, int relu,
+                                     float* out, int Cout, int out_ld, void* stream) {
+    PCGC_REQUIRE(nbr && W && out && K >= 1, "null argument");
+    PCGC_REQUIRE((out_ld & 3) == 0 && (((uintptr_t)out) & 15) == 0, "output rows must be 16-byte aligned");
+    if (n_out == 0) return 0;
+    switch (Cout) {
+        case 16: hipLaunchKernelGGL((k_conv_unit<16>), dim3(grid_for(n_out, 256)), dim3(256), 0, S(stream), nbr, K, n_out, W, bias, relu, out, out_ld); break;
+        case 8: hipLaunchKernelGGL((k_conv_unit<8>), dim3(grid_for(n_out, 256)), dim3(256), 0, S(stream), nbr, K, n_out, W, bias, relu, out, out_ld); break;
+        case 4: hipLaunchKernelGGL((k_conv_unit<4>), dim3(grid_for(n_out, 256)), dim3(256), 0, S(stream), nbr, K, n_out, W, bias, relu, out, out_ld); break;
+        default: pcgc_set_error("conv_gather_unit: unsupported Cout %d (4, 8, 16)", Cout); return -2;
+    }
+    PCGC_CHECK_LAUNCH("conv_gather_unit");
+    return 0;
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // v1 kernel: LDS-DMA gather.  One wave = one tile of 64 output rows x CT output channels (lane = row, accumulators in
 // VGPRs, weights as scalar operands).  What changes vs v0 is how the gathered rows reach the lanes:

@@ -423,6 +423,33 @@ def conv_gather(nbr, x, W, bias, out=None, residual=None, relu=False, n_out=None
     return out
 
 
+UNIT_INPUT_CONV = True     # A/B switch: the first layer on an all-ones input skips the feature gathers (bit-identical)
+
+
+def conv_gather_unit(nbr, W, bias, relu=False):
+    """conv_gather for the all-ones single-channel input (the occupancy indicator every coded cloud starts from):
+    out = relu?(sum of W[k][0][:] over the present offsets k, ascending, + bias)."""
+    _f32(W, 'W')
+    K, Cin, Cout = W.shape
+    if Cin != 1 or nbr.shape[0] != K:
+        raise PcgcError('conv_gather_unit: kernel [K, 1, Cout] and a [K, n] map expected')
+    n_out = nbr.shape[1]
+    out = torch.empty((n_out, Cout), dtype=torch.float32, device=W.device)
+    key = ('conv', 1, Cout, n_out)
+    prof = K == 27 and PROFILE.want(key)
+    if prof:
+        e0, e1 = PROFILE.bracket(key, f'k3 conv 1->{Cout} on the unit input (k_conv_unit: kernel map only, no feature gather)', n_out,
+                                 lambda P, b=Cout, n=n_out: P * 4 + P * 8 + n * b * 4, lambda P, b=Cout: 2 * P * b,
+                                 compulsory=27 * n_out * 4 + n_out * Cout * 4)
+        e0.record()
+    check(lib().pcgc_conv_gather_unit(_p(nbr), K, n_out, _p(W), _p(bias), int(relu), _p(out), Cout, Cout, _stream(nbr)), 'conv_gather_unit')
+    if prof:
+        e1.record()
+    elif PROFILE.counting and K == 27:
+        PROFILE.count(nbr)
+    return out
+
+
 def set_up2_impl(mfma):
     """generative transpose conv kernel for 64->32 / 32->16: 1 fp32 MFMA (default), 0 VALU."""
     check(lib().pcgc_set_up2_impl(int(mfma)), 'set_up2_impl')

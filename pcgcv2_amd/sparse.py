@@ -149,6 +149,7 @@ class SparseTensor:
         if isinstance(tensor_stride, (list, tuple)):
             tensor_stride = tensor_stride[0]
         self._F_thunk = None
+        self.unit_features = False            # True: one channel, every value exactly 1.0 (the occupancy indicator of a coded cloud)
         if coordinate_map is not None:
             self.cmap = coordinate_map
             dev = coordinate_map.C.device
@@ -172,6 +173,8 @@ class SparseTensor:
                 coords, feats = dedup(coords, feats, int(tensor_stride))
             self.cmap = CoordMap(coords, int(tensor_stride), unique=True)
             self.F = feats
+            # (decided once, here, where the constructor synchronises anyway: the first layer then needs no feature gathers)
+            self.unit_features = feats.shape[1] == 1 and feats.shape[0] > 0 and bool((feats == 1).all().item())
 
     @property
     def F(self):

@@ -185,6 +185,36 @@ def test_conv_gather_bit_exact(K, cin, cout, conv_impl):
     assert not buf[:, :cout].any()
 
 
+def test_first_layer_on_the_unit_input():
+    """pcgc_conv_gather_unit (the first layer on the all-ones occupancy indicator: kernel map only) == the general gather conv and the
+    oracle on that input; a SparseTensor notices an all-ones single channel by itself, any other input takes the general kernel."""
+    from pcgcv2_amd.nn import MinkowskiConvolution
+    rng = np.random.default_rng(11)
+    c4 = _coords('shell8')
+    conv = MinkowskiConvolution(1, 16, 3).to(DEV)
+    with torch.no_grad():
+        conv.kernel.copy_(_t(rng.standard_normal((27, 1, 16)).astype(np.float32) * 0.3)); conv.bias.copy_(_t(rng.standard_normal((1, 16)).astype(np.float32)))
+    W, b = conv.kernel.detach().cpu().numpy(), conv.bias.detach().cpu().numpy()
+    ones = np.ones((len(c4), 1), np.float32)
+    want = np.maximum(orc.conv_gather(orc.kmap_k3(c4, 1), ones, W, b), np.float32(0))
+    x = SparseTensor(_t(ones), coordinates=_t(c4), tensor_stride=1, device=DEV)
+    assert x.unit_features
+    with torch.no_grad():
+        got = conv(x, relu=True).F.cpu().numpy()
+        ops.UNIT_INPUT_CONV = False
+        try:
+            general = conv(x, relu=True).F.cpu().numpy()
+        finally:
+            ops.UNIT_INPUT_CONV = True
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(general, want)
+    other = ones.copy(); other[5] = 0.5
+    y = SparseTensor(_t(other), coordinates=_t(c4), tensor_stride=1, device=DEV)
+    assert not y.unit_features
+    with torch.no_grad():
+        np.testing.assert_array_equal(conv(y, relu=True).F.cpu().numpy(), np.maximum(orc.conv_gather(orc.kmap_k3(c4, 1), other, W, b), np.float32(0)))
+
+
 @pytest.mark.parametrize('rows', [64, 32, 16])
 @pytest.mark.parametrize('C', [16, 32, 64])
 def test_fused_inception_resnet_bit_exact(C, rows):
