@@ -305,6 +305,24 @@ int pcgc_d1_nn(const int32_t* a /*[dev na,4]*/, int64_t na, const uint64_t* b_ke
 int64_t pcgc_ply_read_ascii_geo(const char* path, int32_t* xyz /*[host cap,3] or NULL*/, int64_t cap);
 int pcgc_ply_write_ascii_geo(const char* path, const int32_t* xyz /*[host n,3]*/, int64_t n);
 
+/* ---- the bitstream files of several items at once (HOST; native threads): the host half of Coder.encode / Coder.decode
+ *      (coder.py:49-55,85-87,93-100) for the items of a collated batch or for one cloud.  stems[i] = "<prefix><postfix>" of item i;
+ *      sym: int16 symbols [sum rows, C] (items contiguous), ranges [n,2] = (min_v, max_v) per item, counts [n,3] = (N4, N2, N1),
+ *      xyz = stride-8 coordinates / 8, [sum rows, 3].  table_fn = pcgc_reference_table of libpcgc_reftable.so (include/pcgc_reftable.h)
+ *      or any function of that signature; eb_params as it expects them.  index_segments = coder.INDEX_SEGMENTS (0: no sidecar).
+ *      write_coords = 0: `_C.bin` is left to the caller (tmc3).  threads <= 0: the CPUs this process may use. ---- */
+typedef int (*pcgc_table_fn)(const float* params, int C, float min_v, float max_v, uint16_t* table_u16, float* cdf_f32);
+int pcgc_items_encode(int n_items, const char* const* stems, const int16_t* sym, const int32_t* xyz, const int64_t* rows, const float* ranges,
+                      int C, const int32_t* counts, const float* eb_params, pcgc_table_fn table_fn, int index_segments, int write_coords,
+                      int threads);
+/* sizes first: rows[i], channels[0], ranges, counts, native_coords[i] (1: `_C.bin` is a native octree stream of rows[i] points) ... */
+int pcgc_items_probe(int n_items, const char* const* stems, int64_t* rows, int32_t* channels, float* ranges, int32_t* counts,
+                     int32_t* native_coords);
+/* ... then the streams: sym [sum rows, C], xyz [sum rows, 3] (items with native_coords).  -5: a sidecar names another CDF table than
+ * this host derives (the stream would decode to noise). */
+int pcgc_items_decode(int n_items, const char* const* stems, const int64_t* rows, int C, const float* ranges, const int32_t* native_coords,
+                      const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int16_t* sym, int32_t* xyz, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,7 +58,7 @@ def build(force=False, verbose=False):
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s.rsplit('.', 1)[0] + '.o') for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-lz']
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n' + r.stderr[-4000:])

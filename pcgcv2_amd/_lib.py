@@ -88,6 +88,9 @@ SIGNATURES = {
     'pcgc_oct_encode': (i64, [vp, i64, vp, i64]),
     'pcgc_oct_decode_count': (i64, [vp, i64]),
     'pcgc_oct_decode': (ci, [vp, i64, vp, i64]),
+    'pcgc_items_encode': (ci, [ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci]),
+    'pcgc_items_probe': (ci, [ci, vp, vp, vp, vp, vp, vp]),
+    'pcgc_items_decode': (ci, [ci, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp, ci]),
     'pcgc_ply_read_ascii_geo': (i64, [C.c_char_p, vp, i64]),
     'pcgc_ply_write_ascii_geo': (ci, [C.c_char_p, vp, i64]),
 }

@@ -53,6 +53,7 @@ def _slurp(path):
 # The sidecar names the stream it belongs to by length and CRC-32 and carries a CRC over itself; one that does not match (or is
 # absent: a reference-made stream) is ignored and the stream is decoded serially, unguarded — exactly what the reference does.
 INDEX_SEGMENTS = 8                               # checkpoints per stream; 0 = never write or read the sidecar
+NATIVE_ITEMS = True                              # batches: per-item host stages on native threads (False: Python thread pool; A/B and tests)
 INDEX_SUFFIX = '_F.idx'
 _INDEX_HEAD = struct.Struct('<4sIIIII')          # magic, stream bytes, stream CRC-32, checkpoints, table CRC-32, CRC-32 of (head so far + body)
 
@@ -336,15 +337,25 @@ class Coder():
         dev = x.device
         offs = np.concatenate([[0], np.cumsum(rows8)])
 
-        def one(b):
-            a, e = int(offs[b]), int(offs[b + 1])
-            _dump(self.filename + postfixes[b] + '_num_points.bin', _COUNTS.pack(rows4[b], rows2[b], rows1[b]))
-            self.feature_coder.encode_symbols(sym_h[a:e], ranges[b][0], ranges[b][1], postfix=postfixes[b], device=dev)
-            self.coordinate_coder.encode(host_C[a:e, 1:] // lvl8.stride, postfix=postfixes[b])
-        list(_batch_pool().map(one, range(B)))
+        if self._native_items():
+            # every item's table, range coder, sidecar, octree stream and files on native threads (one library call)
+            ops.items_encode([self.filename + p for p in postfixes], sym_h, host_C[:, 1:] // lvl8.stride, rows8, ranges,
+                             list(zip(rows4, rows2, rows1)), self.feature_coder.entropy_model._host_packed(), INDEX_SEGMENTS)
+        else:
+            def one(b):
+                a, e = int(offs[b]), int(offs[b + 1])
+                _dump(self.filename + postfixes[b] + '_num_points.bin', _COUNTS.pack(rows4[b], rows2[b], rows1[b]))
+                self.feature_coder.encode_symbols(sym_h[a:e], ranges[b][0], ranges[b][1], postfix=postfixes[b], device=dev)
+                self.coordinate_coder.encode(host_C[a:e, 1:] // lvl8.stride, postfix=postfixes[b])
+            list(_batch_pool().map(one, range(B)))
         cmap = CoordMap(y_C, lvl8.stride, unique=True)
         cmap._batch_rows = list(rows8)
         return SparseTensor(y_F, coordinate_map=cmap)
+
+    def _native_items(self):
+        """the per-item host stages can run in the library (pcgc_items_*): the table is the reference-arithmetic one and the
+        coordinates use the native octree stream (no tmc3 installed)"""
+        return NATIVE_ITEMS and self.feature_coder.entropy_model.table_mode == 'reference' and gpcc.tmc3_path() is None
 
     @torch.no_grad()
     def decode_batch(self, postfixes, rho=1):
@@ -357,14 +368,25 @@ class Coder():
     def _decode_batch(self, postfixes, rho, dev):
         B = len(postfixes)
 
-        def one(b):
-            xyz8 = np.asarray(self.coordinate_coder.decode(postfixes[b]), dtype=np.int32)
-            counts = _COUNTS.unpack(_slurp(self.filename + postfixes[b] + '_num_points.bin')[:_COUNTS.size])
-            sym_h, min_v = self.feature_coder.decode_symbols(postfix=postfixes[b], device=dev)
-            if len(sym_h) != len(xyz8):
-                raise ValueError(f'item {b}: {len(xyz8)} coordinates but {len(sym_h)} latent rows')
-            return xyz8, counts, sym_h, min_v
-        items = list(_batch_pool().map(one, range(B)))
+        items = None
+        if self._native_items():
+            stems = [self.filename + p for p in postfixes]
+            rows, C, ranges, counts, native = ops.items_probe(stems)
+            if native.all():
+                sym_all, xyz_all = ops.items_decode(stems, rows, C, ranges, native, self.feature_coder.entropy_model._host_packed(),
+                                                    use_sidecar=bool(INDEX_SEGMENTS))
+                offs = np.concatenate([[0], np.cumsum(rows)])
+                items = [(xyz_all[offs[b]:offs[b + 1]], tuple(int(v) for v in counts[b]), sym_all[offs[b]:offs[b + 1]], np.float32(ranges[b, 0]))
+                         for b in range(B)]
+        if items is None:
+            def one(b):
+                xyz8 = np.asarray(self.coordinate_coder.decode(postfixes[b]), dtype=np.int32)
+                counts = _COUNTS.unpack(_slurp(self.filename + postfixes[b] + '_num_points.bin')[:_COUNTS.size])
+                sym_h, min_v = self.feature_coder.decode_symbols(postfix=postfixes[b], device=dev)
+                if len(sym_h) != len(xyz8):
+                    raise ValueError(f'item {b}: {len(xyz8)} coordinates but {len(sym_h)} latent rows')
+                return xyz8, counts, sym_h, min_v
+            items = list(_batch_pool().map(one, range(B)))
         rows8 = [len(it[0]) for it in items]
         C4 = np.zeros((sum(rows8), 4), dtype=np.int32)
         off = 0

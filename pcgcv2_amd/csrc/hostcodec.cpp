@@ -17,6 +17,9 @@
 #include <thread>
 #include <vector>
 #include <immintrin.h>
+#include <memory>
+#include <string>
+#include <zlib.h>
 #include "../../include/pcgc_hip.h"
 void pcgc_set_error(const char* fmt, ...);           // coords.hip
 
@@ -329,7 +332,9 @@ int effective_cpus() {
     cached = (int)(n < 1 ? 1 : n);
     return cached;
 }
+thread_local bool tl_item_worker = false;                // set on the threads that code the items of a batch side by side (pcgc_items_*)
 int rc_threads() {
+    if (tl_item_worker) return 1;                          // the parallelism is across items there: no nested pools
     if (g_rc_threads > 0) return g_rc_threads;
     return std::min(8, effective_cpus());
 }
@@ -744,4 +749,219 @@ extern "C" int pcgc_oct_decode(const uint8_t* in, int64_t nbytes, int32_t* xyz, 
     if ((int64_t)leaves.size() != n) { pcgc_set_error("oct_decode: corrupt or truncated stream (line %d)", __LINE__); return -2; }
     for (int64_t i = 0; i < n; ++i) demorton3(leaves[(size_t)i], xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
     return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------ bitstream files of several items
+// The host half of Coder.encode / Coder.decode for the items of a collated batch (or one cloud), in native threads: per item the CDF
+// table, the range coder, the sidecar, the octree coordinate stream and the four files.  In Python these stages are a few hundred
+// microseconds of interpreter time per item that eight threads serialise on the GIL (2.7 ms for the 8 octant blocks of config 5,
+// each direction); here the items really run side by side.
+//   <stem>_F.bin             range-coded latent (torchac-compatible stream)                                   coder.py:49-55
+//   <stem>_H.bin             int32 rows | int32 C | int8 1 | float32 min_v | float32 max_v  (17 bytes)          coder.py:51-55
+//   <stem>_num_points.bin    int32[3] = N4, N2, N1                                                              coder.py:85-87
+//   <stem>_C.bin             native "PCGO" octree stream of the stride-8 coordinates (gpcc.py's tmc3 stream is written by the caller)
+//   <stem>_F.idx             sidecar: "PCG2" | stream bytes | stream CRC-32 | checkpoints | table CRC-32 | CRC-32(head + body) | checkpoints
+namespace {
+SegmentPool& items_pool() { static SegmentPool p; return p; }
+bool write_file(const std::string& path, const void* data, size_t n) {
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = n == 0 || std::fwrite(data, 1, n, f) == n;
+    return std::fclose(f) == 0 && ok;
+}
+bool read_file(const std::string& path, std::vector<uint8_t>& out) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    const long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    out.resize(n > 0 ? (size_t)n : 0);
+    const bool ok = n <= 0 || std::fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+    std::fclose(f);
+    return ok;
+}
+void put32(std::vector<uint8_t>& v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
+uint32_t get32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+constexpr size_t kSidecarHead = 24;
+// run fn(item) for every item on up to `threads` threads; -> first failing item's code, its message set as the caller's error
+int for_items(int n_items, int threads, const std::function<int(int, std::string&)>& fn) {
+    std::vector<int> rc((size_t)n_items, 0);
+    std::vector<std::string> msg((size_t)n_items);
+    if (threads <= 0) threads = effective_cpus();
+    const bool side_by_side = n_items > 1 && threads > 1;
+    const std::function<void(int)> one = [&](int i) {
+        const bool was = tl_item_worker;
+        tl_item_worker = side_by_side;
+        rc[(size_t)i] = fn(i, msg[(size_t)i]);
+        tl_item_worker = was;
+    };
+    if (!side_by_side) { for (int i = 0; i < n_items; ++i) one(i); }
+    else items_pool().run(n_items, std::min(threads, n_items) - 1, one);
+    for (int i = 0; i < n_items; ++i)
+        if (rc[(size_t)i]) { pcgc_set_error("item %d: %s", i, msg[(size_t)i].c_str()); return rc[(size_t)i]; }
+    return 0;
+}
+}  // namespace
+
+typedef int (*pcgc_table_fn)(const float* params, int C, float min_v, float max_v, uint16_t* table_u16, float* cdf_f32);
+
+namespace {
+// The table is a pure function of (parameters, range): the last few are kept (the decode of a batch this process has just encoded,
+// repeated frames, sequences whose latent range repeats), keyed by the CRC-32 of the parameter bytes + the range.  Same values as a
+// fresh evaluation by construction.
+struct TableKey { uint32_t pcrc; int C; float lo, hi; pcgc_table_fn fn; bool operator==(const TableKey& o) const { return pcrc == o.pcrc && C == o.C && lo == o.lo && hi == o.hi && fn == o.fn; } };
+struct TableEntry { TableKey key; std::shared_ptr<const std::vector<uint16_t>> table; uint32_t crc; };
+std::mutex g_table_mu;
+std::vector<TableEntry> g_tables;                        // most recent last, at most 32
+int cached_table(pcgc_table_fn fn, const float* params, int C, float lo, float hi, std::shared_ptr<const std::vector<uint16_t>>& out, uint32_t& crc) {
+    const TableKey key{(uint32_t)crc32(0L, (const Bytef*)params, (uInt)(44 * C * 4)), C, lo, hi, fn};
+    {
+        std::lock_guard<std::mutex> lk(g_table_mu);
+        for (auto it = g_tables.rbegin(); it != g_tables.rend(); ++it)
+            if (it->key == key) { out = it->table; crc = it->crc; return 0; }
+    }
+    const int L = (int)(hi - lo) + 1;
+    auto t = std::make_shared<std::vector<uint16_t>>((size_t)C * (L + 1));
+    if (fn(params, C, lo, hi, t->data(), nullptr) != 0) return -1;
+    crc = (uint32_t)crc32(0L, (const Bytef*)t->data(), (uInt)(t->size() * 2));
+    out = t;
+    std::lock_guard<std::mutex> lk(g_table_mu);
+    if (g_tables.size() >= 32) g_tables.erase(g_tables.begin());
+    g_tables.push_back(TableEntry{key, out, crc});
+    return 0;
+}
+}  // namespace
+
+extern "C" int pcgc_items_encode(int n_items, const char* const* stems, const int16_t* sym, const int32_t* xyz, const int64_t* rows,
+                                 const float* ranges, int C, const int32_t* counts, const float* eb_params, pcgc_table_fn table_fn,
+                                 int index_segments, int write_coords, int threads) {
+    if (n_items < 0 || (n_items > 0 && (!stems || !sym || !rows || !ranges || !counts || !eb_params || !table_fn)) || C < 1 || (write_coords && !xyz)) {
+        pcgc_set_error("items_encode: bad arguments"); return -2;
+    }
+    std::vector<int64_t> off((size_t)n_items + 1, 0);
+    for (int i = 0; i < n_items; ++i) { if (rows[i] <= 0) { pcgc_set_error("items_encode: item %d is empty", i); return -2; } off[(size_t)i + 1] = off[(size_t)i] + rows[i]; }
+    return for_items(n_items, threads, [&](int i, std::string& err) -> int {
+        const std::string stem = stems[i];
+        const int64_t n = rows[i];
+        const float min_v = ranges[2 * i], max_v = ranges[2 * i + 1];
+        const int L = (int)(max_v - min_v) + 1, Lp = L + 1;
+        if (L < 1 || L > 65000) { err = "symbol range"; return -2; }
+        std::shared_ptr<const std::vector<uint16_t>> tptr;
+        uint32_t table_crc = 0;
+        if (cached_table(table_fn, eb_params, C, min_v, max_v, tptr, table_crc) != 0) { err = "CDF table evaluation failed"; return -1; }
+        const std::vector<uint16_t>& table = *tptr;
+        int segs = (int)std::min<int64_t>(index_segments, n / 2048);
+        if (segs < 2) segs = 0;
+        std::vector<uint32_t> ckpt((size_t)segs * PCGC_RC_CKPT_WORDS);
+        const int16_t* s0 = sym + off[(size_t)i] * C;
+        std::vector<uint8_t> stream((size_t)(n * C) * 2 + 64);
+        int64_t nb = segs ? pcgc_rc_encode_indexed(table.data(), C, Lp, s0, n * C, stream.data(), (int64_t)stream.size(), segs, ckpt.data())
+                          : pcgc_rc_encode(table.data(), C, Lp, s0, n * C, stream.data(), (int64_t)stream.size());
+        if (nb < 0 && nb != INT64_MIN) {
+            stream.resize((size_t)(-nb));
+            nb = segs ? pcgc_rc_encode_indexed(table.data(), C, Lp, s0, n * C, stream.data(), (int64_t)stream.size(), segs, ckpt.data())
+                      : pcgc_rc_encode(table.data(), C, Lp, s0, n * C, stream.data(), (int64_t)stream.size());
+        }
+        if (nb < 0) { err = "symbol outside the CDF table"; return -2; }
+        if (index_segments > 0) {
+            std::vector<uint8_t> side;
+            side.insert(side.end(), {'P', 'C', 'G', '2'});
+            put32(side, (uint32_t)nb); put32(side, (uint32_t)crc32(0L, stream.data(), (uInt)nb)); put32(side, (uint32_t)segs); put32(side, table_crc);
+            uLong c = crc32(0L, side.data(), (uInt)side.size());
+            if (!ckpt.empty()) c = crc32(c, (const Bytef*)ckpt.data(), (uInt)(ckpt.size() * 4));     // (crc32(c, NULL, 0) would RESET the value)
+            put32(side, (uint32_t)c);
+            side.insert(side.end(), (const uint8_t*)ckpt.data(), (const uint8_t*)ckpt.data() + ckpt.size() * 4);
+            if (!write_file(stem + "_F.idx", side.data(), side.size())) { err = "cannot write " + stem + "_F.idx"; return -1; }
+        } else {
+            std::remove((stem + "_F.idx").c_str());
+        }
+        if (!write_file(stem + "_F.bin", stream.data(), (size_t)nb)) { err = "cannot write " + stem + "_F.bin"; return -1; }
+        uint8_t head[17];
+        const int32_t n32 = (int32_t)n, c32 = C;
+        std::memcpy(head, &n32, 4); std::memcpy(head + 4, &c32, 4); head[8] = 1; std::memcpy(head + 9, &min_v, 4); std::memcpy(head + 13, &max_v, 4);
+        if (!write_file(stem + "_H.bin", head, 17)) { err = "cannot write " + stem + "_H.bin"; return -1; }
+        if (!write_file(stem + "_num_points.bin", counts + 3 * i, 12)) { err = "cannot write " + stem + "_num_points.bin"; return -1; }
+        if (write_coords) {
+            const int32_t* p = xyz + off[(size_t)i] * 3;
+            std::vector<uint8_t> cbin((size_t)n * 4 + 64);
+            int64_t cb = pcgc_oct_encode(p, n, cbin.data(), (int64_t)cbin.size());
+            if (cb < 0 && cb != INT64_MIN) { cbin.resize((size_t)(-cb)); cb = pcgc_oct_encode(p, n, cbin.data(), (int64_t)cbin.size()); }
+            if (cb < 0) { err = "coordinates out of the octree codec's range"; return -2; }
+            if (!write_file(stem + "_C.bin", cbin.data(), (size_t)cb)) { err = "cannot write " + stem + "_C.bin"; return -1; }
+        }
+        return 0;
+    });
+}
+
+// sizes of every item's streams: rows[i] (latent rows = stride-8 voxels), channels, ranges, budgets; native_coords[i] = 1 if <stem>_C.bin
+// is a native octree stream of exactly rows[i] points (else the caller decodes it: tmc3)
+extern "C" int pcgc_items_probe(int n_items, const char* const* stems, int64_t* rows, int32_t* channels, float* ranges, int32_t* counts,
+                                int32_t* native_coords) {
+    if (n_items < 0 || (n_items > 0 && (!stems || !rows || !channels || !ranges || !counts || !native_coords))) { pcgc_set_error("items_probe: bad arguments"); return -2; }
+    for (int i = 0; i < n_items; ++i) {
+        const std::string stem = stems[i];
+        std::vector<uint8_t> h, c;
+        if (!read_file(stem + "_H.bin", h) || h.size() < 17 || h[8] != 1) { pcgc_set_error("items_probe: %s_H.bin missing or malformed", stem.c_str()); return -1; }
+        int32_t n32, c32;
+        std::memcpy(&n32, h.data(), 4); std::memcpy(&c32, h.data() + 4, 4);
+        if (n32 < 0 || c32 < 1 || (i > 0 && c32 != channels[0])) { pcgc_set_error("items_probe: %s_H.bin: bad shape", stem.c_str()); return -1; }
+        rows[i] = n32; channels[0] = c32;
+        std::memcpy(ranges + 2 * i, h.data() + 9, 4); std::memcpy(ranges + 2 * i + 1, h.data() + 13, 4);
+        if (!read_file(stem + "_num_points.bin", c) || c.size() < 12) { pcgc_set_error("items_probe: %s_num_points.bin missing", stem.c_str()); return -1; }
+        std::memcpy(counts + 3 * i, c.data(), 12);
+        std::vector<uint8_t> cb;
+        native_coords[i] = (read_file(stem + "_C.bin", cb) && pcgc_oct_decode_count(cb.data(), (int64_t)cb.size()) == rows[i]) ? 1 : 0;
+    }
+    return 0;
+}
+
+// -> sym [sum rows, C] and (for items with native_coords) xyz [sum rows, 3].  use_sidecar = 0: never read <stem>_F.idx.
+// Returns -5 if a sidecar says the stream was coded with another CDF table than this host derives (see coder.py).
+extern "C" int pcgc_items_decode(int n_items, const char* const* stems, const int64_t* rows, int C, const float* ranges, const int32_t* native_coords,
+                                 const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int16_t* sym, int32_t* xyz, int threads) {
+    if (n_items < 0 || (n_items > 0 && (!stems || !rows || !ranges || !native_coords || !eb_params || !table_fn || !sym || !xyz)) || C < 1) {
+        pcgc_set_error("items_decode: bad arguments"); return -2;
+    }
+    std::vector<int64_t> off((size_t)n_items + 1, 0);
+    for (int i = 0; i < n_items; ++i) off[(size_t)i + 1] = off[(size_t)i] + rows[i];
+    return for_items(n_items, threads, [&](int i, std::string& err) -> int {
+        const std::string stem = stems[i];
+        const int64_t n = rows[i];
+        if (native_coords[i]) {
+            std::vector<uint8_t> cb;
+            if (!read_file(stem + "_C.bin", cb)) { err = "cannot read " + stem + "_C.bin"; return -1; }
+            if (pcgc_oct_decode(cb.data(), (int64_t)cb.size(), xyz + off[(size_t)i] * 3, n) != 0) { err = "corrupt " + stem + "_C.bin"; return -2; }
+        }
+        if (n == 0) return 0;
+        const float min_v = ranges[2 * i], max_v = ranges[2 * i + 1];
+        const int L = (int)(max_v - min_v) + 1, Lp = L + 1;
+        if (L < 1 || L > 65000) { err = "symbol range"; return -2; }
+        std::shared_ptr<const std::vector<uint16_t>> tptr;
+        uint32_t mine = 0;
+        if (cached_table(table_fn, eb_params, C, min_v, max_v, tptr, mine) != 0) { err = "CDF table evaluation failed"; return -1; }
+        const std::vector<uint16_t>& table = *tptr;
+        std::vector<uint8_t> stream, side;
+        if (!read_file(stem + "_F.bin", stream)) { err = "cannot read " + stem + "_F.bin"; return -1; }
+        int n_ck = 0; const uint32_t* ck = nullptr;
+        if (use_sidecar && read_file(stem + "_F.idx", side) && side.size() >= kSidecarHead && std::memcmp(side.data(), "PCG2", 4) == 0) {
+            const uint32_t nbytes = get32(side.data() + 4), scrc = get32(side.data() + 8), count = get32(side.data() + 12), tcrc = get32(side.data() + 16), self = get32(side.data() + 20);
+            uLong c = crc32(0L, side.data(), 20);
+            if (side.size() > kSidecarHead) c = crc32(c, side.data() + kSidecarHead, (uInt)(side.size() - kSidecarHead));
+            if (nbytes == stream.size() && side.size() == kSidecarHead + (size_t)count * 4 * PCGC_RC_CKPT_WORDS && self == (uint32_t)c &&
+                scrc == (uint32_t)crc32(0L, stream.data(), (uInt)stream.size())) {
+                if (tcrc != mine) {
+                    char b[160]; std::snprintf(b, sizeof b, "the CDF table derived on this host (CRC-32 %08x) is not the one the stream was coded with (%08x)", mine, tcrc);
+                    err = b; return -5;
+                }
+                if (count >= 2) { n_ck = (int)count; ck = (const uint32_t*)(side.data() + kSidecarHead); }
+            }
+        }
+        int16_t* out = sym + off[(size_t)i] * C;
+        int rc;
+        if (n_ck) rc = pcgc_rc_decode_indexed(table.data(), C, Lp, stream.data(), (int64_t)stream.size(), out, n * C, n_ck, ck);
+        else rc = pcgc_rc_decode(table.data(), C, Lp, stream.data(), (int64_t)stream.size(), out, n * C);
+        if (rc != 0) { err = "range decoder refused " + stem + "_F.bin"; return rc; }
+        return 0;
+    });
 }

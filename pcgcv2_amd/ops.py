@@ -1149,6 +1149,62 @@ def rc_decode(cdf_u16, data, n, index=None):
     return out
 
 
+def _stems(stems):
+    import ctypes
+    enc = [os_fsencode(s) for s in stems]
+    return (ctypes.c_char_p * len(enc))(*enc), enc
+
+
+def os_fsencode(path):
+    import os
+    return os.fsencode(path)
+
+
+def _table_fn():
+    """address of pcgc_reference_table (libpcgc_reftable.so): the CDF table in the reference's arithmetic, callable from native threads"""
+    import ctypes
+    from ._lib import reftable_lib
+    return ctypes.cast(reftable_lib().pcgc_reference_table, ctypes.c_void_p)
+
+
+def items_encode(stems, sym_h, xyz8, rows, ranges, counts, eb_params, index_segments, write_coords=True, threads=0):
+    """Write the bitstream files of every item (native threads): sym_h int16 [sum rows, C], xyz8 int32 [sum rows, 3] (stride-8
+    coordinates / 8), rows / ranges [(min_v, max_v)] / counts [(N4, N2, N1)] per item, eb_params = the 44*C packed entropy parameters."""
+    sym = _np(sym_h, np.int16)
+    C = sym.shape[1]
+    xyz = _np(xyz8, np.int32)
+    arr, keep = _stems(stems)
+    r = np.asarray(rows, np.int64)
+    rg = _np(ranges, np.float32).reshape(-1, 2)
+    ct = _np(counts, np.int32).reshape(-1, 3)
+    P = _np(eb_params, np.float32)
+    check(lib().pcgc_items_encode(len(stems), arr, sym.ctypes.data, xyz.ctypes.data, r.ctypes.data, rg.ctypes.data, C, ct.ctypes.data, P.ctypes.data,
+                                  _table_fn(), int(index_segments), int(write_coords), int(threads)), 'items_encode')
+
+
+def items_probe(stems):
+    """-> (rows int64 [n], C, ranges float32 [n, 2], counts int32 [n, 3], native_coords int32 [n]) from the files of every item."""
+    import ctypes
+    n = len(stems)
+    arr, keep = _stems(stems)
+    rows, ranges, counts, native = np.zeros(n, np.int64), np.zeros((n, 2), np.float32), np.zeros((n, 3), np.int32), np.zeros(n, np.int32)
+    C = ctypes.c_int32(0)
+    check(lib().pcgc_items_probe(n, arr, rows.ctypes.data, ctypes.addressof(C), ranges.ctypes.data, counts.ctypes.data, native.ctypes.data), 'items_probe')
+    return rows, int(C.value), ranges, counts, native
+
+
+def items_decode(stems, rows, C, ranges, native, eb_params, use_sidecar=True, threads=0):
+    """-> (sym int16 [sum rows, C], xyz8 int32 [sum rows, 3]) decoded from the files of every item (native threads)."""
+    arr, keep = _stems(stems)
+    total = int(np.sum(rows))
+    sym, xyz = np.empty((total, C), np.int16), np.empty((total, 3), np.int32)
+    P = _np(eb_params, np.float32)
+    rc = lib().pcgc_items_decode(len(stems), arr, rows.ctypes.data, C, ranges.ctypes.data, native.ctypes.data, P.ctypes.data, _table_fn(), int(use_sidecar),
+                                 sym.ctypes.data, xyz.ctypes.data, int(threads))
+    check(rc, 'items_decode')
+    return sym, xyz
+
+
 def set_oct_tiled(on):
     """Coordinate codec: groups of subtrees coded independently (1, the default for clouds of >= 8192 points; n > 1: that many
     groups) or always one stream (0).  A/B tests."""

@@ -510,3 +510,71 @@ def test_reference_autoencoder_binds_to_the_me_facade(golden_dir):
     want = {k: tuple(v.shape) for k, v in PCCModel().state_dict().items() if k.split('.')[0] in ('encoder', 'decoder')}
     assert got == want and len(got) == 212                        # the 227 checkpoint keys minus the 15 entropy-bottleneck ones (golden G5)
     assert got['encoder.conv0.kernel'] == (27, 1, 16) and got['encoder.down0.kernel'] == (8, 16, 32) and got['encoder.block0.0.conv1_0.kernel'] == (32, 8)
+
+
+def test_native_item_files_equal_the_python_path(tmp_path):
+    """pcgc_items_encode / _probe / _decode (the host half of coding a batch, on native threads) against the Python path item by item:
+    every file byte-identical (`_F.bin`, `_H.bin`, `_num_points.bin`, `_C.bin`, the `_F.idx` sidecar with and without checkpoints),
+    the decoded symbols and coordinates equal, a foreign table CRC refused, INDEX_SEGMENTS = 0 honoured."""
+    import torch
+    from pcgcv2_amd import coder
+    from pcgcv2_amd.entropy_model import EntropyBottleneck
+    rng = np.random.default_rng(21)
+    torch.manual_seed(3)
+    eb = EntropyBottleneck(8)
+    with torch.no_grad():
+        for f in eb._factors:
+            f.copy_(torch.rand(f.shape) - 0.5)
+    rows = [3000, 40, 20000, 1, 700]                      # 20000 rows: a stream with checkpoints; 1 row: the smallest item
+    ranges = [(-7.0, 9.0), (0.0, 0.0), (-20.0, 22.0), (-1.0, 1.0), (-3.0, 2.0)]
+    syms, xyzs = [], []
+    for r, (lo, hi) in zip(rows, ranges):
+        L = int(hi - lo) + 1
+        s_ = np.clip(np.rint(rng.normal(L / 2, L / 6, size=(r, 8))), 0, L - 1).astype(np.int16)
+        s_[0, 0], s_[-1, -1] = 0, L - 1
+        syms.append(s_)
+        xyzs.append(np.unique(rng.integers(0, 60, size=(4 * r + 8, 3)), axis=0)[:r].astype(np.int32))
+    rows = [len(x) for x in xyzs]
+    syms = [s_[:r] for s_, r in zip(syms, rows)]
+    counts = [(r * 3, r * 9, r * 30) for r in rows]
+    py, nat = tmp_path / 'py', tmp_path / 'nat'
+    py.mkdir(); nat.mkdir()
+    for seg in (8, 0):
+        coder.INDEX_SEGMENTS = seg
+        try:
+            fc, cc = coder.FeatureCoder(str(py / 'c'), eb), coder.CoordinateCoder(str(py / 'c'))
+            for i, r in enumerate(rows):
+                fc.encode_symbols(syms[i], np.float32(ranges[i][0]), np.float32(ranges[i][1]), postfix=f'_{i}')
+                cc.encode(xyzs[i], postfix=f'_{i}')
+                coder._dump(str(py / f'c_{i}_num_points.bin'), coder._COUNTS.pack(*counts[i]))
+            stems = [str(nat / f'c_{i}') for i in range(len(rows))]
+            ops.items_encode(stems, np.concatenate(syms), np.concatenate(xyzs), rows, ranges, counts, eb._host_packed(), seg)
+            for i in range(len(rows)):
+                for suffix in coder.STREAMS + ('_F.idx',):
+                    a, b = py / f'c_{i}{suffix}', nat / f'c_{i}{suffix}'
+                    assert a.exists() == b.exists(), (seg, i, suffix)
+                    if a.exists():
+                        assert a.read_bytes() == b.read_bytes(), (seg, i, suffix)
+            got_rows, C, got_ranges, got_counts, native = ops.items_probe(stems)
+            assert list(got_rows) == rows and C == 8 and native.all()
+            np.testing.assert_array_equal(got_ranges, np.asarray(ranges, np.float32))
+            np.testing.assert_array_equal(got_counts, np.asarray(counts, np.int32))
+            sym, xyz = ops.items_decode(stems, got_rows, C, got_ranges, native, eb._host_packed(), use_sidecar=bool(seg))
+            np.testing.assert_array_equal(sym, np.concatenate(syms))
+            off = 0
+            for i, r in enumerate(rows):                  # the octree codec returns the voxels in its own order
+                assert set(map(tuple, xyz[off:off + r])) == set(map(tuple, xyzs[i]))
+                off += r
+        finally:
+            coder.INDEX_SEGMENTS = 8
+    # a sidecar that names another table: refused (the 20000-row item of the first pass is gone; re-encode one item)
+    ops.items_encode([str(nat / 'g')], syms[0], xyzs[0], rows[:1], ranges[:1], counts[:1], eb._host_packed(), 8)
+    blob = bytearray((nat / 'g_F.idx').read_bytes())
+    import struct, zlib
+    blob[16] ^= 0xFF
+    blob[20:24] = struct.pack('<I', zlib.crc32(bytes(blob[:20]) + bytes(blob[24:])))
+    (nat / 'g_F.idx').write_bytes(bytes(blob))
+    r1, C1, rg1, ct1, nv1 = ops.items_probe([str(nat / 'g')])
+    with pytest.raises(PcgcError, match='CDF table'):
+        ops.items_decode([str(nat / 'g')], r1, C1, rg1, nv1, eb._host_packed())
+    ops.items_decode([str(nat / 'g')], r1, C1, rg1, nv1, eb._host_packed(), use_sidecar=False)      # without the sidecar: decodes
