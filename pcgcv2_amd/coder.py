@@ -236,8 +236,14 @@ class Coder():
         y_C.record_stream(main)
         y = SparseTensor(ops.gather_feats(y_list[0].F, order), coordinate_map=CoordMap(y_C, lvl8.stride, unique=True))
         budgets = [len(t) for t in (y_list[1], y_list[2], x)]
-        _dump(self.filename + postfix + '_num_points.bin', _COUNTS.pack(*budgets))
-        self.feature_coder.encode(y.F, postfix=postfix)
+        if self._native_items():
+            # range + symbols in one synchronising copy; table (cached), range coder, sidecar and the three files in one library call
+            min_v, max_v, sym_h = ops.quantize_symbols(y.F)
+            ops.items_encode([self.filename + postfix], sym_h, np.zeros((0, 3), np.int32), [len(sym_h)], [(min_v, max_v)], [budgets],
+                             self.feature_coder.entropy_model._host_packed(), INDEX_SEGMENTS, write_coords=False, threads=1)
+        else:
+            _dump(self.filename + postfix + '_num_points.bin', _COUNTS.pack(*budgets))
+            self.feature_coder.encode(y.F, postfix=postfix)
         coded.result()                                          # (re-raises a coordinate-coder failure)
         return y
 
@@ -273,11 +279,21 @@ class Coder():
         """`_C.bin` -> sorted stride-8 coordinate level on `dev` (coder.py:94-99: host argsort there, device sort here).
         Runs on the helper thread but enqueues on the CALLER's stream (current device and stream are per thread)."""
         torch.cuda.set_device(dev)
-        xyz8 = np.asarray(self.coordinate_coder.decode(postfix), dtype=np.int32)
-        y_C4 = np.zeros((len(xyz8), 4), dtype=np.int32)          # batch column 0, coordinates back at tensor stride 8
-        y_C4[:, 1:] = xyz8 * 8
+        path = self.coordinate_coder._path(postfix)
+        if gpcc.is_native_stream(path):
+            xyz8 = ops.oct_decode(_slurp(path))                  # int32 [n, 3], straight from the library
+        else:
+            xyz8 = np.asarray(self.coordinate_coder.decode(postfix), dtype=np.int32)
+        n = len(xyz8)
+        # batch column 0, coordinates back at tensor stride 8, assembled in pinned memory: the upload is one asynchronous copy
+        pin = getattr(self, '_pinned_dec', None)
+        if pin is None or pin.shape[0] < n:
+            pin = self._pinned_dec = torch.empty((max(n, 1 << 15), 4), dtype=torch.int32, pin_memory=True)
+        host = pin[:n].numpy()
+        host[:, 0] = 0
+        np.multiply(xyz8, 8, out=host[:, 1:])
         with torch.cuda.stream(stream):
-            y_C = torch.from_numpy(y_C4).to(dev)
+            y_C = pin[:n].to(dev, non_blocking=True)
             lvl8 = CoordMap(ops.gather_coords(y_C, ops.sort_zyx(y_C)), 8, unique=True)
             if len(lvl8):
                 lvl8.prepare_up()
@@ -297,8 +313,16 @@ class Coder():
         # since the feature stream is decoded from its index on several threads, the coordinate side is the longer one.
         stream = torch.cuda.current_stream(dev)
         pending = [_POOL.submit(self._decode_geometry, postfix, dev, stream)]
-        n4, n2, n1 = _COUNTS.unpack(_slurp(self.filename + postfix + '_num_points.bin')[:_COUNTS.size])
-        y_F = self.feature_coder.decode(postfix=postfix, device=dev)
+        if self._native_items():
+            stem = [self.filename + postfix]
+            rows, C, ranges, counts, native = ops.items_probe(stem)
+            sym_h, _ = ops.items_decode(stem, rows, C, ranges, np.zeros(1, np.int32), self.feature_coder.entropy_model._host_packed(),
+                                        use_sidecar=bool(INDEX_SEGMENTS), threads=1)          # (the coordinates are the helper's)
+            n4, n2, n1 = (int(v) for v in counts[0])
+            y_F = ops.desymbolize(torch.from_numpy(sym_h).to(dev), np.float32(ranges[0, 0]))
+        else:
+            n4, n2, n1 = _COUNTS.unpack(_slurp(self.filename + postfix + '_num_points.bin')[:_COUNTS.size])
+            y_F = self.feature_coder.decode(postfix=postfix, device=dev)
         y = SparseTensor(features=y_F, coordinate_map=pending[0].result())
         budgets = [[n4], [n2], [int(rho * n1)]]                  # coder.py:105-108
         _, out = self.model.decoder(y, nums_list=budgets, ground_truth_list=[None] * 3, training=False)
