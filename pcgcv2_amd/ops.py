@@ -91,10 +91,12 @@ class _Profile:
         return self.enabled and (self.only is None or self.only == key)
 
     def dominant_key(self):
-        """key of the (kernel, shape) with the largest total bracketed time so far."""
+        """key of the (kernel, shape) with the largest bracketed time: MEDIAN launch time x launches (a single slow sample — a
+        first-touch allocation, a preempted launch — must not decide which kernel the roofline object describes)."""
         best, best_ms = None, -1.0
         for key, r in self.records.items():
-            ms = sum(e0.elapsed_time(e1) for e0, e1 in r['events'])
+            t = sorted(e0.elapsed_time(e1) for e0, e1 in r['events'])
+            ms = t[len(t) // 2] * len(t) if len(t) % 2 else 0.5 * (t[len(t) // 2 - 1] + t[len(t) // 2]) * len(t)
             if ms > best_ms:
                 best, best_ms = key, ms
         return best
