@@ -284,6 +284,11 @@ class Coder():
             xyz8 = ops.oct_decode(_slurp(path))                  # int32 [n, 3], straight from the library
         else:
             xyz8 = np.asarray(self.coordinate_coder.decode(postfix), dtype=np.int32)
+        return self._stage_geometry(xyz8, dev, stream)
+
+    def _stage_geometry(self, xyz8, dev, stream):
+        """decoded stride-8 voxels (host, any order) -> the sorted coordinate level on the device + the coordinate-only part of the
+        first decoder stage (children level, kernel maps)"""
         n = len(xyz8)
         # batch column 0, coordinates back at tensor stride 8, assembled in pinned memory: the upload is one asynchronous copy
         pin = getattr(self, '_pinned_dec', None)
@@ -312,18 +317,30 @@ class Coder():
         # features (native calls that release the GIL; both threads enqueue on this thread's stream).  The helper goes first:
         # since the feature stream is decoded from its index on several threads, the coordinate side is the longer one.
         stream = torch.cuda.current_stream(dev)
-        pending = [_POOL.submit(self._decode_geometry, postfix, dev, stream)]
+        lvl8 = None
         if self._native_items():
             stem = [self.filename + postfix]
             rows, C, ranges, counts, native = ops.items_probe(stem)
-            sym_h, _ = ops.items_decode(stem, rows, C, ranges, np.zeros(1, np.int32), self.feature_coder.entropy_model._host_packed(),
-                                        use_sidecar=bool(INDEX_SEGMENTS), threads=1)          # (the coordinates are the helper's)
             n4, n2, n1 = (int(v) for v in counts[0])
+            if native[0]:
+                # coordinate stream and feature stream decoded side by side INSIDE the library (two native tasks, each with its own pool
+                # of group / segment threads): no Python thread hop on the path to the first decoder kernel
+                sym_h, xyz8 = ops.items_decode(stem, rows, C, ranges, native, self.feature_coder.entropy_model._host_packed(),
+                                               use_sidecar=bool(INDEX_SEGMENTS), threads=2)
+                lvl8 = self._stage_geometry(xyz8, dev, stream)
+            else:                                                # tmc3 stream: the subprocess protocol runs on the helper thread
+                pending = _POOL.submit(self._decode_geometry, postfix, dev, stream)
+                sym_h, _ = ops.items_decode(stem, rows, C, ranges, native, self.feature_coder.entropy_model._host_packed(),
+                                            use_sidecar=bool(INDEX_SEGMENTS), threads=1)
             y_F = ops.desymbolize(torch.from_numpy(sym_h).to(dev), np.float32(ranges[0, 0]))
+            if lvl8 is None:
+                lvl8 = pending.result()
         else:
+            pending = _POOL.submit(self._decode_geometry, postfix, dev, stream)
             n4, n2, n1 = _COUNTS.unpack(_slurp(self.filename + postfix + '_num_points.bin')[:_COUNTS.size])
             y_F = self.feature_coder.decode(postfix=postfix, device=dev)
-        y = SparseTensor(features=y_F, coordinate_map=pending[0].result())
+            lvl8 = pending.result()
+        y = SparseTensor(features=y_F, coordinate_map=lvl8)
         budgets = [[n4], [n2], [int(rho * n1)]]                  # coder.py:105-108
         _, out = self.model.decoder(y, nums_list=budgets, ground_truth_list=[None] * 3, training=False)
         return out

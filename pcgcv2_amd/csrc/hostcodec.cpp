@@ -785,21 +785,22 @@ void put32(std::vector<uint8_t>& v, uint32_t x) { for (int i = 0; i < 4; ++i) v.
 uint32_t get32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 constexpr size_t kSidecarHead = 24;
 // run fn(item) for every item on up to `threads` threads; -> first failing item's code, its message set as the caller's error
-int for_items(int n_items, int threads, const std::function<int(int, std::string&)>& fn) {
+int for_items(int n_items, int threads, const std::function<int(int, std::string&)>& fn, int tasks_per_item = 1) {
     std::vector<int> rc((size_t)n_items, 0);
     std::vector<std::string> msg((size_t)n_items);
     if (threads <= 0) threads = effective_cpus();
     const bool side_by_side = n_items > 1 && threads > 1;
+    const bool nested_serial = n_items > 2 && threads > 1;          // more than one item: the parallelism is across items, inner pools stay idle
     const std::function<void(int)> one = [&](int i) {
         const bool was = tl_item_worker;
-        tl_item_worker = side_by_side;
+        tl_item_worker = nested_serial;
         rc[(size_t)i] = fn(i, msg[(size_t)i]);
         tl_item_worker = was;
     };
     if (!side_by_side) { for (int i = 0; i < n_items; ++i) one(i); }
     else items_pool().run(n_items, std::min(threads, n_items) - 1, one);
     for (int i = 0; i < n_items; ++i)
-        if (rc[(size_t)i]) { pcgc_set_error("item %d: %s", i, msg[(size_t)i].c_str()); return rc[(size_t)i]; }
+        if (rc[(size_t)i]) { pcgc_set_error("item %d: %s", i / tasks_per_item, msg[(size_t)i].c_str()); return rc[(size_t)i]; }
     return 0;
 }
 }  // namespace
@@ -925,13 +926,19 @@ extern "C" int pcgc_items_decode(int n_items, const char* const* stems, const in
     }
     std::vector<int64_t> off((size_t)n_items + 1, 0);
     for (int i = 0; i < n_items; ++i) off[(size_t)i + 1] = off[(size_t)i] + rows[i];
-    return for_items(n_items, threads, [&](int i, std::string& err) -> int {
+    // two tasks per item — its coordinate stream and its feature stream are independent — so that ONE cloud (the single-frame path)
+    // decodes both side by side as well, each on its own pool of segment / group threads
+    return for_items(2 * n_items, threads, [&](int task, std::string& err) -> int {
+        const int i = task >> 1;
         const std::string stem = stems[i];
         const int64_t n = rows[i];
-        if (native_coords[i]) {
-            std::vector<uint8_t> cb;
-            if (!read_file(stem + "_C.bin", cb)) { err = "cannot read " + stem + "_C.bin"; return -1; }
-            if (pcgc_oct_decode(cb.data(), (int64_t)cb.size(), xyz + off[(size_t)i] * 3, n) != 0) { err = "corrupt " + stem + "_C.bin"; return -2; }
+        if ((task & 1) == 0) {
+            if (native_coords[i]) {
+                std::vector<uint8_t> cb;
+                if (!read_file(stem + "_C.bin", cb)) { err = "cannot read " + stem + "_C.bin"; return -1; }
+                if (pcgc_oct_decode(cb.data(), (int64_t)cb.size(), xyz + off[(size_t)i] * 3, n) != 0) { err = "corrupt " + stem + "_C.bin"; return -2; }
+            }
+            return 0;
         }
         if (n == 0) return 0;
         const float min_v = ranges[2 * i], max_v = ranges[2 * i + 1];
@@ -963,5 +970,5 @@ extern "C" int pcgc_items_decode(int n_items, const char* const* stems, const in
         else rc = pcgc_rc_decode(table.data(), C, Lp, stream.data(), (int64_t)stream.size(), out, n * C);
         if (rc != 0) { err = "range decoder refused " + stem + "_F.bin"; return rc; }
         return 0;
-    });
+    }, 2);
 }
