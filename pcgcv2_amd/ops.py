@@ -3,6 +3,8 @@
 PyTorch is used for device memory and streams only; all arithmetic happens in libpcgc_hip.so.  Every function
 requires ROCm device tensors and raises otherwise — there is no CPU path in the product.
 """
+import os as _os
+
 import numpy as np
 import torch
 
@@ -1152,14 +1154,10 @@ def rc_decode(cdf_u16, data, n, index=None):
 
 
 def _stems(stems):
+    """file stems as a C array of byte strings (+ the Python objects that own the bytes)"""
     import ctypes
-    enc = [os_fsencode(s) for s in stems]
+    enc = [_os.fsencode(s) for s in stems]
     return (ctypes.c_char_p * len(enc))(*enc), enc
-
-
-def os_fsencode(path):
-    import os
-    return os.fsencode(path)
 
 
 def _table_fn():
