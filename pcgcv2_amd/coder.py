@@ -226,10 +226,10 @@ class Coder():
         # encoder's convolutions instead of in front of them; the helper thread waits for the copy and runs the host coordinate coder.
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(x.device))       # the pyramid is complete after this
-        x.cmap.k3                                               # the encoder's kernel maps, coarse to fine: enqueued first, so the GPU has
-        order, y_C, sorted_ev, arrived, host_C = self._sort_and_stage(lvl8.C, ready)     # work while the host sets up the side stream
-        coded = _POOL.submit(self._encode_geometry, arrived, host_C, lvl8.stride, postfix)
-        y_list = self.model.encoder(x)                          # ~40 kernel launches, enqueued while the octree is coded
+        x.cmap.k3                                               # the encoder's kernel maps, coarse to fine, then its ~40 layer launches:
+        y_list = self.model.encoder(x)                          # the GPU has 2 ms of work queued before the host turns to the side stream
+        order, y_C, sorted_ev, arrived, host_C = self._sort_and_stage(lvl8.C, ready)     # (its dozen sort launches run beside the convolutions)
+        coded = _POOL.submit(self._encode_geometry, arrived, host_C, lvl8.stride, postfix)     # the octree is coded while the GPU works
         main = torch.cuda.current_stream(x.device)
         main.wait_event(sorted_ev)
         order.record_stream(main)
