@@ -457,19 +457,44 @@ inline void demorton3(uint64_t m, int32_t& x, int32_t& y, int32_t& z) {
     x = compact(m); y = compact(m >> 1); z = compact(m >> 2);
 }
 
+// ascending sort of keys below 2^bits: LSD radix passes of 11 bits (std::sort is 60 % of the time to code the 18.7 k stride-8 voxels
+// of a vox10 frame: 21-bit keys, two passes here)
+void sort_codes(std::vector<uint64_t>& v, int bits) {
+    if (v.size() < 512 || bits > 44) { std::sort(v.begin(), v.end()); return; }
+    std::vector<uint64_t> tmp(v.size());
+    uint64_t* src = v.data(); uint64_t* dst = tmp.data();
+    for (int shift = 0; shift < bits; shift += 11) {
+        uint32_t count[2048] = {0};
+        for (size_t i = 0; i < v.size(); ++i) ++count[(src[i] >> shift) & 2047];
+        uint32_t at = 0;
+        for (int b = 0; b < 2048; ++b) { const uint32_t c = count[b]; count[b] = at; at += c; }
+        for (size_t i = 0; i < v.size(); ++i) dst[count[(src[i] >> shift) & 2047]++] = src[i];
+        std::swap(src, dst);
+    }
+    if (src != v.data()) std::memcpy(v.data(), src, v.size() * sizeof(uint64_t));
+}
+
 // Occupancy of one octree level: a Morton-indexed bitmap while the level has at most 2^24 cells (2 MiB), binary search in
-// the sorted node list beyond that.  `grow` variant: the level under construction (children appended in Morton order).
+// the sorted node list beyond that.  The bitmaps are two per-thread buffers that are ALL ZERO whenever no stream is being coded:
+// a level's bits are cleared again by walking its node list, never by a fill (a fresh 256 KB vector per level and group — the mmap,
+// its page faults and the zero fill — was a third of the time to code the 18.7 k stride-8 voxels of a vox10 frame, and the page
+// faults of eight threads serialise in the kernel).
+struct OccBuffers { std::vector<uint64_t> buf[2]; };
+inline OccBuffers& occ_buffers() { static thread_local OccBuffers b; return b; }
 struct LevelOcc {
     const std::vector<uint64_t>* nodes = nullptr; int level_bits = 0; bool use_bitmap = false;
-    std::vector<uint64_t> bits;
-    void begin(const std::vector<uint64_t>& n, int lb, bool prefill) {
+    uint64_t* bits = nullptr;
+    void begin(const std::vector<uint64_t>& n, int lb, std::vector<uint64_t>& storage) {
         nodes = &n; level_bits = lb; use_bitmap = 3 * lb <= 24;
         if (use_bitmap) {
-            bits.assign(((size_t)1 << (3 * lb)) / 64 + 1, 0);
-            if (prefill) for (uint64_t c : n) bits[c >> 6] |= 1ull << (c & 63);
+            const size_t words = ((size_t)1 << (3 * lb)) / 64 + 1;
+            if (storage.size() < words) storage.resize(words, 0);        // (grows with zeros; what was there is zero by the invariant)
+            bits = storage.data();
         }
     }
     inline void mark(uint64_t c) { if (use_bitmap) bits[c >> 6] |= 1ull << (c & 63); }
+    inline void fill(const std::vector<uint64_t>& n) { if (use_bitmap) for (uint64_t c : n) bits[c >> 6] |= 1ull << (c & 63); }
+    inline void wipe(const std::vector<uint64_t>& n) { if (use_bitmap) for (uint64_t c : n) bits[c >> 6] = 0; }
     inline bool has(uint64_t c) const {
         return use_bitmap ? ((bits[c >> 6] >> (c & 63)) & 1ull) != 0 : std::binary_search(nodes->begin(), nodes->end(), c);
     }
@@ -494,25 +519,43 @@ struct OctCoder {
     bool has_hi[3] = {false, false, false};          // parent-level neighbour on the +x / +y / +z side exists
     bool lo_ok[3] = {false, false, false};           // parent has a neighbour slot on the -x / -y / -z side (inside the cube)
     uint64_t lo_code[3] = {0, 0, 0};                 // Morton code of P - e_axis (its children are already coded)
+    // `nodes`: the level's nodes (their bits are set here); `next`: the level under construction (marked as its nodes are coded).
+    // end_level() leaves both buffers all zero again.
     void begin_level(const std::vector<uint64_t>& nodes, const std::vector<uint64_t>& next, int lvl, int depth) {
         bucket = std::min(kBuckets - 1, depth - 1 - lvl);
-        parent.begin(nodes, lvl, true);
-        child.begin(next, lvl + 1, false);
+        OccBuffers& ob = occ_buffers();
+        parent.begin(nodes, lvl, ob.buf[0]);
+        parent.fill(nodes);
+        child.begin(next, lvl + 1, ob.buf[1]);
     }
+    void end_level() { parent.wipe(*parent.nodes); child.wipe(*child.nodes); }
+    // The six face neighbours of P in Morton space: a step along one axis is an add / subtract on that axis' dilated bits (the
+    // carry runs through the other axes' positions when they are filled with ones / zeros) — no de- and re-interleaving.
     void begin_node(uint64_t node) {
-        int px, py, pz; demorton3(node, px, py, pz);
-        const int lim = parent.lim();
-        const int p[3] = {px, py, pz};
+        constexpr uint64_t kX = 0x1249249249249249ull;
+        const uint64_t level_mask = parent.level_bits >= 21 ? ~0ull >> 1 : ((1ull << (3 * parent.level_bits)) - 1);
         int cnt = 0;
         for (int a = 0; a < 3; ++a) {
-            int q[3] = {px, py, pz};
-            lo_ok[a] = p[a] > 0;
-            if (lo_ok[a]) { q[a] = p[a] - 1; lo_code[a] = morton3(q[0], q[1], q[2]); cnt += parent.has(lo_code[a]); }
+            const uint64_t M = (kX << a) & level_mask, own = node & M, rest = node & ~M;
+            lo_ok[a] = own != 0;
+            if (lo_ok[a]) { lo_code[a] = ((own - 1) & M) | rest; cnt += parent.has(lo_code[a]); }
             has_hi[a] = false;
-            if (p[a] + 1 < lim) { q[a] = p[a] + 1; has_hi[a] = parent.has(morton3(q[0], q[1], q[2])); cnt += has_hi[a]; }
+            if (own != M) { has_hi[a] = parent.has((((own | ~M) + 1) & M) | rest); cnt += has_hi[a]; }
         }
         nb_class = (cnt + 1) / 2;                                   // 0, 1-2, 3-4, 5-6
+        // the three axis bits of every child's context at once: the level under construction, indexed by child code, IS a byte per
+        // node (bit j = child j), so the low-side neighbours' children come as one byte each
+        if (child.use_bitmap) {
+            const uint8_t* occ = (const uint8_t*)child.bits;
+            for (int j = 0; j < 8; ++j) axis_of[j] = 0;
+            for (int a = 0; a < 3; ++a) {
+                const int bit = 1 << a;
+                const unsigned lo = lo_ok[a] ? occ[lo_code[a]] : 0u;
+                for (int j = 0; j < 8; ++j) axis_of[j] |= (uint8_t)(((j & bit) ? (unsigned)has_hi[a] : ((lo >> (j | bit)) & 1u)) << a);
+            }
+        }
     }
+    uint8_t axis_of[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // outward neighbour of child j along axis a: high side -> parent-level knowledge; low side -> the child (j | bit_a) of
     // P - e_a, looked up in the level under construction
     inline bool outward(int j, int a) const {
@@ -521,7 +564,7 @@ struct OctCoder {
         return lo_ok[a] && child.has((lo_code[a] << 3) | (uint64_t)(j | bit));
     }
     inline uint16_t& ctx(int j, int occupied_before) {
-        const int axis = (int)outward(j, 0) | ((int)outward(j, 1) << 1) | ((int)outward(j, 2) << 2);
+        const int axis = child.use_bitmap ? (int)axis_of[j] : ((int)outward(j, 0) | ((int)outward(j, 1) << 1) | ((int)outward(j, 2) << 2));
         return prob[(((size_t)bucket * kAxis + axis) * kPos + (j * 9 + occupied_before)) * kNb + nb_class];
     }
 };
@@ -555,6 +598,7 @@ std::vector<uint8_t> oct_encode_part(const std::vector<uint64_t>& roots, int lvl
                 if (bit) { const uint64_t c = (node << 3) | (uint64_t)j; next.push_back(c); oc.child.mark(c); ++before; }
             }
         }
+        oc.end_level();
         level_nodes.swap(next);
     }
     enc.finish();
@@ -597,8 +641,9 @@ int oct_decode_part(const uint8_t* in, int64_t nbytes, const std::vector<uint64_
                 const int bit = dec.decode(oc.ctx(j, before));
                 if (bit) { const uint64_t c = (node << 3) | (uint64_t)j; next.push_back(c); oc.child.mark(c); ++before; }
             }
-            if ((int64_t)next.size() > max_nodes) return -2;          // corrupt stream
+            if ((int64_t)next.size() > max_nodes) { oc.end_level(); return -2; }          // corrupt stream
         }
+        oc.end_level();
         level_nodes.swap(next);
     }
     out.swap(level_nodes);
@@ -628,7 +673,7 @@ extern "C" int64_t pcgc_oct_encode(const int32_t* xyz, int64_t n, uint8_t* out, 
     int depth = 1; while ((1u << depth) <= maxc) ++depth;
     std::vector<uint64_t> leaves((size_t)n);
     for (int64_t i = 0; i < n; ++i) leaves[(size_t)i] = morton3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
-    std::sort(leaves.begin(), leaves.end());
+    sort_codes(leaves, 3 * depth);
     leaves.erase(std::unique(leaves.begin(), leaves.end()), leaves.end());
     const int64_t n_unique = (int64_t)leaves.size();
     const uint32_t n32 = (uint32_t)n_unique;

@@ -219,6 +219,27 @@ def test_octree_codec_roundtrip(case):
         assert bits_per_point < 2.1, bits_per_point              # neighbour-context model: 1.88 bit/pt here, 1.47 on the vox10 frame
 
 
+def test_octree_stream_bytes_are_pinned():
+    """The `_C.bin` container is a FORMAT: files written by one build must decode with the next.  The streams of the bench frame's
+    stride-8 level (version 2 = one stream, version 3 = groups of subtrees) are pinned by hash — a faster coder (round 3: Morton-space
+    neighbour steps, radix sort, per-thread occupancy buffers) must reproduce them bit for bit."""
+    import hashlib
+    pts = np.unique(synthetic.shell('shell10').numpy() // 8, axis=0).astype(np.int32)
+    want = {0: (3434, 2, '7ff1c2c56af7cd67446d0d0aae2b0752effeb22291bac33a3fc289364b1bfb35'),
+            1: (3949, 3, '43d8e8e41bcdbf50c0573deb0f7b228ae004a9bed2e1c9bba9f25e2f237870db')}
+    try:
+        for tiled, (size, version, digest) in want.items():
+            ops.set_oct_tiled(tiled)
+            data = ops.oct_encode(pts)
+            assert (len(data), data[4]) == (size, version)
+            assert hashlib.sha256(data).hexdigest() == digest
+    finally:
+        ops.set_oct_tiled(1)
+    small = ops.oct_encode(np.unique(synthetic.shell('shell9').numpy() // 8, axis=0).astype(np.int32))       # below 8192 points: version 2
+    assert (len(small), small[4]) == (1076, 2)
+    assert hashlib.sha256(small).hexdigest() == '9e803865eb61dcd08fb477e287cf146577effc8ebbc111a9ddbed875aeb5ae64'
+
+
 @pytest.mark.parametrize('groups', [0, 1, 3, 12])
 def test_octree_codec_groups_of_subtrees(groups):
     """Stream version 3 (independent groups of subtrees, coded and decoded side by side) against version 2 on the stride-8 level
