@@ -26,22 +26,23 @@ void pcgc_set_error(const char* fmt, ...);           // coords.hip
 // ------------------------------------------------------------------------------------------------ torchac-compatible
 namespace {
 inline int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
-// MSB-first bit writer: bits are staged in a 64-bit word; a whole 32-bit word is stored speculatively on every call and
-// only kept (len advanced) when it is complete — no data-dependent branch (the reference appends one bit at a time).
+// MSB-first bit writer: the bits not yet stored sit LEFT-aligned in a 64-bit word (fewer than 8 of them between calls); every call
+// stores the whole word speculatively at the current byte position and advances by the bytes that are complete — no data-dependent
+// branch, ~10 instructions (the reference appends one bit at a time).
 struct Sink {
-    uint8_t* out; int64_t cap; int64_t len = 0; uint64_t acc = 0; int nbits = 0;   // nbits < 32 between calls
-    inline void put(uint32_t v, int n) {            // n <= 32, v < 2^n
-        acc = (acc << n) | (uint64_t)v;
+    uint8_t* out; int64_t cap; int64_t len = 0; uint64_t acc = 0; int nbits = 0;   // nbits < 8 between calls
+    inline void put(uint64_t v, int n) {            // n <= 56, v < 2^n
+        acc |= (v << 1) << (63 - nbits - n);
         nbits += n;
-        const int full = nbits >= 32;
-        const int keep = nbits - (full << 5);
-        const uint32_t w = __builtin_bswap32((uint32_t)(acc >> keep));
-        if (len + 4 <= cap) std::memcpy(out + len, &w, 4);
-        len += full << 2;
-        nbits = keep;
+        const int adv = nbits >> 3;
+        if (__builtin_expect(len + 8 <= cap, 1)) { const uint64_t w = __builtin_bswap64(acc); std::memcpy(out + len, &w, 8); }
+        else for (int b = 0; b < adv; ++b) if (len + b < cap) out[len + b] = (uint8_t)(acc >> (56 - 8 * b));
+        len += adv;
+        acc <<= adv << 3;
+        nbits &= 7;
     }
     inline void put_run(uint32_t bit, uint64_t count) { const uint32_t word = bit ? 0xFFFFFFFFu : 0u; while (count >= 32) { put(word, 32); count -= 32; } put(count ? (word >> (32 - count)) : 0u, (int)count); }
-    inline void flush() { while (nbits > 0) { int take = nbits >= 8 ? 8 : nbits; uint8_t b = (uint8_t)((nbits >= 8 ? (acc >> (nbits - 8)) : (acc << (8 - nbits))) & 0xff); if (len < cap) out[len] = b; ++len; nbits -= take; } }
+    inline void flush() { if (nbits > 0) { if (len < cap) out[len] = (uint8_t)(acc >> 56); ++len; nbits = 0; acc = 0; } }    // zero-padded to a byte
 };
 // MSB-first bit readers over a zero-padded copy of the stream (past the end the reference's reader yields zeros too).
 struct Source {                                      // refills 32 bits at a time
@@ -93,37 +94,66 @@ __attribute__((always_inline)) inline int64_t rc_encode_body(const uint16_t* cdf
     int next_ck = 0; int64_t ck_at = n_ck > 0 ? (int64_t)ck[0].sym : -1;
     const int top_symbol = Lp - 2;
     const std::vector<uint32_t> rows = widen_rows(cdf, C, Lp);
-    int ch = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        const uint32_t* row = rows.data() + (size_t)ch * Lp;
-        if (++ch == C) ch = 0;
-        const int s = sym[i];
-        if ((unsigned)s > (unsigned)top_symbol) return INT64_MIN;
-        if (__builtin_expect(i == ck_at, 0)) {                  // (a handful of checkpoints per stream)
-            // renormalisation shifts so far = bits written + pending E3 bits (every E1/E2 shift writes one, every E3 shift defers one);
-            // pending > 0 exactly when the last shift run ended in E3 steps (an E1/E2 shift resolves all of them)
-            const uint64_t shifts = (uint64_t)sink.len * 8 + (uint64_t)sink.nbits + pending;
-            RcCkpt& k = ck[next_ck];
-            k.bitpos_lo = (uint32_t)shifts; k.bitpos_hi = (uint32_t)(shifts >> 32); k.low = low; k.span_m1 = (uint32_t)(span - 1);
-            k.off = pending ? 0x80000000u : 0u;
-            ck_at = ++next_ck < n_ck ? (int64_t)ck[next_ck].sym : -1;
-        }
+    {                                                           // symbols are checked up front (a vectorised pass), not one by one in the chain below
+        unsigned bad = 0;
+        for (int64_t i = 0; i < n; ++i) bad |= (unsigned)((unsigned)sym[i] > (unsigned)top_symbol);
+        if (bad) return INT64_MIN;
+    }
+    auto checkpoint = [&]() {
+        // renormalisation shifts so far = bits written + pending E3 bits (every E1/E2 shift writes one, every E3 shift defers one);
+        // pending > 0 exactly when the last shift run ended in E3 steps (an E1/E2 shift resolves all of them)
+        const uint64_t shifts = (uint64_t)sink.len * 8 + (uint64_t)sink.nbits + pending;
+        RcCkpt& k = ck[next_ck];
+        k.bitpos_lo = (uint32_t)shifts; k.bitpos_hi = (uint32_t)(shifts >> 32); k.low = low; k.span_m1 = (uint32_t)(span - 1);
+        k.off = pending ? 0x80000000u : 0u;
+        ck_at = ++next_ck < n_ck ? (int64_t)ck[next_ck].sym : -1;
+    };
+    auto step = [&](const uint32_t* row, const int s) __attribute__((always_inline)) {
         const uint32_t c_lo = (uint32_t)((span * row[s]) >> 16), c_hi = (uint32_t)((span * row[s + 1]) >> 16);
         const uint32_t lo = low + c_lo, hi = low + c_hi - 1;
         const int nshare = lz(lo ^ hi);
-        const int t = lz(~(lo & ~hi) & (uint32_t)(0x7FFFFFFFull >> nshare)) - 1;
+        // (2) in the domain shifted up by one, with the lowest bit set: the "- 1" and the all-ones special case disappear, and the
+        // shifted operand does not depend on nshare (one instruction less on the loop-carried chain; nshare < 32: hi > lo always)
+        const int t = lz((((~lo | hi) << 1) | 1u) & (0xFFFFFFFFu >> nshare));
         // the coder state first: this is the loop-carried dependency chain; the bit emission below hangs off it
         low = (uint32_t)((uint64_t)lo << t) & 0x7FFFFFFFu;
         span = (uint64_t)(c_hi - c_lo) << t;
-        if (nshare) {                                           // (almost always taken: > 1 bit per symbol)
-            const uint32_t bits = (uint32_t)(((uint64_t)lo << nshare) >> 32);
-            const uint32_t first = bits >> (nshare - 1);
-            if (pending > 31) { sink.put(first, 1); sink.put_run(first ^ 1u, pending); }
-            else sink.put(((1u << pending) - 1u) + first, (int)pending + 1);
-            sink.put(bits & ((1u << (nshare - 1)) - 1u), nshare - 1);
-            pending = 0;
+        // "first shared bit, `pending` copies of its complement, the other shared bits" as ONE field of pending + nshare bits: the
+        // first two parts are the number (2^pending - 1) + first, so the field is bits + (2^pending - 1) 2^(nshare - 1).  No shared
+        // bit (a symbol of probability > 1/2 may not settle one): a field of zero bits, by masks instead of a branch — whether a
+        // symbol settles a bit is what the stream encodes, i.e. unpredictable.
+        const uint64_t emit = (uint64_t)0 - (uint64_t)(nshare != 0);
+        if (__builtin_expect(pending + (uint64_t)nshare > 56, 0)) {                // (a run of > 24 E3 steps: never seen, handled)
+            if (nshare) {
+                const uint32_t bits = (uint32_t)(((uint64_t)lo << nshare) >> 32), first = bits >> (nshare - 1);
+                sink.put(first, 1); sink.put_run(first ^ 1u, pending);
+                sink.put(bits & ((1u << (nshare - 1)) - 1u), nshare - 1);
+            }
+        } else {
+            const uint64_t bits = ((uint64_t)lo << nshare) >> 32;                    // the nshare shared bits
+            sink.put((bits + (((1ull << pending) - 1ull) << ((nshare - 1) & 63))) & emit, (int)((pending + (uint64_t)nshare) & emit));
         }
-        pending += (uint64_t)(t - nshare);
+        pending = (pending & ~emit) + (uint64_t)(t - nshare);
+    };
+    // whole points (C symbols, one table row each) with the checkpoint test once per point — checkpoints sit on point boundaries
+    // (pcgc_rc_encode_indexed) — then the ragged tail, if any, symbol by symbol
+    bool on_points = true;
+    for (int c = 0; c < n_ck; ++c) on_points = on_points && ck[c].sym % (uint32_t)C == 0;
+    const int64_t points = on_points ? n / C : 0;
+    const size_t stride = (size_t)Lp;
+    for (int64_t r = 0; r < points; ++r) {
+        if (__builtin_expect(r * C == ck_at, 0)) checkpoint();
+        const int16_t* sp = sym + r * C;
+        const uint32_t* row = rows.data();
+        for (int ch = 0; ch < C; ++ch, row += stride) step(row, sp[ch]);
+    }
+    {
+        int ch = 0;
+        for (int64_t i = points * C; i < n; ++i) {
+            if (__builtin_expect(i == ck_at, 0)) checkpoint();
+            step(rows.data() + (size_t)ch * Lp, sym[i]);
+            if (++ch == C) ch = 0;
+        }
     }
     ++pending;
     const uint32_t last = low < 0x40000000u ? 0u : 1u;
@@ -256,7 +286,7 @@ static void rc_decode_avx512_seg(const RcWideTables& tb, int C, const uint8_t* p
         const uint32_t c_lo = (uint32_t)((span * row[cnt]) >> 16), c_hi = (uint32_t)((span * row[cnt + 1]) >> 16);   // cdf[s], cdf[s + 1]
         const uint32_t lo = low + c_lo, hi = low + c_hi - 1;
         const int nshare = (int)_lzcnt_u32(lo ^ hi);
-        const int t = (int)_lzcnt_u32(~(lo & ~hi) & (uint32_t)(0x7FFFFFFFull >> nshare)) - 1;
+        const int t = (int)_lzcnt_u32((((~lo | hi) << 1) | 1u) & (0xFFFFFFFFu >> nshare));       // (as in rc_encode_body)
         low = (uint32_t)((uint64_t)lo << t) & 0x7FFFFFFFu;
         span = (uint64_t)(c_hi - c_lo) << t;
         off = (uint32_t)((uint64_t)(off - c_lo) << t) | src.take(t);

@@ -107,6 +107,35 @@ def test_range_coder_adversarial_tables(shape, rc_impl):
         ops.rc_decode(table, a[:len(a) // 2], sym.size, index=index)
 
 
+def test_range_coder_long_pending_runs_and_exact_buffers(rc_impl):
+    """The encoder's rare paths against the bit-serial oracle: (1) a symbol of probability 2^-15 that straddles the interval midpoint,
+    repeated — every one defers ~15 E3 bits, so the pending count passes the 56 bits the one-field emission holds (4 repeats) and the
+    32 bits of one run chunk (put_run); (2) an output buffer of exactly the stream's size (the speculative 8-byte stores of the bit
+    writer must not be what puts the last bytes in place), and one byte less (refused with the size needed)."""
+    C = 8
+    pmf = np.tile([0.5 - 2.0 ** -16, 2.0 ** -15, 0.5 - 2.0 ** -16], (C, 1))
+    table = _table_from_pmf(np.asarray(pmf, np.float64))
+    rng = np.random.default_rng(3)
+    for n, p_mid in ((2, 1.0), (40, 1.0), (125, 0.9), (1000, 0.7)):
+        sym = np.where(rng.random((n, C)) < p_mid, 1, rng.integers(0, 3, (n, C))).astype(np.int16)
+        a = ops.rc_encode(table, sym)
+        assert a == orc.rc_encode(table, sym)
+        np.testing.assert_array_equal(ops.rc_decode(table, a, sym.size), sym.ravel())
+        a2, index = ops.rc_encode(table, sym, checkpoints=4)
+        assert a2 == a
+        np.testing.assert_array_equal(ops.rc_decode(table, a, sym.size, index=index), sym.ravel())
+        cdf = np.ascontiguousarray(table, np.uint16)
+        flat = np.ascontiguousarray(sym.ravel())
+        for slack in (0, 1, 7, 8):
+            buf = np.full(len(a) + slack + 16, 0xA5, np.uint8)                     # 16 guard bytes behind the capacity
+            got = int(ops.lib().pcgc_rc_encode(cdf.ctypes.data, C, cdf.shape[1], flat.ctypes.data, flat.size, buf.ctypes.data, len(a) + slack))
+            assert got == len(a) and buf[:got].tobytes() == a
+            assert (buf[len(a) + slack:] == 0xA5).all(), 'wrote past the capacity'
+        buf = np.full(len(a) + 16, 0xA5, np.uint8)
+        assert int(ops.lib().pcgc_rc_encode(cdf.ctypes.data, C, cdf.shape[1], flat.ctypes.data, flat.size, buf.ctypes.data, len(a) - 1)) == -len(a)
+        assert (buf[len(a) - 1:] == 0xA5).all()
+
+
 def test_range_decoder_rejects_malformed_index():
     rng = np.random.default_rng(5)
     table = _table_from_pmf(np.tile(np.exp(-0.5 * ((np.arange(21) - 10) / 2.0) ** 2), (8, 1)))
