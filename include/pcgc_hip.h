@@ -323,6 +323,10 @@ int pcgc_items_probe(int n_items, const char* const* stems, int64_t* rows, int32
 int pcgc_items_decode(int n_items, const char* const* stems, const int64_t* rows, int C, const float* ranges, const int32_t* native_coords,
                       const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int16_t* sym, int32_t* xyz, int threads);
 
+/* zlib's crc32(crc, buf, len) (the CRC-32 of the `_F.idx` sidecar's stream and table guards; coder.py of this package uses
+ * zlib.crc32 for the same fields), folded with carry-less multiplies on long buffers.  HOST. */
+uint32_t pcgc_crc32(uint32_t crc, const uint8_t* buf, int64_t len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,12 +6,17 @@
 //     the external G-PCC `tmc3` binary of gpcc.py:6-41 is not installed.  Not G-PCC interoperable (magic "PCGO").
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <sched.h>
+#include <cerrno>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -26,12 +31,36 @@ void pcgc_set_error(const char* fmt, ...);           // coords.hip
 // ------------------------------------------------------------------------------------------------ torchac-compatible
 namespace {
 inline int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
-// MSB-first bit writer: the bits not yet stored sit LEFT-aligned in a 64-bit word (fewer than 8 of them between calls); every call
-// stores the whole word speculatively at the current byte position and advances by the bytes that are complete — no data-dependent
-// branch, ~10 instructions (the reference appends one bit at a time).
+#ifndef PCGC_SINK_BYTES
+// MSB-first bit writer: fields are appended to a 64-bit word (shift, or, add, compare: the whole common path); a full word is stored
+// big-endian when the next field does not fit — once per ~19 symbols of a latent stream.  (The reference appends one bit at a time.)
+struct Sink {
+    uint8_t* out; int64_t cap; int64_t len = 0; uint64_t acc = 0; int nbits = 0;   // nbits < 64 bits of acc (right-aligned) not yet stored
+    __attribute__((always_inline)) inline void put(uint64_t v, int n) {            // n <= 56, v < 2^n
+        const int room = 64 - nbits;                                               // >= 1
+        if (__builtin_expect(n < room, 1)) { acc = (acc << n) | v; nbits += n; return; }
+        const int spill = n - room;                                                // bits of v that start the next word
+        const uint64_t word = __builtin_bswap64((acc << (room & 63)) | (v >> spill));   // (room = 64 never gets here: n <= 56)
+        if (__builtin_expect(len + 8 <= cap, 1)) std::memcpy(out + len, &word, 8);
+        else for (int b = 0; b < 8; ++b) if (len + b < cap) out[len + b] = (uint8_t)(word >> (8 * b));
+        len += 8;
+        acc = v & ((1ull << spill) - 1ull); nbits = spill;
+    }
+    uint64_t bits_written() const { return (uint64_t)len * 8 + (uint64_t)nbits; }
+    // (not inlined, and called on a COPY in the coder's loop: a call that takes the writer's address would pin its fields — and
+    // with them the loop's whole state — to the stack)
+    __attribute__((noinline)) void put_run(uint32_t bit, uint64_t count) { const uint32_t word = bit ? 0xFFFFFFFFu : 0u; while (count >= 32) { put(word, 32); count -= 32; } put(count ? (word >> (32 - count)) : 0u, (int)count); }
+    inline void flush() {                                                           // the last bits, zero-padded to a byte
+        const int bytes = (nbits + 7) >> 3;
+        const uint64_t word = nbits ? acc << (64 - nbits) : 0;
+        for (int b = 0; b < bytes; ++b) if (len + b < cap) out[len + b] = (uint8_t)(word >> (56 - 8 * b));
+        len += bytes; nbits = 0; acc = 0;
+    }
+};
+#else
 struct Sink {
     uint8_t* out; int64_t cap; int64_t len = 0; uint64_t acc = 0; int nbits = 0;   // nbits < 8 between calls
-    inline void put(uint64_t v, int n) {            // n <= 56, v < 2^n
+    __attribute__((always_inline)) inline void put(uint64_t v, int n) {            // n <= 56, v < 2^n
         acc |= (v << 1) << (63 - nbits - n);
         nbits += n;
         const int adv = nbits >> 3;
@@ -41,21 +70,29 @@ struct Sink {
         acc <<= adv << 3;
         nbits &= 7;
     }
-    inline void put_run(uint32_t bit, uint64_t count) { const uint32_t word = bit ? 0xFFFFFFFFu : 0u; while (count >= 32) { put(word, 32); count -= 32; } put(count ? (word >> (32 - count)) : 0u, (int)count); }
+    uint64_t bits_written() const { return (uint64_t)len * 8 + (uint64_t)nbits; }
+    __attribute__((noinline)) void put_run(uint32_t bit, uint64_t count) { const uint32_t word = bit ? 0xFFFFFFFFu : 0u; while (count >= 32) { put(word, 32); count -= 32; } put(count ? (word >> (32 - count)) : 0u, (int)count); }
     inline void flush() { if (nbits > 0) { if (len < cap) out[len] = (uint8_t)(acc >> 56); ++len; nbits = 0; acc = 0; } }    // zero-padded to a byte
 };
-// MSB-first bit readers over a zero-padded copy of the stream (past the end the reference's reader yields zeros too).
+#endif
+// MSB-first bit readers over a copy of the stream with 64 zero bytes behind it: past the end the stream reads as zeros (the
+// reference's reader too).  The read position is clamped to `limit` = stream bytes + 8, inside the zeros: a corrupt stream can ask
+// for any number of bits and keeps getting zeros, without the decoder ever leaving the buffer (the copy used to be padded by four
+// bytes per symbol instead: 700 KB of page faults and zero fill per frame).
 struct Source {                                      // refills 32 bits at a time
-    const uint8_t* in; int64_t pos = 0; uint64_t acc = 0; int nbits = 0;
+    const uint8_t* in; int64_t limit; int64_t pos = 0; uint64_t acc = 0; int nbits = 0;
     inline uint32_t take(int n) {
-        if (nbits < n) { uint32_t w; std::memcpy(&w, in + pos, 4); pos += 4; acc = (acc << 32) | __builtin_bswap32(w); nbits += 32; }
+        if (nbits < n) { if (pos > limit) pos = limit; uint32_t w; std::memcpy(&w, in + pos, 4); pos += 4; acc = (acc << 32) | __builtin_bswap32(w); nbits += 32; }
         nbits -= n;
         return n == 0 ? 0u : (uint32_t)((acc >> nbits) & ((n == 32) ? 0xFFFFFFFFull : ((1ull << n) - 1ull)));
     }
 };
 struct SourceBF {                                    // branch-free: refill() leaves >= 56 valid bits at the top of acc
-    const uint8_t* in; int64_t pos = 0; uint64_t acc = 0; int nbits = 0;
-    inline void refill() { uint64_t w; std::memcpy(&w, in + pos, 8); acc |= __builtin_bswap64(w) >> nbits; pos += (63 - nbits) >> 3; nbits |= 56; }
+    const uint8_t* in; int64_t limit; int64_t pos = 0; uint64_t acc = 0; int nbits = 0;
+    inline void refill() {
+        pos = pos > limit ? limit : pos;
+        uint64_t w; std::memcpy(&w, in + pos, 8); acc |= __builtin_bswap64(w) >> nbits; pos += (63 - nbits) >> 3; nbits |= 56;
+    }
     inline uint32_t take(int n) { const uint32_t v = (uint32_t)((acc >> 1) >> (63 - n)); acc <<= n; nbits -= n; return v; }   // n <= 32
 };
 // One 16-bit CDF row per channel, widened to 32 bits with the last boundary pinned to 2^16 (torchac hard-codes
@@ -99,14 +136,15 @@ __attribute__((always_inline)) inline int64_t rc_encode_body(const uint16_t* cdf
         for (int64_t i = 0; i < n; ++i) bad |= (unsigned)((unsigned)sym[i] > (unsigned)top_symbol);
         if (bad) return INT64_MIN;
     }
-    auto checkpoint = [&]() {
+    // (state passed BY VALUE: a by-reference capture in a lambda that is not inlined would keep low / span / pending in memory)
+    auto checkpoint = [ck, n_ck](int at, uint64_t bits_written, uint64_t pend, uint32_t lo_now, uint64_t span_now) -> int64_t {
         // renormalisation shifts so far = bits written + pending E3 bits (every E1/E2 shift writes one, every E3 shift defers one);
         // pending > 0 exactly when the last shift run ended in E3 steps (an E1/E2 shift resolves all of them)
-        const uint64_t shifts = (uint64_t)sink.len * 8 + (uint64_t)sink.nbits + pending;
-        RcCkpt& k = ck[next_ck];
-        k.bitpos_lo = (uint32_t)shifts; k.bitpos_hi = (uint32_t)(shifts >> 32); k.low = low; k.span_m1 = (uint32_t)(span - 1);
-        k.off = pending ? 0x80000000u : 0u;
-        ck_at = ++next_ck < n_ck ? (int64_t)ck[next_ck].sym : -1;
+        const uint64_t shifts = bits_written + pend;
+        RcCkpt& k = ck[at];
+        k.bitpos_lo = (uint32_t)shifts; k.bitpos_hi = (uint32_t)(shifts >> 32); k.low = lo_now; k.span_m1 = (uint32_t)(span_now - 1);
+        k.off = pend ? 0x80000000u : 0u;
+        return at + 1 < n_ck ? (int64_t)ck[at + 1].sym : -1;           // where the next checkpoint is due
     };
     auto step = [&](const uint32_t* row, const int s) __attribute__((always_inline)) {
         const uint32_t c_lo = (uint32_t)((span * row[s]) >> 16), c_hi = (uint32_t)((span * row[s + 1]) >> 16);
@@ -126,8 +164,10 @@ __attribute__((always_inline)) inline int64_t rc_encode_body(const uint16_t* cdf
         if (__builtin_expect(pending + (uint64_t)nshare > 56, 0)) {                // (a run of > 24 E3 steps: never seen, handled)
             if (nshare) {
                 const uint32_t bits = (uint32_t)(((uint64_t)lo << nshare) >> 32), first = bits >> (nshare - 1);
-                sink.put(first, 1); sink.put_run(first ^ 1u, pending);
-                sink.put(bits & ((1u << (nshare - 1)) - 1u), nshare - 1);
+                Sink far = sink;
+                far.put(first, 1); far.put_run(first ^ 1u, pending);
+                far.put(bits & ((1u << (nshare - 1)) - 1u), nshare - 1);
+                sink = far;
             }
         } else {
             const uint64_t bits = ((uint64_t)lo << nshare) >> 32;                    // the nshare shared bits
@@ -142,7 +182,7 @@ __attribute__((always_inline)) inline int64_t rc_encode_body(const uint16_t* cdf
     const int64_t points = on_points ? n / C : 0;
     const size_t stride = (size_t)Lp;
     for (int64_t r = 0; r < points; ++r) {
-        if (__builtin_expect(r * C == ck_at, 0)) checkpoint();
+        if (__builtin_expect(r * C == ck_at, 0)) { ck_at = checkpoint(next_ck, sink.bits_written(), pending, low, span); ++next_ck; }
         const int16_t* sp = sym + r * C;
         const uint32_t* row = rows.data();
         for (int ch = 0; ch < C; ++ch, row += stride) step(row, sp[ch]);
@@ -150,14 +190,14 @@ __attribute__((always_inline)) inline int64_t rc_encode_body(const uint16_t* cdf
     {
         int ch = 0;
         for (int64_t i = points * C; i < n; ++i) {
-            if (__builtin_expect(i == ck_at, 0)) checkpoint();
+            if (__builtin_expect(i == ck_at, 0)) { ck_at = checkpoint(next_ck, sink.bits_written(), pending, low, span); ++next_ck; }
             step(rows.data() + (size_t)ch * Lp, sym[i]);
             if (++ch == C) ch = 0;
         }
     }
     ++pending;
     const uint32_t last = low < 0x40000000u ? 0u : 1u;
-    sink.put(last, 1); sink.put_run(last ^ 1u, pending); sink.flush();
+    { Sink far = sink; far.put(last, 1); far.put_run(last ^ 1u, pending); far.flush(); sink = far; }
     if (sink.len > cap) return -sink.len;
     // The decoder keeps off = value - low, and value is the 32-bit window of the stream at its read position, minus 2^31 while
     // the last renormalisation ended in E3 steps (torchac flips the top bit there; the flip is shifted out by the next shift):
@@ -217,9 +257,9 @@ struct RcScalarTables {
         for (int c = 0; c < C; ++c) { const uint32_t* row = rows.data() + (size_t)c * Lp; int m = 0; for (int b = 0; b < 256; ++b) { const uint32_t t = (uint32_t)b << 8; while (m < top_symbol && row[m + 1] <= t) ++m; seed[(size_t)c * 256 + b] = (int16_t)m; } }
     }
 };
-static void rc_decode_scalar_seg(const RcScalarTables& tb, int C, int Lp, const uint8_t* padded, const RcStart& st, int16_t* sym) {
+static void rc_decode_scalar_seg(const RcScalarTables& tb, int C, int Lp, const uint8_t* padded, int64_t limit, const RcStart& st, int16_t* sym) {
     const uint64_t start = st.bitpos + 32;                       // the decoder has read 32 bits beyond the bits it has shifted out
-    Source src{padded, (int64_t)(start >> 3)};
+    Source src{padded, limit, (int64_t)(start >> 3)};
     (void)src.take((int)(start & 7));
     uint32_t low = st.low, high = (uint32_t)(st.low + st.span - 1); uint32_t value = st.low + st.off;
     int ch = (int)(st.first % C);
@@ -263,9 +303,9 @@ struct RcWideTables {
     }
 };
 __attribute__((target("avx512f,avx512bw,avx512dq,popcnt,lzcnt,bmi,bmi2")))
-static void rc_decode_avx512_seg(const RcWideTables& tb, int C, const uint8_t* padded, const RcStart& st, int16_t* sym) {
+static void rc_decode_avx512_seg(const RcWideTables& tb, int C, const uint8_t* padded, int64_t limit, const RcStart& st, int16_t* sym) {
     const uint64_t start = st.bitpos + 32;
-    SourceBF src{padded, (int64_t)(start >> 3)};
+    SourceBF src{padded, limit, (int64_t)(start >> 3)};
     src.refill();
     (void)src.take((int)(start & 7));
     uint32_t low = st.low; uint64_t span = st.span; uint32_t off = st.off;
@@ -375,16 +415,20 @@ bool rc_use_avx512(int Lp) {
 // decode the given starts (disjoint symbol ranges of one stream) with up to `threads` threads
 int rc_decode_starts(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int64_t nbytes, int16_t* sym, int64_t n, std::vector<RcStart> starts,
                      int threads) {
-    std::vector<uint8_t> padded((size_t)nbytes + 64 + (size_t)n * 4, 0);     // past its end the stream reads as zeros (the reference's reader too)
-    std::memcpy(padded.data(), in, (size_t)nbytes);
+    static thread_local std::vector<uint8_t> padded_store;                    // kept per calling thread: no allocation per frame
+    if (padded_store.size() < (size_t)nbytes + 64) padded_store.resize((size_t)nbytes + 64);
+    uint8_t* const padded = padded_store.data();
+    std::memcpy(padded, in, (size_t)nbytes);
+    std::memset(padded + nbytes, 0, 64);
+    const int64_t limit = nbytes + 8;
     for (RcStart& st : starts)                                                // at the start of the stream, off = value = its first 32 bits
         if (st.first == 0) st.off = ((uint32_t)padded[0] << 24) | ((uint32_t)padded[1] << 16) | ((uint32_t)padded[2] << 8) | padded[3];
     const bool wide = rc_use_avx512(Lp);
     RcWideTables* wt = wide ? new RcWideTables(cdf, C, Lp) : nullptr;
     RcScalarTables* stb = wide ? nullptr : new RcScalarTables(cdf, C, Lp);
     const std::function<void(int)> one = [&](int k) {
-        if (wide) rc_decode_avx512_seg(*wt, C, padded.data(), starts[(size_t)k], sym);
-        else rc_decode_scalar_seg(*stb, C, Lp, padded.data(), starts[(size_t)k], sym);
+        if (wide) rc_decode_avx512_seg(*wt, C, padded, limit, starts[(size_t)k], sym);
+        else rc_decode_scalar_seg(*stb, C, Lp, padded, limit, starts[(size_t)k], sym);
     };
     const int tasks = (int)starts.size();
     if (tasks <= 1 || threads <= 1) { for (int k = 0; k < tasks; ++k) one(k); }
@@ -838,22 +882,113 @@ extern "C" int pcgc_oct_decode(const uint8_t* in, int64_t nbytes, int32_t* xyz, 
 //   <stem>_C.bin             native "PCGO" octree stream of the stride-8 coordinates (gpcc.py's tmc3 stream is written by the caller)
 //   <stem>_F.idx             sidecar: "PCG2" | stream bytes | stream CRC-32 | checkpoints | table CRC-32 | CRC-32(head + body) | checkpoints
 namespace {
+// CRC-32 (zlib's: IEEE 802.3, reflected) of the bitstream with carry-less multiplies: four 128-bit lanes folded per 64 bytes, then
+// to 128, 64 and (Barrett) 32 bits — the folding constants are x^n mod P for the lane distances, from Gopal et al., "Fast CRC
+// Computation for Generic Polynomials Using PCLMULQDQ" (Intel, 2009).  ~10x zlib 1.2.11's table walk (a 97 KB latent stream: 50 -> 5 us,
+// once per direction and frame); the first / last bytes that do not fill 16-byte blocks go through zlib.  Same value by construction
+// (tested against zlib over random lengths and seeds).
+__attribute__((target("pclmul,sse4.1")))
+uint32_t crc32_clmul_blocks(uint32_t crc /*pre-inverted register value*/, const uint8_t* buf, size_t len /*>= 64, multiple of 16*/) {
+    alignas(16) static const uint64_t k1k2[2] = {0x0154442bd4ull, 0x01c6e41596ull};
+    alignas(16) static const uint64_t k3k4[2] = {0x01751997d0ull, 0x00ccaa009eull};
+    alignas(16) static const uint64_t k5k0[2] = {0x0163cd6124ull, 0x0000000000ull};
+    alignas(16) static const uint64_t poly[2] = {0x01db710641ull, 0x01f7011641ull};
+    __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
+    x1 = _mm_loadu_si128((const __m128i*)(buf + 0x00)); x2 = _mm_loadu_si128((const __m128i*)(buf + 0x10));
+    x3 = _mm_loadu_si128((const __m128i*)(buf + 0x20)); x4 = _mm_loadu_si128((const __m128i*)(buf + 0x30));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
+    x0 = _mm_load_si128((const __m128i*)k1k2);
+    buf += 64; len -= 64;
+    while (len >= 64) {
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+        x7 = _mm_clmulepi64_si128(x3, x0, 0x00); x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+        x3 = _mm_clmulepi64_si128(x3, x0, 0x11); x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+        y5 = _mm_loadu_si128((const __m128i*)(buf + 0x00)); y6 = _mm_loadu_si128((const __m128i*)(buf + 0x10));
+        y7 = _mm_loadu_si128((const __m128i*)(buf + 0x20)); y8 = _mm_loadu_si128((const __m128i*)(buf + 0x30));
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5); x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7); x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
+        buf += 64; len -= 64;
+    }
+    x0 = _mm_load_si128((const __m128i*)k3k4);                                 // four lanes -> one
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+    while (len >= 16) {                                                        // remaining whole blocks
+        x2 = _mm_loadu_si128((const __m128i*)buf);
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+        buf += 16; len -= 16;
+    }
+    x2 = _mm_clmulepi64_si128(x1, x0, 0x10);                                   // 128 -> 64 bits
+    x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+    x1 = _mm_srli_si128(x1, 8); x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_loadl_epi64((const __m128i*)k5k0);
+    x2 = _mm_srli_si128(x1, 4); x1 = _mm_and_si128(x1, x3); x1 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_load_si128((const __m128i*)poly);                                 // Barrett reduction to 32 bits
+    x2 = _mm_and_si128(x1, x3); x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+    x2 = _mm_and_si128(x2, x3); x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+}  // namespace
+// zlib's crc32(crc, buf, len), faster on long buffers
+extern "C" uint32_t pcgc_crc32(uint32_t crc, const uint8_t* buf, int64_t len) {
+    static const bool have = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+    if (len <= 0 || !buf) return crc;
+    if (have && len >= 256) {
+        const size_t blocks = (size_t)len & ~(size_t)15;
+        crc = ~crc32_clmul_blocks(~crc, buf, blocks);
+        buf += blocks; len -= (int64_t)blocks;
+    }
+    while (len > 0) { const uInt part = (uInt)std::min<int64_t>(len, 1 << 30); crc = (uint32_t)crc32(crc, buf, part); buf += part; len -= part; }
+    return crc;
+}
+namespace {
+// PCGC_ITEMS_TRACE=1: per-stage microseconds of every item task on stderr (diagnostics; tools/host_timeline.py shows the calls' totals)
+bool items_trace() { static const bool on = [] { const char* e = std::getenv("PCGC_ITEMS_TRACE"); return e && *e && *e != '0'; }(); return on; }
+struct StageClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0; std::string line;
+    void mark(const char* what) {
+        if (!items_trace()) return;
+        const auto now = std::chrono::steady_clock::now();
+        char b[64]; std::snprintf(b, sizeof b, " %s %.0f", what, std::chrono::duration<double, std::micro>(now - last).count());
+        line += b; last = now;
+    }
+    void done(const char* task, int item) {
+        if (!items_trace()) return;
+        std::fprintf(stderr, "[pcgc items] %s %d:%s | total %.0f us\n", task, item, line.c_str(), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
 SegmentPool& items_pool() { static SegmentPool p; return p; }
+// plain system calls: a stdio stream per file is a buffer allocation and two more calls on each of the ten small files of a frame
 bool write_file(const std::string& path, const void* data, size_t n) {
-    FILE* f = std::fopen(path.c_str(), "wb");
-    if (!f) return false;
-    const bool ok = n == 0 || std::fwrite(data, 1, n, f) == n;
-    return std::fclose(f) == 0 && ok;
+    const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+    if (fd < 0) return false;
+    const uint8_t* p = (const uint8_t*)data;
+    bool ok = true;
+    while (n > 0) {
+        const ssize_t w = ::write(fd, p, n);
+        if (w < 0) { if (errno == EINTR) continue; ok = false; break; }
+        p += w; n -= (size_t)w;
+    }
+    return ::close(fd) == 0 && ok;
 }
 bool read_file(const std::string& path, std::vector<uint8_t>& out) {
-    FILE* f = std::fopen(path.c_str(), "rb");
-    if (!f) return false;
-    std::fseek(f, 0, SEEK_END);
-    const long n = std::ftell(f);
-    std::fseek(f, 0, SEEK_SET);
-    out.resize(n > 0 ? (size_t)n : 0);
-    const bool ok = n <= 0 || std::fread(out.data(), 1, (size_t)n, f) == (size_t)n;
-    std::fclose(f);
+    const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return false;
+    struct stat st;
+    if (::fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd); return false; }
+    out.resize((size_t)st.st_size);
+    size_t got = 0;
+    bool ok = true;
+    while (got < out.size()) {
+        const ssize_t r = ::read(fd, out.data() + got, out.size() - got);
+        if (r < 0) { if (errno == EINTR) continue; ok = false; break; }
+        if (r == 0) break;                                       // (shrank under us)
+        got += (size_t)r;
+    }
+    ::close(fd);
+    out.resize(got);
     return ok;
 }
 void put32(std::vector<uint8_t>& v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
@@ -927,11 +1062,15 @@ extern "C" int pcgc_items_encode(int n_items, const char* const* stems, const in
         uint32_t table_crc = 0;
         if (cached_table(table_fn, eb_params, C, min_v, max_v, tptr, table_crc) != 0) { err = "CDF table evaluation failed"; return -1; }
         const std::vector<uint16_t>& table = *tptr;
+        StageClock clk;
+        clk.mark("table");
         int segs = (int)std::min<int64_t>(index_segments, n / 2048);
         if (segs < 2) segs = 0;
         std::vector<uint32_t> ckpt((size_t)segs * PCGC_RC_CKPT_WORDS);
         const int16_t* s0 = sym + off[(size_t)i] * C;
-        std::vector<uint8_t> stream((size_t)(n * C) * 2 + 64);
+        // the stream buffer is kept per thread: a fresh 300 KB vector per frame is an mmap, its page faults and a zero fill (~50 us)
+        static thread_local std::vector<uint8_t> stream;
+        if (stream.size() < (size_t)(n * C) * 2 + 64) stream.resize((size_t)(n * C) * 2 + 64);
         int64_t nb = segs ? pcgc_rc_encode_indexed(table.data(), C, Lp, s0, n * C, stream.data(), (int64_t)stream.size(), segs, ckpt.data())
                           : pcgc_rc_encode(table.data(), C, Lp, s0, n * C, stream.data(), (int64_t)stream.size());
         if (nb < 0 && nb != INT64_MIN) {
@@ -940,10 +1079,11 @@ extern "C" int pcgc_items_encode(int n_items, const char* const* stems, const in
                       : pcgc_rc_encode(table.data(), C, Lp, s0, n * C, stream.data(), (int64_t)stream.size());
         }
         if (nb < 0) { err = "symbol outside the CDF table"; return -2; }
+        clk.mark("range");
         if (index_segments > 0) {
             std::vector<uint8_t> side;
             side.insert(side.end(), {'P', 'C', 'G', '2'});
-            put32(side, (uint32_t)nb); put32(side, (uint32_t)crc32(0L, stream.data(), (uInt)nb)); put32(side, (uint32_t)segs); put32(side, table_crc);
+            put32(side, (uint32_t)nb); put32(side, pcgc_crc32(0, stream.data(), nb)); put32(side, (uint32_t)segs); put32(side, table_crc);
             uLong c = crc32(0L, side.data(), (uInt)side.size());
             if (!ckpt.empty()) c = crc32(c, (const Bytef*)ckpt.data(), (uInt)(ckpt.size() * 4));     // (crc32(c, NULL, 0) would RESET the value)
             put32(side, (uint32_t)c);
@@ -958,6 +1098,7 @@ extern "C" int pcgc_items_encode(int n_items, const char* const* stems, const in
         std::memcpy(head, &n32, 4); std::memcpy(head + 4, &c32, 4); head[8] = 1; std::memcpy(head + 9, &min_v, 4); std::memcpy(head + 13, &max_v, 4);
         if (!write_file(stem + "_H.bin", head, 17)) { err = "cannot write " + stem + "_H.bin"; return -1; }
         if (!write_file(stem + "_num_points.bin", counts + 3 * i, 12)) { err = "cannot write " + stem + "_num_points.bin"; return -1; }
+        clk.mark("files");
         if (write_coords) {
             const int32_t* p = xyz + off[(size_t)i] * 3;
             std::vector<uint8_t> cbin((size_t)n * 4 + 64);
@@ -965,7 +1106,9 @@ extern "C" int pcgc_items_encode(int n_items, const char* const* stems, const in
             if (cb < 0 && cb != INT64_MIN) { cbin.resize((size_t)(-cb)); cb = pcgc_oct_encode(p, n, cbin.data(), (int64_t)cbin.size()); }
             if (cb < 0) { err = "coordinates out of the octree codec's range"; return -2; }
             if (!write_file(stem + "_C.bin", cbin.data(), (size_t)cb)) { err = "cannot write " + stem + "_C.bin"; return -1; }
+            clk.mark("coords");
         }
+        clk.done("encode", i);
         return 0;
     });
 }
@@ -1007,12 +1150,16 @@ extern "C" int pcgc_items_decode(int n_items, const char* const* stems, const in
         const int i = task >> 1;
         const std::string stem = stems[i];
         const int64_t n = rows[i];
-        if ((task & 1) == 0) {
-            if (native_coords[i]) {
+        StageClock clk;
+        if ((task & 1) == 1) {                                   // (the feature stream is the longer task: the calling thread starts it at once,
+            if (native_coords[i]) {                              //  the coordinate stream goes to the helper, whose wake-up it can afford)
                 std::vector<uint8_t> cb;
                 if (!read_file(stem + "_C.bin", cb)) { err = "cannot read " + stem + "_C.bin"; return -1; }
+                clk.mark("read");
                 if (pcgc_oct_decode(cb.data(), (int64_t)cb.size(), xyz + off[(size_t)i] * 3, n) != 0) { err = "corrupt " + stem + "_C.bin"; return -2; }
+                clk.mark("octree");
             }
+            clk.done("decode coords", i);
             return 0;
         }
         if (n == 0) return 0;
@@ -1023,15 +1170,17 @@ extern "C" int pcgc_items_decode(int n_items, const char* const* stems, const in
         uint32_t mine = 0;
         if (cached_table(table_fn, eb_params, C, min_v, max_v, tptr, mine) != 0) { err = "CDF table evaluation failed"; return -1; }
         const std::vector<uint16_t>& table = *tptr;
+        clk.mark("table");
         std::vector<uint8_t> stream, side;
         if (!read_file(stem + "_F.bin", stream)) { err = "cannot read " + stem + "_F.bin"; return -1; }
+        clk.mark("read");
         int n_ck = 0; const uint32_t* ck = nullptr;
         if (use_sidecar && read_file(stem + "_F.idx", side) && side.size() >= kSidecarHead && std::memcmp(side.data(), "PCG2", 4) == 0) {
             const uint32_t nbytes = get32(side.data() + 4), scrc = get32(side.data() + 8), count = get32(side.data() + 12), tcrc = get32(side.data() + 16), self = get32(side.data() + 20);
             uLong c = crc32(0L, side.data(), 20);
             if (side.size() > kSidecarHead) c = crc32(c, side.data() + kSidecarHead, (uInt)(side.size() - kSidecarHead));
             if (nbytes == stream.size() && side.size() == kSidecarHead + (size_t)count * 4 * PCGC_RC_CKPT_WORDS && self == (uint32_t)c &&
-                scrc == (uint32_t)crc32(0L, stream.data(), (uInt)stream.size())) {
+                scrc == pcgc_crc32(0, stream.data(), (int64_t)stream.size())) {
                 if (tcrc != mine) {
                     char b[160]; std::snprintf(b, sizeof b, "the CDF table derived on this host (CRC-32 %08x) is not the one the stream was coded with (%08x)", mine, tcrc);
                     err = b; return -5;
@@ -1039,11 +1188,14 @@ extern "C" int pcgc_items_decode(int n_items, const char* const* stems, const in
                 if (count >= 2) { n_ck = (int)count; ck = (const uint32_t*)(side.data() + kSidecarHead); }
             }
         }
+        clk.mark("sidecar");
         int16_t* out = sym + off[(size_t)i] * C;
         int rc;
         if (n_ck) rc = pcgc_rc_decode_indexed(table.data(), C, Lp, stream.data(), (int64_t)stream.size(), out, n * C, n_ck, ck);
         else rc = pcgc_rc_decode(table.data(), C, Lp, stream.data(), (int64_t)stream.size(), out, n * C);
         if (rc != 0) { err = "range decoder refused " + stem + "_F.bin"; return rc; }
+        clk.mark("range");
+        clk.done("decode features", i);
         return 0;
     }, 2);
 }

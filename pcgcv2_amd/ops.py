@@ -1116,6 +1116,12 @@ def set_rc_threads(threads):
     check(lib().pcgc_set_rc_threads(int(threads)), 'set_rc_threads')
 
 
+def crc32(data, crc=0):
+    """zlib.crc32(data, crc), by the library's carry-less-multiply fold (the value the native item files carry in their sidecars)"""
+    src = np.frombuffer(data, np.uint8)
+    return int(lib().pcgc_crc32(int(crc) & 0xFFFFFFFF, src.ctypes.data if src.size else None, src.size))
+
+
 def rc_encode(cdf_u16, sym, checkpoints=0):
     """-> stream bytes, or (stream bytes, index uint32 [checkpoints, RC_CKPT_WORDS]) when checkpoints > 0: the decoder state at
     evenly spread row boundaries, for rc_decode(index=...).  The stream is the same either way."""

@@ -136,6 +136,22 @@ def test_range_coder_long_pending_runs_and_exact_buffers(rc_impl):
         assert (buf[len(a) - 1:] == 0xA5).all()
 
 
+def test_library_crc32_is_zlibs():
+    """pcgc_crc32 (carry-less-multiply fold of the sidecar's stream CRC) against zlib.crc32: every length around the 16 / 64-byte
+    block boundaries and the 256-byte switch-over, running values, unaligned starts."""
+    import zlib
+    rng = np.random.default_rng(9)
+    blob = rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()
+    for n in list(range(0, 400)) + [1023, 1024, 4097, 65535, 69999]:
+        for off in (0, 1, 13):
+            assert ops.crc32(blob[off:off + n]) == zlib.crc32(blob[off:off + n]), (n, off)
+    run_a = run_b = 0
+    for lo, hi in ((0, 5), (5, 300), (300, 301), (301, 40000), (40000, 70000)):
+        run_a, run_b = ops.crc32(blob[lo:hi], run_a), zlib.crc32(blob[lo:hi], run_b)
+        assert run_a == run_b
+    assert run_a == zlib.crc32(blob)
+
+
 def test_range_decoder_rejects_malformed_index():
     rng = np.random.default_rng(5)
     table = _table_from_pmf(np.tile(np.exp(-0.5 * ((np.arange(21) - 10) / 2.0) ** 2), (8, 1)))

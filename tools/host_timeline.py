@@ -32,12 +32,12 @@ feats = torch.ones((len(pts), 1), device=dev)
 model = PCCModel().to(dev); model.load_state_dict(synthetic.synthetic_state_dict())
 coder = Coder(model, os.path.join(tempfile.mkdtemp(dir='/dev/shm'), 'f'))
 x = SparseTensor(feats, coordinates=coords, tensor_stride=1, device=dev)
-for cls, names in ((Coder, ['encode', 'decode', '_decode_geometry']), (coder_mod.FeatureCoder, ['encode', 'decode']),
+for cls, names in ((Coder, ['encode', 'decode', '_decode_geometry', '_stage_geometry', '_sort_and_stage']), (coder_mod.FeatureCoder, ['encode', 'decode']),
                    (coder_mod.CoordinateCoder, ['encode', 'decode']), (sparse.CoordMap, ['down', 'prepare_up']),
                    (type(model.encoder), ['forward']), (type(model.decoder), ['forward'])):
     for n in names:
         wrap(cls, n, f'{cls.__name__}.{n}')
-for n in ('rc_encode', 'rc_decode', 'quantize_symbols', 'sort_zyx', 'desymbolize', 'topk_mask'):
+for n in ('rc_encode', 'rc_decode', 'quantize_symbols', 'sort_zyx', 'desymbolize', 'topk_mask', 'items_encode', 'items_probe', 'items_decode'):
     wrap(ops, n, 'ops.' + n)
 wrap(coder_mod, '_dump'); wrap(coder_mod, '_slurp')
 from pcgcv2_amd import entropy_model
