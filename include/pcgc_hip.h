@@ -318,10 +318,13 @@ int pcgc_items_encode(int n_items, const char* const* stems, const int16_t* sym,
 /* sizes first: rows[i], channels[0], ranges, counts, native_coords[i] (1: `_C.bin` is a native octree stream of rows[i] points) ... */
 int pcgc_items_probe(int n_items, const char* const* stems, int64_t* rows, int32_t* channels, float* ranges, int32_t* counts,
                      int32_t* native_coords);
-/* ... then the streams: sym [sum rows, C], xyz [sum rows, 3] (items with native_coords).  -5: a sidecar names another CDF table than
- * this host derives (the stream would decode to noise). */
+/* ... then the streams: sym [sum rows, C] and the coordinates of the items with native_coords — coord_layout 0: xyz [sum rows, 3], voxel
+ * indices in stream order; coord_layout 1: xyz [sum rows, 4] = the coordinate level Coder.decode starts from (coder.py:97-102), rows
+ * (item index, coord_scale x, coord_scale y, coord_scale z), every item in (z, y, x) order (sort_spare_tensor, data_utils.py:91-101).
+ * -5: a sidecar names another CDF table than this host derives (the stream would decode to noise). */
 int pcgc_items_decode(int n_items, const char* const* stems, const int64_t* rows, int C, const float* ranges, const int32_t* native_coords,
-                      const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int16_t* sym, int32_t* xyz, int threads);
+                      const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int16_t* sym, int32_t* xyz, int coord_layout,
+                      int coord_scale, int threads);
 
 /* zlib's crc32(crc, buf, len) (the CRC-32 of the `_F.idx` sidecar's stream and table guards; coder.py of this package uses
  * zlib.crc32 for the same fields), folded with carry-less multiplies on long buffers.  HOST. */

@@ -286,19 +286,45 @@ class Coder():
             xyz8 = np.asarray(self.coordinate_coder.decode(postfix), dtype=np.int32)
         return self._stage_geometry(xyz8, dev, stream)
 
+    def _pinned_level(self, n):
+        """numpy view [>= n, 4] int32 of the pinned staging buffer of the decoded coordinate level"""
+        busy = getattr(self, '_pinned_dec_busy', None)
+        if busy is not None:                                     # the previous upload from this buffer (normally long complete)
+            busy.synchronize()
+            self._pinned_dec_busy = None
+        pin = getattr(self, '_pinned_dec', None)
+        if pin is None or pin.shape[0] < n:
+            pin = self._pinned_dec = torch.empty((max(n, 1 << 15), 4), dtype=torch.int32, pin_memory=True)
+            self._pinned_dec_np = pin.numpy()
+        return self._pinned_dec_np
+
+    def _upload_level(self, n, dev):
+        """asynchronous copy of the first n rows of the pinned staging buffer (current stream); the buffer is not reused before it is done"""
+        y_C = self._pinned_dec[:n].to(dev, non_blocking=True)
+        self._pinned_dec_busy = torch.cuda.Event()
+        self._pinned_dec_busy.record(torch.cuda.current_stream(dev))
+        return y_C
+
+    def _stage_level(self, n, dev, stream):
+        """the coordinate level the library has written into the pinned buffer — sorted, batch column and tensor stride in place
+        (pcgc_items_decode, coord_layout 1) -> device level + the coordinate-only part of the first decoder stage.  One asynchronous
+        copy; no device sort."""
+        with torch.cuda.stream(stream):
+            lvl8 = CoordMap(self._upload_level(n, dev), 8, unique=True)
+            if n:
+                lvl8.prepare_up()
+        return lvl8
+
     def _stage_geometry(self, xyz8, dev, stream):
         """decoded stride-8 voxels (host, any order) -> the sorted coordinate level on the device + the coordinate-only part of the
         first decoder stage (children level, kernel maps)"""
         n = len(xyz8)
         # batch column 0, coordinates back at tensor stride 8, assembled in pinned memory: the upload is one asynchronous copy
-        pin = getattr(self, '_pinned_dec', None)
-        if pin is None or pin.shape[0] < n:
-            pin = self._pinned_dec = torch.empty((max(n, 1 << 15), 4), dtype=torch.int32, pin_memory=True)
-        host = pin[:n].numpy()
+        host = self._pinned_level(n)[:n]
         host[:, 0] = 0
         np.multiply(xyz8, 8, out=host[:, 1:])
         with torch.cuda.stream(stream):
-            y_C = pin[:n].to(dev, non_blocking=True)
+            y_C = self._upload_level(n, dev)
             lvl8 = CoordMap(ops.gather_coords(y_C, ops.sort_zyx(y_C)), 8, unique=True)
             if len(lvl8):
                 lvl8.prepare_up()
@@ -327,9 +353,10 @@ class Coder():
                 # of group / segment threads): no Python thread hop on the path to the first decoder kernel.  (Measured against the
                 # feature stream on a Python helper thread with this thread decoding and staging the coordinates meanwhile: the host
                 # timeline looks 0.1 ms shorter that way, the frame is 0.07 ms LONGER — four A/B pairs on one box.)
-                sym_h, xyz8 = ops.items_decode(stem, rows, C, ranges, native, self.feature_coder.entropy_model._host_packed(),
-                                               use_sidecar=bool(INDEX_SEGMENTS), threads=2)
-                lvl8 = self._stage_geometry(xyz8, dev, stream)
+                n8 = int(rows[0])
+                sym_h, level = ops.items_decode(stem, rows, C, ranges, native, self.feature_coder.entropy_model._host_packed(),
+                                                use_sidecar=bool(INDEX_SEGMENTS), threads=2, level_scale=8, level_out=self._pinned_level(n8))
+                lvl8 = self._stage_level(n8, dev, stream)
             else:                                                # tmc3 stream: the subprocess protocol runs on the helper thread
                 pending = _POOL.submit(self._decode_geometry, postfix, dev, stream)
                 sym_h, _ = ops.items_decode(stem, rows, C, ranges, native, self.feature_coder.entropy_model._host_packed(),
@@ -416,11 +443,14 @@ class Coder():
             stems = [self.filename + p for p in postfixes]
             rows, C, ranges, counts, native = ops.items_probe(stems)
             if native.all():
-                sym_all, xyz_all = ops.items_decode(stems, rows, C, ranges, native, self.feature_coder.entropy_model._host_packed(),
-                                                    use_sidecar=bool(INDEX_SEGMENTS))
+                # the batch's coordinate level comes out of the library sorted (items contiguous, each in its coded (z, y, x) order) and
+                # with the item index in column 0
+                sym_all, level = ops.items_decode(stems, rows, C, ranges, native, self.feature_coder.entropy_model._host_packed(),
+                                                  use_sidecar=bool(INDEX_SEGMENTS), level_scale=8, level_out=self._pinned_level(int(rows.sum())))
                 offs = np.concatenate([[0], np.cumsum(rows)])
-                items = [(xyz_all[offs[b]:offs[b + 1]], tuple(int(v) for v in counts[b]), sym_all[offs[b]:offs[b + 1]], np.float32(ranges[b, 0]))
-                         for b in range(B)]
+                items = [(None, tuple(int(v) for v in counts[b]), sym_all[offs[b]:offs[b + 1]], np.float32(ranges[b, 0])) for b in range(B)]
+                rows8 = [int(r) for r in rows]
+                y_C = self._upload_level(int(rows.sum()), dev)
         if items is None:
             def one(b):
                 xyz8 = np.asarray(self.coordinate_coder.decode(postfixes[b]), dtype=np.int32)
@@ -430,15 +460,16 @@ class Coder():
                     raise ValueError(f'item {b}: {len(xyz8)} coordinates but {len(sym_h)} latent rows')
                 return xyz8, counts, sym_h, min_v
             items = list(_batch_pool().map(one, range(B)))
-        rows8 = [len(it[0]) for it in items]
-        C4 = np.zeros((sum(rows8), 4), dtype=np.int32)
-        off = 0
-        for b, (xyz8, _, _, _) in enumerate(items):
-            C4[off:off + rows8[b], 0] = b
-            C4[off:off + rows8[b], 1:] = xyz8 * 8
-            off += rows8[b]
-        y_C = torch.from_numpy(C4).to(dev)
-        y_C = ops.gather_coords(y_C, ops.sort_zyx(y_C, batch_major=True))      # items stay contiguous, each in its coded (z, y, x) order
+        if items[0][0] is not None:                                            # (items decoded one by one: assemble and sort here)
+            rows8 = [len(it[0]) for it in items]
+            C4 = np.zeros((sum(rows8), 4), dtype=np.int32)
+            off = 0
+            for b, (xyz8, _, _, _) in enumerate(items):
+                C4[off:off + rows8[b], 0] = b
+                C4[off:off + rows8[b], 1:] = xyz8 * 8
+                off += rows8[b]
+            y_C = torch.from_numpy(C4).to(dev)
+            y_C = ops.gather_coords(y_C, ops.sort_zyx(y_C, batch_major=True))  # items stay contiguous, each in its coded (z, y, x) order
         sym = torch.from_numpy(np.concatenate([it[2] for it in items], 0)).to(dev)
         y_F = torch.empty(sym.shape, dtype=torch.float32, device=dev)
         off = 0

@@ -1138,8 +1138,10 @@ extern "C" int pcgc_items_probe(int n_items, const char* const* stems, int64_t* 
 // -> sym [sum rows, C] and (for items with native_coords) xyz [sum rows, 3].  use_sidecar = 0: never read <stem>_F.idx.
 // Returns -5 if a sidecar says the stream was coded with another CDF table than this host derives (see coder.py).
 extern "C" int pcgc_items_decode(int n_items, const char* const* stems, const int64_t* rows, int C, const float* ranges, const int32_t* native_coords,
-                                 const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int16_t* sym, int32_t* xyz, int threads) {
-    if (n_items < 0 || (n_items > 0 && (!stems || !rows || !ranges || !native_coords || !eb_params || !table_fn || !sym || !xyz)) || C < 1) {
+                                 const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int16_t* sym, int32_t* xyz, int coord_layout,
+                                 int coord_scale, int threads) {
+    if (n_items < 0 || (n_items > 0 && (!stems || !rows || !ranges || !native_coords || !eb_params || !table_fn || !sym || !xyz)) || C < 1 ||
+        coord_layout < 0 || coord_layout > 1 || coord_scale < 1) {
         pcgc_set_error("items_decode: bad arguments"); return -2;
     }
     std::vector<int64_t> off((size_t)n_items + 1, 0);
@@ -1156,8 +1158,31 @@ extern "C" int pcgc_items_decode(int n_items, const char* const* stems, const in
                 std::vector<uint8_t> cb;
                 if (!read_file(stem + "_C.bin", cb)) { err = "cannot read " + stem + "_C.bin"; return -1; }
                 clk.mark("read");
-                if (pcgc_oct_decode(cb.data(), (int64_t)cb.size(), xyz + off[(size_t)i] * 3, n) != 0) { err = "corrupt " + stem + "_C.bin"; return -2; }
-                clk.mark("octree");
+                if (coord_layout == 0) {
+                    if (pcgc_oct_decode(cb.data(), (int64_t)cb.size(), xyz + off[(size_t)i] * 3, n) != 0) { err = "corrupt " + stem + "_C.bin"; return -2; }
+                    clk.mark("octree");
+                } else {
+                    // the coordinate LEVEL the decoder starts from (coder.py:97-102): rows (item, scale x, scale y, scale z) in (z, y, x) order —
+                    // sorted here, on the thread that has the voxels in cache, instead of by a dozen launches after an upload
+                    static thread_local std::vector<int32_t> v;
+                    static thread_local std::vector<uint64_t> keys;
+                    if (v.size() < (size_t)n * 3) v.resize((size_t)n * 3);
+                    if (pcgc_oct_decode(cb.data(), (int64_t)cb.size(), v.data(), n) != 0) { err = "corrupt " + stem + "_C.bin"; return -2; }
+                    clk.mark("octree");
+                    const int d = cb.size() > 5 ? cb[5] : 21;                     // bits per coordinate (the tree's depth)
+                    keys.resize((size_t)n);
+                    for (int64_t r = 0; r < n; ++r)
+                        keys[(size_t)r] = ((uint64_t)(uint32_t)v[3 * r + 2] << (2 * d)) | ((uint64_t)(uint32_t)v[3 * r + 1] << d) | (uint64_t)(uint32_t)v[3 * r];
+                    sort_codes(keys, 3 * d);
+                    const uint64_t m = (1ull << d) - 1;
+                    int32_t* L = xyz + off[(size_t)i] * 4;
+                    for (int64_t r = 0; r < n; ++r) {
+                        const uint64_t k = keys[(size_t)r];
+                        L[4 * r] = i; L[4 * r + 1] = (int32_t)(k & m) * coord_scale;
+                        L[4 * r + 2] = (int32_t)((k >> d) & m) * coord_scale; L[4 * r + 3] = (int32_t)(k >> (2 * d)) * coord_scale;
+                    }
+                    clk.mark("level");
+                }
             }
             clk.done("decode coords", i);
             return 0;

@@ -1199,16 +1199,26 @@ def items_probe(stems):
     return rows, int(C.value), ranges, counts, native
 
 
-def items_decode(stems, rows, C, ranges, native, eb_params, use_sidecar=True, threads=0):
-    """-> (sym int16 [sum rows, C], xyz8 int32 [sum rows, 3]) decoded from the files of every item (native threads)."""
+def items_decode(stems, rows, C, ranges, native, eb_params, use_sidecar=True, threads=0, level_scale=0, level_out=None):
+    """-> (sym int16 [sum rows, C], coordinates) decoded from the files of every item (native threads).  Coordinates: xyz8 int32
+    [sum rows, 3] in stream order, or with level_scale = s > 0 the sorted coordinate level int32 [sum rows, 4] = (item, s x, s y, s z),
+    every item in (z, y, x) order — written into `level_out` (e.g. a pinned buffer's numpy view, at least [sum rows, 4]) if given."""
     arr, keep = _stems(stems)
     total = int(np.sum(rows))
-    sym, xyz = np.empty((total, C), np.int16), np.empty((total, 3), np.int32)
+    sym = np.empty((total, C), np.int16)
+    if level_scale:
+        if level_out is None:
+            level_out = np.empty((total, 4), np.int32)
+        if level_out.dtype != np.int32 or level_out.ndim != 2 or level_out.shape[1] != 4 or level_out.shape[0] < total or not level_out.flags.c_contiguous:
+            raise PcgcError('items_decode: level_out must be a C-contiguous int32 [>= rows, 4] array')
+        xyz = level_out
+    else:
+        xyz = np.empty((total, 3), np.int32)
     P = _np(eb_params, np.float32)
     rc = lib().pcgc_items_decode(len(stems), arr, rows.ctypes.data, C, ranges.ctypes.data, native.ctypes.data, P.ctypes.data, _table_fn(), int(use_sidecar),
-                                 sym.ctypes.data, xyz.ctypes.data, int(threads))
+                                 sym.ctypes.data, xyz.ctypes.data, 1 if level_scale else 0, int(level_scale) if level_scale else 1, int(threads))
     check(rc, 'items_decode')
-    return sym, xyz
+    return sym, xyz[:total]
 
 
 def set_oct_tiled(on):

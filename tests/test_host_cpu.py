@@ -631,6 +631,21 @@ def test_native_item_files_equal_the_python_path(tmp_path):
             for i, r in enumerate(rows):                  # the octree codec returns the voxels in its own order
                 assert set(map(tuple, xyz[off:off + r])) == set(map(tuple, xyzs[i]))
                 off += r
+            # coord_layout 1: the coordinate LEVEL Coder.decode starts from (coder.py:97-102) — rows (item, 8x, 8y, 8z), every item in
+            # sort_spare_tensor's (z, y, x) order (data_utils.py:91-101), written into a caller's buffer
+            buf = np.full((sum(rows) + 5, 4), -7, np.int32)
+            sym2, level = ops.items_decode(stems, got_rows, C, got_ranges, native, eb._host_packed(), use_sidecar=bool(seg), level_scale=8, level_out=buf)
+            np.testing.assert_array_equal(sym2, sym)
+            assert level.base is buf or level is buf or np.shares_memory(level, buf)
+            assert (buf[sum(rows):] == -7).all()
+            off = 0
+            for i, r in enumerate(rows):
+                want = xyzs[i][np.lexsort((xyzs[i][:, 0], xyzs[i][:, 1], xyzs[i][:, 2]))]
+                np.testing.assert_array_equal(level[off:off + r, 0], i)
+                np.testing.assert_array_equal(level[off:off + r, 1:], want * 8)
+                off += r
+            with pytest.raises(PcgcError):
+                ops.items_decode(stems, got_rows, C, got_ranges, native, eb._host_packed(), level_scale=8, level_out=np.zeros((3, 4), np.int32))
         finally:
             coder.INDEX_SEGMENTS = 8
     # a sidecar that names another table: refused (the 20000-row item of the first pass is gone; re-encode one item)
