@@ -52,7 +52,7 @@ def _slurp(path):
 # table; a decoder that derives a different table REFUSES the stream instead of returning noise.
 # The sidecar names the stream it belongs to by length and CRC-32 and carries a CRC over itself; one that does not match (or is
 # absent: a reference-made stream) is ignored and the stream is decoded serially, unguarded — exactly what the reference does.
-INDEX_SEGMENTS = 8                               # checkpoints per stream; 0 = never write or read the sidecar
+INDEX_SEGMENTS = 16                              # checkpoints per stream (two segments per decoder thread); 0 = never write or read the sidecar
 NATIVE_ITEMS = True                              # batches: per-item host stages on native threads (False: Python thread pool; A/B and tests)
 INDEX_SUFFIX = '_F.idx'
 _INDEX_HEAD = struct.Struct('<4sIIIII')          # magic, stream bytes, stream CRC-32, checkpoints, table CRC-32, CRC-32 of (head so far + body)
@@ -153,7 +153,7 @@ class FeatureCoder():
 
     def encode(self, feats, postfix=''):
         n, c = feats.shape
-        segments = min(int(INDEX_SEGMENTS), n // 2048)           # (a segment shorter than ~16 k symbols is not worth a thread)
+        segments = min(int(INDEX_SEGMENTS), n // 1024)           # (a segment shorter than ~8 k symbols is not worth a checkpoint)
         info = {}
         if segments >= 2:
             payload, min_v, max_v, index = self.entropy_model.compress(feats, checkpoints=segments, info=info)
@@ -165,7 +165,7 @@ class FeatureCoder():
     def encode_symbols(self, sym_h, min_v, max_v, postfix='', device=None):
         """encode() from the host side on: int16 symbols [n, c] and their range (one item of a batch, coder.Coder.encode_batch)."""
         n, c = sym_h.shape
-        segments = min(int(INDEX_SEGMENTS), n // 2048)
+        segments = min(int(INDEX_SEGMENTS), n // 1024)
         info = {}
         if segments >= 2:
             payload, min_v, max_v, index = self.entropy_model.compress_symbols(sym_h, min_v, max_v, checkpoints=segments, info=info, device=device)

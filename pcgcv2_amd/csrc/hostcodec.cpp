@@ -302,35 +302,52 @@ struct RcWideTables {
         for (int c = 0; c < C; ++c) for (int j = 0; j < W; ++j) wide[(size_t)c * W + j] = j < Lp - 1 ? cdf[(size_t)c * Lp + j] : 0x10000u;
     }
 };
+// One or TWO segments per call: a symbol's decode is one dependency chain of ~40 cycles (broadcast, multiply, compare, mask count,
+// table row, two leading-zero counts, shifts) that leaves most of the core idle; two segments advanced in lock step are two
+// independent chains in the same loop — 1.8x the symbols per thread and second.
+struct RcWideState { SourceBF src; uint32_t low; uint64_t span; uint32_t off; int ch; int64_t i; };
 __attribute__((target("avx512f,avx512bw,avx512dq,popcnt,lzcnt,bmi,bmi2")))
-static void rc_decode_avx512_seg(const RcWideTables& tb, int C, const uint8_t* padded, int64_t limit, const RcStart& st, int16_t* sym) {
-    const uint64_t start = st.bitpos + 32;
-    SourceBF src{padded, limit, (int64_t)(start >> 3)};
-    src.refill();
-    (void)src.take((int)(start & 7));
-    uint32_t low = st.low; uint64_t span = st.span; uint32_t off = st.off;
+static void rc_decode_avx512_seg(const RcWideTables& tb, int C, const uint8_t* padded, int64_t limit, const RcStart& st0, const RcStart* st1, int16_t* sym) {
     const int nvec = tb.nvec, W = tb.W, RS = tb.RS;
-    int ch = (int)(st.first % C);
-    for (int64_t i = st.first; i < st.first + st.count; ++i) {
-        const uint32_t* row = tb.rows.data() + (size_t)ch * RS; const uint64_t* wr = tb.wide + (size_t)ch * W;
-        if (++ch == C) ch = 0;
-        src.refill();
-        const __m512i vs = _mm512_set1_epi64((long long)(span - 1)), voff = _mm512_set1_epi64((long long)(uint64_t)off);
+    const uint32_t* const rows = tb.rows.data(); const uint64_t* const wide = tb.wide;
+    auto open = [&](const RcStart& st) __attribute__((always_inline, target("avx512f,avx512bw,avx512dq,popcnt,lzcnt,bmi,bmi2"))) {
+        const uint64_t start = st.bitpos + 32;
+        RcWideState S{SourceBF{padded, limit, (int64_t)(start >> 3)}, st.low, st.span, st.off, (int)(st.first % C), st.first};
+        S.src.refill();
+        (void)S.src.take((int)(start & 7));
+        return S;
+    };
+    auto step = [&](RcWideState& S) __attribute__((always_inline, target("avx512f,avx512bw,avx512dq,popcnt,lzcnt,bmi,bmi2"))) {
+        const uint32_t* row = rows + (size_t)S.ch * RS; const uint64_t* wr = wide + (size_t)S.ch * W;
+        if (++S.ch == C) S.ch = 0;
+        S.src.refill();
+        const __m512i vs = _mm512_set1_epi64((long long)(S.span - 1)), voff = _mm512_set1_epi64((long long)(uint64_t)S.off);
         unsigned cnt = 0;                                                          // = s + 1
         for (int v = 0; v < nvec; ++v) {
             const __m512i r = _mm512_load_si512((const void*)(wr + 8 * v));
             const __m512i cum = _mm512_srli_epi64(_mm512_add_epi64(_mm512_mul_epu32(vs, r), r), 16);
             cnt += (unsigned)__builtin_popcount((unsigned)_mm512_cmple_epu64_mask(cum, voff));
         }
-        sym[i] = (int16_t)((int)cnt - 1);
-        const uint32_t c_lo = (uint32_t)((span * row[cnt]) >> 16), c_hi = (uint32_t)((span * row[cnt + 1]) >> 16);   // cdf[s], cdf[s + 1]
-        const uint32_t lo = low + c_lo, hi = low + c_hi - 1;
+        sym[S.i++] = (int16_t)((int)cnt - 1);
+        const uint32_t c_lo = (uint32_t)((S.span * row[cnt]) >> 16), c_hi = (uint32_t)((S.span * row[cnt + 1]) >> 16);   // cdf[s], cdf[s + 1]
+        const uint32_t lo = S.low + c_lo, hi = S.low + c_hi - 1;
         const int nshare = (int)_lzcnt_u32(lo ^ hi);
         const int t = (int)_lzcnt_u32((((~lo | hi) << 1) | 1u) & (0xFFFFFFFFu >> nshare));       // (as in rc_encode_body)
-        low = (uint32_t)((uint64_t)lo << t) & 0x7FFFFFFFu;
-        span = (uint64_t)(c_hi - c_lo) << t;
-        off = (uint32_t)((uint64_t)(off - c_lo) << t) | src.take(t);
+        S.low = (uint32_t)((uint64_t)lo << t) & 0x7FFFFFFFu;
+        S.span = (uint64_t)(c_hi - c_lo) << t;
+        S.off = (uint32_t)((uint64_t)(S.off - c_lo) << t) | S.src.take(t);
+    };
+    RcWideState A = open(st0);
+    int64_t left_a = st0.count;
+    if (st1) {
+        RcWideState B = open(*st1);
+        int64_t left_b = st1->count;
+        const int64_t both = std::min(left_a, left_b);
+        for (int64_t j = 0; j < both; ++j) { step(A); step(B); }
+        left_a -= both; left_b -= both;
+        for (int64_t j = 0; j < left_b; ++j) step(B);
     }
+    for (int64_t j = 0; j < left_a; ++j) step(A);
 }
 
 // ---- a small persistent pool for the indexed decoder (segments of one stream decoded side by side)
@@ -338,19 +355,27 @@ namespace {
 class SegmentPool {
     std::vector<std::thread> workers; std::mutex m; std::condition_variable work, done;
     std::mutex serial;                                 // one run() at a time per pool
-    const std::function<void(int)>* job = nullptr; int n_tasks = 0; std::atomic<int> next{0}; int active = 0; uint64_t gen = 0; bool stop = false;
+    const std::function<void(int)>* job = nullptr; int n_tasks = 0; std::atomic<int> next{0}; int active = 0; bool stop = false;
+    std::atomic<uint64_t> gen{0};                      // bumped by run() and prewake(); changes under the mutex, read by spinning workers without it
+    std::atomic<int64_t> warm_until{0};                // steady-clock ns until which idle workers spin instead of sleeping (prewake)
     int wanted = 0, joined = 0;                        // helpers this run asked for / workers that have joined it (tickets)
+    static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     static void drain(const std::function<void(int)>& fn, std::atomic<int>& next, int n) { for (int i; (i = next.fetch_add(1)) < n;) fn(i); }
     void loop() {
         uint64_t seen = 0;
         for (;;) {
             std::unique_lock<std::mutex> lk(m);
-            work.wait(lk, [&] { return stop || gen != seen; });
+            work.wait(lk, [&] { return stop || gen.load(std::memory_order_relaxed) != seen; });
             if (stop) return;
-            seen = gen;
-            const std::function<void(int)>* fn = job;  // null once run() has finished: a worker that wakes late has nothing to do,
-            if (!fn) continue;                         // and run() does not wait for it
-            if (joined >= wanted) continue;            // the run asked for fewer helpers than the pool has grown to (pcgc_set_rc_threads)
+            seen = gen.load(std::memory_order_relaxed);
+            const std::function<void(int)>* fn = job;  // null: a prewake, or a run() that has finished already (a worker that wakes late has
+            if (!fn || joined >= wanted) {             // nothing to do, and run() does not wait for it) / the run asked for fewer helpers
+                lk.unlock();
+                // stay awake for the work that was announced: a thread asleep on the condition variable takes 50-150 us to run again
+                // (measured: the caller had decoded two or three segments before its helpers arrived); a spinning one takes none
+                while (now_ns() < warm_until.load(std::memory_order_relaxed) && gen.load(std::memory_order_acquire) == seen) _mm_pause();
+                continue;
+            }
             ++joined;
             const int n = n_tasks;
             ++active;
@@ -360,6 +385,7 @@ class SegmentPool {
             if (--active == 0) done.notify_one();
         }
     }
+    void grow(int helpers) { while ((int)workers.size() < helpers) workers.emplace_back([this] { loop(); }); }
 public:
     ~SegmentPool() { { std::lock_guard<std::mutex> lk(m); stop = true; } work.notify_all(); for (auto& t : workers) t.join(); }
     // run fn(0..tasks-1) on the calling thread plus up to `helpers` pool threads
@@ -367,14 +393,27 @@ public:
         std::lock_guard<std::mutex> one(serial);
         {
             std::lock_guard<std::mutex> lk(m);
-            while ((int)workers.size() < helpers) workers.emplace_back([this] { loop(); });
-            job = &fn; n_tasks = tasks; next.store(0); wanted = helpers; joined = 0; ++gen;
+            grow(helpers);
+            job = &fn; n_tasks = tasks; next.store(0); wanted = helpers; joined = 0; gen.fetch_add(1, std::memory_order_release);
         }
         work.notify_all();
         drain(fn, next, tasks);                        // returns once every task has been taken
         std::unique_lock<std::mutex> lk(m);
         done.wait(lk, [&] { return active == 0; });    // ... and the ones taken by workers are finished
         job = nullptr;
+    }
+    // work for up to `helpers` pool threads is about to arrive (within `us` microseconds): wake them now and let them spin for it
+    void prewake(int helpers, int us) {
+        if (helpers <= 0) return;
+        if (!serial.try_lock()) return;                // a run is in progress: the workers are awake anyway
+        {
+            std::lock_guard<std::mutex> lk(m);
+            grow(helpers);
+            warm_until.store(now_ns() + (int64_t)us * 1000, std::memory_order_relaxed);
+            gen.fetch_add(1, std::memory_order_release);
+        }
+        serial.unlock();
+        work.notify_all();
     }
 };
 SegmentPool& segment_pool() { static SegmentPool p; return p; }     // range decoder
@@ -426,11 +465,15 @@ int rc_decode_starts(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int6
     const bool wide = rc_use_avx512(Lp);
     RcWideTables* wt = wide ? new RcWideTables(cdf, C, Lp) : nullptr;
     RcScalarTables* stb = wide ? nullptr : new RcScalarTables(cdf, C, Lp);
+    // more segments than threads (and the two-chain decoder): two segments per task
+    const int nseg = (int)starts.size();
+    const bool pairs = wide && nseg > std::max(threads, 1);
     const std::function<void(int)> one = [&](int k) {
-        if (wide) rc_decode_avx512_seg(*wt, C, padded, limit, starts[(size_t)k], sym);
+        if (pairs) rc_decode_avx512_seg(*wt, C, padded, limit, starts[(size_t)2 * k], 2 * k + 1 < nseg ? &starts[(size_t)2 * k + 1] : nullptr, sym);
+        else if (wide) rc_decode_avx512_seg(*wt, C, padded, limit, starts[(size_t)k], nullptr, sym);
         else rc_decode_scalar_seg(*stb, C, Lp, padded, limit, starts[(size_t)k], sym);
     };
-    const int tasks = (int)starts.size();
+    const int tasks = pairs ? (nseg + 1) / 2 : nseg;
     if (tasks <= 1 || threads <= 1) { for (int k = 0; k < tasks; ++k) one(k); }
     else segment_pool().run(tasks, std::min(threads, tasks) - 1, one);
     delete wt; delete stb;
@@ -1018,6 +1061,17 @@ int for_items(int n_items, int threads, const std::function<int(int, std::string
 typedef int (*pcgc_table_fn)(const float* params, int C, float min_v, float max_v, uint16_t* table_u16, float* cdf_f32);
 
 namespace {
+// The decode of n_items is about to need its pools: wake their threads now (they spin for the announced work for up to `us`).
+// One item: its two tasks run on the caller + one helper, each with the segment / group pool; more items: one thread per task.
+void prewake_for_decode(int n_items, int threads, int us) {
+    if (n_items <= 0) return;
+    if (threads <= 0) threads = effective_cpus();
+    if (n_items > 1 && threads > 1) { items_pool().prewake(std::min(threads, 2 * n_items) - 1, us); return; }      // (for_items: nested pools idle)
+    if (threads > 1) items_pool().prewake(1, us);
+    const int inner = rc_threads();
+    if (inner > 1) { segment_pool().prewake(inner - 1, us); octree_pool().prewake(inner - 1, us); }
+}
+
 // The table is a pure function of (parameters, range): the last few are kept (the decode of a batch this process has just encoded,
 // repeated frames, sequences whose latent range repeats), keyed by the CRC-32 of the parameter bytes + the range.  Same values as a
 // fresh evaluation by construction.
@@ -1064,7 +1118,7 @@ extern "C" int pcgc_items_encode(int n_items, const char* const* stems, const in
         const std::vector<uint16_t>& table = *tptr;
         StageClock clk;
         clk.mark("table");
-        int segs = (int)std::min<int64_t>(index_segments, n / 2048);
+        int segs = (int)std::min<int64_t>(index_segments, n / 1024);
         if (segs < 2) segs = 0;
         std::vector<uint32_t> ckpt((size_t)segs * PCGC_RC_CKPT_WORDS);
         const int16_t* s0 = sym + off[(size_t)i] * C;
@@ -1118,6 +1172,7 @@ extern "C" int pcgc_items_encode(int n_items, const char* const* stems, const in
 extern "C" int pcgc_items_probe(int n_items, const char* const* stems, int64_t* rows, int32_t* channels, float* ranges, int32_t* counts,
                                 int32_t* native_coords) {
     if (n_items < 0 || (n_items > 0 && (!stems || !rows || !channels || !ranges || !counts || !native_coords))) { pcgc_set_error("items_probe: bad arguments"); return -2; }
+    prewake_for_decode(n_items, 0, 500);               // pcgc_items_decode follows within ~0.1 ms: its threads wake up meanwhile
     for (int i = 0; i < n_items; ++i) {
         const std::string stem = stems[i];
         std::vector<uint8_t> h, c;
@@ -1144,6 +1199,7 @@ extern "C" int pcgc_items_decode(int n_items, const char* const* stems, const in
         coord_layout < 0 || coord_layout > 1 || coord_scale < 1) {
         pcgc_set_error("items_decode: bad arguments"); return -2;
     }
+    prewake_for_decode(n_items, threads, 300);
     std::vector<int64_t> off((size_t)n_items + 1, 0);
     for (int i = 0; i < n_items; ++i) off[(size_t)i + 1] = off[(size_t)i] + rows[i];
     // two tasks per item — its coordinate stream and its feature stream are independent — so that ONE cloud (the single-frame path)

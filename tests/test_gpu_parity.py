@@ -539,7 +539,7 @@ def test_full_size_frame_properties(sd, tmp_path):
     with pytest.raises(Exception, match='CDF table'):
         coder.decode()
     idx.write_bytes(blob)
-    coder_mod.INDEX_SEGMENTS = 0
+    keep_segments, coder_mod.INDEX_SEGMENTS = coder_mod.INDEX_SEGMENTS, 0
     try:
         coder3 = Coder(m, str(tmp_path / 'plain'))
         coder3.encode(x)
@@ -547,7 +547,7 @@ def test_full_size_frame_properties(sd, tmp_path):
         assert (tmp_path / 'plain_F.bin').read_bytes() == files['F']
         np.testing.assert_array_equal(coder3.decode().C.cpu().numpy(), oc)
     finally:
-        coder_mod.INDEX_SEGMENTS = 8
+        coder_mod.INDEX_SEGMENTS = keep_segments
 
 
 def test_batch_coding_identical_to_one_by_one(sd, sd_np, tmp_path):

@@ -605,7 +605,8 @@ def test_native_item_files_equal_the_python_path(tmp_path):
     counts = [(r * 3, r * 9, r * 30) for r in rows]
     py, nat = tmp_path / 'py', tmp_path / 'nat'
     py.mkdir(); nat.mkdir()
-    for seg in (8, 0):
+    default_segments = coder.INDEX_SEGMENTS
+    for seg in (default_segments, 8, 3, 0):                  # (3: an odd number of segments — the two-chain decoder's last task is a single)
         coder.INDEX_SEGMENTS = seg
         try:
             fc, cc = coder.FeatureCoder(str(py / 'c'), eb), coder.CoordinateCoder(str(py / 'c'))
@@ -647,7 +648,7 @@ def test_native_item_files_equal_the_python_path(tmp_path):
             with pytest.raises(PcgcError):
                 ops.items_decode(stems, got_rows, C, got_ranges, native, eb._host_packed(), level_scale=8, level_out=np.zeros((3, 4), np.int32))
         finally:
-            coder.INDEX_SEGMENTS = 8
+            coder.INDEX_SEGMENTS = default_segments
     # a sidecar that names another table: refused (the 20000-row item of the first pass is gone; re-encode one item)
     ops.items_encode([str(nat / 'g')], syms[0], xyzs[0], rows[:1], ranges[:1], counts[:1], eb._host_packed(), 8)
     blob = bytearray((nat / 'g_F.idx').read_bytes())

@@ -25,8 +25,14 @@ def med(fn, n=60):
         t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
     return statistics.median(ts) * 1e3
 s, idx = ops.rc_encode(tab, sym_h, checkpoints=8)
+s16, idx16 = ops.rc_encode(tab, sym_h, checkpoints=16)
 print(f'symbols {sym_h.size}  bytes {len(s)}  alphabet {tab.shape[1] - 1}')
 print(f'rc_encode          {med(lambda: ops.rc_encode(tab, sym_h)):.3f} ms')
 print(f'rc_encode indexed  {med(lambda: ops.rc_encode(tab, sym_h, checkpoints=8)):.3f} ms')
 print(f'rc_decode serial   {med(lambda: ops.rc_decode(tab, s, sym_h.size)):.3f} ms')
-print(f'rc_decode indexed  {med(lambda: ops.rc_decode(tab, s, sym_h.size, index=idx)):.3f} ms')
+print(f'rc_decode indexed 8   {med(lambda: ops.rc_decode(tab, s, sym_h.size, index=idx)):.3f} ms')
+print(f'rc_decode indexed 16  {med(lambda: ops.rc_decode(tab, s16, sym_h.size, index=idx16)):.3f} ms')
+for thr in (2, 4):
+    ops.set_rc_threads(thr)
+    print(f'  {thr} threads: 8 -> {med(lambda: ops.rc_decode(tab, s, sym_h.size, index=idx)):.3f} ms, 16 -> {med(lambda: ops.rc_decode(tab, s16, sym_h.size, index=idx16)):.3f} ms')
+ops.set_rc_threads(0)
