@@ -416,7 +416,7 @@ def main():
                        'bpp_reference_files_only': round(total_bits / max(total_coded, 1), 5),
                        'reference_format_only': plain, 'units_one_by_one': one_by_one, 'host_threads': host_threads,
                        'entropy_decode': '`_F.bin` (bit-identical to the reference-format stream, decodable without it) comes with a sidecar '
-                                         '`_F.idx` of decoder states at 8 row boundaries: its segments are decoded on 8 threads; `_C.bin` '
+                                         f'`_F.idx` of decoder states at {coder_mod.INDEX_SEGMENTS} row boundaries: its segments are decoded two per thread (two dependency chains per loop) on up to 8 threads; `_C.bin` '
                                          '(native octree, tmc3 absent) is coded as up to 8 independent groups of subtrees',
                        'coord_codec': 'native-octree (tmc3 absent)', 'coord_coder_ms': coord_ms, 'serving_throughput': serving,
                        'step_ms_rank0': step_ms,

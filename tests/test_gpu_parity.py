@@ -521,7 +521,7 @@ def test_full_size_frame_properties(sd, tmp_path):
     # stream), with a sidecar of another stream (ignored), and `_F.bin` is the same when no index is written at all
     from pcgcv2_amd import coder as coder_mod
     idx = tmp_path / 'full_F.idx'
-    assert idx.exists() and coder_mod.index_bits(str(tmp_path / 'full')) == 8 * (coder_mod._INDEX_HEAD.size + 8 * 4 * ops.RC_CKPT_WORDS)
+    assert idx.exists() and coder_mod.index_bits(str(tmp_path / 'full')) == 8 * (coder_mod._INDEX_HEAD.size + coder_mod.INDEX_SEGMENTS * 4 * ops.RC_CKPT_WORDS)
     blob = idx.read_bytes()
     idx.unlink()
     np.testing.assert_array_equal(coder.decode().C.cpu().numpy(), oc)
