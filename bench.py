@@ -100,6 +100,7 @@ def main():
     shard.FORCE_COLLECTIVES = dist_on and world == 1
     from pcgcv2_amd.pcc_model import PCCModel
     from pcgcv2_amd.coder import Coder, STREAMS
+    from pcgcv2_amd import coder as coder_mod
     from pcgcv2_amd.data_utils import scale_sparse_tensor
     from pcgcv2_amd.sparse import SparseTensor
     if args.irn_rows:
@@ -271,7 +272,6 @@ def main():
     # reference-made stream would be) — reported beside `value`, so rate and speed of BOTH configurations are on the line
     plain = None
     if cfg == 'frame' and not args.no_extra:
-        from pcgcv2_amd import coder as coder_mod
         keep_segments, coder_mod.INDEX_SEGMENTS = coder_mod.INDEX_SEGMENTS, 0
         try:
             step()
