@@ -326,6 +326,13 @@ int pcgc_items_decode(int n_items, const char* const* stems, const int64_t* rows
                       const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int16_t* sym, int32_t* xyz, int coord_layout,
                       int coord_scale, int threads);
 
+/* One cloud in one call — Coder.decode's host half (coder.py:93-104): probe + both streams, into buffers the caller keeps (pinned memory:
+ * both uploads are then asynchronous copies).  sym [cap_rows, C], level [cap_rows, 4] (coord_layout 1 above, coord_scale = the level's
+ * tensor stride).  info[6] = rows, channels, N4, N2, N1, native_coords; range[2] = min_v, max_v.  -> 0; 1: cap_rows too small (info[0]
+ * rows needed, nothing decoded); < 0: error (-5 as above).  `_C.bin` not a native stream (tmc3): info[5] = 0, `level` untouched. */
+int pcgc_frame_decode(const char* stem, int C, const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int coord_scale,
+                      int64_t cap_rows, int16_t* sym, int32_t* level, int64_t* info, float* range, int threads);
+
 /* zlib's crc32(crc, buf, len) (the CRC-32 of the `_F.idx` sidecar's stream and table guards; coder.py of this package uses
  * zlib.crc32 for the same fields), folded with carry-less multiplies on long buffers.  HOST. */
 uint32_t pcgc_crc32(uint32_t crc, const uint8_t* buf, int64_t len);

@@ -286,6 +286,20 @@ class Coder():
             xyz8 = np.asarray(self.coordinate_coder.decode(postfix), dtype=np.int32)
         return self._stage_geometry(xyz8, dev, stream)
 
+    def _decode_buffers(self, C, rows=0):
+        """pinned staging buffers of decode(): symbols int16 [cap, C] and coordinate level int32 [cap, 4] -> their numpy views.
+        Waits for the uploads of the previous decode before handing them out again (normally long complete)."""
+        self._pinned_level(max(rows, 1))
+        sym = getattr(self, '_pinned_sym', None)
+        if sym is None or sym.shape[0] < self._pinned_dec.shape[0] or sym.shape[1] != C:
+            self._pinned_sym = torch.empty((self._pinned_dec.shape[0], C), dtype=torch.int16, pin_memory=True)
+            self._pinned_sym_np = self._pinned_sym.numpy()
+        return self._pinned_sym_np, self._pinned_dec_np
+
+    def _mark_uploads(self, dev):
+        self._pinned_dec_busy = torch.cuda.Event()
+        self._pinned_dec_busy.record(torch.cuda.current_stream(dev))
+
     def _pinned_level(self, n):
         """numpy view [>= n, 4] int32 of the pinned staging buffer of the decoded coordinate level"""
         busy = getattr(self, '_pinned_dec_busy', None)
@@ -345,25 +359,29 @@ class Coder():
         stream = torch.cuda.current_stream(dev)
         lvl8 = None
         if self._native_items():
-            stem = [self.filename + postfix]
-            rows, C, ranges, counts, native = ops.items_probe(stem)
-            n4, n2, n1 = (int(v) for v in counts[0])
-            if native[0]:
-                # coordinate stream and feature stream decoded side by side INSIDE the library (two native tasks, each with its own pool
-                # of group / segment threads): no Python thread hop on the path to the first decoder kernel.  (Measured against the
-                # feature stream on a Python helper thread with this thread decoding and staging the coordinates meanwhile: the host
-                # timeline looks 0.1 ms shorter that way, the frame is 0.07 ms LONGER — four A/B pairs on one box.)
-                n8 = int(rows[0])
-                sym_h, level = ops.items_decode(stem, rows, C, ranges, native, self.feature_coder.entropy_model._host_packed(),
-                                                use_sidecar=bool(INDEX_SEGMENTS), threads=2, level_scale=8, level_out=self._pinned_level(n8))
+            # ONE library call: sizes, coordinate stream and feature stream (two native tasks side by side, each with its own pool of
+            # group / segment threads — no Python thread hop on the path to the first decoder kernel), written into pinned buffers this
+            # coder keeps: the symbols and the sorted coordinate level go up as two asynchronous copies.  (Measured against the
+            # feature stream on a Python helper thread with this thread decoding and staging the coordinates meanwhile: the host
+            # timeline looks 0.1 ms shorter that way, the frame is 0.07 ms LONGER — four A/B pairs on one box.)
+            C = self.feature_coder.entropy_model._channels
+            stem = self.filename + postfix
+            packed = self.feature_coder.entropy_model._host_packed()
+            while True:
+                sym_np, level_np = self._decode_buffers(C)
+                n8, rng, counts, native = ops.frame_decode(stem, C, packed, sym_np, level_np, use_sidecar=bool(INDEX_SEGMENTS), level_scale=8)
+                if rng is not None:
+                    break
+                self._decode_buffers(C, rows=n8)                  # (a larger cloud than any before: grow and decode)
+            n4, n2, n1 = counts
+            with torch.cuda.stream(stream):
+                sym_d = self._pinned_sym[:n8].to(dev, non_blocking=True)
+            if native:
                 lvl8 = self._stage_level(n8, dev, stream)
-            else:                                                # tmc3 stream: the subprocess protocol runs on the helper thread
-                pending = _POOL.submit(self._decode_geometry, postfix, dev, stream)
-                sym_h, _ = ops.items_decode(stem, rows, C, ranges, native, self.feature_coder.entropy_model._host_packed(),
-                                            use_sidecar=bool(INDEX_SEGMENTS), threads=1)
-            y_F = ops.desymbolize(torch.from_numpy(sym_h).to(dev), np.float32(ranges[0, 0]))
-            if lvl8 is None:
-                lvl8 = pending.result()
+            else:                                                # tmc3 stream: the subprocess protocol (helper thread in the general path)
+                self._mark_uploads(dev)
+                lvl8 = self._decode_geometry(postfix, dev, stream)
+            y_F = ops.desymbolize(sym_d, rng[0])
         else:
             pending = _POOL.submit(self._decode_geometry, postfix, dev, stream)
             n4, n2, n1 = _COUNTS.unpack(_slurp(self.filename + postfix + '_num_points.bin')[:_COUNTS.size])

@@ -1280,3 +1280,21 @@ extern "C" int pcgc_items_decode(int n_items, const char* const* stems, const in
         return 0;
     }, 2);
 }
+
+// One cloud in ONE call (the single-frame path of Coder.decode, coder.py:93-104): what pcgc_items_probe + pcgc_items_decode do for it,
+// into buffers the caller keeps (pinned memory: both uploads are asynchronous copies).  sym [cap_rows, C] int16, level [cap_rows, 4] int32
+// (coord_layout 1 of pcgc_items_decode).  info[6] = rows, channels, N4, N2, N1, native_coords; range[2] = min_v, max_v.
+// -> 0; 1 = cap_rows is too small (info[0] rows are needed: grow the buffers and call again; nothing was decoded); < 0 error.
+// A `_C.bin` that is not a native octree stream (tmc3): info[5] = 0, the features are decoded and `level` is left untouched.
+extern "C" int pcgc_frame_decode(const char* stem, int C, const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int coord_scale,
+                                 int64_t cap_rows, int16_t* sym, int32_t* level, int64_t* info, float* range, int threads) {
+    if (!stem || !eb_params || !table_fn || !sym || !level || !info || !range || C < 1 || cap_rows < 0) { pcgc_set_error("frame_decode: bad arguments"); return -2; }
+    int64_t rows = 0; int32_t channels = 0, counts[3] = {0, 0, 0}, native = 0;
+    const int rc = pcgc_items_probe(1, &stem, &rows, &channels, range, counts, &native);
+    if (rc != 0) return rc;
+    info[0] = rows; info[1] = channels; info[2] = counts[0]; info[3] = counts[1]; info[4] = counts[2]; info[5] = native;
+    if (channels != C) { pcgc_set_error("frame_decode: %s_H.bin has %d channels, the model %d", stem, (int)channels, C); return -2; }
+    if (rows > cap_rows) return 1;
+    return pcgc_items_decode(1, &stem, &rows, C, range, &native, eb_params, table_fn, use_sidecar, sym, level, 1, coord_scale > 0 ? coord_scale : 1, threads);
+}
+

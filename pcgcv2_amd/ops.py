@@ -1221,6 +1221,26 @@ def items_decode(stems, rows, C, ranges, native, eb_params, use_sidecar=True, th
     return sym, xyz[:total]
 
 
+def frame_decode(stem, C, eb_params, sym_buf, level_buf, use_sidecar=True, level_scale=8, threads=2):
+    """One cloud's files -> symbols and sorted coordinate level, in ONE library call, into the caller's (pinned) numpy buffers sym_buf
+    int16 [cap, C] and level_buf int32 [cap, 4].  -> (rows, (min_v, max_v), (N4, N2, N1), native_coords), or (rows_needed, None, None,
+    None) when the buffers are too small (nothing decoded: grow them and call again)."""
+    import ctypes
+    cap = min(sym_buf.shape[0], level_buf.shape[0])
+    if sym_buf.dtype != np.int16 or level_buf.dtype != np.int32 or sym_buf.shape[1:] != (C,) or level_buf.shape[1:] != (4,) \
+            or not sym_buf.flags.c_contiguous or not level_buf.flags.c_contiguous:
+        raise PcgcError('frame_decode: buffers must be C-contiguous int16 [cap, C] and int32 [cap, 4]')
+    info = (ctypes.c_int64 * 6)()
+    rng = (ctypes.c_float * 2)()
+    P = _np(eb_params, np.float32)
+    rc = lib().pcgc_frame_decode(_os.fsencode(stem), int(C), P.ctypes.data, _table_fn(), int(bool(use_sidecar)), int(level_scale), cap,
+                                 sym_buf.ctypes.data, level_buf.ctypes.data, info, rng, int(threads))
+    if rc == 1:
+        return int(info[0]), None, None, None
+    check(rc, 'frame_decode')
+    return int(info[0]), (np.float32(rng[0]), np.float32(rng[1])), (int(info[2]), int(info[3]), int(info[4])), bool(info[5])
+
+
 def set_oct_tiled(on):
     """Coordinate codec: groups of subtrees coded independently (1, the default for clouds of >= 8192 points; n > 1: that many
     groups) or always one stream (0).  A/B tests."""

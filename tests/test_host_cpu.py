@@ -647,6 +647,20 @@ def test_native_item_files_equal_the_python_path(tmp_path):
                 off += r
             with pytest.raises(PcgcError):
                 ops.items_decode(stems, got_rows, C, got_ranges, native, eb._host_packed(), level_scale=8, level_out=np.zeros((3, 4), np.int32))
+            # pcgc_frame_decode: one cloud, probe + both streams in one call into the caller's buffers; too small -> the size needed
+            off = 0
+            for i, r in enumerate(rows):
+                sym_buf, level_buf = np.full((r + 3, 8), -9, np.int16), np.full((r + 3, 4), -9, np.int32)
+                n, rng_i, counts_i, nat_i = ops.frame_decode(stems[i], 8, eb._host_packed(), sym_buf, level_buf, use_sidecar=bool(seg))
+                assert (n, nat_i, counts_i) == (r, True, tuple(counts[i])) and tuple(float(v) for v in rng_i) == tuple(ranges[i])
+                np.testing.assert_array_equal(sym_buf[:r], syms[i])
+                np.testing.assert_array_equal(level_buf[:r, 1:], level[off:off + r, 1:])
+                assert (level_buf[:r, 0] == 0).all() and (sym_buf[r:] == -9).all() and (level_buf[r:] == -9).all()
+                if r > 1:
+                    assert ops.frame_decode(stems[i], 8, eb._host_packed(), sym_buf[:r - 1], level_buf[:r - 1]) == (r, None, None, None)
+                off += r
+            with pytest.raises(PcgcError, match='channels'):
+                ops.frame_decode(stems[0], 4, eb._host_packed(), np.zeros((rows[0], 4), np.int16), np.zeros((rows[0], 4), np.int32))
         finally:
             coder.INDEX_SEGMENTS = default_segments
     # a sidecar that names another table: refused (the 20000-row item of the first pass is gone; re-encode one item)
