@@ -202,6 +202,12 @@ int pcgc_set_child_tuning(int waves_per_group, int ring_depth);       /* A/B swi
 int pcgc_irn_child_pass(const int32_t* parent_nbr, int64_t n_parent, int C, int pass, const float* in, int in_ld,
                         const float* table, int64_t table_bytes, const float* b0, const float* b1, const float* b2,
                         const float* x, int x_ld, float* out, int out_ld, void* stream);
+/* The same two passes at C = 64 on a PLAIN level (the encoder's stride-4 level, autoencoder.py:104-110) through the level's own
+ * k3 map nbr [27][n]: LDS-resident fragment table, one wave per 16-row tile walking the 27 offsets (csrc/rows_irn.hip); tables as
+ * for the children-level C = 64 passes (ops.child_irn_tables). */
+int pcgc_irn_rows_pass(const int32_t* nbr, int64_t n, int C, int pass, const float* in, int in_ld, const float* table,
+                       int64_t table_bytes, const float* b0, const float* b1, const float* b2, const float* x, int x_ld, float* out,
+                       int out_ld, void* stream);
 
 /* ‡ conventions the reference's results depend on but its sources do not pin (un-vendored MinkowskiEngine / torch.topk on ME's row
  * order): what = 0: top-k tie rule, value 0 = the lower row wins (default), 1 = the higher row wins.  The dedup policy is an argument of

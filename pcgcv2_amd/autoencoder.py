@@ -35,6 +35,12 @@ class InceptionResNet(torch.nn.Module):
                 if c == 64:
                     return SparseTensor(ops.irn_block_child64(x.cmap.origin[1].k3, x.F, params, self._child_tables), coordinate_map=x.cmap)
                 return SparseTensor(ops.irn_block_child(x.cmap.origin[1].k3, x.F, params, self._child_tables), coordinate_map=x.cmap)
+            if c == 64 and ops.ROWS_IRN64 and x.F.shape[0] >= ops.ROWS_IRN64_MIN:
+                # plain level, C = 64 (the encoder's stride-4 level): LDS-resident fragment table, one wave per 16-row tile (csrc/rows_irn.hip)
+                stamp = tuple((p.data_ptr(), p._version) for p in params)
+                if getattr(self, '_child_stamp', None) != stamp:
+                    self._child_tables, self._child_stamp = ops.child_irn_tables(params), stamp
+                return SparseTensor(ops.irn_block_rows64(x.cmap.k3, x.F, params, self._child_tables), coordinate_map=x.cmap)
             if c == 64 and ops.MFMA_IRN and x.F.shape[0] >= 512:       # (1-18 k rows: 117-123 us per block against 177-220 on the VALU passes)
                 # block-sparse MFMA path; the fused weights are rebuilt whenever a parameter tensor was replaced or modified
                 stamp = tuple((p.data_ptr(), p._version) for p in params)

@@ -83,6 +83,15 @@ constexpr int cy_of(int c) { return (c >> 2) & 3; }
 constexpr int cx_of(int c) { return c & 3; }
 constexpr bool in02(int v) { return v >= 0 && v <= 2; }
 
+// Where a variant's gathered rows come from.  Children levels (the default): the 64 halo cells of a 16-parent tile — cell c is child
+// cell_child(c) of the neighbour parent at map offset cell_kp(c), rows 8 p + j.  A variant may override these (rows_irn.hip: plain
+// levels, "cell" k = kernel offset k of the tile's own 16 rows, one map row per offset).
+struct HaloGeometry {
+    static constexpr int NCELLS = 64, ROW_MUL = 8;
+    static constexpr int kp(int c) { return cell_kp(c); }
+    static constexpr int child(int c) { return cell_child(c); }
+};
+
 // ---- layer variants.  A variant says: how wide the gathered rows are (NB 16-channel blocks, ROWCHUNKS 16-byte chunks present
 //      per block), how many accumulator tiles there are (T), how many K-steps of a block a tile consumes (KS, starting at
 //      kfirst(t)), which cells feed a tile (active) and which B fragment of the table a (cell, tile) pair multiplies by (frag).
@@ -90,7 +99,7 @@ constexpr bool in02(int v) { return v >= 0 && v <= 2; }
 //      8 of a tile's 16 columns are meaningful: lanes of columns 8-15 alias columns 0-7 (their results are never stored).
 // HZ: -1 = all eight children; 0 / 1 = the four children with that z bit (half units: see k_child_irn_a)
 template <int NB_, int NT, int HZ = -1>
-struct PlainConv {                     // k3 conv Cin = 16 NB -> Cout = 16 NT: tile t = (child j, column tile n), fragment = slice of offset k
+struct PlainConv : HaloGeometry {                     // k3 conv Cin = 16 NB -> Cout = 16 NT: tile t = (child j, column tile n), fragment = slice of offset k
     static constexpr int NB = NB_, ROWCHUNKS = 4, T = 8 * NT, KS = 4;
     static constexpr int Z_HALF = HZ;
     static constexpr bool HALF = false;
@@ -103,7 +112,7 @@ struct PlainConv {                     // k3 conv Cin = 16 NB -> Cout = 16 NT: t
     static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 64 * KS * 4; }      // byte offset in the table
 };
 template <int NB_>
-struct ClsHead {                       // k3 conv C -> 1: one tile, column j (0..7) = child j; one fragment per cell
+struct ClsHead : HaloGeometry {                       // k3 conv C -> 1: one tile, column j (0..7) = child j; one fragment per cell
     static constexpr int NB = NB_, ROWCHUNKS = 4, T = 1, KS = 4;
     static constexpr bool HALF = true;
     static constexpr int kfirst(int) { return 0; }
@@ -119,7 +128,7 @@ struct ClsHead {                       // k3 conv C -> 1: one tile, column j (0.
 // cell that IS the child: offset k = 13).
 // HZ (C = 64 only): -1 = all eight children; 0 / 1 = only the four children with that z bit (a half unit: see k_child_irn_a)
 template <int C, int HZ = -1>
-struct PassA {
+struct PassA : HaloGeometry {
     static constexpr int Q = C / 4, NB = C / 16, ROWCHUNKS = 4, CPT = 16 / Q /*children per tile: 4, 2 or 1*/, TH = 8 / CPT, T = 2 * TH, KS = 4;
     static_assert(HZ < 0 || CPT <= 2, "half units: tiles of one or two children (a z-half tile holds both halves' columns)");
     static constexpr int Z_HALF = HZ;
@@ -161,7 +170,7 @@ struct PassA {
 // first Q channels, conv1_1 (k3 Q -> Q) the last Q: with Q = 8 (C = 32) those are K-steps {0,1} / {2,3} of the one 16-channel
 // block, with Q = 4 (C = 16) K-step 0 / 1 of a half-width block.
 template <int C, int HZ = -1>
-struct PassB {
+struct PassB : HaloGeometry {
     static constexpr int Q = C / 4, NB = 1, ROWCHUNKS = Q / 2 /*2Q floats = Q/2 chunks*/, KS = Q / 4;
     static constexpr int CPT0 = 16 / (2 * Q) /*children per conv0_1 tile: 1 or 2*/, T0 = 8 / CPT0, CPT1 = 16 / Q, T1 = 8 / CPT1, T = T0 + T1;
     static constexpr int Z_HALF = HZ;
@@ -199,7 +208,7 @@ struct PassB {
 // pass B at C = 64 (Q = 16): t is 32 wide = two 16-channel blocks; block 0 feeds conv0_1 (k3 16 -> 32: two column tiles per child),
 // block 1 feeds conv1_1 (k3 16 -> 16: one tile per child).  Fragments: conv0_1 (k, n) = 54, conv1_1 k = 27, conv1_2 (k1 16 -> 32) = 2.
 template <int HZ = -1>
-struct PassB64 {
+struct PassB64 : HaloGeometry {
     static constexpr int Q = 16, NB = 2, ROWCHUNKS = 4, KS = 4, T0 = 16, T1 = 8, T = 24;
     static constexpr int Z_HALF = HZ;                      // -1 = all eight children; 0 / 1 = the four children with that z bit (half units)
     static constexpr bool HALF = false;
@@ -288,7 +297,7 @@ __device__ __forceinline__ void child_stage_table(const float* __restrict__ tabl
 struct ChildCells { int n; int c[64]; };
 template <class V> constexpr ChildCells child_cells() {
     ChildCells L{};
-    for (int c = 0; c < 64; ++c) {
+    for (int c = 0; c < V::NCELLS; ++c) {
         bool used = false;
         for (int t = 0; t < V::T; ++t) used = used || V::active(c, t);
         if (used) L.c[L.n++] = c;
@@ -321,7 +330,7 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
     const unsigned row_bytes = (unsigned)in_ld * 4u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // map entries loaded (and the previous tile's stores retired): vmcnt now counts DMAs only
 #pragma unroll
-    for (int kp = 0; kp < 27; ++kp) rowb[kp] = (row_ok && (int)rowb[kp] >= 0) ? rowb[kp] * (8u * row_bytes) : ABSENT;
+    for (int kp = 0; kp < 27; ++kp) rowb[kp] = (row_ok && (int)rowb[kp] >= 0) ? rowb[kp] * ((unsigned)V::ROW_MUL * row_bytes) : ABSENT;
     const unsigned lane_off = chunk_ok ? (unsigned)dma_chunk * 16u : ABSENT;
     CHILD_T(t_loop0);
 
@@ -330,7 +339,7 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
     auto issue = [&](auto ii) {
         constexpr int i = decltype(ii)::value, c = CL.c[i];
         float4* dst = ring + (i & (D - 1)) * (NB * 64);
-        unsigned voff = rowb[cell_kp(c)] + (unsigned)cell_child(c) * row_bytes + lane_off;
+        unsigned voff = rowb[V::kp(c)] + (unsigned)V::child(c) * row_bytes + lane_off;
         if constexpr (V::ROWCHUNKS < 4) voff = chunk_ok ? voff : 0xFFFFFFF0u;       // (ABSENT + ABSENT would wrap)
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb)
@@ -527,7 +536,7 @@ __device__ __forceinline__ void child_flush(const float* scratch, int rows, int6
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                                                        \
     float4* ring = (float4*)(lds_raw + table_bytes) + wave * (RING_FLOAT4);                                                   \
     child_stage_table<NW>(table, table_bytes, lds_raw);                                                                        \
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(8 * n_p * in_ld * 4), 0x00020000); \
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(V::ROW_MUL * n_p * in_ld * 4), 0x00020000); \
     const int64_t ntiles = (n_p + 15) >> 4;
 
 template <class T_> struct child_type_tag { using type = T_; };

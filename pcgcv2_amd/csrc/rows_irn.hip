@@ -1,0 +1,157 @@
+// Fused InceptionResNet passes (autoencoder.py:52-57) at C = 64 on a PLAIN level — the encoder's stride-4 level — with the machinery of the
+// children-level kernels (child_kernels.h): the whole B-fragment table resident in LDS, one wave = one 16-row M tile that walks the 27
+// kernel offsets on its own (rows fetched by `buffer_load ... lds` into a per-wave ring, D - 1 offsets of gather in flight behind the
+// MFMAs), no workgroup barrier and no weight staging per offset.  The block-sparse gather kernels these replace on that level
+// (k_conv_gather_mfma_pipe<64,32,2> / <32,48,2> + k_irn_tail) stage one weight slice per offset through LDS for four waves at a
+// time: 54 barrier-separated steps of 1.85 us carrying 0.2-0.5 us of MFMA work each (profiles/r03_child_skip_experiment.md §5).
+//
+// Geometry: "cell" k of a tile = kernel offset k of its own 16 rows: row nbr[k][r] of the level itself (ROW_MUL = 1, no child index), fed
+// to the accumulator tiles in ascending k — the same fmaf chain per output element as every other kernel of this library (ascending
+// offset, then ascending input channel: 16-channel block, K-step, K index).  Tables: ops.child_irn_tables(params) at C = 64 (one
+// fragment per (offset, 16-channel block): the layout the children-level C = 64 kernels use).
+#include "child_kernels.h"
+
+namespace {
+
+struct RowsGeometry {
+    static constexpr int NCELLS = 27, ROW_MUL = 1;
+    static constexpr int kp(int c) { return c; }
+    static constexpr int child(int) { return 0; }
+};
+// pass A: x rows (64 wide, four 16-channel blocks) -> tile 0 = conv0_0 (k3 64 -> 16), tile 1 = conv1_0 (k1 64 -> 16: the centre offset only)
+struct RowsPassA64 : RowsGeometry {
+    static constexpr int NB = 4, ROWCHUNKS = 4, T = 2, KS = 4, Z_HALF = -1, NBATCH = 1;
+    static constexpr bool HALF = false;
+    static constexpr int kfirst(int) { return 0; }
+    static constexpr bool active(int c, int t) { return t == 0 || c == 13; }
+    static constexpr int frag(int c, int t) { return t == 0 ? c : 27; }
+    static constexpr bool uses_block(int, int) { return true; }
+    static constexpr int batch(int) { return 0; }
+    static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 1024; }
+};
+// pass B: t rows (32 wide: block 0 = relu(conv0_0), block 1 = relu(conv1_0)) -> tiles 0, 1 = conv0_1 (k3 16 -> 32) from block 0,
+// tile 2 = conv1_1 (k3 16 -> 16) from block 1.  Fragments: conv0_1 (k, n) = 2 k + n, conv1_1 k = 54 + k, conv1_2 (k1 16 -> 32) n = 81 + n.
+struct RowsPassB64 : RowsGeometry {
+    static constexpr int NB = 2, ROWCHUNKS = 4, T = 3, KS = 4, Z_HALF = -1, NBATCH = 1, FRAG_W12 = 81;
+    static constexpr bool HALF = false;
+    static constexpr int kfirst(int) { return 0; }
+    static constexpr bool active(int, int) { return true; }
+    static constexpr int frag(int c, int t) { return t < 2 ? 2 * c + t : 54 + c; }
+    static constexpr bool uses_block(int t, int cb) { return t < 2 ? cb == 0 : cb == 1; }
+    static constexpr int batch(int) { return 0; }
+    static constexpr int frag_off(int c, int t, int) { return frag(c, t) * 1024; }
+};
+
+// pass A:  t[row][0:16] = relu(conv0_0 + b00), t[row][16:32] = relu(conv1_0 + b10)        acc[t][r] = row 4 mq + r of the tile, column mi
+template <int NW, int D>
+__global__ void __launch_bounds__(NW * 64)
+k_rows_irn_a64(const int32_t* __restrict__ pnbr, int64_t n_p /* rows of the level */, const float* __restrict__ in, int in_ld,
+               const float* __restrict__ table, int table_bytes, IrnEpi ep) {
+    using V = RowsPassA64;
+    CHILD_KERNEL_PROLOGUE(V, NW, D, D * V::NB * 64)
+    const float b00 = ep.b0[mi], b10 = ep.b1[mi];
+    float* scratch = (float*)ring;                             // [16 rows][32]: 2 KB of the (idle) gather ring
+    for (int i = 0;; ++i) {
+        const int64_t tile = child_tile<NW>(i, wave, ntiles);
+        if (tile < 0) break;
+        const int64_t row0 = tile * 16;
+        f32x4 acc[V::T];
+        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            scratch[(4 * mq + r) * 32 + mi] = fmaxf(acc[0][r] + b00, 0.0f);
+            scratch[(4 * mq + r) * 32 + 16 + mi] = fmaxf(acc[1][r] + b10, 0.0f);
+        }
+        wave_lds_sync();
+        child_flush<32>(scratch, 16, row0, n_p, ep.out, 32, nullptr, 0, 0, lane);
+        wave_lds_sync();
+    }
+}
+
+// pass B:  out[row][0:32]  = (conv0_1(t[:, :16]) + b01) + x[row][0:32]
+//          out[row][32:64] = (conv1_2(relu(conv1_1(t[:, 16:]) + b11)) + b12) + x[row][32:64]      (conv1_2: 8 MFMAs on u through the scratch)
+template <int NW, int D>
+__global__ void __launch_bounds__(NW * 64)
+k_rows_irn_b64(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in /* t [.., 32] */, int in_ld,
+               const float* __restrict__ table, int table_bytes, IrnEpi ep) {
+    using V = RowsPassB64;
+    constexpr int NEEDF4 = (16 * 16 + 16 * 64) / 4;                                        // us [16][16] + stage [16][64]
+    constexpr int RINGF4 = (D * V::NB * 64 > NEEDF4) ? D * V::NB * 64 : NEEDF4;
+    CHILD_KERNEL_PROLOGUE(V, NW, D, RINGF4)
+    float* us = (float*)ring;
+    float* stage = us + 16 * 16;
+    f32x4 w12[2];                                                                          // conv1_2 B fragments: W12[4 jj + mq][16 n + mi]
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2) w12[n2] = *((const f32x4*)(lds_raw + (V::FRAG_W12 + n2) * 1024) + lane);
+    const float b01a = ep.b0[mi], b01b = ep.b0[16 + mi], b11 = ep.b1[mi], b12a = ep.b2[mi], b12b = ep.b2[16 + mi];
+    for (int i = 0;; ++i) {
+        const int64_t tile = child_tile<NW>(i, wave, ntiles);
+        if (tile < 0) break;
+        const int64_t row0 = tile * 16;
+        f32x4 acc[V::T];
+        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            us[(4 * mq + r) * 16 + mi] = fmaxf(acc[2][r] + b11, 0.0f);
+            stage[(4 * mq + r) * 64 + mi] = acc[0][r] + b01a;
+            stage[(4 * mq + r) * 64 + 16 + mi] = acc[1][r] + b01b;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+            f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) d = __builtin_amdgcn_mfma_f32_16x16x4f32(us[mi * 16 + 4 * jj + mq], w12[n2][jj], d, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[(4 * mq + r) * 64 + 32 + 16 * n2 + mi] = d[r] + (n2 ? b12b : b12a);
+        }
+        wave_lds_sync();
+        child_flush<64>(stage, 16, row0, n_p, ep.out, ep.out_ld, ep.x, ep.x_ld, 0, lane);
+        wave_lds_sync();
+    }
+}
+
+// persistent grid over 16-row tiles (child_grid counts 16-PARENT tiles: the same number here)
+template <typename K>
+int launch_rows(K kern, int nw, size_t lds, const int32_t* nbr, int64_t n, const float* in, int in_ld, const float* table, int table_bytes,
+                const IrnEpi& ep, hipStream_t s, ChildLdsGrant& granted) {
+    if (int rc = child_lds_limit(kern, lds, granted)) return rc;
+    hipLaunchKernelGGL(kern, dim3(child_grid(n, nw, lds)), dim3(nw * 64), lds, s, nbr, n, in, in_ld, table, table_bytes, ep);
+    return 0;
+}
+
+}  // namespace
+
+// Fused InceptionResNet passes at C = 64 on a plain level through its own k3 map nbr [27][n].  pass 1 (A): in = x [n, 64] -> out = t [n, 32];
+// pass 2 (B): in = t -> out [n, 64] with the residual x.  tables: ops.child_irn_tables(params) (112 KB / 83 KB).
+extern "C" int pcgc_irn_rows_pass(const int32_t* nbr, int64_t n, int C, int pass, const float* in, int in_ld, const float* table,
+                                  int64_t table_bytes, const float* b0, const float* b1, const float* b2, const float* x, int x_ld, float* out,
+                                  int out_ld, void* stream) {
+    PCGC_REQUIRE(nbr && in && table, "null argument");
+    PCGC_REQUIRE((in_ld & 3) == 0 && (((uintptr_t)in | (uintptr_t)table) & 15) == 0, "unaligned input");
+    PCGC_REQUIRE(n * (int64_t)in_ld * 4 < (int64_t)0xF0000000, "tensor too large for 32-bit buffer offsets");
+    PCGC_REQUIRE(C == 64, "channels must be 64");
+    PCGC_REQUIRE(pass == 1 || pass == 2, "pass must be 1 (A) or 2 (B)");
+    PCGC_REQUIRE(out && b0 && b1 && (pass == 1 || (b2 && x)), "null argument");
+    PCGC_REQUIRE((out_ld & 3) == 0 && (((uintptr_t)out) & 15) == 0 && (pass == 1 || ((x_ld & 3) == 0 && (((uintptr_t)x) & 15) == 0)),
+                 "rows must be 16-byte aligned");
+    PCGC_REQUIRE(pass == 2 || out_ld == 32, "pass A writes a dense [rows, 32] tensor");
+    PCGC_REQUIRE(pass == 1 ? in_ld >= 64 : in_ld >= 32, "input rows narrower than the pass reads");
+    PCGC_REQUIRE(table_bytes == (pass == 1 ? 28 * 4 * 1024 : 83 * 1024), "table size");
+    if (n == 0) return 0;
+    hipStream_t s = S(stream);
+    IrnEpi ep{b0, b1, b2, x, x_ld, out, out_ld};
+    int rc;
+    if (pass == 1) {                                           // 112 KB table + 6 waves x 2 ring slots of 4 KB
+        static ChildLdsGrant granted;
+        constexpr int NW = 6, D = 2;
+        rc = launch_rows(k_rows_irn_a64<NW, D>, NW, (size_t)table_bytes + NW * D * 4096, nbr, n, in, in_ld, table, (int)table_bytes, ep, s, granted);
+    } else {                                                   // 83 KB table + 8 waves x 4 ring slots of 2 KB (also the epilogue scratch: 5 KB)
+        static ChildLdsGrant granted;
+        constexpr int NW = 8, D = 4;
+        rc = launch_rows(k_rows_irn_b64<NW, D>, NW, (size_t)table_bytes + NW * D * 2048, nbr, n, in, in_ld, table, (int)table_bytes, ep, s, granted);
+    }
+    if (rc) return rc;
+    PCGC_CHECK_LAUNCH("irn_rows_pass");
+    return 0;
+}

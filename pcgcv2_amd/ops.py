@@ -619,6 +619,39 @@ def irn_block_child64(parent_nbr, x, params, tables):
     return out
 
 
+ROWS_IRN64 = _os.environ.get('PCGC_ROWS_IRN64', '1') != '0'         # C = 64 blocks on plain levels: LDS-resident table, one wave per 16-row tile (csrc/rows_irn.hip); A/B switch
+ROWS_IRN64_MIN = 2048     # rows from which that path is taken (below: the block-sparse gather kernels)
+
+
+def irn_block_rows64(nbr, x, params, tables):
+    """C = 64 InceptionResNet on a plain level through its own k3 map (k_rows_irn_a64, k_rows_irn_b64; tables = child_irn_tables(params));
+    bit-identical to irn_block / irn_block_mfma64."""
+    _f32(x, 'x')
+    n = x.shape[0]
+    ta, tb = tables
+    t = torch.empty((n, 32), dtype=torch.float32, device=x.device)
+    out = torch.empty((n, 64), dtype=torch.float32, device=x.device)
+    P = [p.data_ptr() for p in params]
+    s = _stream(x)
+    if PROFILE.counting:
+        PROFILE.count(nbr)
+    tiles = (n + 15) // 16
+    forms = _irn_pass_formulas(n, 64, 27 * n * 4, ('k_rows_irn_a64', 'k_rows_irn_b64'))
+    per_tile = (27 * 16 + 16, 27 * 12 + 8)                   # MFMA instructions per 16-row tile (pass B incl. the conv1_2 products)
+    calls = (lambda: lib().pcgc_irn_rows_pass(_p(nbr), n, 64, 1, _p(x), _ld(x), _p(ta), ta.numel() * 4, P[1], P[5], None, None, 0, _p(t), 32, s),
+             lambda: lib().pcgc_irn_rows_pass(_p(nbr), n, 64, 2, _p(t), 32, _p(tb), tb.numel() * 4, P[3], P[7], P[9], _p(x), _ld(x), _p(out), 64, s))
+    for (ps, name, bf, ff, comp), call, mf in zip(forms, calls, per_tile):
+        prof = PROFILE.want((name, n))
+        if prof:
+            e0, e1 = PROFILE.bracket((name, n), name + ' (fused InceptionResNet pass on a plain level, LDS-resident table + per-wave row ring, fp32 MFMA)', n, bf, ff,
+                                     compulsory=comp, mfma_issued=tiles * mf * 2048)
+            e0.record()
+        check(call(), 'irn_rows_pass')
+        if prof:
+            e1.record()
+    return out
+
+
 def irn_eligible(x):
     return FUSE_IRN and x.shape[1] in (16, 32, 64) and x.shape[0] * x.shape[1] * 4 < 0xFFFFFFF0
 

@@ -257,21 +257,39 @@ def test_fused_inception_resnet_bit_exact(C, rows):
                 np.testing.assert_array_equal(blk(xs).F.cpu().numpy(), want)
         finally:
             ops.set_irn_cb16_rows(-1)
-    if C == 64:                                              # both schedules of the block-sparse MFMA kernels
-        for mode in (0, 1):
-            ops.set_mfma_pipe(mode)
+    if C == 64:
+        # `fused` above ran the LDS-resident-table kernels (csrc/rows_irn.hip: the default from ops.ROWS_IRN64_MIN rows on); with them
+        # switched off, both schedules of the block-sparse MFMA kernels, then the VALU-fused form
+        assert len(c4) >= ops.ROWS_IRN64_MIN and ops.ROWS_IRN64
+        ops.ROWS_IRN64 = False
+        try:
+            for mode in (0, 1):
+                ops.set_mfma_pipe(mode)
+                try:
+                    with torch.no_grad():
+                        np.testing.assert_array_equal(blk(xs).F.cpu().numpy(), want)
+                finally:
+                    ops.set_mfma_pipe(-1)
+            if rows == 64:
+                ops.MFMA_IRN = False
+                try:
+                    with torch.no_grad():
+                        np.testing.assert_array_equal(blk(xs).F.cpu().numpy(), want)
+                finally:
+                    ops.MFMA_IRN = True
+        finally:
+            ops.ROWS_IRN64 = True
+        # ragged sizes of the rows kernels: a level that is not a multiple of the 16-row tile, one tile, one row
+        for m in (len(c4) - 5, 17, 16, 1):
+            sub = np.ascontiguousarray(c4[:m])
+            want_m = orc.inception_resnet(sd, 'b', orc.Level(sub, 1), x[:m])
+            xm = SparseTensor(_t(x[:m]), coordinate_map=CoordMap(_t(sub), 1, unique=True))
+            keep_min, ops.ROWS_IRN64_MIN = ops.ROWS_IRN64_MIN, 1
             try:
                 with torch.no_grad():
-                    np.testing.assert_array_equal(blk(xs).F.cpu().numpy(), want)
+                    np.testing.assert_array_equal(blk(xm).F.cpu().numpy(), want_m)
             finally:
-                ops.set_mfma_pipe(-1)
-    if C == 64 and rows == 64:                               # VALU-fused form too (the default for C = 64 is the MFMA form)
-        ops.MFMA_IRN = False
-        try:
-            with torch.no_grad():
-                np.testing.assert_array_equal(blk(xs).F.cpu().numpy(), want)
-        finally:
-            ops.MFMA_IRN = True
+                ops.ROWS_IRN64_MIN = keep_min
 
 
 @pytest.mark.parametrize('impl', [1, 0], ids=['mfma', 'valu'])
