@@ -208,6 +208,10 @@ int pcgc_irn_child_pass(const int32_t* parent_nbr, int64_t n_parent, int C, int 
 int pcgc_irn_rows_pass(const int32_t* nbr, int64_t n, int C, int pass, const float* in, int in_ld, const float* table,
                        int64_t table_bytes, const float* b0, const float* b1, const float* b2, const float* x, int x_ld, float* out,
                        int out_ld, void* stream);
+/* Plain k3 conv 32 -> 32 on a plain level (the encoder's conv1, autoencoder.py:90-96) by the same kernel family: table =
+ * ops.child_conv_table(kernel) (108 KB, LDS-resident); epilogue as pcgc_conv_gather. */
+int pcgc_conv_rows(const int32_t* nbr, int64_t n, const float* in, int Cin, int in_ld, const float* table, int64_t table_bytes,
+                   const float* bias, const float* residual, int res_ld, int relu, float* out, int Cout, int out_ld, void* stream);
 
 /* ‡ conventions the reference's results depend on but its sources do not pin (un-vendored MinkowskiEngine / torch.topk on ME's row
  * order): what = 0: top-k tie rule, value 0 = the lower row wins (default), 1 = the higher row wins.  The dedup policy is an argument of

@@ -111,10 +111,57 @@ k_rows_irn_b64(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __res
     }
 }
 
+// plain k3 conv Cin = 16 NB -> Cout = 16 NT on a plain level: tile n = output columns [16 n, 16 n + 16), fragment (k, n) = the offset's
+// weight slice (ops.child_conv_table: [k][n][cb])
+template <int NB_, int NT>
+struct RowsConv : RowsGeometry {
+    static constexpr int NB = NB_, ROWCHUNKS = 4, T = NT, KS = 4, Z_HALF = -1, NBATCH = 1;
+    static constexpr bool HALF = false;
+    static constexpr int kfirst(int) { return 0; }
+    static constexpr bool active(int, int) { return true; }
+    static constexpr int frag(int c, int t) { return c * NT + t; }
+    static constexpr bool uses_block(int, int) { return true; }
+    static constexpr int batch(int) { return 0; }
+    static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 1024; }
+};
+template <int NB, int NT, int NW, int D>
+__global__ void __launch_bounds__(NW * 64)
+k_rows_conv(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in, int in_ld,
+            const float* __restrict__ table, int table_bytes, ChildEpi ep) {
+    using V = RowsConv<NB, NT>;
+    constexpr int W = 16 * NT;
+    constexpr int NEEDF4 = 16 * W / 4;                         // epilogue staging [16 rows][W]
+    constexpr int RINGF4 = (D * NB * 64 > NEEDF4) ? D * NB * 64 : NEEDF4;
+    CHILD_KERNEL_PROLOGUE(V, NW, D, RINGF4)
+    float* scratch = (float*)ring;
+    float bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = ep.bias ? ep.bias[16 * t + mi] : 0.0f;
+    for (int i = 0;; ++i) {
+        const int64_t tile = child_tile<NW>(i, wave, ntiles);
+        if (tile < 0) break;
+        const int64_t row0 = tile * 16;
+        f32x4 acc[V::T];
+        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[t][r];
+                if (ep.bias) v = v + bv[t];
+                scratch[(4 * mq + r) * W + 16 * t + mi] = v;
+            }
+        }
+        wave_lds_sync();
+        child_flush<W>(scratch, 16, row0, n_p, ep.out, ep.out_ld, ep.res, ep.res_ld, ep.relu, lane);
+        wave_lds_sync();
+    }
+}
+
 // persistent grid over 16-row tiles (child_grid counts 16-PARENT tiles: the same number here)
-template <typename K>
+template <typename K, typename EPI>
 int launch_rows(K kern, int nw, size_t lds, const int32_t* nbr, int64_t n, const float* in, int in_ld, const float* table, int table_bytes,
-                const IrnEpi& ep, hipStream_t s, ChildLdsGrant& granted) {
+                const EPI& ep, hipStream_t s, ChildLdsGrant& granted) {
     if (int rc = child_lds_limit(kern, lds, granted)) return rc;
     hipLaunchKernelGGL(kern, dim3(child_grid(n, nw, lds)), dim3(nw * 64), lds, s, nbr, n, in, in_ld, table, table_bytes, ep);
     return 0;
@@ -142,16 +189,51 @@ extern "C" int pcgc_irn_rows_pass(const int32_t* nbr, int64_t n, int C, int pass
     hipStream_t s = S(stream);
     IrnEpi ep{b0, b1, b2, x, x_ld, out, out_ld};
     int rc;
-    if (pass == 1) {                                           // 112 KB table + 6 waves x 2 ring slots of 4 KB
-        static ChildLdsGrant granted;
-        constexpr int NW = 6, D = 2;
-        rc = launch_rows(k_rows_irn_a64<NW, D>, NW, (size_t)table_bytes + NW * D * 4096, nbr, n, in, in_ld, table, (int)table_bytes, ep, s, granted);
-    } else {                                                   // 83 KB table + 8 waves x 4 ring slots of 2 KB (also the epilogue scratch: 5 KB)
-        static ChildLdsGrant granted;
-        constexpr int NW = 8, D = 4;
-        rc = launch_rows(k_rows_irn_b64<NW, D>, NW, (size_t)table_bytes + NW * D * 2048, nbr, n, in, in_ld, table, (int)table_bytes, ep, s, granted);
+    static ChildLdsGrant granted[8];
+#define ROWS_GO(SLOT, KERN, NW_, RINGBYTES) launch_rows(KERN, NW_, (size_t)table_bytes + (size_t)(NW_) * (RINGBYTES), nbr, n, in, in_ld, table, (int)table_bytes, ep, s, granted[SLOT])
+    const int nw = g_child_nw, depth = g_child_depth;          // A/B switches (pcgc_set_child_tuning); 0 = defaults
+    if (pass == 1) {                                           // 112 KB table: 48 KB for the rings (4 KB per slot)
+        if (nw == 6 && depth == 2) rc = ROWS_GO(0, (k_rows_irn_a64<6, 2>), 6, 2 * 4096);
+        else if (nw == 8 && depth == 1) rc = ROWS_GO(1, (k_rows_irn_a64<8, 1>), 8, 1 * 4096);
+        else rc = ROWS_GO(3, (k_rows_irn_a64<12, 1>), 12, 1 * 4096);
+    } else {                                                   // 83 KB table: 8 KB per wave (ring slots of 2 KB; the epilogue scratch needs 5 KB)
+        if (nw == 15 && depth == 1) rc = ROWS_GO(4, (k_rows_irn_b64<15, 1>), 15, 5120);
+        else if (nw == 12 && depth == 1) rc = ROWS_GO(5, (k_rows_irn_b64<12, 1>), 12, 5120);
+        else if (nw == 8 && depth == 4) rc = ROWS_GO(6, (k_rows_irn_b64<8, 4>), 8, 4 * 2048);
+        else rc = ROWS_GO(7, (k_rows_irn_b64<12, 2>), 12, 5120);
     }
+#undef ROWS_GO
     if (rc) return rc;
     PCGC_CHECK_LAUNCH("irn_rows_pass");
     return 0;
 }
+
+// Plain k3 conv 32 -> 32 on a plain level (the encoder's conv1, autoencoder.py:90-96) through its own k3 map: 108 KB of fragments
+// resident in LDS (ops.child_conv_table), one wave per 16-row tile.  Epilogue as pcgc_conv_gather: (+ bias) (+ residual) (relu).
+extern "C" int pcgc_conv_rows(const int32_t* nbr, int64_t n, const float* in, int Cin, int in_ld, const float* table, int64_t table_bytes,
+                              const float* bias, const float* residual, int res_ld, int relu, float* out, int Cout, int out_ld, void* stream) {
+    PCGC_REQUIRE(nbr && in && table && out, "null argument");
+    PCGC_REQUIRE((in_ld & 3) == 0 && (((uintptr_t)in | (uintptr_t)table) & 15) == 0, "unaligned input");
+    PCGC_REQUIRE((out_ld & 3) == 0 && (((uintptr_t)out) & 15) == 0, "output rows must be 16-byte aligned");
+    PCGC_REQUIRE(residual == nullptr || ((res_ld & 3) == 0 && (((uintptr_t)residual) & 15) == 0), "residual rows must be 16-byte aligned");
+    PCGC_REQUIRE(n * (int64_t)in_ld * 4 < (int64_t)0xF0000000, "tensor too large for 32-bit buffer offsets");
+    PCGC_REQUIRE(Cin == 32 && Cout == 32, "conv_rows: 32 -> 32");
+    PCGC_REQUIRE(in_ld >= Cin && out_ld >= Cout, "rows narrower than the layer");
+    PCGC_REQUIRE(table_bytes == (int64_t)27 * Cin * Cout * 4, "table size");
+    if (n == 0) return 0;
+    hipStream_t s = S(stream);
+    ChildEpi ep{bias, residual, res_ld, relu, out, out_ld, Cout / 16};
+    static ChildLdsGrant granted[4];
+    const int nw = g_child_nw, depth = g_child_depth;          // A/B switches; 0 = default
+    int rc;
+#define ROWS_GO(SLOT, KERN, NW_, RINGBYTES) launch_rows(KERN, NW_, (size_t)table_bytes + (size_t)(NW_) * (RINGBYTES), nbr, n, in, in_ld, table, (int)table_bytes, ep, s, granted[SLOT])
+    if (nw == 8 && depth == 2) rc = ROWS_GO(0, (k_rows_conv<2, 2, 8, 2>), 8, 2 * 2048);
+    else if (nw == 16 && depth == 1) rc = ROWS_GO(1, (k_rows_conv<2, 2, 16, 1>), 16, 2048);
+    else if (nw == 12 && depth == 1) rc = ROWS_GO(2, (k_rows_conv<2, 2, 12, 1>), 12, 2048);
+    else rc = ROWS_GO(3, (k_rows_conv<2, 2, 12, 2>), 12, 2 * 2048);
+#undef ROWS_GO
+    if (rc) return rc;
+    PCGC_CHECK_LAUNCH("conv_rows");
+    return 0;
+}
+

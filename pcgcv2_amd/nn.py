@@ -46,6 +46,13 @@ class MinkowskiConvolution(_ConvBase):
                 and self.out_channels in (4, 8, 16):
             # the codec's first layer on the occupancy indicator (all ones): a sum of kernel slices over the present offsets
             return SparseTensor(ops.conv_gather_unit(x.cmap.k3, self.kernel, self.bias, relu=relu), coordinate_map=x.cmap)
+        elif k == 3 and s == 1 and ops.conv_rows_eligible(x, self.in_channels, self.out_channels):
+            # plain level, 32 -> 32 (the encoder's conv1): LDS-resident fragment table, one wave per 16-row tile (csrc/rows_irn.hip)
+            stamp = (self.kernel.data_ptr(), self.kernel._version)
+            if getattr(self, '_child_stamp', None) != stamp:
+                self._child_table, self._child_stamp = ops.child_conv_table(self.kernel), stamp
+            y = ops.conv_rows(x.cmap.k3, x.F, self._child_table, self.bias, self.out_channels, out=out, residual=residual, relu=relu)
+            return SparseTensor(y, coordinate_map=x.cmap)
         elif k == 3 and s == 1:
             cmap, nbr = x.cmap, x.cmap.k3
         elif k == 1 and s == 1:

@@ -927,6 +927,38 @@ def conv_child(parent_nbr, x, table, bias, Cout, out=None, residual=None, relu=F
     return out
 
 
+ROWS_CONV = _os.environ.get('PCGC_ROWS_CONV', '1') != '0'      # k3 32 -> 32 on plain levels: LDS-resident table, one wave per 16-row tile; A/B switch
+ROWS_CONV_MIN = 32768     # rows from which that path is taken
+
+
+def conv_rows_eligible(x, cin, cout):
+    return ROWS_CONV and cin == 32 and cout == 32 and x.F.shape[0] >= ROWS_CONV_MIN and x.F.shape[0] * x.F.shape[1] * 4 < 0xF0000000
+
+
+def conv_rows(nbr, x, table, bias, Cout, out=None, residual=None, relu=False):
+    """k3 conv 32 -> 32 on a plain level through its own map (csrc/rows_irn.hip: k_rows_conv); table = child_conv_table(kernel)."""
+    _f32(x, 'x')
+    n, Cin = x.shape
+    if out is None:
+        out = torch.empty((n, Cout), dtype=torch.float32, device=x.device)
+    res_p, res_ld = (None, 0) if residual is None else (_p(_f32(residual)), _ld(residual))
+    key = ('conv', Cin, Cout, n)
+    prof = PROFILE.want(key)
+    if prof:
+        e0, e1 = PROFILE.bracket(key, f'k_rows_conv<{Cin // 16}, {Cout // 16}> (k3 {Cin}->{Cout} on a plain level, LDS-resident table + per-wave row ring, fp32 MFMA)', n,
+                                 lambda P, a=Cin, b=Cout: P * a * 4 + P * 8 + n * b * 4, lambda P, a=Cin, b=Cout: 2 * P * a * b,
+                                 compulsory=n * Cin * 4 + 27 * n * 4 + n * Cout * 4 + (0 if residual is None else n * Cout * 4),
+                                 mfma_issued=2 * 27 * ((n + 15) // 16 * 16) * Cin * Cout)
+        e0.record()
+    check(lib().pcgc_conv_rows(_p(nbr), n, _p(x), Cin, _ld(x), _p(table), table.numel() * 4, _p(bias), res_p, res_ld, int(relu), _p(out), Cout,
+                               _ld(out), _stream(x)), 'conv_rows')
+    if prof:
+        e1.record()
+    elif PROFILE.counting:
+        PROFILE.count(nbr)
+    return out
+
+
 def conv_up2(x, W, bias, relu=False):
     _f32(x, 'x'); _f32(W, 'W')
     K, Cin, Cout = W.shape

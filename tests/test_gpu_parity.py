@@ -215,6 +215,51 @@ def test_first_layer_on_the_unit_input():
         np.testing.assert_array_equal(conv(y, relu=True).F.cpu().numpy(), np.maximum(orc.conv_gather(orc.kmap_k3(c4, 1), other, W, b), np.float32(0)))
 
 
+@pytest.mark.parametrize('waves,depth', [(0, 0), (8, 2), (16, 1), (12, 1)])
+def test_conv_rows_bit_exact(waves, depth):
+    """pcgc_conv_rows (k3 32 -> 32 on a plain level: LDS-resident fragment table, one wave per 16-row tile, csrc/rows_irn.hip) against the
+    oracle's fmaf chain: plain, fused epilogue (residual + relu into a column slice), ragged sizes, every waves / ring-depth build."""
+    rng = np.random.default_rng(32)
+    c4 = _coords('shell7')
+    W = (rng.standard_normal((27, 32, 32)) / np.sqrt(27 * 32)).astype(np.float32)
+    b = rng.standard_normal((1, 32)).astype(np.float32)
+    table = ops.child_conv_table(_t(W))
+    ops.set_child_tuning(waves, depth)
+    try:
+        for m in (len(c4), len(c4) - 7, 33, 16, 1):
+            sub = np.ascontiguousarray(c4[:m])
+            nbr = orc.kmap_k3(sub, 1)
+            x = rng.standard_normal((m, 32)).astype(np.float32)
+            want = orc.conv_gather(nbr, x, W, b)
+            got = ops.conv_rows(_t(nbr), _t(x), table, _t(b), 32)
+            np.testing.assert_array_equal(got.cpu().numpy(), want)
+            res = rng.standard_normal((m, 64)).astype(np.float32)
+            buf = torch.zeros((m, 64), device=DEV)
+            wide = torch.zeros((m, 48), device=DEV)                        # input rows wider than the layer (a column slice of another tensor)
+            wide[:, :32] = _t(x)
+            ops.conv_rows(_t(nbr), wide[:, :32], table, _t(b), 32, out=buf[:, 32:], residual=_t(res)[:, 32:], relu=True)
+            np.testing.assert_array_equal(buf[:, 32:].cpu().numpy(), np.maximum(want + res[:, 32:], np.float32(0)))
+            assert not buf[:, :32].any()
+    finally:
+        ops.set_child_tuning(0, 0)
+    # the module takes this path on its own from ops.ROWS_CONV_MIN rows on, and the general kernels below
+    from pcgcv2_amd.nn import MinkowskiConvolution
+    conv = MinkowskiConvolution(32, 32, kernel_size=3, stride=1, bias=True, dimension=3).to(DEV)
+    with torch.no_grad():
+        conv.kernel.copy_(_t(W)); conv.bias.copy_(_t(b))
+    x = rng.standard_normal((len(c4), 32)).astype(np.float32)
+    xs = SparseTensor(_t(x), coordinate_map=CoordMap(_t(c4), 1, unique=True))
+    want = np.maximum(orc.conv_gather(orc.kmap_k3(c4, 1), x, W, b), np.float32(0))
+    keep, ops.ROWS_CONV_MIN = ops.ROWS_CONV_MIN, 1
+    try:
+        with torch.no_grad():
+            np.testing.assert_array_equal(conv(xs, relu=True).F.cpu().numpy(), want)
+            ops.ROWS_CONV_MIN = 1 << 40
+            np.testing.assert_array_equal(conv(xs, relu=True).F.cpu().numpy(), want)
+    finally:
+        ops.ROWS_CONV_MIN = keep
+
+
 @pytest.mark.parametrize('rows', [64, 32, 16])
 @pytest.mark.parametrize('C', [16, 32, 64])
 def test_fused_inception_resnet_bit_exact(C, rows):
