@@ -620,7 +620,7 @@ def irn_block_child64(parent_nbr, x, params, tables):
 
 
 ROWS_IRN64 = _os.environ.get('PCGC_ROWS_IRN64', '1') != '0'         # C = 64 blocks on plain levels: LDS-resident table, one wave per 16-row tile (csrc/rows_irn.hip); A/B switch
-ROWS_IRN64_MIN = 2048     # rows from which that path is taken (below: the block-sparse gather kernels)
+ROWS_IRN64_MIN = 1024     # rows from which that path is taken (tools/rows_gate_ab.py: 65 vs 135 us per block at 1.1-18 k rows, 103 vs 198 at 71 k)
 
 
 def irn_block_rows64(nbr, x, params, tables):
@@ -928,7 +928,7 @@ def conv_child(parent_nbr, x, table, bias, Cout, out=None, residual=None, relu=F
 
 
 ROWS_CONV = _os.environ.get('PCGC_ROWS_CONV', '1') != '0'      # k3 32 -> 32 on plain levels: LDS-resident table, one wave per 16-row tile; A/B switch
-ROWS_CONV_MIN = 32768     # rows from which that path is taken
+ROWS_CONV_MIN = 1024      # rows from which that path is taken (tools/rows_gate_ab.py: 34 vs 51 us at 1.1-18 k rows, 127 vs 159 at 256 k)
 
 
 def conv_rows_eligible(x, cin, cout):
