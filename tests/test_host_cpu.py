@@ -661,6 +661,8 @@ def test_native_item_files_equal_the_python_path(tmp_path):
                 off += r
             with pytest.raises(PcgcError, match='channels'):
                 ops.frame_decode(stems[0], 4, eb._host_packed(), np.zeros((rows[0], 4), np.int16), np.zeros((rows[0], 4), np.int32))
+            with pytest.raises(PcgcError, match='_H.bin'):           # no such cloud
+                ops.frame_decode(str(nat / 'nothing_here'), 8, eb._host_packed(), np.zeros((4, 8), np.int16), np.zeros((4, 4), np.int32))
         finally:
             coder.INDEX_SEGMENTS = default_segments
     # a sidecar that names another table: refused (the 20000-row item of the first pass is gone; re-encode one item)
