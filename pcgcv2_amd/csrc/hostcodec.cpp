@@ -302,17 +302,18 @@ struct RcWideTables {
         for (int c = 0; c < C; ++c) for (int j = 0; j < W; ++j) wide[(size_t)c * W + j] = j < Lp - 1 ? cdf[(size_t)c * Lp + j] : 0x10000u;
     }
 };
-// One or TWO segments per call: a symbol's decode is one dependency chain of ~40 cycles (broadcast, multiply, compare, mask count,
-// table row, two leading-zero counts, shifts) that leaves most of the core idle; two segments advanced in lock step are two
-// independent chains in the same loop — 1.8x the symbols per thread and second.
+// K = 1, 2 or 4 segments per call: a symbol's decode is one dependency chain of ~40 cycles (broadcast, multiply, compare, mask count,
+// table row, two leading-zero counts, shifts) that leaves most of the core idle; K segments advanced in lock step are K independent
+// chains in the same loop (two: 1.8x the symbols per thread and second; four, measured: 1.34x — the dispatcher uses one or two).
 struct RcWideState { SourceBF src; uint32_t low; uint64_t span; uint32_t off; int ch; int64_t i; };
+template <int K>
 __attribute__((target("avx512f,avx512bw,avx512dq,popcnt,lzcnt,bmi,bmi2")))
-static void rc_decode_avx512_seg(const RcWideTables& tb, int C, const uint8_t* padded, int64_t limit, const RcStart& st0, const RcStart* st1, int16_t* sym) {
+static void rc_decode_avx512_segs(const RcWideTables& tb, int C, const uint8_t* padded, int64_t limit, const RcStart* st /*[n_st <= K]*/, int n_st, int16_t* sym) {
     const int nvec = tb.nvec, W = tb.W, RS = tb.RS;
     const uint32_t* const rows = tb.rows.data(); const uint64_t* const wide = tb.wide;
-    auto open = [&](const RcStart& st) __attribute__((always_inline, target("avx512f,avx512bw,avx512dq,popcnt,lzcnt,bmi,bmi2"))) {
-        const uint64_t start = st.bitpos + 32;
-        RcWideState S{SourceBF{padded, limit, (int64_t)(start >> 3)}, st.low, st.span, st.off, (int)(st.first % C), st.first};
+    auto open = [&](const RcStart& s0) __attribute__((always_inline, target("avx512f,avx512bw,avx512dq,popcnt,lzcnt,bmi,bmi2"))) {
+        const uint64_t start = s0.bitpos + 32;
+        RcWideState S{SourceBF{padded, limit, (int64_t)(start >> 3)}, s0.low, s0.span, s0.off, (int)(s0.first % C), s0.first};
         S.src.refill();
         (void)S.src.take((int)(start & 7));
         return S;
@@ -337,17 +338,20 @@ static void rc_decode_avx512_seg(const RcWideTables& tb, int C, const uint8_t* p
         S.span = (uint64_t)(c_hi - c_lo) << t;
         S.off = (uint32_t)((uint64_t)(S.off - c_lo) << t) | S.src.take(t);
     };
-    RcWideState A = open(st0);
-    int64_t left_a = st0.count;
-    if (st1) {
-        RcWideState B = open(*st1);
-        int64_t left_b = st1->count;
-        const int64_t both = std::min(left_a, left_b);
-        for (int64_t j = 0; j < both; ++j) { step(A); step(B); }
-        left_a -= both; left_b -= both;
-        for (int64_t j = 0; j < left_b; ++j) step(B);
+    static_assert(K == 1 || K == 2 || K == 4, "chains per call");
+    if (n_st < K) {                                            // (the last task of an odd division)
+        if constexpr (K > 1) { rc_decode_avx512_segs<K / 2>(tb, C, padded, limit, st, n_st < K / 2 ? n_st : K / 2, sym);
+                               if (n_st > K / 2) rc_decode_avx512_segs<K / 2>(tb, C, padded, limit, st + K / 2, n_st - K / 2, sym); }
+        return;
     }
-    for (int64_t j = 0; j < left_a; ++j) step(A);
+    RcWideState S[K]; int64_t left[K]; int64_t both = st[0].count;
+    for (int k = 0; k < K; ++k) { S[k] = open(st[k]); left[k] = st[k].count; both = std::min(both, left[k]); }
+    for (int64_t j = 0; j < both; ++j) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) step(S[k]);
+    }
+    for (int k = 0; k < K; ++k)                                // (segments differ by a point or two)
+        for (int64_t j = both; j < left[k]; ++j) step(S[k]);
 }
 
 // ---- a small persistent pool for the indexed decoder (segments of one stream decoded side by side)
@@ -465,15 +469,18 @@ int rc_decode_starts(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int6
     const bool wide = rc_use_avx512(Lp);
     RcWideTables* wt = wide ? new RcWideTables(cdf, C, Lp) : nullptr;
     RcScalarTables* stb = wide ? nullptr : new RcScalarTables(cdf, C, Lp);
-    // more segments than threads (and the two-chain decoder): two segments per task
+    // more segments than threads (and the vector decoder): two or four segments per task, advanced in lock step
     const int nseg = (int)starts.size();
-    const bool pairs = wide && nseg > std::max(threads, 1);
+    const int th = std::max(threads, 1);
+    const int per = !wide || nseg <= th ? 1 : 2;           // (four chains per loop are SLOWER than two: 0.53 vs 0.46 ms on two threads)
     const std::function<void(int)> one = [&](int k) {
-        if (pairs) rc_decode_avx512_seg(*wt, C, padded, limit, starts[(size_t)2 * k], 2 * k + 1 < nseg ? &starts[(size_t)2 * k + 1] : nullptr, sym);
-        else if (wide) rc_decode_avx512_seg(*wt, C, padded, limit, starts[(size_t)k], nullptr, sym);
-        else rc_decode_scalar_seg(*stb, C, Lp, padded, limit, starts[(size_t)k], sym);
+        const int first = per * k, n_here = std::min(per, nseg - first);
+        if (!wide) rc_decode_scalar_seg(*stb, C, Lp, padded, limit, starts[(size_t)k], sym);
+        else if (per == 1) rc_decode_avx512_segs<1>(*wt, C, padded, limit, &starts[(size_t)first], n_here, sym);
+        else if (per == 2) rc_decode_avx512_segs<2>(*wt, C, padded, limit, &starts[(size_t)first], n_here, sym);
+        else rc_decode_avx512_segs<4>(*wt, C, padded, limit, &starts[(size_t)first], n_here, sym);
     };
-    const int tasks = pairs ? (nseg + 1) / 2 : nseg;
+    const int tasks = (nseg + per - 1) / per;
     if (tasks <= 1 || threads <= 1) { for (int k = 0; k < tasks; ++k) one(k); }
     else segment_pool().run(tasks, std::min(threads, tasks) - 1, one);
     delete wt; delete stb;

@@ -32,7 +32,7 @@ print(f'rc_encode indexed  {med(lambda: ops.rc_encode(tab, sym_h, checkpoints=8)
 print(f'rc_decode serial   {med(lambda: ops.rc_decode(tab, s, sym_h.size)):.3f} ms')
 print(f'rc_decode indexed 8   {med(lambda: ops.rc_decode(tab, s, sym_h.size, index=idx)):.3f} ms')
 print(f'rc_decode indexed 16  {med(lambda: ops.rc_decode(tab, s16, sym_h.size, index=idx16)):.3f} ms')
-for thr in (2, 4):
+for thr in (1, 2, 4):
     ops.set_rc_threads(thr)
     print(f'  {thr} threads: 8 -> {med(lambda: ops.rc_decode(tab, s, sym_h.size, index=idx)):.3f} ms, 16 -> {med(lambda: ops.rc_decode(tab, s16, sym_h.size, index=idx16)):.3f} ms')
 ops.set_rc_threads(0)
