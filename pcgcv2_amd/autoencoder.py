@@ -35,7 +35,7 @@ class InceptionResNet(torch.nn.Module):
                 if c == 64:
                     return SparseTensor(ops.irn_block_child64(x.cmap.origin[1].k3, x.F, params, self._child_tables), coordinate_map=x.cmap)
                 return SparseTensor(ops.irn_block_child(x.cmap.origin[1].k3, x.F, params, self._child_tables), coordinate_map=x.cmap)
-            if c == 64 and ops.ROWS_IRN64 and x.F.shape[0] >= ops.ROWS_IRN64_MIN:
+            if c == 64 and ops.ROWS_IRN64 and ops.ROWS_IRN64_MIN <= x.F.shape[0] < 0xF0000000 // (4 * max(c, x.F.stride(0))):
                 # plain level, C = 64 (the encoder's stride-4 level): LDS-resident fragment table, one wave per 16-row tile (csrc/rows_irn.hip)
                 stamp = tuple((p.data_ptr(), p._version) for p in params)
                 if getattr(self, '_child_stamp', None) != stamp:
