@@ -1260,13 +1260,25 @@ extern "C" int pcgc_items_decode(int n_items, const char* const* stems, const in
                     const int d = cb[5];                                          // bits per coordinate (the tree's depth; checked by the decoder)
                     keys.resize((size_t)n);
                     zyx_keys(leaves.data(), n, d, keys.data());
-                    sort_codes(keys, 3 * d);
                     const uint64_t m = (1ull << d) - 1;
                     int32_t* L = xyz + off[(size_t)i] * 4;
-                    for (int64_t r = 0; r < n; ++r) {
-                        const uint64_t k = keys[(size_t)r];
+                    auto row = [&](int64_t r, uint64_t k) {
                         L[4 * r] = i; L[4 * r + 1] = (int32_t)(k & m) * coord_scale;
                         L[4 * r + 2] = (int32_t)((k >> d) & m) * coord_scale; L[4 * r + 3] = (int32_t)(k >> (2 * d)) * coord_scale;
+                    };
+                    if (3 * d <= 22 && n >= 512) {
+                        // two 11-bit radix passes with both histograms from one sweep, the second pass scattering the finished rows
+                        static thread_local std::vector<uint64_t> tmp;
+                        if (tmp.size() < (size_t)n) tmp.resize((size_t)n);
+                        uint32_t c0[2048] = {0}, c1[2048] = {0};
+                        for (int64_t r = 0; r < n; ++r) { const uint64_t k = keys[(size_t)r]; ++c0[k & 2047]; ++c1[(k >> 11) & 2047]; }
+                        uint32_t a0 = 0, a1 = 0;
+                        for (int b = 0; b < 2048; ++b) { const uint32_t x0 = c0[b], x1 = c1[b]; c0[b] = a0; c1[b] = a1; a0 += x0; a1 += x1; }
+                        for (int64_t r = 0; r < n; ++r) { const uint64_t k = keys[(size_t)r]; tmp[c0[k & 2047]++] = k; }
+                        for (int64_t r = 0; r < n; ++r) { const uint64_t k = tmp[(size_t)r]; row((int64_t)c1[(k >> 11) & 2047]++, k); }
+                    } else {
+                        sort_codes(keys, 3 * d);
+                        for (int64_t r = 0; r < n; ++r) row(r, keys[(size_t)r]);
                     }
                     clk.mark("level");
                 }

@@ -599,7 +599,8 @@ def test_native_item_files_equal_the_python_path(tmp_path):
         s_ = np.clip(np.rint(rng.normal(L / 2, L / 6, size=(r, 8))), 0, L - 1).astype(np.int16)
         s_[0, 0], s_[-1, -1] = 0, L - 1
         syms.append(s_)
-        xyzs.append(np.unique(rng.integers(0, 60, size=(4 * r + 8, 3)), axis=0)[:r].astype(np.int32))
+        extent = 600 if r == 700 else 60                       # (one item with 10-bit coordinates: the sorted-level builder's general path)
+        xyzs.append(rng.permutation(np.unique(rng.integers(0, extent, size=(4 * r + 8, 3)), axis=0))[:r].astype(np.int32))
     rows = [len(x) for x in xyzs]
     syms = [s_[:r] for s_, r in zip(syms, rows)]
     counts = [(r * 3, r * 9, r * 30) for r in rows]
