@@ -32,6 +32,10 @@ class InceptionResNet(torch.nn.Module):
                 stamp = tuple((p.data_ptr(), p._version) for p in params)
                 if getattr(self, '_child_stamp', None) != stamp:
                     self._child_tables, self._child_stamp = ops.child_irn_tables(params), stamp
+                if c == 64 and ops.ROWS_IRN64 and ops.ROWS_IRN64_CHILD and x.cmap._k3 is not None and x.F.shape[0] < 0xF0000000 // (4 * max(c, x.F.stride(0))):
+                    # the level's own map exists already (its 64 -> 64 conv runs on the gather kernels): the plain-rows kernels are
+                    # faster here than the halo kernels (150 k rows: 171 vs 197 us per block, tools/rows_vs_child64.py) — same tables
+                    return SparseTensor(ops.irn_block_rows64(x.cmap._k3, x.F, params, self._child_tables), coordinate_map=x.cmap)
                 if c == 64:
                     return SparseTensor(ops.irn_block_child64(x.cmap.origin[1].k3, x.F, params, self._child_tables), coordinate_map=x.cmap)
                 return SparseTensor(ops.irn_block_child(x.cmap.origin[1].k3, x.F, params, self._child_tables), coordinate_map=x.cmap)

@@ -620,6 +620,7 @@ def irn_block_child64(parent_nbr, x, params, tables):
 
 
 ROWS_IRN64 = _os.environ.get('PCGC_ROWS_IRN64', '1') != '0'         # C = 64 blocks on plain levels: LDS-resident table, one wave per 16-row tile (csrc/rows_irn.hip); A/B switch
+ROWS_IRN64_CHILD = _os.environ.get('PCGC_ROWS_IRN64_CHILD', '1') != '0'    # ... also on the decoder's C = 64 children level when its own map is at hand
 ROWS_IRN64_MIN = 1024     # rows from which that path is taken (tools/rows_gate_ab.py: 65 vs 135 us per block at 1.1-18 k rows, 103 vs 198 at 71 k)
 
 
