@@ -10,6 +10,8 @@ dev = torch.device('cuda:0')
 pts = synthetic.shell('shell10', device=dev)
 c4 = torch.cat([torch.zeros((len(pts), 1), dtype=torch.int32, device=dev), pts], 1).contiguous()
 lvl = CoordMap(c4, 1, unique=True).build_pyramid(2)
+if len(sys.argv) > 1 and sys.argv[1] == 'decoder':                 # the decoder's first level: the 8 x N8 children rows, through their own map
+    lvl = lvl.build_pyramid(1).up()
 n = len(lvl)
 nbr = lvl.k3
 blk = InceptionResNet(64).to(dev)
