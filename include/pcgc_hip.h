@@ -212,6 +212,11 @@ int pcgc_irn_rows_pass(const int32_t* nbr, int64_t n, int C, int pass, const flo
  * ops.child_conv_table(kernel) (108 KB, LDS-resident); epilogue as pcgc_conv_gather. */
 int pcgc_conv_rows(const int32_t* nbr, int64_t n, const float* in, int Cin, int in_ld, const float* table, int64_t table_bytes,
                    const float* bias, const float* residual, int res_ld, int relu, float* out, int Cout, int out_ld, void* stream);
+/* k2 s2 down conv (the encoder's down0 / down1 / down2, autoencoder.py:78-84,97-103,116-122: 16 -> 32, 32 -> 64, 64 -> 32) by the same
+ * kernel family: tile = 16 coarse rows, the 8 child offsets through the level pair's `down` map [8][n_coarse] (fine rows, -1 = absent);
+ * table = ops.child_conv_table(kernel). */
+int pcgc_conv_down_rows(const int32_t* down, int64_t n_coarse, const float* in, int64_t n_in, int Cin, int in_ld, const float* table,
+                        int64_t table_bytes, const float* bias, int relu, float* out, int Cout, int out_ld, void* stream);
 
 /* ‡ conventions the reference's results depend on but its sources do not pin (un-vendored MinkowskiEngine / torch.topk on ME's row
  * order): what = 0: top-k tie rule, value 0 = the lower row wins (default), 1 = the higher row wins.  The dedup policy is an argument of

@@ -58,6 +58,7 @@ SIGNATURES = {
     'pcgc_conv_child': (ci, [vp, i64, vp, ci, ci, vp, i64, vp, vp, ci, ci, vp, ci, ci, vp]),
     'pcgc_set_child_tuning': (ci, [ci, ci]),
     'pcgc_irn_child_pass': (ci, [vp, i64, ci, ci, vp, ci, vp, i64, vp, vp, vp, vp, ci, vp, ci, vp]),
+    'pcgc_conv_down_rows': (ci, [vp, i64, vp, i64, ci, ci, vp, i64, vp, ci, vp, ci, ci, vp]),
     'pcgc_conv_rows': (ci, [vp, i64, vp, ci, ci, vp, i64, vp, vp, ci, ci, vp, ci, ci, vp]),
     'pcgc_irn_rows_pass': (ci, [vp, i64, ci, ci, vp, ci, vp, i64, vp, vp, vp, vp, ci, vp, ci, vp]),
     'pcgc_conv_up2': (ci, [i64, vp, ci, ci, vp, vp, ci, vp, ci, vp]),

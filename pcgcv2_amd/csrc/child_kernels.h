@@ -87,7 +87,7 @@ constexpr bool in02(int v) { return v >= 0 && v <= 2; }
 // cell_child(c) of the neighbour parent at map offset cell_kp(c), rows 8 p + j.  A variant may override these (rows_irn.hip: plain
 // levels, "cell" k = kernel offset k of the tile's own 16 rows, one map row per offset).
 struct HaloGeometry {
-    static constexpr int NCELLS = 64, ROW_MUL = 8;
+    static constexpr int NCELLS = 64, ROW_MUL = 8, NMAP = 27;      // NMAP: rows of the kernel map ([NMAP][n])
     static constexpr int kp(int c) { return cell_kp(c); }
     static constexpr int child(int c) { return cell_child(c); }
 };
@@ -321,16 +321,16 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
     // byte offset of each neighbour parent's first child row; absent -> a value no in-row offset can bring back into range (the
     // entry point checks the tensor is smaller than ABSENT), so the per-cell address is ONE add and needs no select
     constexpr unsigned ABSENT = 0xF0000000u;
-    unsigned rowb[27];
+    unsigned rowb[V::NMAP];
 #pragma unroll
-    for (int kp = 0; kp < 27; ++kp) rowb[kp] = (unsigned)pnbr[(int64_t)kp * n_p + (row_ok ? p0 + dma_r : 0)];
+    for (int kp = 0; kp < V::NMAP; ++kp) rowb[kp] = (unsigned)pnbr[(int64_t)kp * n_p + (row_ok ? p0 + dma_r : 0)];
     const int f_a = (0x78 >> (2 * (mi >> 2))) & 3;             // read-side swizzle of the A image (see conv.hip v2)
     const int dma_chunk = (lane & 3) ^ ((0x78 >> (2 * ((dma_r >> 2) & 3))) & 3);
     const bool chunk_ok = dma_chunk < V::ROWCHUNKS;            // rows narrower than 64 bytes: the other lanes fetch nothing (zeros)
     const unsigned row_bytes = (unsigned)in_ld * 4u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // map entries loaded (and the previous tile's stores retired): vmcnt now counts DMAs only
 #pragma unroll
-    for (int kp = 0; kp < 27; ++kp) rowb[kp] = (row_ok && (int)rowb[kp] >= 0) ? rowb[kp] * ((unsigned)V::ROW_MUL * row_bytes) : ABSENT;
+    for (int kp = 0; kp < V::NMAP; ++kp) rowb[kp] = (row_ok && (int)rowb[kp] >= 0) ? rowb[kp] * ((unsigned)V::ROW_MUL * row_bytes) : ABSENT;
     const unsigned lane_off = chunk_ok ? (unsigned)dma_chunk * 16u : ABSENT;
     CHILD_T(t_loop0);
 
@@ -530,13 +530,15 @@ __device__ __forceinline__ void child_flush(const float* scratch, int rows, int6
     }
 }
 
+// rows of the gathered tensor: the children of the n_p parents, or the level itself (a kernel whose input is ANOTHER level redefines it)
+#define CHILD_IN_ROWS(V, n_p) (V::ROW_MUL * (n_p))
 #define CHILD_KERNEL_PROLOGUE(V, NW, D, RING_FLOAT4)                                                                          \
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];                                                   \
     const int lane = threadIdx.x & 63, mi = lane & 15, mq = lane >> 4;                                                        \
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                                                        \
     float4* ring = (float4*)(lds_raw + table_bytes) + wave * (RING_FLOAT4);                                                   \
     child_stage_table<NW>(table, table_bytes, lds_raw);                                                                        \
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(V::ROW_MUL * n_p * in_ld * 4), 0x00020000); \
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(CHILD_IN_ROWS(V, n_p) * in_ld * 4), 0x00020000); \
     const int64_t ntiles = (n_p + 15) >> 4;
 
 template <class T_> struct child_type_tag { using type = T_; };

@@ -14,7 +14,7 @@
 namespace {
 
 struct RowsGeometry {
-    static constexpr int NCELLS = 27, ROW_MUL = 1;
+    static constexpr int NCELLS = 27, ROW_MUL = 1, NMAP = 27;
     static constexpr int kp(int c) { return c; }
     static constexpr int child(int) { return 0; }
 };
@@ -158,6 +158,61 @@ k_rows_conv(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restri
     }
 }
 
+// k2 s2 down conv (autoencoder.py:78-84,97-103,116-122): tile = 16 COARSE rows, "cell" k = child offset k of the coarse row: row
+// down[k][r] of the FINE level (absent children: zero rows), fragment (k, n) = W[k][:, 16 n : 16 n + 16].  Same chain as the gather
+// kernels: ascending k, ascending input channel.
+struct DownGeometry {
+    static constexpr int NCELLS = 8, ROW_MUL = 1, NMAP = 8;
+    static constexpr int kp(int c) { return c; }
+    static constexpr int child(int) { return 0; }
+};
+template <int NB_, int NT>
+struct RowsDown : DownGeometry {
+    static constexpr int NB = NB_, ROWCHUNKS = 4, T = NT, KS = 4, Z_HALF = -1, NBATCH = 1;
+    static constexpr bool HALF = false;
+    static constexpr int kfirst(int) { return 0; }
+    static constexpr bool active(int, int) { return true; }
+    static constexpr int frag(int c, int t) { return c * NT + t; }
+    static constexpr bool uses_block(int, int) { return true; }
+    static constexpr int batch(int) { return 0; }
+    static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 1024; }
+};
+template <int NB, int NT, int NW, int D>
+__global__ void __launch_bounds__(NW * 64)
+k_rows_down(const int32_t* __restrict__ pnbr /* down [8][n_p] */, int64_t n_p /* coarse rows */, const float* __restrict__ in, int in_ld,
+            const float* __restrict__ table, int table_bytes, ChildEpi ep, int64_t n_in /* fine rows */) {
+    using V = RowsDown<NB, NT>;
+    constexpr int W = 16 * NT;
+    constexpr int NEEDF4 = 16 * W / 4;                         // epilogue staging [16 rows][W]
+    constexpr int RINGF4 = (D * NB * 64 > NEEDF4) ? D * NB * 64 : NEEDF4;
+    CHILD_KERNEL_PROLOGUE(V, NW, D, RINGF4)
+    (void)rs_in;                                               // (sized for the coarse level: the gathered rows are the fine level's)
+    const __amdgpu_buffer_rsrc_t rs_fine = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(n_in * in_ld * 4), 0x00020000);
+    float* scratch = (float*)ring;
+    float bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = ep.bias ? ep.bias[16 * t + mi] : 0.0f;
+    for (int i = 0;; ++i) {
+        const int64_t tile = child_tile<NW>(i, wave, ntiles);
+        if (tile < 0) break;
+        const int64_t row0 = tile * 16;
+        f32x4 acc[V::T];
+        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_fine, in_ld, lds_raw, ring, acc);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[t][r];
+                if (ep.bias) v = v + bv[t];
+                scratch[(4 * mq + r) * W + 16 * t + mi] = v;
+            }
+        }
+        wave_lds_sync();
+        child_flush<W>(scratch, 16, row0, n_p, ep.out, ep.out_ld, ep.res, ep.res_ld, ep.relu, lane);
+        wave_lds_sync();
+    }
+}
+
 // persistent grid over 16-row tiles (child_grid counts 16-PARENT tiles: the same number here)
 template <typename K, typename EPI>
 int launch_rows(K kern, int nw, size_t lds, const int32_t* nbr, int64_t n, const float* in, int in_ld, const float* table, int table_bytes,
@@ -234,6 +289,40 @@ extern "C" int pcgc_conv_rows(const int32_t* nbr, int64_t n, const float* in, in
 #undef ROWS_GO
     if (rc) return rc;
     PCGC_CHECK_LAUNCH("conv_rows");
+    return 0;
+}
+
+// k2 s2 down conv through the level pair's `down` map [8][n_coarse] (entries: fine rows, -1 = no such child): 16 -> 32, 32 -> 64, 64 -> 32
+// (the encoder's down0 / down1 / down2).  table: ops.child_conv_table(kernel) ([k][n][cb] fragments, 16 / 64 / 64 KB).
+extern "C" int pcgc_conv_down_rows(const int32_t* down, int64_t n_coarse, const float* in, int64_t n_in, int Cin, int in_ld, const float* table,
+                                   int64_t table_bytes, const float* bias, int relu, float* out, int Cout, int out_ld, void* stream) {
+    PCGC_REQUIRE(down && in && table && out, "null argument");
+    PCGC_REQUIRE((in_ld & 3) == 0 && (((uintptr_t)in | (uintptr_t)table) & 15) == 0, "unaligned input");
+    PCGC_REQUIRE((out_ld & 3) == 0 && (((uintptr_t)out) & 15) == 0, "output rows must be 16-byte aligned");
+    PCGC_REQUIRE(n_in * (int64_t)in_ld * 4 < (int64_t)0xF0000000, "tensor too large for 32-bit buffer offsets");
+    PCGC_REQUIRE((Cin == 16 && Cout == 32) || (Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 32), "conv_down_rows: 16 -> 32, 32 -> 64 or 64 -> 32");
+    PCGC_REQUIRE(in_ld >= Cin && out_ld >= Cout, "rows narrower than the layer");
+    PCGC_REQUIRE(table_bytes == (int64_t)8 * Cin * Cout * 4, "table size");
+    if (n_coarse == 0) return 0;
+    hipStream_t s = S(stream);
+    ChildEpi ep{bias, nullptr, 0, relu, out, out_ld, Cout / 16};
+    static ChildLdsGrant granted[3];
+    int rc;
+#define DOWN_GO(SLOT, NB_, NT_, NW_, D_)                                                                                                       \
+    do {                                                                                                                                       \
+        constexpr int need = 16 * 16 * (NT_) * 4, ringb = ((D_) * (NB_) * 1024 > need) ? (D_) * (NB_) * 1024 : need;                           \
+        const size_t lds = (size_t)table_bytes + (size_t)(NW_) * ringb;                                                                        \
+        auto kern = k_rows_down<NB_, NT_, NW_, D_>;                                                                                            \
+        rc = child_lds_limit(kern, lds, granted[SLOT]);                                                                                        \
+        if (!rc) hipLaunchKernelGGL(kern, dim3(child_grid(n_coarse, NW_, lds)), dim3((NW_) * 64), lds, s, down, n_coarse, in, in_ld, table,   \
+                                    (int)table_bytes, ep, n_in);                                                                               \
+    } while (0)
+    if (Cin == 16) DOWN_GO(0, 1, 2, 16, 2);
+    else if (Cin == 32) DOWN_GO(1, 2, 4, 12, 2);
+    else DOWN_GO(2, 4, 2, 12, 1);
+#undef DOWN_GO
+    if (rc) return rc;
+    PCGC_CHECK_LAUNCH("conv_down_rows");
     return 0;
 }
 

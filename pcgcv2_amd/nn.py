@@ -59,6 +59,12 @@ class MinkowskiConvolution(_ConvBase):
             cmap, nbr = x.cmap, None
         elif k == 2 and s == 2:
             cmap, nbr = x.cmap.down()
+            if out is None and residual is None and ops.conv_down_rows_eligible(x, self.in_channels, self.out_channels, nbr.shape[1]):
+                # LDS-resident fragment table, one wave per 16 coarse rows walking the 8 child offsets (csrc/rows_irn.hip)
+                stamp = (self.kernel.data_ptr(), self.kernel._version)
+                if getattr(self, '_child_stamp', None) != stamp:
+                    self._child_table, self._child_stamp = ops.child_conv_table(self.kernel), stamp
+                return SparseTensor(ops.conv_down_rows(nbr, x.F, self._child_table, self.bias, self.out_channels, relu=relu), coordinate_map=cmap)
         else:
             raise NotImplementedError(f'MinkowskiConvolution(kernel_size={k}, stride={s}) is not on the PCGCv2 path')
         y = ops.conv_gather(nbr, x.F, self.kernel, self.bias, out=out, residual=residual, relu=relu)

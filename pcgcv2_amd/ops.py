@@ -705,9 +705,9 @@ def child_conv_table(W):
     """B-fragment table of pcgc_conv_child for a plain k3 conv `kernel` [27, Cin, Cout]:
     table[k][n][cb][lane][jj] = W[k][16 cb + 4 jj + (lane >> 4)][16 n + (lane & 15)]   (one lane-linear 1 KB fragment per
     (offset, column tile, 16-channel block): a lane's four K-step values are contiguous -> one conflict-free ds_read_b128)."""
-    K, Cin, Cout = W.shape
+    K, Cin, Cout = W.shape                                     # (K = 27; 8 for the k2 s2 down convs of conv_down_rows)
     NB, NT = Cin // 16, Cout // 16
-    return W.detach().reshape(27, NB, 4, 4, NT, 16).permute(0, 4, 1, 3, 5, 2).contiguous().reshape(-1)      # [k][n][cb][mq][mi][jj]
+    return W.detach().reshape(K, NB, 4, 4, NT, 16).permute(0, 4, 1, 3, 5, 2).contiguous().reshape(-1)       # [k][n][cb][mq][mi][jj]
 
 
 def _fragment(col_weights, NB, KS=4, k0=0, half=False):
@@ -957,6 +957,25 @@ def conv_rows(nbr, x, table, bias, Cout, out=None, residual=None, relu=False):
         e1.record()
     elif PROFILE.counting:
         PROFILE.count(nbr)
+    return out
+
+
+ROWS_DOWN = _os.environ.get('PCGC_ROWS_DOWN', '1') != '0'      # k2 s2 down convs: LDS-resident table, one wave per 16 coarse rows; A/B switch
+ROWS_DOWN_MIN = 1024
+
+
+def conv_down_rows_eligible(x, cin, cout, n_coarse):
+    return ROWS_DOWN and (cin, cout) in ((16, 32), (32, 64), (64, 32)) and n_coarse >= ROWS_DOWN_MIN and x.F.shape[0] * x.F.stride(0) * 4 < 0xF0000000
+
+
+def conv_down_rows(down, x, table, bias, Cout, relu=False):
+    """k2 s2 down conv through the `down` map [8][n_coarse] (csrc/rows_irn.hip: k_rows_down); table = child_conv_table(kernel)."""
+    _f32(x, 'x')
+    n_in, Cin = x.shape
+    n_c = down.shape[1]
+    out = torch.empty((n_c, Cout), dtype=torch.float32, device=x.device)
+    check(lib().pcgc_conv_down_rows(_p(down), n_c, _p(x), n_in, Cin, _ld(x), _p(table), table.numel() * 4, _p(bias), int(relu), _p(out), Cout,
+                                    _ld(out), _stream(x)), 'conv_down_rows')
     return out
 
 

@@ -215,6 +215,40 @@ def test_first_layer_on_the_unit_input():
         np.testing.assert_array_equal(conv(y, relu=True).F.cpu().numpy(), np.maximum(orc.conv_gather(orc.kmap_k3(c4, 1), other, W, b), np.float32(0)))
 
 
+@pytest.mark.parametrize('cin,cout', [(16, 32), (32, 64), (64, 32)])
+def test_conv_down_rows_bit_exact(cin, cout):
+    """pcgc_conv_down_rows (the encoder's k2 s2 down convs on the LDS-resident-table kernels) against the oracle's fmaf chain, whole level
+    and ragged prefixes; the module takes the path on its own from ops.ROWS_DOWN_MIN coarse rows on and the gather kernels below."""
+    rng = np.random.default_rng(cin + cout)
+    c4 = _coords('shell8')
+    coarse, _ = orc.stride2_coords(c4, 2)
+    down = orc.kmap_down(c4, coarse, 1)                                       # [8][n_coarse]
+    x = rng.standard_normal((len(c4), cin)).astype(np.float32)
+    W = (rng.standard_normal((8, cin, cout)) / np.sqrt(8 * cin)).astype(np.float32)
+    b = rng.standard_normal((1, cout)).astype(np.float32)
+    want = np.maximum(orc.conv_gather(down, x, W, b), np.float32(0))
+    table = ops.child_conv_table(_t(W))
+    for m in (down.shape[1], down.shape[1] - 3, 17, 1):
+        got = ops.conv_down_rows(_t(np.ascontiguousarray(down[:, :m])), _t(x), table, _t(b), cout, relu=True)
+        np.testing.assert_array_equal(got.cpu().numpy(), want[:m])
+    from pcgcv2_amd.nn import MinkowskiConvolution
+    conv = MinkowskiConvolution(cin, cout, kernel_size=2, stride=2, bias=True, dimension=3).to(DEV)
+    with torch.no_grad():
+        conv.kernel.copy_(_t(W)); conv.bias.copy_(_t(b))
+    xs = SparseTensor(_t(x), coordinate_map=CoordMap(_t(c4), 1, unique=True))
+    keep = ops.ROWS_DOWN_MIN
+    try:
+        for gate in (1, 1 << 40):
+            ops.ROWS_DOWN_MIN = gate
+            with torch.no_grad():
+                y = conv(xs, relu=True)
+            # the module's coarse level is in first-occurrence order, the oracle's too (stride2_coords): same rows, same order
+            np.testing.assert_array_equal(y.C.cpu().numpy(), coarse)
+            np.testing.assert_array_equal(y.F.cpu().numpy(), want)
+    finally:
+        ops.ROWS_DOWN_MIN = keep
+
+
 @pytest.mark.parametrize('waves,depth', [(0, 0), (8, 2), (16, 1), (12, 1)])
 def test_conv_rows_bit_exact(waves, depth):
     """pcgc_conv_rows (k3 32 -> 32 on a plain level: LDS-resident fragment table, one wave per 16-row tile, csrc/rows_irn.hip) against the
