@@ -45,6 +45,12 @@ class InceptionResNet(torch.nn.Module):
                 if getattr(self, '_child_stamp', None) != stamp:
                     self._child_tables, self._child_stamp = ops.child_irn_tables(params), stamp
                 return SparseTensor(ops.irn_block_rows64(x.cmap.k3, x.F, params, self._child_tables), coordinate_map=x.cmap)
+            if c == 32 and ops.ROWS_IRN32 and ops.ROWS_IRN32_MIN <= x.F.shape[0] <= ops.ROWS_IRN32_MAX:
+                # small plain level, C = 32 (the encoder's stride-8 level): the rows kernels instead of the row-split VALU passes
+                stamp = tuple((p.data_ptr(), p._version) for p in params)
+                if getattr(self, '_rows32_stamp', None) != stamp:
+                    self._rows32_tables, self._rows32_stamp = ops.rows_irn32_tables(params), stamp
+                return SparseTensor(ops.irn_block_rows32(x.cmap.k3, x.F, params, self._rows32_tables), coordinate_map=x.cmap)
             if c == 64 and ops.MFMA_IRN and x.F.shape[0] >= 512:       # (1-18 k rows: 117-123 us per block against 177-220 on the VALU passes)
                 # block-sparse MFMA path; the fused weights are rebuilt whenever a parameter tensor was replaced or modified
                 stamp = tuple((p.data_ptr(), p._version) for p in params)

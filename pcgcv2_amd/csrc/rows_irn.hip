@@ -111,6 +111,92 @@ k_rows_irn_b64(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __res
     }
 }
 
+// ---- C = 32 (Q = 8) on a plain level: the small levels (the encoder's stride-8 level: 18.7 k rows), where the row-split VALU kernels are
+// chains of launch-sized latencies.  Pass A: ONE tile per offset — columns 0-7 = conv0_0 (k3 32 -> 8), columns 8-15 = conv1_0 (k1 32 -> 8:
+// zero columns except at the centre offset; fma(x, 0, acc) = acc).  Pass B: t rows are 16 wide = one block: K-steps {0, 1} (channels 0-7 =
+// relu(conv0_0)) feed tile 0 = conv0_1 (k3 8 -> 16), K-steps {2, 3} (relu(conv1_0)) feed tile 1 = conv1_1 (k3 8 -> 8, columns 8-15 zero).
+// Tables: ops.rows_irn32_tables.
+struct RowsPassA32 : RowsGeometry {
+    static constexpr int NB = 2, ROWCHUNKS = 4, T = 1, KS = 4, Z_HALF = -1, NBATCH = 1;
+    static constexpr bool HALF = false;
+    static constexpr int kfirst(int) { return 0; }
+    static constexpr bool active(int, int) { return true; }
+    static constexpr int frag(int c, int) { return c; }
+    static constexpr bool uses_block(int, int) { return true; }
+    static constexpr int batch(int) { return 0; }
+    static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 1024; }
+};
+struct RowsPassB32 : RowsGeometry {
+    static constexpr int NB = 1, ROWCHUNKS = 4, T = 2, KS = 2, Z_HALF = -1, NBATCH = 1, FRAG_W12 = 54;
+    static constexpr bool HALF = false;
+    static constexpr int kfirst(int t) { return t == 0 ? 0 : 2; }
+    static constexpr bool active(int, int) { return true; }
+    static constexpr int frag(int c, int t) { return t == 0 ? c : 27 + c; }
+    static constexpr bool uses_block(int, int) { return true; }
+    static constexpr int batch(int) { return 0; }
+    static constexpr int frag_off(int c, int t, int) { return frag(c, t) * 512; }
+};
+// pass A:  t[row][0:8] = relu(conv0_0 + b00), t[row][8:16] = relu(conv1_0 + b10)
+template <int NW, int D>
+__global__ void __launch_bounds__(NW * 64)
+k_rows_irn_a32(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in, int in_ld,
+               const float* __restrict__ table, int table_bytes, IrnEpi ep) {
+    using V = RowsPassA32;
+    CHILD_KERNEL_PROLOGUE(V, NW, D, D * V::NB * 64)
+    const float bcol = mi < 8 ? ep.b0[mi] : ep.b1[mi - 8];
+    float* scratch = (float*)ring;                             // [16 rows][16]: 1 KB
+    for (int i = 0;; ++i) {
+        const int64_t tile = child_tile<NW>(i, wave, ntiles);
+        if (tile < 0) break;
+        const int64_t row0 = tile * 16;
+        f32x4 acc[V::T];
+        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) scratch[(4 * mq + r) * 16 + mi] = fmaxf(acc[0][r] + bcol, 0.0f);
+        wave_lds_sync();
+        child_flush<16>(scratch, 16, row0, n_p, ep.out, 16, nullptr, 0, 0, lane);
+        wave_lds_sync();
+    }
+}
+// pass B:  out[row][0:16]  = (conv0_1(t[:, :8]) + b01) + x[row][0:16]
+//          out[row][16:32] = (conv1_2(relu(conv1_1(t[:, 8:]) + b11)) + b12) + x[row][16:32]       (conv1_2 k1 8 -> 16: two MFMAs on u)
+template <int NW, int D>
+__global__ void __launch_bounds__(NW * 64)
+k_rows_irn_b32(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in /* t [.., 16] */, int in_ld,
+               const float* __restrict__ table, int table_bytes, IrnEpi ep) {
+    using V = RowsPassB32;
+    constexpr int NEEDF4 = (16 * 8 + 16 * 32) / 4;                                         // us [16][8] + stage [16][32]
+    constexpr int RINGF4 = (D * V::NB * 64 > NEEDF4) ? D * V::NB * 64 : NEEDF4;
+    CHILD_KERNEL_PROLOGUE(V, NW, D, RINGF4)
+    float* us = (float*)ring;
+    float* stage = us + 16 * 8;
+    float w12[2];                                                                          // conv1_2 B fragment: W12[4 jj + mq][mi]
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) w12[jj] = ((const float*)(lds_raw + V::FRAG_W12 * 512))[lane * 2 + jj];
+    const float b01 = ep.b0[mi], b11 = mi < 8 ? ep.b1[mi] : 0.0f, b12 = ep.b2[mi];
+    for (int i = 0;; ++i) {
+        const int64_t tile = child_tile<NW>(i, wave, ntiles);
+        if (tile < 0) break;
+        const int64_t row0 = tile * 16;
+        f32x4 acc[V::T];
+        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (mi < 8) us[(4 * mq + r) * 8 + mi] = fmaxf(acc[1][r] + b11, 0.0f);
+            stage[(4 * mq + r) * 32 + mi] = acc[0][r] + b01;
+        }
+        wave_lds_sync();
+        f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) d = __builtin_amdgcn_mfma_f32_16x16x4f32(us[mi * 8 + 4 * jj + mq], w12[jj], d, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage[(4 * mq + r) * 32 + 16 + mi] = d[r] + b12;
+        wave_lds_sync();
+        child_flush<32>(stage, 16, row0, n_p, ep.out, ep.out_ld, ep.x, ep.x_ld, 0, lane);
+        wave_lds_sync();
+    }
+}
+
 // plain k3 conv Cin = 16 NB -> Cout = 16 NT on a plain level: tile n = output columns [16 n, 16 n + 16), fragment (k, n) = the offset's
 // weight slice (ops.child_conv_table: [k][n][cb])
 template <int NB_, int NT>
@@ -232,14 +318,14 @@ extern "C" int pcgc_irn_rows_pass(const int32_t* nbr, int64_t n, int C, int pass
     PCGC_REQUIRE(nbr && in && table, "null argument");
     PCGC_REQUIRE((in_ld & 3) == 0 && (((uintptr_t)in | (uintptr_t)table) & 15) == 0, "unaligned input");
     PCGC_REQUIRE(n * (int64_t)in_ld * 4 < (int64_t)0xF0000000, "tensor too large for 32-bit buffer offsets");
-    PCGC_REQUIRE(C == 64, "channels must be 64");
+    PCGC_REQUIRE(C == 64 || C == 32, "channels must be 32 or 64");
     PCGC_REQUIRE(pass == 1 || pass == 2, "pass must be 1 (A) or 2 (B)");
     PCGC_REQUIRE(out && b0 && b1 && (pass == 1 || (b2 && x)), "null argument");
     PCGC_REQUIRE((out_ld & 3) == 0 && (((uintptr_t)out) & 15) == 0 && (pass == 1 || ((x_ld & 3) == 0 && (((uintptr_t)x) & 15) == 0)),
                  "rows must be 16-byte aligned");
-    PCGC_REQUIRE(pass == 2 || out_ld == 32, "pass A writes a dense [rows, 32] tensor");
-    PCGC_REQUIRE(pass == 1 ? in_ld >= 64 : in_ld >= 32, "input rows narrower than the pass reads");
-    PCGC_REQUIRE(table_bytes == (pass == 1 ? 28 * 4 * 1024 : 83 * 1024), "table size");
+    PCGC_REQUIRE(pass == 2 || out_ld == C / 2, "pass A writes a dense [rows, C/2] tensor");
+    PCGC_REQUIRE(pass == 1 ? in_ld >= C : in_ld >= C / 2, "input rows narrower than the pass reads");
+    PCGC_REQUIRE(table_bytes == (C == 64 ? (pass == 1 ? 28 * 4 * 1024 : 83 * 1024) : (pass == 1 ? 27 * 2 * 1024 : 55 * 512)), "table size");
     if (n == 0) return 0;
     hipStream_t s = S(stream);
     IrnEpi ep{b0, b1, b2, x, x_ld, out, out_ld};
@@ -247,6 +333,13 @@ extern "C" int pcgc_irn_rows_pass(const int32_t* nbr, int64_t n, int C, int pass
     static ChildLdsGrant granted[8];
 #define ROWS_GO(SLOT, KERN, NW_, RINGBYTES) launch_rows(KERN, NW_, (size_t)table_bytes + (size_t)(NW_) * (RINGBYTES), nbr, n, in, in_ld, table, (int)table_bytes, ep, s, granted[SLOT])
     const int nw = g_child_nw, depth = g_child_depth;          // A/B switches (pcgc_set_child_tuning); 0 = defaults
+    if (C == 32) {                                             // 54 KB / 27.5 KB tables; 16 waves, ring slots of 2 KB / 1 KB (pass B: scratch 2.5 KB)
+        static ChildLdsGrant granted32[4];
+#define ROWS_GO32(SLOT, KERN, NW_, RINGBYTES) launch_rows(KERN, NW_, (size_t)table_bytes + (size_t)(NW_) * (RINGBYTES), nbr, n, in, in_ld, table, (int)table_bytes, ep, s, granted32[SLOT])
+        if (pass == 1) rc = (nw == 8) ? ROWS_GO32(0, (k_rows_irn_a32<8, 2>), 8, 2 * 2048) : ROWS_GO32(1, (k_rows_irn_a32<16, 2>), 16, 2 * 2048);
+        else rc = (nw == 8) ? ROWS_GO32(2, (k_rows_irn_b32<8, 4>), 8, 4 * 1024) : ROWS_GO32(3, (k_rows_irn_b32<16, 4>), 16, 4 * 1024);
+#undef ROWS_GO32
+    } else
     if (pass == 1) {                                           // 112 KB table: 48 KB for the rings (4 KB per slot)
         if (nw == 6 && depth == 2) rc = ROWS_GO(0, (k_rows_irn_a64<6, 2>), 6, 2 * 4096);
         else if (nw == 8 && depth == 1) rc = ROWS_GO(1, (k_rows_irn_a64<8, 1>), 8, 1 * 4096);

@@ -653,6 +653,58 @@ def irn_block_rows64(nbr, x, params, tables):
     return out
 
 
+def _rows_irn32_index():
+    """Gather indices of the two pass tables of the plain-level C = 32 InceptionResNet (csrc/rows_irn.hip: RowsPassA32 / RowsPassB32)."""
+    C, Q = 32, 8
+    shapes = [(27, C, Q), (27, Q, 2 * Q), (C, Q), (27, Q, Q), (Q, 2 * Q)]
+    off, Ws = 0, []
+    for shp in shapes:
+        n = int(np.prod(shp))
+        Ws.append(np.arange(off, off + n, dtype=np.int64).reshape(shp))
+        off += n
+    W00, W01, W10, W11, W12 = Ws
+    # pass A: one fragment per offset and 16-channel block: columns 0-7 conv0_0, columns 8-15 conv1_0 (centre offset only)
+    fa = [_fragment([W00[k][:, co] for co in range(Q)] + [(W10[:, co] if k == 13 else None) for co in range(Q)], 2) for k in range(27)]
+    # pass B: t rows are 16 wide: channels 0-7 (K-steps 0, 1) feed conv0_1, channels 8-15 (K-steps 2, 3) conv1_1 (columns 8-15 zero)
+    pad = lambda w: np.concatenate([np.full(Q, -1, np.int64), w])
+    fb = [_fragment([W01[k][:, co] for co in range(16)], 1, KS=2, k0=0) for k in range(27)]
+    fb += [_fragment([pad(W11[k][:, co]) for co in range(Q)] + [None] * Q, 1, KS=2, k0=2) for k in range(27)]
+    fb.append(_fragment([W12[:, co] for co in range(16)], 1, KS=2, k0=0))
+    return np.concatenate([f.reshape(-1) for f in fa]), np.concatenate([f.reshape(-1) for f in fb])
+
+
+def rows_irn32_tables(params):
+    """(table A 54 KB, table B 27.5 KB) of the plain-level C = 32 InceptionResNet passes; params as in irn_block."""
+    W00, b00, W01, b01, W10, b10, W11, b11, W12, b12 = params
+    key = ('rows_irn32', W00.device)
+    if key not in _TABLE_INDEX:
+        ia, ib = _rows_irn32_index()
+        _TABLE_INDEX[key] = (torch.from_numpy(ia).to(W00.device), torch.from_numpy(ib).to(W00.device))
+    flat = torch.cat([w.detach().reshape(-1) for w in (W00, W01, W10, W11, W12)])
+    ia, ib = _TABLE_INDEX[key]
+    return _gather_table(ia, flat), _gather_table(ib, flat)
+
+
+ROWS_IRN32 = _os.environ.get('PCGC_ROWS_IRN32', '1') != '0'        # C = 32 blocks on plain levels (the encoder's stride-2 and stride-8 levels); A/B switch
+ROWS_IRN32_MIN, ROWS_IRN32_MAX = 1024, 1 << 40                     # (tools/rows_gate_ab.py: ahead of the VALU passes at every size: 47 vs 74 us per block at 49 k rows, 119 vs 127 at 256 k)
+
+
+def irn_block_rows32(nbr, x, params, tables):
+    """C = 32 InceptionResNet on a plain level through its own k3 map (k_rows_irn_a32 / _b32); bit-identical to irn_block."""
+    _f32(x, 'x')
+    n = x.shape[0]
+    ta, tb = tables
+    t = torch.empty((n, 16), dtype=torch.float32, device=x.device)
+    out = torch.empty((n, 32), dtype=torch.float32, device=x.device)
+    P = [p.data_ptr() for p in params]
+    s = _stream(x)
+    if PROFILE.counting:
+        PROFILE.count(nbr)
+    check(lib().pcgc_irn_rows_pass(_p(nbr), n, 32, 1, _p(x), _ld(x), _p(ta), ta.numel() * 4, P[1], P[5], None, None, 0, _p(t), 16, s), 'irn_rows_pass')
+    check(lib().pcgc_irn_rows_pass(_p(nbr), n, 32, 2, _p(t), 16, _p(tb), tb.numel() * 4, P[3], P[7], P[9], _p(x), _ld(x), _p(out), 32, s), 'irn_rows_pass')
+    return out
+
+
 def irn_eligible(x):
     return FUSE_IRN and x.shape[1] in (16, 32, 64) and x.shape[0] * x.shape[1] * 4 < 0xFFFFFFF0
 

@@ -19,6 +19,17 @@ def _t(a, dt=None):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(DEV)
 
 
+@pytest.fixture(autouse=True)
+def _restore_path_switches():
+    """the A/B switches of the rows kernels are module globals some tests flip: whatever a test leaves behind is undone"""
+    names = ('ROWS_IRN64', 'ROWS_IRN64_CHILD', 'ROWS_IRN64_MIN', 'ROWS_IRN32', 'ROWS_IRN32_MIN', 'ROWS_IRN32_MAX', 'ROWS_CONV', 'ROWS_CONV_MIN',
+             'ROWS_DOWN', 'ROWS_DOWN_MIN')
+    keep = {n: getattr(ops, n) for n in names}
+    yield
+    for n, v in keep.items():
+        setattr(ops, n, v)
+
+
 def _coords(name):
     c = synthetic.shell(name).numpy()
     return np.concatenate([np.zeros((len(c), 1), np.int32), c], 1)
@@ -311,6 +322,27 @@ def test_fused_inception_resnet_bit_exact(C, rows):
     sd = {'b.' + k: v.detach().cpu().numpy() for k, v in blk.state_dict().items()}
     want = orc.inception_resnet(sd, 'b', orc.Level(c4, 1), x)
     assert ops.irn_eligible(xs.F)
+    if C == 32:
+        # small plain levels take the rows kernels (csrc/rows_irn.hip: RowsPassA32 / B32) by default: checked here, with ragged sizes, then
+        # switched off so that the rest of this test reaches the VALU forms it is about
+        assert ops.ROWS_IRN32 and ops.ROWS_IRN32_MIN <= len(c4) <= ops.ROWS_IRN32_MAX
+        with torch.no_grad():
+            np.testing.assert_array_equal(blk(xs).F.cpu().numpy(), want)
+        keep_min, ops.ROWS_IRN32_MIN = ops.ROWS_IRN32_MIN, 1
+        try:
+            for m in (len(c4) - 5, 17, 16, 1):
+                sub = np.ascontiguousarray(c4[:m])
+                xm = SparseTensor(_t(x[:m]), coordinate_map=CoordMap(_t(sub), 1, unique=True))
+                with torch.no_grad():
+                    np.testing.assert_array_equal(blk(xm).F.cpu().numpy(), orc.inception_resnet(sd, 'b', orc.Level(sub, 1), x[:m]))
+            if rows == 64:
+                ops.set_child_tuning(8, 0)
+                with torch.no_grad():
+                    np.testing.assert_array_equal(blk(xs).F.cpu().numpy(), want)
+        finally:
+            ops.ROWS_IRN32_MIN = keep_min
+            ops.set_child_tuning(0, 0)
+        ops.ROWS_IRN32 = False
     ops.set_irn_rows(rows)
     try:
         with torch.no_grad():

@@ -25,9 +25,9 @@ for name in ('shell8', 'shell9', 'shell10'):
         levels.append(lvl)
         lvl = lvl.build_pyramid(1)
 levels = sorted({len(l): l for l in levels}.values(), key=len)
-blk = InceptionResNet(64).to(dev); conv = MinkowskiConvolution(32, 32, kernel_size=3, stride=1, bias=True, dimension=3).to(dev)
+blk = InceptionResNet(64).to(dev); blk32 = InceptionResNet(32).to(dev); conv = MinkowskiConvolution(32, 32, kernel_size=3, stride=1, bias=True, dimension=3).to(dev)
 with torch.no_grad():
-    print('rows        IRN64 gather  IRN64 rows   conv32 gather  conv32 rows   (us)')
+    print('rows        IRN64 gather  IRN64 rows   conv32 gather  conv32 rows   IRN32 VALU  IRN32 rows   (us)')
     for lvl in levels:
         n = len(lvl)
         if n < 200 or n > 400000: continue
@@ -41,4 +41,7 @@ with torch.no_grad():
         for on in (False, True):
             ops.ROWS_CONV, ops.ROWS_CONV_MIN = on, 1
             res.append(med(lambda: conv(x32, relu=True)))
-        print(f'{n:8d}   {res[0]:10.1f}  {res[1]:10.1f}   {res[2]:10.1f}  {res[3]:10.1f}')
+        for on in (False, True):
+            ops.ROWS_IRN32, ops.ROWS_IRN32_MIN, ops.ROWS_IRN32_MAX = on, 1, 1 << 40
+            res.append(med(lambda: blk32(x32)))
+        print(f'{n:8d}   {res[0]:10.1f}  {res[1]:10.1f}   {res[2]:10.1f}  {res[3]:10.1f}   {res[4]:10.1f}  {res[5]:10.1f}')
