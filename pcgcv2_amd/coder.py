@@ -352,10 +352,8 @@ class Coder():
             return self._decode(rho, postfix, dev)
 
     def _decode(self, rho, postfix, dev):
-        # the two bitstreams are independent: a helper thread decodes the coordinates, uploads and sorts them and prebuilds
-        # the coordinate-only part of the first decoder stage (children level + kernel maps) while this thread decodes the
-        # features (native calls that release the GIL; both threads enqueue on this thread's stream).  The helper goes first:
-        # since the feature stream is decoded from its index on several threads, the coordinate side is the longer one.
+        # coder.py:93-112.  The two bitstreams are independent and decoded side by side; the general path (tmc3 coordinates, or
+        # NATIVE_ITEMS off) does it with a helper thread for the geometry, the native path inside one library call.
         stream = torch.cuda.current_stream(dev)
         lvl8 = None
         if self._native_items():
