@@ -341,6 +341,12 @@ int pcgc_items_decode(int n_items, const char* const* stems, const int64_t* rows
                       const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int16_t* sym, int32_t* xyz, int coord_layout,
                       int coord_scale, int threads);
 
+/* The coordinate-only part of the first decoder stage on a freshly decoded level in one call: hash (cap = pcgc_hash_capacity(n)), k3 map
+ * nbr [27][n], children level [8 n][4] (MinkowskiGenerativeConvolutionTranspose's coordinates, autoencoder.py:155-161) and its k3 map
+ * [27][8 n] — pcgc_hash_clear + _insert + pcgc_kmap_k3 + pcgc_coords_children + pcgc_kmap_k3_children without the host in between. */
+int pcgc_level_prepare_children(const int32_t* coords, int64_t n, int32_t stride, uint64_t* keys, int32_t* vals, int64_t cap, int32_t* nbr,
+                                int32_t* children, int32_t* nbr_children, void* stream);
+
 /* One cloud in one call — Coder.decode's host half (coder.py:93-104): probe + both streams, into buffers the caller keeps (pinned memory:
  * both uploads are then asynchronous copies).  sym [cap_rows, C], level [cap_rows, 4] (coord_layout 1 above, coord_scale = the level's
  * tensor stride).  info[6] = rows, channels, N4, N2, N1, native_coords; range[2] = min_v, max_v.  -> 0; 1: cap_rows too small (info[0]

@@ -574,3 +574,18 @@ extern "C" int pcgc_d1_nn(const int32_t* a, int64_t na, const uint64_t* b_keys, 
     PCGC_CHECK_LAUNCH("d1_nn");
     return 0;
 }
+
+// The coordinate-only part of a decoder stage on a freshly decoded level, in ONE call (five launches: the host round trips between them
+// are what the GPU waits for at the head of a decode): hash of the level, its k3 map, the children level
+// (MinkowskiGenerativeConvolutionTranspose's output coordinates, autoencoder.py:155-161) and the children level's k3 map.
+// keys / vals: cap = pcgc_hash_capacity(n) entries; nbr [27][n]; children [8 n][4]; nbr_children [27][8 n].
+extern "C" int pcgc_level_prepare_children(const int32_t* coords, int64_t n, int32_t stride, uint64_t* keys, int32_t* vals, int64_t cap, int32_t* nbr,
+                                           int32_t* children, int32_t* nbr_children, void* stream) {
+    PCGC_REQUIRE(coords && keys && vals && nbr && children && nbr_children, "null argument");
+    if (int rc = pcgc_hash_clear(keys, vals, cap, stream)) return rc;
+    if (int rc = pcgc_hash_insert(coords, n, stride, keys, vals, cap, stream)) return rc;
+    if (int rc = pcgc_kmap_k3(coords, n, stride, keys, vals, cap, nbr, stream)) return rc;
+    if (int rc = pcgc_coords_children(coords, n, stride, children, stream)) return rc;
+    return pcgc_kmap_k3_children(nbr, n, nbr_children, stream);
+}
+

@@ -200,6 +200,21 @@ class HashTable:
                                             _stream(coords)), 'hash_insert')
 
 
+def level_prepare_children(coords, stride):
+    """hash table, k3 map, children level and the children level's k3 map of a level, in one library call
+    -> (HashTable, nbr [27, n], children [8 n, 4], nbr_children [27, 8 n])"""
+    n, dev = coords.shape[0], coords.device
+    table = HashTable.__new__(HashTable)
+    table.cap, table.stride = int(lib().pcgc_hash_capacity(n)), int(stride)
+    table.keys = torch.empty(table.cap, dtype=torch.int64, device=dev)
+    table.vals = torch.empty(table.cap, dtype=torch.int32, device=dev)
+    ints = torch.empty(27 * n + 32 * n + 27 * 8 * n, dtype=torch.int32, device=dev)      # one allocation: nbr | children | nbr_children
+    nbr, children, nbr_c = ints[:27 * n].view(27, n), ints[27 * n:59 * n].view(8 * n, 4), ints[59 * n:].view(27, 8 * n)
+    check(lib().pcgc_level_prepare_children(_p(_i32(coords)), n, int(stride), _p(table.keys), _p(table.vals), table.cap, _p(nbr), _p(children),
+                                            _p(nbr_c), _stream(coords)), 'level_prepare_children')
+    return table, nbr, children, nbr_c
+
+
 def check_coords(coords, what='coordinates'):
     """Raise PcgcError if any row is outside the range the coordinate key can hold (the hash kernels would skip it)."""
     bad = torch.empty(1, dtype=torch.int32, device=coords.device)

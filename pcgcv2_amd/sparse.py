@@ -122,6 +122,14 @@ class CoordMap:
     def prepare_up(self):
         """Build the children level and its k3 kernel map ahead of time (the decoder's first stage needs both); used to
         overlap this coordinate-only work with host-side entropy decoding."""
+        if (self.origin is None and self._table is None and self._k3 is None and self._prepared_up is None and 0 < len(self) <= HASH_LEVEL_MAX
+                and self.stride >= 2 and self._batch_rows is None):
+            # a freshly decoded level: everything in one library call (the GPU is waiting for exactly these launches)
+            self._table, self._k3, kids, kids_k3 = ops.level_prepare_children(self.C, self.stride)
+            child = CoordMap(kids, self.stride // 2, unique=True, origin=('children', self))
+            child._k3 = kids_k3
+            self._prepared_up = child
+            return
         child = self.up()
         child.k3
         self._prepared_up = child
