@@ -323,6 +323,11 @@ class Coder():
         """the coordinate level the library has written into the pinned buffer — sorted, batch column and tensor stride in place
         (pcgc_items_decode, coord_layout 1) -> device level + the coordinate-only part of the first decoder stage.  One asynchronous
         copy; no device sort."""
+        if stream == torch.cuda.current_stream(dev):                        # (the decode path: no stream switch to pay for)
+            lvl8 = CoordMap(self._upload_level(n, dev), 8, unique=True)
+            if n:
+                lvl8.prepare_up()
+            return lvl8
         with torch.cuda.stream(stream):
             lvl8 = CoordMap(self._upload_level(n, dev), 8, unique=True)
             if n:
@@ -372,8 +377,7 @@ class Coder():
                     break
                 self._decode_buffers(C, rows=n8)                  # (a larger cloud than any before: grow and decode)
             n4, n2, n1 = counts
-            with torch.cuda.stream(stream):
-                sym_d = self._pinned_sym[:n8].to(dev, non_blocking=True)
+            sym_d = self._pinned_sym[:n8].to(dev, non_blocking=True)          # (`stream` is this thread's current stream)
             if native:
                 lvl8 = self._stage_level(n8, dev, stream)
             else:                                                # tmc3 stream: the subprocess protocol (helper thread in the general path)
