@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -1144,8 +1145,10 @@ extern "C" int pcgc_items_encode(int n_items, const char* const* stems, const in
         const std::string stem = stems[i];
         const int64_t n = rows[i];
         const float min_v = ranges[2 * i], max_v = ranges[2 * i + 1];
+        // (a header's range must be two integral values, as compress() writes them: the table callback sizes its output from the same
+        //  two numbers in ITS arithmetic — a fractional bound from a damaged `_H.bin` made it write one row entry past this allocation)
+        if (!(min_v <= max_v) || min_v != std::floor(min_v) || max_v != std::floor(max_v) || max_v - min_v > 65000.0f) { err = "symbol range"; return -2; }
         const int L = (int)(max_v - min_v) + 1, Lp = L + 1;
-        if (L < 1 || L > 65000) { err = "symbol range"; return -2; }
         std::shared_ptr<const std::vector<uint16_t>> tptr;
         uint32_t table_crc = 0;
         if (cached_table(table_fn, eb_params, C, min_v, max_v, tptr, table_crc) != 0) { err = "CDF table evaluation failed"; return -1; }
@@ -1288,8 +1291,10 @@ extern "C" int pcgc_items_decode(int n_items, const char* const* stems, const in
         }
         if (n == 0) return 0;
         const float min_v = ranges[2 * i], max_v = ranges[2 * i + 1];
+        // (a header's range must be two integral values, as compress() writes them: the table callback sizes its output from the same
+        //  two numbers in ITS arithmetic — a fractional bound from a damaged `_H.bin` made it write one row entry past this allocation)
+        if (!(min_v <= max_v) || min_v != std::floor(min_v) || max_v != std::floor(max_v) || max_v - min_v > 65000.0f) { err = "symbol range"; return -2; }
         const int L = (int)(max_v - min_v) + 1, Lp = L + 1;
-        if (L < 1 || L > 65000) { err = "symbol range"; return -2; }
         std::shared_ptr<const std::vector<uint16_t>> tptr;
         uint32_t mine = 0;
         if (cached_table(table_fn, eb_params, C, min_v, max_v, tptr, mine) != 0) { err = "CDF table evaluation failed"; return -1; }

@@ -7,6 +7,7 @@
 // Python dispatch: ~60 tiny operators cost ~0.07 ms here against ~0.25 ms from Python, and the call sits on the critical path of every
 // encode and decode).  pcgcv2_amd/entropy_model.py:reference_table is the same sequence in Python; tests pin both to golden tables
 // generated from the reference.  Host only; links libtorch_cpu (the library the reference itself computes with).
+#include <cmath>
 #include <ATen/ATen.h>
 #include <c10/core/InferenceMode.h>
 #include <cstdint>
@@ -15,6 +16,9 @@
 extern "C" int pcgc_reference_table(const float* params /*[host 44*C]: matrices 0..3 | biases 0..3 | factors 0..3*/, int C, float min_v,
                                     float max_v, uint16_t* table_u16 /*[host C, L+1]*/, float* cdf_f32 /*[host C, L+1] or NULL*/) {
     if (!params || !table_u16 || C < 1 || !(max_v >= min_v)) return -2;
+    // the caller sizes the outputs as [C, (int)(max_v - min_v) + 2]; arange(min_v, max_v + 1) has that many entries only for integral
+    // bounds (what compress() writes): a fractional bound from a damaged header would run past the buffer
+    if (min_v != std::floor(min_v) || max_v != std::floor(max_v) || max_v - min_v > 65000.0f) return -2;
     try {
         c10::InferenceMode guard;
         const int F[5] = {1, 3, 3, 3, 1};

@@ -316,6 +316,56 @@ def test_octree_rejects_foreign_stream():
         ops.oct_decode(b'not a stream at all')
 
 
+def test_frame_decode_survives_damaged_files(tmp_path):
+    """pcgc_frame_decode on truncated / bit-flipped files: an error (PcgcError) or a decode — never a crash, a hang or a write outside the
+    caller's buffers (guard rows behind the capacity stay untouched)."""
+    from pcgcv2_amd.entropy_model import EntropyBottleneck
+    rng = np.random.default_rng(77)
+    torch.manual_seed(5)
+    eb = EntropyBottleneck(8)
+    r = 6000
+    sym = np.clip(np.rint(rng.normal(8, 2.5, size=(r, 8))), 0, 16).astype(np.int16)
+    sym[0, 0], sym[-1, -1] = 0, 16
+    xyz = rng.permutation(np.unique(rng.integers(0, 90, size=(4 * r, 3)), axis=0))[:r].astype(np.int32)
+    stem = str(tmp_path / 'f')
+    ops.items_encode([stem], sym, xyz, [r], [(-8.0, 8.0)], [(r * 3, r * 9, r * 30)], eb._host_packed(), 16)
+    good = {sfx: open(stem + sfx, 'rb').read() for sfx in ('_C.bin', '_F.bin', '_H.bin', '_num_points.bin', '_F.idx')}
+    def attempt():
+        sym_buf, level_buf = np.full((r + 8, 8), -3, np.int16), np.full((r + 8, 4), -3, np.int32)
+        try:
+            ops.frame_decode(stem, 8, eb._host_packed(), sym_buf[:r + 4], level_buf[:r + 4])
+        except PcgcError:
+            pass
+        assert (sym_buf[r + 4:] == -3).all() and (level_buf[r + 4:] == -3).all()
+    attempt()
+    for sfx, blob in good.items():
+        for kind in ('truncate_half', 'truncate_3', 'flip_early', 'flip_late', 'empty'):
+            bad = bytearray(blob)
+            if kind == 'truncate_half': bad = bad[:len(bad) // 2]
+            elif kind == 'truncate_3': bad = bad[:max(0, len(bad) - 3)]
+            elif kind == 'flip_early' and len(bad) > 6: bad[5] ^= 0x5A
+            elif kind == 'flip_late' and len(bad) > 6: bad[len(bad) * 3 // 4] ^= 0xFF
+            elif kind == 'empty': bad = bytearray()
+            with open(stem + sfx, 'wb') as fh:
+                fh.write(bytes(bad))
+            attempt()
+        with open(stem + sfx, 'wb') as fh:
+            fh.write(blob)
+    n, rng_, counts, native = ops.frame_decode(stem, 8, eb._host_packed(), np.zeros((r, 8), np.int16), np.zeros((r, 4), np.int32))
+    assert (n, native, counts) == (r, True, (r * 3, r * 9, r * 30))
+    # a header whose range is not integral (what a flipped mantissa bit makes of it): the table callback would size its output from
+    # arange(min_v, max_v + 1) — one entry more than (int)(max_v - min_v) + 2 — so the range is refused before any table is built
+    import struct
+    head = bytearray(good['_H.bin'])
+    head[9:13] = struct.pack('<f', -8.5)
+    with open(stem + '_H.bin', 'wb') as fh:
+        fh.write(bytes(head))
+    with pytest.raises(PcgcError, match='symbol range'):
+        ops.frame_decode(stem, 8, eb._host_packed(), np.zeros((r, 8), np.int16), np.zeros((r, 4), np.int32))
+    with pytest.raises(PcgcError):
+        eb.reference_table_native(np.float32(-8.5), np.float32(8.0))
+
+
 def test_state_dict_layout_matches_reference(golden_dir):
     from pcgcv2_amd.pcc_model import PCCModel
     m = PCCModel()
