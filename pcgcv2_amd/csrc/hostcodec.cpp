@@ -1217,6 +1217,9 @@ extern "C" int pcgc_items_probe(int n_items, const char* const* stems, int64_t* 
         int32_t n32, c32;
         std::memcpy(&n32, h.data(), 4); std::memcpy(&c32, h.data() + 4, 4);
         if (n32 < 0 || c32 < 1 || (i > 0 && c32 != channels[0])) { pcgc_set_error("items_probe: %s_H.bin: bad shape", stem.c_str()); return -1; }
+        if (n32 > (1 << 27) || c32 > 4096) {               // (a damaged header must not make the caller allocate gigabytes of pinned memory)
+            pcgc_set_error("items_probe: %s_H.bin: implausible shape %d x %d", stem.c_str(), (int)n32, (int)c32); return -1;
+        }
         rows[i] = n32; channels[0] = c32;
         std::memcpy(ranges + 2 * i, h.data() + 9, 4); std::memcpy(ranges + 2 * i + 1, h.data() + 13, 4);
         if (!read_file(stem + "_num_points.bin", c) || c.size() < 12) { pcgc_set_error("items_probe: %s_num_points.bin missing", stem.c_str()); return -1; }

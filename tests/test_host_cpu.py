@@ -364,6 +364,12 @@ def test_frame_decode_survives_damaged_files(tmp_path):
         ops.frame_decode(stem, 8, eb._host_packed(), np.zeros((r, 8), np.int16), np.zeros((r, 4), np.int32))
     with pytest.raises(PcgcError):
         eb.reference_table_native(np.float32(-8.5), np.float32(8.0))
+    head = bytearray(good['_H.bin'])
+    head[0:4] = struct.pack('<i', 1 << 30)                     # a row count no cloud has: refused, not handed to the caller as a size to allocate
+    with open(stem + '_H.bin', 'wb') as fh:
+        fh.write(bytes(head))
+    with pytest.raises(PcgcError, match='implausible'):
+        ops.frame_decode(stem, 8, eb._host_packed(), np.zeros((r, 8), np.int16), np.zeros((r, 4), np.int32))
 
 
 def test_state_dict_layout_matches_reference(golden_dir):
