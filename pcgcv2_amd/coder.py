@@ -389,6 +389,8 @@ class Coder():
             n4, n2, n1 = _COUNTS.unpack(_slurp(self.filename + postfix + '_num_points.bin')[:_COUNTS.size])
             y_F = self.feature_coder.decode(postfix=postfix, device=dev)
             lvl8 = pending.result()
+        if min(n4, n2, n1) < 0:
+            raise ops.PcgcError(f'{self.filename + postfix}_num_points.bin: negative point counts {n4, n2, n1}')
         y = SparseTensor(features=y_F, coordinate_map=lvl8)
         budgets = [[n4], [n2], [int(rho * n1)]]                  # coder.py:105-108
         _, out = self.model.decoder(y, nums_list=budgets, ground_truth_list=[None] * 3, training=False)
