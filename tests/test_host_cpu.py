@@ -316,6 +316,42 @@ def test_octree_rejects_foreign_stream():
         ops.oct_decode(b'not a stream at all')
 
 
+def test_frame_decode_from_several_threads(tmp_path):
+    """Four host threads decode four different clouds at once (shard.code_units(in_flight=F) does this with one Coder per thread): the
+    pools are shared (one run at a time each, helpers woken ahead), the scratch buffers are per thread — every result must be the
+    cloud's own."""
+    import threading
+    from pcgcv2_amd.entropy_model import EntropyBottleneck
+    torch.manual_seed(9)
+    eb = EntropyBottleneck(8)
+    packed = eb._host_packed()
+    clouds = []
+    for t in range(4):
+        rng = np.random.default_rng(100 + t)
+        r = 3000 + 1500 * t
+        sym = np.clip(np.rint(rng.normal(6 + t, 2.0, size=(r, 8))), 0, 14 + t).astype(np.int16)
+        sym[0, 0], sym[-1, -1] = 0, 14 + t
+        xyz = rng.permutation(np.unique(rng.integers(0, 70 + 10 * t, size=(4 * r, 3)), axis=0))[:r].astype(np.int32)
+        stem = str(tmp_path / f'c{t}')
+        ops.items_encode([stem], sym, xyz, [r], [(-7.0 - t, 7.0)], [(r, 2 * r, 3 * r)], packed, 16)
+        want = xyz[np.lexsort((xyz[:, 0], xyz[:, 1], xyz[:, 2]))] * 8
+        clouds.append((stem, r, sym, want))
+    errors = []
+    def worker(t):
+        stem, r, sym, want = clouds[t]
+        sym_buf, level_buf = np.zeros((r, 8), np.int16), np.zeros((r, 4), np.int32)
+        for _ in range(12):
+            sym_buf[:] = -1; level_buf[:] = -1
+            n, rng_, counts, native = ops.frame_decode(stem, 8, packed, sym_buf, level_buf)
+            if n != r or not native or counts != (r, 2 * r, 3 * r) or not np.array_equal(sym_buf, sym) or not np.array_equal(level_buf[:, 1:], want) \
+                    or level_buf[:, 0].any():
+                errors.append(t)
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+
+
 def test_frame_decode_survives_damaged_files(tmp_path):
     """pcgc_frame_decode on truncated / bit-flipped files: an error (PcgcError) or a decode — never a crash, a hang or a write outside the
     caller's buffers (guard rows behind the capacity stay untouched)."""
