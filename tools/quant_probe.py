@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """k3 64 -> 64 on prefixes of the decoder's first children level: is the gather kernel's time a step function of the workgroup rounds?
 (Measured: 291 us at 1024 groups of 128 rows, 339 us at 1031-1171: the step is one extra group per CU on an XCD, and 1171 / 1024 x 291 = 333 —
-the kernel is throughput-bound at 2.2-2.3 ns per row, not tail-bound.)"""
+the kernel is throughput-bound at 2.2-2.3 ns per row, not tail-bound.  Capping the resident workgroups per CU with extra dynamic LDS:
+8 or 6 per CU 341 us, 5 / 4 / 3 per CU 416-420 us — occupancy helps, it does not hurt.)"""
 import os, sys, statistics
 sys.path.insert(0, os.getcwd())
 import torch
