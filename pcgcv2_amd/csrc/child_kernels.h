@@ -90,6 +90,7 @@ struct HaloGeometry {
     static constexpr int NCELLS = 64, ROW_MUL = 8, NMAP = 27;      // NMAP: rows of the kernel map ([NMAP][n])
     static constexpr int kp(int c) { return cell_kp(c); }
     static constexpr int child(int c) { return cell_child(c); }
+    static constexpr int byte_off(int) { return 0; }            // a cell may be a PART of a row: byte offset of its first channel (rows_irn.hip)
 };
 
 // ---- layer variants.  A variant says: how wide the gathered rows are (NB 16-channel blocks, ROWCHUNKS 16-byte chunks present
@@ -339,7 +340,7 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
     auto issue = [&](auto ii) {
         constexpr int i = decltype(ii)::value, c = CL.c[i];
         float4* dst = ring + (i & (D - 1)) * (NB * 64);
-        unsigned voff = rowb[V::kp(c)] + (unsigned)V::child(c) * row_bytes + lane_off;
+        unsigned voff = rowb[V::kp(c)] + (unsigned)V::child(c) * row_bytes + lane_off + (unsigned)V::byte_off(c);
         if constexpr (V::ROWCHUNKS < 4) voff = chunk_ok ? voff : 0xFFFFFFF0u;       // (ABSENT + ABSENT would wrap)
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb)

@@ -17,6 +17,7 @@ struct RowsGeometry {
     static constexpr int NCELLS = 27, ROW_MUL = 1, NMAP = 27;
     static constexpr int kp(int c) { return c; }
     static constexpr int child(int) { return 0; }
+    static constexpr int byte_off(int) { return 0; }
 };
 // pass A: x rows (64 wide, four 16-channel blocks) -> tile 0 = conv0_0 (k3 64 -> 16), tile 1 = conv1_0 (k1 64 -> 16: the centre offset only)
 struct RowsPassA64 : RowsGeometry {
@@ -28,6 +29,24 @@ struct RowsPassA64 : RowsGeometry {
     static constexpr bool uses_block(int, int) { return true; }
     static constexpr int batch(int) { return 0; }
     static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 1024; }
+};
+// pass A in HALF-row cells: cell 2 k + h = channels [32 h, 32 h + 32) of offset k's rows (two 16-channel blocks, 2 KB per 16 rows), so that
+// twelve waves can each keep TWO gathers in flight in the 48 KB the 112 KB table leaves (whole-row cells: one 4 KB slot per wave — nothing in
+// flight behind a wave's own MFMAs): 54.5 -> 51 us on 71 k rows, 103 -> 93 on 150 k.  (Quarter-row cells, four in flight: no further gain.)
+// Same chain: ascending offset, then ascending channel.
+struct RowsPassA64H {
+    static constexpr int NCELLS = 54, ROW_MUL = 1, NMAP = 27;
+    static constexpr int kp(int c) { return c >> 1; }
+    static constexpr int child(int) { return 0; }
+    static constexpr int byte_off(int c) { return (c & 1) * 128; }
+    static constexpr int NB = 2, ROWCHUNKS = 4, T = 2, KS = 4, Z_HALF = -1, NBATCH = 1;
+    static constexpr bool HALF = false;
+    static constexpr int kfirst(int) { return 0; }
+    static constexpr bool active(int c, int t) { return t == 0 || (c >> 1) == 13; }
+    static constexpr int frag(int c, int t) { return t == 0 ? (c >> 1) : 27; }
+    static constexpr bool uses_block(int, int) { return true; }
+    static constexpr int batch(int) { return 0; }
+    static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * 4 + 2 * (c & 1) + cb) * 1024; }
 };
 // pass B: t rows (32 wide: block 0 = relu(conv0_0), block 1 = relu(conv1_0)) -> tiles 0, 1 = conv0_1 (k3 16 -> 32) from block 0,
 // tile 2 = conv1_1 (k3 16 -> 16) from block 1.  Fragments: conv0_1 (k, n) = 2 k + n, conv1_1 k = 54 + k, conv1_2 (k1 16 -> 32) n = 81 + n.
@@ -43,11 +62,10 @@ struct RowsPassB64 : RowsGeometry {
 };
 
 // pass A:  t[row][0:16] = relu(conv0_0 + b00), t[row][16:32] = relu(conv1_0 + b10)        acc[t][r] = row 4 mq + r of the tile, column mi
-template <int NW, int D>
+template <int NW, int D, class V = RowsPassA64>
 __global__ void __launch_bounds__(NW * 64)
 k_rows_irn_a64(const int32_t* __restrict__ pnbr, int64_t n_p /* rows of the level */, const float* __restrict__ in, int in_ld,
                const float* __restrict__ table, int table_bytes, IrnEpi ep) {
-    using V = RowsPassA64;
     CHILD_KERNEL_PROLOGUE(V, NW, D, D * V::NB * 64)
     const float b00 = ep.b0[mi], b10 = ep.b1[mi];
     float* scratch = (float*)ring;                             // [16 rows][32]: 2 KB of the (idle) gather ring
@@ -251,6 +269,7 @@ struct DownGeometry {
     static constexpr int NCELLS = 8, ROW_MUL = 1, NMAP = 8;
     static constexpr int kp(int c) { return c; }
     static constexpr int child(int) { return 0; }
+    static constexpr int byte_off(int) { return 0; }
 };
 template <int NB_, int NT>
 struct RowsDown : DownGeometry {
@@ -342,8 +361,9 @@ extern "C" int pcgc_irn_rows_pass(const int32_t* nbr, int64_t n, int C, int pass
     } else
     if (pass == 1) {                                           // 112 KB table: 48 KB for the rings (4 KB per slot)
         if (nw == 6 && depth == 2) rc = ROWS_GO(0, (k_rows_irn_a64<6, 2>), 6, 2 * 4096);
-        else if (nw == 8 && depth == 1) rc = ROWS_GO(1, (k_rows_irn_a64<8, 1>), 8, 1 * 4096);
-        else rc = ROWS_GO(3, (k_rows_irn_a64<12, 1>), 12, 1 * 4096);
+        else if (nw == 12 && depth == 1) rc = ROWS_GO(1, (k_rows_irn_a64<12, 1>), 12, 1 * 4096);
+        else if (nw == 8 && depth == 2) rc = ROWS_GO(2, (k_rows_irn_a64<8, 2, RowsPassA64H>), 8, 2 * 2048);
+        else rc = ROWS_GO(3, (k_rows_irn_a64<12, 2, RowsPassA64H>), 12, 2 * 2048);
     } else {                                                   // 83 KB table: 8 KB per wave (ring slots of 2 KB; the epilogue scratch needs 5 KB)
         if (nw == 15 && depth == 1) rc = ROWS_GO(4, (k_rows_irn_b64<15, 1>), 15, 5120);
         else if (nw == 12 && depth == 1) rc = ROWS_GO(5, (k_rows_irn_b64<12, 1>), 12, 5120);

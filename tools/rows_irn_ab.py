@@ -31,7 +31,7 @@ def time_pass(ps, reps=30):
         e0.record(); call(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
     return statistics.median(ts)
 print(n, 'rows')
-for ps, cfgs in ((1, [(0, 0), (6, 2), (8, 1)]), (2, [(0, 0), (15, 1), (12, 1), (8, 4)])):
+for ps, cfgs in ((1, [(0, 0), (8, 2), (12, 1), (6, 2)]), (2, [(0, 0), (15, 1), (12, 1), (8, 4)])):
     ref = None
     for nw, d in cfgs:
         ops.set_child_tuning(nw, d)
