@@ -354,6 +354,11 @@ int pcgc_level_prepare_children(const int32_t* coords, int64_t n, int32_t stride
 int pcgc_frame_decode(const char* stem, int C, const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int coord_scale,
                       int64_t cap_rows, int16_t* sym, int32_t* level, int64_t* info, float* range, int threads);
 
+/* The CDF-table cache behind pcgc_items_encode / pcgc_items_decode / pcgc_frame_decode (a table is a pure function of the entropy
+ * parameters and the symbol range; the reference evaluates it in every compress() and decompress(), entropy_model.py:165-171,185-190).
+ * mode 0: drop every cached table; 1: cache (default); -1: never cache.  -> tables dropped.  HOST. */
+int pcgc_table_cache(int mode);
+
 /* zlib's crc32(crc, buf, len) (the CRC-32 of the `_F.idx` sidecar's stream and table guards; coder.py of this package uses
  * zlib.crc32 for the same fields), folded with carry-less multiplies on long buffers.  HOST. */
 uint32_t pcgc_crc32(uint32_t crc, const uint8_t* buf, int64_t len);

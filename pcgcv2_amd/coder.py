@@ -414,6 +414,7 @@ class Coder():
 
     def _encode_batch(self, x, postfixes):
         B = len(postfixes)
+        _check_batch_size(B, 'encode_batch')
         lvl8 = x.cmap.build_pyramid(3)
         l2 = x.cmap._down[0]
         l4 = l2._down[0]
@@ -459,11 +460,16 @@ class Coder():
 
     def _decode_batch(self, postfixes, rho, dev):
         B = len(postfixes)
+        _check_batch_size(B, 'decode_batch')
 
         items = None
         if self._native_items():
             stems = [self.filename + p for p in postfixes]
             rows, C, ranges, counts, native = ops.items_probe(stems)
+            if C != self.feature_coder.entropy_model._channels:
+                # (a damaged or foreign `_H.bin`: the library would size the table and the symbol rows from the header's channel count)
+                raise ops.PcgcError(f'decode_batch: the `_H.bin` files name {C} channels, the model codes '
+                                    f'{self.feature_coder.entropy_model._channels}')
             if native.all():
                 # the batch's coordinate level comes out of the library sorted (items contiguous, each in its coded (z, y, x) order) and
                 # with the item index in column 0
@@ -510,6 +516,14 @@ class Coder():
             outs.append(_coords_only(c, out.cmap.stride))
             off += r
         return outs
+
+
+MAX_BATCH_ITEMS = 16            # the batch index is a 4-bit field of every coordinate key (csrc/pcgc_common.h); per-item top-k segments likewise
+
+
+def _check_batch_size(n_items, what):
+    if not 1 <= n_items <= MAX_BATCH_ITEMS:
+        raise ops.PcgcError(f'{what}: {n_items} items; a collated batch holds 1 to {MAX_BATCH_ITEMS} clouds (code larger sets in several batches)')
 
 
 def _coords_only(coords, stride):

@@ -1114,6 +1114,7 @@ struct TableKey { uint32_t pcrc; int C; float lo, hi; pcgc_table_fn fn; bool ope
 struct TableEntry { TableKey key; std::shared_ptr<const std::vector<uint16_t>> table; uint32_t crc; };
 std::mutex g_table_mu;
 std::vector<TableEntry> g_tables;                        // most recent last, at most 32
+bool g_table_cache_on = true;                            // pcgc_table_cache(): off = every call evaluates its table, as the reference does
 int cached_table(pcgc_table_fn fn, const float* params, int C, float lo, float hi, std::shared_ptr<const std::vector<uint16_t>>& out, uint32_t& crc) {
     const TableKey key{(uint32_t)crc32(0L, (const Bytef*)params, (uInt)(44 * C * 4)), C, lo, hi, fn};
     {
@@ -1127,11 +1128,23 @@ int cached_table(pcgc_table_fn fn, const float* params, int C, float lo, float h
     crc = (uint32_t)crc32(0L, (const Bytef*)t->data(), (uInt)(t->size() * 2));
     out = t;
     std::lock_guard<std::mutex> lk(g_table_mu);
+    if (!g_table_cache_on) return 0;
     if (g_tables.size() >= 32) g_tables.erase(g_tables.begin());
     g_tables.push_back(TableEntry{key, out, crc});
     return 0;
 }
 }  // namespace
+
+// The CDF-table cache of pcgc_items_encode / _decode / pcgc_frame_decode.  mode 0: drop every cached table (the next call of each
+// (parameters, range) evaluates it again: what a codec process sees on its first frame, and what the reference does on EVERY call,
+// entropy_model.py:165-171,185-190); 1: keep tables (default); -1: keep nothing from now on.  -> number of tables dropped.
+extern "C" int pcgc_table_cache(int mode) {
+    std::lock_guard<std::mutex> lk(g_table_mu);
+    const int n = (int)g_tables.size();
+    if (mode <= 0) g_tables.clear();
+    if (mode != 0) g_table_cache_on = mode > 0;
+    return mode <= 0 ? n : 0;
+}
 
 extern "C" int pcgc_items_encode(int n_items, const char* const* stems, const int16_t* sym, const int32_t* xyz, const int64_t* rows,
                                  const float* ranges, int C, const int32_t* counts, const float* eb_params, pcgc_table_fn table_fn,

@@ -20,6 +20,9 @@ the same uint16 values.  `table_mode`:
   'device'               the fused HIP kernel pcgc_cdf_table (fp64 evaluation rounded to fp32): self-consistent between
                          this encoder and decoder, within 1 count of the reference table, NOT interoperable with it.
 """
+import threading
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -27,6 +30,32 @@ from torch.nn.parameter import Parameter
 
 from . import ops
 from ._lib import PcgcError
+
+
+_TABLE_LOCK = threading.Lock()
+TABLE_CACHE = True          # host CDF tables are kept per (parameters, range); table_cache(False) = evaluate on every call, as the reference does
+
+
+def table_cache(on=None, clear=False):
+    """Policy of the CDF-table caches (this module's and the library's, pcgc_table_cache).  `clear`: drop what is cached now — the next
+    compress / decompress of every (parameters, range) evaluates its table again, which is what the reference does on EVERY call
+    (entropy_model.py:165-171, 185-190) and what a decoder process that did not encode the frame sees; `on` = False / True: stop /
+    resume caching.  -> tables dropped from the library's cache."""
+    global TABLE_CACHE
+    from ._lib import lib
+    dropped = 0
+    if on is not None:
+        TABLE_CACHE = bool(on)
+        dropped += lib().pcgc_table_cache(1 if on else -1)
+    if clear:
+        dropped += lib().pcgc_table_cache(0)
+        with _TABLE_LOCK:
+            for m in list(_MODELS):
+                m.__dict__.pop('_table_cache', None)
+    return dropped
+
+
+_MODELS = weakref.WeakSet()
 
 
 class EntropyBottleneck(nn.Module):
@@ -51,6 +80,7 @@ class EntropyBottleneck(nn.Module):
         self.table_mode = 'reference'
         self._packed = self._packed_stamp = None
         self._host = self._host_stamp = None
+        _MODELS.add(self)                                    # (table_cache(clear=True) reaches every live model's cache)
 
     def cpu(self):
         """coder.py:44 calls `entropy_model.cpu()`; the tables are evaluated on the GPU here, so the module stays put."""
@@ -167,24 +197,29 @@ class EntropyBottleneck(nn.Module):
         sequence whose latent range repeats re-use the evaluated table (0.1-0.2 ms of ATen operator dispatch each) and its
         CRC-32; results are identical by construction (same stamp = same parameter values)."""
         import zlib
+        if self.table_mode not in ('reference', 'reference-python', 'device'):
+            raise PcgcError(f"table_mode must be 'reference', 'reference-python' or 'device', got {self.table_mode!r}")
+        if self.table_mode == 'device' and device is None:
+            device = self._matrices[0].device                                    # (encode_symbols / decode_symbols may not name one)
         key = (self._stamp(), float(min_v), float(max_v), self.table_mode, str(device) if self.table_mode == 'device' else '')
-        cache = self.__dict__.setdefault('_table_cache', {})
-        hit = cache.get(key)
+        with _TABLE_LOCK:                                                        # (compress_symbols / decompress_symbols run on pool threads)
+            cache = self.__dict__.setdefault('_table_cache', {})
+            hit = cache.get(key) if TABLE_CACHE else None
         if hit is None:
             if self.table_mode == 'reference':
                 table = self.reference_table_native(min_v, max_v)
             elif self.table_mode == 'reference-python':
                 table = self.reference_table(min_v, max_v)[1]
-            elif self.table_mode == 'device':
-                table = self.cdf_table(min_v, max_v, device)[0].cpu().numpy().view(np.uint16)
             else:
-                raise PcgcError(f"table_mode must be 'reference', 'reference-python' or 'device', got {self.table_mode!r}")
+                table = self.cdf_table(min_v, max_v, device)[0].cpu().numpy().view(np.uint16)
             table = np.ascontiguousarray(table)
             table.setflags(write=False)
             hit = (table, zlib.crc32(table.tobytes()))
-            if len(cache) >= self.TABLE_CACHE_SIZE:
-                cache.pop(next(iter(cache)))                                    # (dicts keep insertion order: drop the oldest)
-            cache[key] = hit
+            if TABLE_CACHE:
+                with _TABLE_LOCK:
+                    while len(cache) >= self.TABLE_CACHE_SIZE:
+                        cache.pop(next(iter(cache)), None)                       # (dicts keep insertion order: drop the oldest)
+                    cache[key] = hit
         return hit if want_crc else hit[0]
 
     @torch.no_grad()

@@ -42,7 +42,7 @@ class MinkowskiConvolution(_ConvBase):
             y = ops.conv_child(x.cmap.origin[1].k3, x.F, self._child_table, self.bias, self.out_channels, out=out,
                                residual=residual, relu=relu)
             return SparseTensor(y, coordinate_map=x.cmap)
-        elif k == 3 and s == 1 and self.in_channels == 1 and x.unit_features and ops.UNIT_INPUT_CONV and out is None and residual is None \
+        elif k == 3 and s == 1 and self.in_channels == 1 and x.has_unit_features() and ops.UNIT_INPUT_CONV and out is None and residual is None \
                 and self.out_channels in (4, 8, 16):
             # the codec's first layer on the occupancy indicator (all ones): a sum of kernel slices over the present offsets
             return SparseTensor(ops.conv_gather_unit(x.cmap.k3, self.kernel, self.bias, relu=relu), coordinate_map=x.cmap)

@@ -701,7 +701,7 @@ def rows_irn32_tables(params):
 
 
 ROWS_IRN32 = _os.environ.get('PCGC_ROWS_IRN32', '1') != '0'        # C = 32 blocks on plain levels (the encoder's stride-2 and stride-8 levels); A/B switch
-ROWS_IRN32_MIN, ROWS_IRN32_MAX = 1024, 1 << 40                     # (tools/rows_gate_ab.py: ahead of the VALU passes at every size: 47 vs 74 us per block at 49 k rows, 119 vs 127 at 256 k)
+ROWS_IRN32_MIN, ROWS_IRN32_MAX = 1024, 0xF0000000 // (32 * 4) - 1     # upper bound = the kernels' 32-bit buffer offsets (n * 32 * 4 B < 0xF0000000)                     # (tools/rows_gate_ab.py: ahead of the VALU passes at every size: 47 vs 74 us per block at 49 k rows, 119 vs 127 at 256 k)
 
 
 def irn_block_rows32(nbr, x, params, tables):
@@ -1032,7 +1032,9 @@ ROWS_DOWN_MIN = 1024
 
 
 def conv_down_rows_eligible(x, cin, cout, n_coarse):
-    return ROWS_DOWN and (cin, cout) in ((16, 32), (32, 64), (64, 32)) and n_coarse >= ROWS_DOWN_MIN and x.F.shape[0] * x.F.stride(0) * 4 < 0xF0000000
+    # (both tensors are addressed with 32-bit offsets: input rows through the buffer descriptor, output rows in the staged epilogue)
+    return ROWS_DOWN and (cin, cout) in ((16, 32), (32, 64), (64, 32)) and n_coarse >= ROWS_DOWN_MIN and x.F.shape[0] * x.F.stride(0) * 4 < 0xF0000000 \
+        and n_coarse * cout * 4 < 0xF0000000
 
 
 def conv_down_rows(down, x, table, bias, Cout, relu=False):
@@ -1336,6 +1338,8 @@ def items_encode(stems, sym_h, xyz8, rows, ranges, counts, eb_params, index_segm
     rg = _np(ranges, np.float32).reshape(-1, 2)
     ct = _np(counts, np.int32).reshape(-1, 3)
     P = _np(eb_params, np.float32)
+    if P.size != 44 * C:
+        raise PcgcError(f'items_encode: {P.size} entropy parameters for {C} channels (44 per channel)')
     check(lib().pcgc_items_encode(len(stems), arr, sym.ctypes.data, xyz.ctypes.data, r.ctypes.data, rg.ctypes.data, C, ct.ctypes.data, P.ctypes.data,
                                   _table_fn(), int(index_segments), int(write_coords), int(threads)), 'items_encode')
 
@@ -1367,6 +1371,9 @@ def items_decode(stems, rows, C, ranges, native, eb_params, use_sidecar=True, th
     else:
         xyz = np.empty((total, 3), np.int32)
     P = _np(eb_params, np.float32)
+    if P.size != 44 * C:
+        # (the library reads 44 * C floats: a channel count taken from a damaged `_H.bin` must never reach it)
+        raise PcgcError(f'items_decode: {P.size} entropy parameters for {C} channels (44 per channel)')
     rc = lib().pcgc_items_decode(len(stems), arr, rows.ctypes.data, C, ranges.ctypes.data, native.ctypes.data, P.ctypes.data, _table_fn(), int(use_sidecar),
                                  sym.ctypes.data, xyz.ctypes.data, 1 if level_scale else 0, int(level_scale) if level_scale else 1, int(threads))
     check(rc, 'items_decode')
@@ -1385,6 +1392,8 @@ def frame_decode(stem, C, eb_params, sym_buf, level_buf, use_sidecar=True, level
     info = (ctypes.c_int64 * 6)()
     rng = (ctypes.c_float * 2)()
     P = _np(eb_params, np.float32)
+    if P.size != 44 * int(C):
+        raise PcgcError(f'frame_decode: {P.size} entropy parameters for {C} channels (44 per channel)')
     rc = lib().pcgc_frame_decode(_os.fsencode(stem), int(C), P.ctypes.data, _table_fn(), int(bool(use_sidecar)), int(level_scale), cap,
                                  sym_buf.ctypes.data, level_buf.ctypes.data, info, rng, int(threads))
     if rc == 1:

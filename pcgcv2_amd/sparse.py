@@ -181,8 +181,11 @@ class SparseTensor:
                 coords, feats = dedup(coords, feats, int(tensor_stride))
             self.cmap = CoordMap(coords, int(tensor_stride), unique=True)
             self.F = feats
-            # (decided once, here, where the constructor synchronises anyway: the first layer then needs no feature gathers)
-            self.unit_features = feats.shape[1] == 1 and feats.shape[0] > 0 and bool((feats == 1).all().item())
+            # (decided once, here, where the constructor synchronises anyway: the first layer then needs no feature gathers; the
+            #  claim is tied to this very tensor in this very state — see has_unit_features)
+            if feats.shape[1] == 1 and feats.shape[0] > 0 and bool((feats == 1).all().item()):
+                self.unit_features = True
+                self._unit_stamp = (feats.data_ptr(), feats._version)
 
     @property
     def F(self):
@@ -193,6 +196,15 @@ class SparseTensor:
     @F.setter
     def F(self, value):
         self._F, self._F_thunk = value, None
+        self.unit_features = False            # (new features: whatever was known about the old ones is void)
+
+    def has_unit_features(self):
+        """True iff the features are STILL the all-ones [N, 1] tensor the constructor saw: same storage, no in-place write since
+        (`x.F.mul_(2)`, `x.F[...] = v` bump the tensor's version; `x.F = other` clears the flag).  MinkowskiEngine and the reference
+        honour the actual feature values; the gather-free first layer (nn.MinkowskiConvolution -> ops.conv_gather_unit) is only
+        taken while this holds."""
+        f = self._F
+        return bool(self.unit_features and f is not None and getattr(self, '_unit_stamp', None) == (f.data_ptr(), f._version))
 
     @property
     def C(self):

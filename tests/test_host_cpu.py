@@ -769,3 +769,117 @@ def test_native_item_files_equal_the_python_path(tmp_path):
     with pytest.raises(PcgcError, match='CDF table'):
         ops.items_decode([str(nat / 'g')], r1, C1, rg1, nv1, eb._host_packed())
     ops.items_decode([str(nat / 'g')], r1, C1, rg1, nv1, eb._host_packed(), use_sidecar=False)      # without the sidecar: decodes
+
+
+def test_items_decode_refuses_a_foreign_channel_count(tmp_path):
+    """a damaged / foreign `_H.bin` names C = 4096 channels; the library sizes the table and the parameter read (44 * C floats)
+    from whatever C it is handed, so a header's C must never travel past the binding with the model's 44 * 8 parameters."""
+    import struct
+    from pcgcv2_amd.entropy_model import EntropyBottleneck
+    rng = np.random.default_rng(5)
+    torch.manual_seed(5)
+    eb = EntropyBottleneck(8)
+    r = 500
+    sym = np.clip(np.rint(rng.normal(5, 2.0, size=(r, 8))), 0, 10).astype(np.int16)
+    sym[0, 0], sym[-1, -1] = 0, 10
+    xyz = rng.permutation(np.unique(rng.integers(0, 40, size=(4 * r, 3)), axis=0))[:r].astype(np.int32)
+    stem = str(tmp_path / 'h')
+    ops.items_encode([stem], sym, xyz, [r], [(-5.0, 5.0)], [(r, 2 * r, 3 * r)], eb._host_packed(), 16)
+    head = bytearray(open(stem + '_H.bin', 'rb').read())
+    head[4:8] = struct.pack('<i', 4096)
+    open(stem + '_H.bin', 'wb').write(bytes(head))
+    rows, C, ranges, counts, native = ops.items_probe([stem])
+    assert C == 4096
+    with pytest.raises(PcgcError, match='entropy parameters'):
+        ops.items_decode([stem], rows, C, ranges, native, eb._host_packed())
+    with pytest.raises(PcgcError, match='entropy parameters'):
+        ops.items_encode([stem], sym[:, :4].copy(), xyz, [r], [(-5.0, 5.0)], [(r, 2 * r, 3 * r)], eb._host_packed(), 16)
+
+
+def test_table_cache_policy(tmp_path):
+    """pcgc_table_cache / entropy_model.table_cache: dropping or disabling the caches changes no byte — only who evaluates the table."""
+    from pcgcv2_amd import entropy_model
+    from pcgcv2_amd.entropy_model import EntropyBottleneck
+    from pcgcv2_amd._lib import lib
+    rng = np.random.default_rng(8)
+    torch.manual_seed(8)
+    eb = EntropyBottleneck(8)
+    r = 2500
+    sym = np.clip(np.rint(rng.normal(6, 2.0, size=(r, 8))), 0, 12).astype(np.int16)
+    sym[0, 0], sym[-1, -1] = 0, 12
+    xyz = rng.permutation(np.unique(rng.integers(0, 50, size=(4 * r, 3)), axis=0))[:r].astype(np.int32)
+
+    def code(stem):
+        ops.items_encode([stem], sym, xyz, [r], [(-6.0, 6.0)], [(r, 2 * r, 3 * r)], eb._host_packed(), 16)
+        sb, lb = np.zeros((r, 8), np.int16), np.zeros((r, 4), np.int32)
+        ops.frame_decode(stem, 8, eb._host_packed(), sb, lb)
+        np.testing.assert_array_equal(sb, sym)
+        return {k: open(stem + k, 'rb').read() for k in ('_F.bin', '_H.bin', '_F.idx')}
+    try:
+        entropy_model.table_cache(on=True, clear=True)
+        a = code(str(tmp_path / 'a'))
+        assert lib().pcgc_table_cache(0) >= 1                       # the table of (parameters, -6..6) was cached ... and is dropped now
+        assert lib().pcgc_table_cache(0) == 0
+        b = code(str(tmp_path / 'b'))                               # evaluated afresh: same bytes
+        entropy_model.table_cache(on=False)
+        c = code(str(tmp_path / 'c'))                               # nothing is kept ...
+        assert lib().pcgc_table_cache(0) == 0
+        t1, crc1 = eb.host_table(np.float32(-6), np.float32(6), None, want_crc=True)
+        assert '_table_cache' not in eb.__dict__ or not eb.__dict__['_table_cache']
+        entropy_model.table_cache(on=True)
+        t2, crc2 = eb.host_table(np.float32(-6), np.float32(6), None, want_crc=True)
+        assert eb.host_table(np.float32(-6), np.float32(6), None) is t2 and crc1 == crc2 and np.array_equal(t1, t2)
+        assert entropy_model.table_cache(clear=True) >= 0 and not eb.__dict__.get('_table_cache')
+        assert a == b == c
+    finally:
+        entropy_model.table_cache(on=True)
+
+
+def test_host_table_cache_under_concurrent_misses():
+    """compress_symbols / decompress_symbols run on pool threads; with a full cache, concurrent misses used to evict the same
+    oldest key (KeyError) or trip over a dict that changed size.  32 threads x 40 distinct ranges against a 16-entry cache."""
+    from concurrent.futures import ThreadPoolExecutor
+    from pcgcv2_amd.entropy_model import EntropyBottleneck
+    torch.manual_seed(2)
+    eb = EntropyBottleneck(8)
+
+    def work(t):
+        for i in range(40):
+            lo = -float(1 + (i * 7 + t) % 23)
+            tab = eb.host_table(np.float32(lo), np.float32(5.0), None)
+            assert tab.shape == (8, int(5.0 - lo) + 2)
+        return True
+    with ThreadPoolExecutor(16) as ex:
+        assert all(ex.map(work, range(32)))
+    assert len(eb.__dict__['_table_cache']) <= eb.TABLE_CACHE_SIZE
+
+
+@pytest.mark.parametrize('name,n', [('solid_cube_s', 13824), ('solid_ball_s', 14592), ('noisy_s', 11086), ('multi_s', 15733), ('sparse_s', 7571)])
+def test_geometry_families_on_the_oracle(name, n):
+    """The non-shell synthetic clouds (synthetic.CLOUDS: filled bodies with masses of exactly tied logits, noisy / holed surfaces,
+    several components with one-voxel sheets and rods, a thinned surface): deterministic, unique, and the oracle codes them — the
+    bitstream does not depend on the row order of the input (the latent is sorted, coder.py:83), the decoded COUNT follows the budgets
+    in either order, and up-sampling (rho = 4, coder.py:107) keeps min(4 N1, candidates) voxels."""
+    p = synthetic.cloud(name).numpy()
+    assert len(p) == n and len(np.unique(p, axis=0)) == n and p.min() >= 0
+    q = synthetic.cloud(name, order='shuffled', seed=3).numpy()
+    assert not np.array_equal(p, q) and set(map(tuple, p)) == set(map(tuple, q))
+    np.testing.assert_array_equal(q, synthetic.cloud(name, order='shuffled', seed=3).numpy())
+    sd = synthetic.state_dict_to_numpy(synthetic.synthetic_state_dict())
+    encs = []
+    for pts in (p, q):
+        c4 = np.concatenate([np.zeros((len(pts), 1), np.int32), pts], 1)
+        enc = orc.encode(sd, c4)
+        out = orc.decode(sd, enc['coords8'], enc['F'], enc['H'], enc['num_points'])
+        assert len(out) == n and len(np.unique(out, axis=0)) == n
+        encs.append(enc)
+    for k in ('F', 'H', 'num_points'):
+        assert encs[0][k] == encs[1][k], k
+    n4, n2, n1 = np.frombuffer(encs[0]['num_points'], np.int32)
+    up = orc.decode(sd, encs[0]['coords8'], encs[0]['F'], encs[0]['H'], encs[0]['num_points'], rho=4.0)
+    assert len(up) == min(4 * n1, 8 * n2) and len(np.unique(up, axis=0)) == len(up)
+
+
+def test_full_size_geometry_families_have_the_documented_sizes():
+    for name, n in (('solid_cube', 512000), ('solid_ball', 539152), ('multi10', 1022977)):
+        assert len(synthetic.cloud(name)) == n, name
