@@ -6,9 +6,13 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-OBJ = os.path.join(CSRC, '_obj')
-LIB = os.path.join(HERE, 'libpcgc_hip.so')
-SOURCES = ['coords.hip', 'select.hip', 'conv.hip', 'child_conv.hip', 'child_conv32.hip', 'child_cls_w.hip', 'child_irn.hip', 'child_irn_a16.hip', 'child_irn_b16.hip',
+# PCGC_BUILD_VARIANT=<name> (experiments only): a second library libpcgc_hip_<name>.so from objects in csrc/_obj_<name>/, built with
+# PCGC_EXTRA_HIPCC_FLAGS — e.g. the per-phase cycle counters of the children-level kernels (-DPCGC_CHILD_TIMING) next to the product
+# build; load it with PCGC_LIB=<path> (pcgcv2_amd/_lib.py).  Objects whose source does not include child_kernels.h are copied over.
+VARIANT = os.environ.get('PCGC_BUILD_VARIANT', '')
+OBJ = os.path.join(CSRC, '_obj' + ('_' + VARIANT if VARIANT else ''))
+LIB = os.path.join(HERE, 'libpcgc_hip' + ('_' + VARIANT if VARIANT else '') + '.so')
+SOURCES = ['coords.hip', 'select.hip', 'conv.hip', 'child_conv.hip', 'child_conv32.hip', 'child_cls_w.hip', 'child_irn.hip', 'child_irn_a16.hip', 'child_irn_b16.hip', 'child_irn_a16_mt2.hip',
            'child_irn_a32.hip', 'child_irn_b32.hip', 'child_irn_a64.hip', 'child_irn_b64.hip', 'rows_irn.hip', 'entropy.hip', 'hostcodec.cpp', 'ply.cpp']
 HEADERS = [os.path.join(CSRC, 'pcgc_common.h'), os.path.join(CSRC, 'mfma_util.h'), os.path.join(CSRC, 'child_kernels.h'), os.path.join(HERE, '..', 'include', 'pcgc_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-Wall', '-Wno-unused-result'] + \
@@ -31,6 +35,14 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
+    if VARIANT:
+        import shutil
+        base = os.path.join(CSRC, '_obj')
+        for src in SOURCES:
+            o = src.rsplit('.', 1)[0] + '.o'
+            if 'child_kernels.h' not in open(os.path.join(CSRC, src)).read() and os.path.exists(os.path.join(base, o)) \
+                    and not os.path.exists(os.path.join(OBJ, o)):
+                shutil.copy2(os.path.join(base, o), os.path.join(OBJ, o))
     hipcc = _hipcc()
     jobs = []
     only = [t for t in os.environ.get('PCGC_BUILD_ONLY', '').split(',') if t]      # (kernel experiments: rebuild just these units,
@@ -62,7 +74,8 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n' + r.stderr[-4000:])
-    build_reftable(force=force)
+    if not VARIANT:
+        build_reftable(force=force)
     return LIB
 
 

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpcgc_hip.so')
+LIB_PATH = os.environ.get('PCGC_LIB') or os.path.join(_HERE, 'libpcgc_hip.so')       # (PCGC_LIB: an experiment build, pcgcv2_amd/_build.py)
 
 vp, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 ci = C.c_int

@@ -53,6 +53,7 @@ def _slurp(path):
 # The sidecar names the stream it belongs to by length and CRC-32 and carries a CRC over itself; one that does not match (or is
 # absent: a reference-made stream) is ignored and the stream is decoded serially, unguarded — exactly what the reference does.
 INDEX_SEGMENTS = 16                              # checkpoints per stream (two segments per decoder thread); 0 = never write or read the sidecar
+WARM_TABLE_CODE = True                           # encode: a throw-away table evaluation while the host waits for the GPU (ops.table_warm)
 NATIVE_ITEMS = True                              # batches: per-item host stages on native threads (False: Python thread pool; A/B and tests)
 INDEX_SUFFIX = '_F.idx'
 _INDEX_HEAD = struct.Struct('<4sIIIII')          # magic, stream bytes, stream CRC-32, checkpoints, table CRC-32, CRC-32 of (head so far + body)
@@ -237,7 +238,11 @@ class Coder():
         y = SparseTensor(ops.gather_feats(y_list[0].F, order), coordinate_map=CoordMap(y_C, lvl8.stride, unique=True))
         budgets = [len(t) for t in (y_list[1], y_list[2], x)]
         if self._native_items():
-            # range + symbols in one synchronising copy; table (cached), range coder, sidecar and the three files in one library call
+            # range + symbols in one synchronising copy; table (cached), range coder, sidecar and the three files in one library call.
+            # The host is about to wait for the GPU: it spends that wait pulling the table evaluation's code path into its caches
+            # (ops.table_warm: a dummy range, result discarded — the real table is evaluated below, once the range is known)
+            if WARM_TABLE_CODE:
+                ops.table_warm(self.feature_coder.entropy_model._host_packed(), self.feature_coder.entropy_model._channels)
             min_v, max_v, sym_h = ops.quantize_symbols(y.F)
             ops.items_encode([self.filename + postfix], sym_h, np.zeros((0, 3), np.int32), [len(sym_h)], [(min_v, max_v)], [budgets],
                              self.feature_coder.entropy_model._host_packed(), INDEX_SEGMENTS, write_coords=False, threads=1)

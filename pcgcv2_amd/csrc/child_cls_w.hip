@@ -7,3 +7,4 @@
 // with four, the 1171 tiles of the 150 k-row level were two rounds of a tile that waits a gather round trip per cell: 84 us)
 DEF_CONV_LAUNCH(pcgc_child_cls32) { return launch_child_cls<2, 16, 2>(parent_nbr, n_parent, in, in_ld, table, table_bytes, ep, s); }
 DEF_CONV_LAUNCH(pcgc_child_cls64) { return launch_child_cls<4, 7, 1>(parent_nbr, n_parent, in, in_ld, table, table_bytes, ep, s); }
+CHILD_TIMING_READER(pcgc_child_timing_cls_w)

@@ -7,3 +7,4 @@ DEF_IRN_LAUNCH(pcgc_irn_child_b16) {
     return (nw == 4) ? launch_child_irn_b<16, 4, 4>(parent_nbr, n_parent, in, in_ld, table, table_bytes, ep, s)
                      : launch_child_irn_b<16, 16, 8>(parent_nbr, n_parent, in, in_ld, table, table_bytes, ep, s);
 }
+CHILD_TIMING_READER(pcgc_child_timing_b16)

@@ -5,3 +5,4 @@
                                       int table_bytes, const IrnEpi& ep, hipStream_t s)
 // half units (see k_child_irn_a)
 DEF_IRN_LAUNCH(pcgc_irn_child_b32) { (void)nw; return launch_child_irn_b_split<32, 12, 8>(parent_nbr, n_parent, in, in_ld, table, table_bytes, ep, s); }
+CHILD_TIMING_READER(pcgc_child_timing_b32)

@@ -33,13 +33,32 @@
 
 #ifdef PCGC_CHILD_TIMING
 // per-phase shader-clock cycles summed over waves: [0] tile prologue (neighbour-parent loads + drain), [1] gather/MFMA loop,
-// [3] tiles, [4] whole tile iterations (prologue + loop + epilogue); experiments only (tools/child_timing.py)
+// [3] tiles, [4] whole tile iterations (prologue + loop + epilogue), [5] the wait for the tile's stores; experiments only
+// (tools/child_phase_times.py).  Accumulated in registers, ONE atomic per slot and wave at the end of the kernel (atomics inside the
+// loop would sit in the very vmcnt queue the kernel's waits count).
 static __device__ unsigned long long g_child_dbg[8];
 #define CHILD_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define CHILD_TADD(slot, a, b) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_child_dbg[slot], (b) - (a)); } while (0)
+#define CHILD_TADD(slot, a, b) do { child_dbg[slot] += (b) - (a); } while (0)
+#define CHILD_DBG_DECL unsigned long long child_dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define CHILD_DBG_PARAM , unsigned long long (&child_dbg)[8]
+#define CHILD_DBG_ARG , child_dbg
+#define CHILD_TFLUSH do { if ((threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 8; ++q_) if (child_dbg[q_]) atomicAdd(&g_child_dbg[q_], child_dbg[q_]); } } while (0)
+// the counters are per translation unit (static __device__): every unit with kernels exports its own reader
+#define CHILD_TIMING_READER(NAME)                                                                                      \
+    extern "C" int NAME(unsigned long long* out8, int reset) {                                                         \
+        (void)hipDeviceSynchronize();                                                                                  \
+        if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_child_dbg), 8 * sizeof(unsigned long long));           \
+        if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_child_dbg), z, sizeof(z)); }  \
+        return 0;                                                                                                      \
+    }
 #else
 #define CHILD_T(var)
 #define CHILD_TADD(slot, a, b)
+#define CHILD_DBG_DECL
+#define CHILD_DBG_PARAM
+#define CHILD_DBG_ARG
+#define CHILD_TFLUSH
+#define CHILD_TIMING_READER(NAME)
 #endif
 
 struct ChildEpi {
@@ -306,32 +325,44 @@ template <class V> constexpr ChildCells child_cells() {
     return L;
 }
 
-// The gather + MFMA main loop of one 16-parent tile, shared by every variant: leaves acc[t] (t < V::T) for the epilogue.
-template <class V, int D>
-__device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ pnbr, int64_t n_p, int64_t p0,
-                                                    const __amdgpu_buffer_rsrc_t& rs_in, int in_ld, const unsigned char* lds_raw,
-                                                    float4* ring, f32x4 (&acc)[V::T]) {
+// The gather + MFMA main loop of one tile of 16 MT parents, shared by every variant: leaves acc[m][t] (t < V::T) for the epilogue.
+// MT = 2 (round 4): a wave owns TWO MFMA M tiles (parents p0 .. p0 + 15 and p0 + 16 .. p0 + 31).  Every B fragment read from the LDS
+// table, every `s_waitcnt` and every address computation of a cell serves both; the per-tile prologue (map loads and their latency, the
+// first D cells' gather latency) and the epilogue's hand-offs are paid once per 32 parents.  A ring slot holds the cell's rows of both M
+// tiles (M tile m at + m NB KB).  Per output element nothing changes: same products, same order.
+template <class V, int D, int MT>
+__device__ __forceinline__ void child_tile_mainloop_mt(const int32_t* __restrict__ pnbr, int64_t n_p, int64_t p0,
+                                                       const __amdgpu_buffer_rsrc_t& rs_in, int in_ld, const unsigned char* lds_raw,
+                                                       float4* ring, f32x4 (&acc)[MT][V::T] CHILD_DBG_PARAM) {
     constexpr int NB = V::NB, T = V::T, KS = V::KS;
+    static_assert(MT == 1 || MT == 2, "one or two M tiles per wave");
     static_assert((D & (D - 1)) == 0, "ring depth must be a power of two");
-    static_assert((D - 1) * NB < 64, "vmcnt is 6 bits");
+    static_assert((D - 1) * NB * MT < 64, "vmcnt is 6 bits");
     CHILD_T(t_tile0);
     const int lane = threadIdx.x & 63;
     const int mi = lane & 15, mq = lane >> 4;
     const int dma_r = lane >> 2;                               // tile row (parent) this lane fetches for
-    const bool row_ok = p0 + dma_r < n_p;
+    bool row_ok[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) row_ok[m] = p0 + 16 * m + dma_r < n_p;
     // byte offset of each neighbour parent's first child row; absent -> a value no in-row offset can bring back into range (the
     // entry point checks the tensor is smaller than ABSENT), so the per-cell address is ONE add and needs no select
     constexpr unsigned ABSENT = 0xF0000000u;
-    unsigned rowb[V::NMAP];
+    unsigned rowb[MT][V::NMAP];
 #pragma unroll
-    for (int kp = 0; kp < V::NMAP; ++kp) rowb[kp] = (unsigned)pnbr[(int64_t)kp * n_p + (row_ok ? p0 + dma_r : 0)];
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int kp = 0; kp < V::NMAP; ++kp) rowb[m][kp] = (unsigned)pnbr[(int64_t)kp * n_p + (row_ok[m] ? p0 + 16 * m + dma_r : 0)];
     const int f_a = (0x78 >> (2 * (mi >> 2))) & 3;             // read-side swizzle of the A image (see conv.hip v2)
     const int dma_chunk = (lane & 3) ^ ((0x78 >> (2 * ((dma_r >> 2) & 3))) & 3);
     const bool chunk_ok = dma_chunk < V::ROWCHUNKS;            // rows narrower than 64 bytes: the other lanes fetch nothing (zeros)
     const unsigned row_bytes = (unsigned)in_ld * 4u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // map entries loaded (and the previous tile's stores retired): vmcnt now counts DMAs only
 #pragma unroll
-    for (int kp = 0; kp < V::NMAP; ++kp) rowb[kp] = (row_ok && (int)rowb[kp] >= 0) ? rowb[kp] * ((unsigned)V::ROW_MUL * row_bytes) : ABSENT;
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int kp = 0; kp < V::NMAP; ++kp)
+            rowb[m][kp] = (row_ok[m] && (int)rowb[m][kp] >= 0) ? rowb[m][kp] * ((unsigned)V::ROW_MUL * row_bytes) : ABSENT;
     const unsigned lane_off = chunk_ok ? (unsigned)dma_chunk * 16u : ABSENT;
     CHILD_T(t_loop0);
 
@@ -339,17 +370,22 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
     constexpr int NC = CL.n;                                   // cells of this variant; position i in the list uses ring slot i mod D
     auto issue = [&](auto ii) {
         constexpr int i = decltype(ii)::value, c = CL.c[i];
-        float4* dst = ring + (i & (D - 1)) * (NB * 64);
-        unsigned voff = rowb[V::kp(c)] + (unsigned)V::child(c) * row_bytes + lane_off + (unsigned)V::byte_off(c);
-        if constexpr (V::ROWCHUNKS < 4) voff = chunk_ok ? voff : 0xFFFFFFF0u;       // (ABSENT + ABSENT would wrap)
+        float4* dst = ring + (i & (D - 1)) * (MT * NB * 64);
 #pragma unroll
-        for (int cb = 0; cb < NB; ++cb)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_ptr)(dst + cb * 64), 16, (int)(voff + cb * 64), 0, 0, 0);
+        for (int m = 0; m < MT; ++m) {
+            unsigned voff = rowb[m][V::kp(c)] + (unsigned)V::child(c) * row_bytes + lane_off + (unsigned)V::byte_off(c);
+            if constexpr (V::ROWCHUNKS < 4) voff = chunk_ok ? voff : 0xFFFFFFF0u;   // (ABSENT + ABSENT would wrap)
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_ptr)(dst + (m * NB + cb) * 64), 16, (int)(voff + cb * 64), 0, 0, 0);
+        }
         asm volatile("" ::: "memory");
     };
 
 #pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const unsigned tab_lane = (unsigned)(uintptr_t)(lds_void_ptr)((const float*)lds_raw + (V::HALF ? (mq * 8 + (mi & 7)) : lane) * KS);
     // A operand straight in MFMA layout: lane (mi, mq) needs channel 4 jj + mq of row mi for K-step jj; chunk jj of row mi sits at
     // slot position jj ^ f(mi >> 2) of the (source-swizzled) image, so four ds_read_b32 — conflict-free: bank = 16 (mi & 3) +
@@ -363,6 +399,7 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
     constexpr bool BLOCKWISE = NB * T > 32;                                    // wide layers: B fragments one 16-channel block (and batch) at a time
     static_assert(BLOCKWISE || V::NBATCH == 1, "batches only exist in the block-wise form");
     if constexpr (BLOCKWISE) {
+        static_assert(!BLOCKWISE || MT == 1, "the block-wise (C = 64) form keeps one M tile per wave");
         // C = 64 variants: one or two waves per SIMD and one tile per wave, so little but the wave itself covers an LDS round trip.
         // Every LDS read is requested one step ahead of its use: the B fragments of the next block / batch, and — during a cell's last
         // step — the A operand and the first B fragments of the next cell (two register sets each).  A step is: wait for what was
@@ -432,7 +469,7 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
                     static_for<0, T>([&](auto it) {
                         constexpr int t = decltype(it)::value;
                         if constexpr (V::active(c, t) && V::uses_block(t, cb) && V::batch(t) == bt && jj >= V::kfirst(t) && jj < V::kfirst(t) + KS)
-                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i & 1][cb][jj], bp[cur][t].get(jj - V::kfirst(t)), acc[t], 0, 0, 0);
+                            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i & 1][cb][jj], bp[cur][t].get(jj - V::kfirst(t)), acc[0][t], 0, 0, 0);
                     });
                 });
             });
@@ -444,15 +481,18 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
     static_for<0, NC>([&](auto ii) {
         constexpr int i = decltype(ii)::value, c = CL.c[i];
         constexpr int younger = (NC - 1 - i) < (D - 1) ? (NC - 1 - i) : (D - 1);       // cells issued after this one that may stay in flight
-        wait_vmcnt<younger * NB>();
-        float a[NB][4];
+        wait_vmcnt<younger * NB * MT>();
+        float a[MT][NB][4];
         BFrag<KS> b[NB][T];
         static_for<0, NB>([&](auto icb) {                                      // all LDS reads of the cell, one wait
             constexpr int cb = decltype(icb)::value;
-            static_for<0, 4>([&](auto ij) {
-                constexpr int jj = decltype(ij)::value;
-                if constexpr ((ksteps_used >> jj) & 1)
-                    a[cb][jj] = lds_ld32_off<((i & (D - 1)) * NB + cb) * 1024>(a_addr[jj]);
+            static_for<0, MT>([&](auto im) {
+                constexpr int m = decltype(im)::value;
+                static_for<0, 4>([&](auto ij) {
+                    constexpr int jj = decltype(ij)::value;
+                    if constexpr ((ksteps_used >> jj) & 1)
+                        a[m][cb][jj] = lds_ld32_off<(((i & (D - 1)) * MT + m) * NB + cb) * 1024>(a_addr[jj]);
+                });
             });
             static_for<0, T>([&](auto it) {
                 constexpr int t = decltype(it)::value;
@@ -466,9 +506,11 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         static_for<0, NB>([&](auto icb) {
             constexpr int cb = decltype(icb)::value;
-            static_for<0, 4>([&](auto ij) {
-                constexpr int jj = decltype(ij)::value;
-                if constexpr ((ksteps_used >> jj) & 1) lds_tie(a[cb][jj]);
+            static_for<0, MT>([&](auto im) {
+                static_for<0, 4>([&](auto ij) {
+                    constexpr int jj = decltype(ij)::value;
+                    if constexpr ((ksteps_used >> jj) & 1) lds_tie(a[decltype(im)::value][cb][jj]);
+                });
             });
             static_for<0, T>([&](auto it) {
                 constexpr int t = decltype(it)::value;
@@ -482,20 +524,31 @@ __device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ 
                 constexpr int jj = decltype(ij)::value;
                 static_for<0, T>([&](auto it) {
                     constexpr int t = decltype(it)::value;
-                    if constexpr (V::active(c, t) && V::uses_block(t, cb) && jj >= V::kfirst(t) && jj < V::kfirst(t) + KS)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][jj], b[cb][t].get(jj - V::kfirst(t)), acc[t], 0, 0, 0);
+                    if constexpr (V::active(c, t) && V::uses_block(t, cb) && jj >= V::kfirst(t) && jj < V::kfirst(t) + KS) {
+                        static_for<0, MT>([&](auto im) {                       // both M tiles against the one B fragment, back to back
+                            constexpr int m = decltype(im)::value;
+                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][cb][jj], b[cb][t].get(jj - V::kfirst(t)), acc[m][t], 0, 0, 0);
+                        });
+                    }
                 });
             });
         });
     });
     }
 #ifdef PCGC_CHILD_TIMING
-    asm volatile("s_nop 0" : "+v"(acc[0]));                     // (keeps the stamp behind the last MFMA's issue)
+    asm volatile("s_nop 0" : "+v"(acc[0][0]));                  // (keeps the stamp behind the last MFMA's issue)
     CHILD_T(t_loop1);
     CHILD_TADD(0, t_tile0, t_loop0);
     CHILD_TADD(1, t_loop0, t_loop1);
     CHILD_TADD(3, 0ull, 1ull);
 #endif
+}
+
+template <class V, int D>
+__device__ __forceinline__ void child_tile_mainloop(const int32_t* __restrict__ pnbr, int64_t n_p, int64_t p0,
+                                                    const __amdgpu_buffer_rsrc_t& rs_in, int in_ld, const unsigned char* lds_raw,
+                                                    float4* ring, f32x4 (&acc)[V::T] CHILD_DBG_PARAM) {
+    child_tile_mainloop_mt<V, D, 1>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, reinterpret_cast<f32x4 (&)[1][V::T]>(acc) CHILD_DBG_ARG);
 }
 
 // Lanes of one wave exchange data through LDS in the epilogues (one group of lanes writes, all lanes read).  The hardware runs a wave's
@@ -513,6 +566,51 @@ __device__ __forceinline__ void wave_lds_sync() {
 // ring, idle by then) in row-major order, CH rows at a time, and leave as 16-byte-per-lane stores: whole rows, fully coalesced;
 // residual rows are read the same way.  Arithmetic order per element is unchanged: (acc + bias) [+ residual] [relu].
 // `half` (0 / 1, or -1 = all rows): only the rows of the children with that z bit (rows 4 half .. 4 half + 3 of every parent's eight).
+// Round 4: the trip count is static (ROWS x W / 4 sixteen-byte pieces over 64 lanes) and the residual rows are REQUESTED before anything
+// else — `child_flush_prefetch` at the start of a chunk, ahead of the staging writes and the hand-off — so that one memory latency is paid
+// per chunk instead of one per piece (the loop form waited `vmcnt(0)` for every residual piece, and with it for the previous piece's
+// store: 44 k of pass B's 86 k cycles per tile and wave, tools/child_phase_times.py).
+template <int W, int ROWS>
+struct ChildResidual { float4 x[(ROWS * (W / 4) + 63) / 64]; };
+template <int W, int ROWS>
+__device__ __forceinline__ void child_flush_prefetch(ChildResidual<W, ROWS>& rr, int64_t row0, int64_t rows_total, const float* __restrict__ res,
+                                                     int res_ld, int lane, int half = -1) {
+    constexpr int C4 = W / 4, N = (ROWS * C4 + 63) / 64;
+    if (!res) return;                                          // (rr is never read then)
+#pragma unroll
+    for (int it = 0; it < N; ++it) {
+        const int i = lane + 64 * it, lr = i / C4, c4 = i % C4;
+        const int64_t row = row0 + lr;
+        const bool ok = i < ROWS * C4 && row < rows_total && !(half >= 0 && ((lr >> 2) & 1) != half);
+        rr.x[it] = ok ? *(const float4*)(res + row * res_ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+// (rr by reference + a flag: a pointer that may be null put the struct on the stack — scratch memory — instead of in registers)
+template <int W, int ROWS>
+__device__ __forceinline__ void child_flush(const float* scratch, const ChildResidual<W, ROWS>& rr, bool has_res, int64_t row0, int64_t rows_total,
+                                            float* __restrict__ out, int out_ld, int relu, int lane, int half = -1) {
+    constexpr int C4 = W / 4, N = (ROWS * C4 + 63) / 64;
+#pragma unroll
+    for (int it = 0; it < N; ++it) {
+        const int i = lane + 64 * it, lr = i / C4, c4 = i % C4;
+        const int64_t row = row0 + lr;
+        if (i >= ROWS * C4 || row >= rows_total || (half >= 0 && ((lr >> 2) & 1) != half)) continue;
+        float4 v = ((const float4*)scratch)[i];
+        if (has_res) {
+            const float4 x = rr.x[it];
+            v.x = v.x + x.x; v.y = v.y + x.y; v.z = v.z + x.z; v.w = v.w + x.w;
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+        *(float4*)(out + row * out_ld + 4 * c4) = v;
+    }
+}
+template <int W, int ROWS>
+__device__ __forceinline__ void child_flush(const float* scratch, int64_t row0, int64_t rows_total, float* __restrict__ out, int out_ld,
+                                            int relu, int lane, int half = -1) {
+    ChildResidual<W, ROWS> none;
+    child_flush<W, ROWS>(scratch, none, false, row0, rows_total, out, out_ld, relu, lane, half);
+}
+// (runtime row count, no residual: the plain-rows kernels of rows_irn.hip whose chunk is 16 rows)
 template <int W>
 __device__ __forceinline__ void child_flush(const float* scratch, int rows, int64_t row0, int64_t rows_total, float* __restrict__ out,
                                             int out_ld, const float* __restrict__ res, int res_ld, int relu, int lane, int half = -1) {
@@ -534,6 +632,7 @@ __device__ __forceinline__ void child_flush(const float* scratch, int rows, int6
 // rows of the gathered tensor: the children of the n_p parents, or the level itself (a kernel whose input is ANOTHER level redefines it)
 #define CHILD_IN_ROWS(V, n_p) (V::ROW_MUL * (n_p))
 #define CHILD_KERNEL_PROLOGUE(V, NW, D, RING_FLOAT4)                                                                          \
+    CHILD_DBG_DECL                                                                                                            \
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];                                                   \
     const int lane = threadIdx.x & 63, mi = lane & 15, mq = lane >> 4;                                                        \
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                                                        \
@@ -544,89 +643,102 @@ __device__ __forceinline__ void child_flush(const float* scratch, int rows, int6
 
 template <class T_> struct child_type_tag { using type = T_; };
 // plain conv:  acc[t][r] = out[8 (p0 + 4 mq + r) + j][16 n + mi],  t = j * NT + n.   SPLIT: half units (see k_child_irn_a)
-template <int NB, int NT, int NW, int D, bool SPLIT = false>
+template <int NB, int NT, int NW, int D, bool SPLIT = false, int MT = 1>
 __global__ void __launch_bounds__(NW * 64)
 k_child_conv(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in, int in_ld,
              const float* __restrict__ table, int table_bytes, ChildEpi ep) {
     using V = PlainConv<NB, NT>;
-    CHILD_KERNEL_PROLOGUE(V, NW, D, D * NB * 64)
-    auto unit = [&](auto tag, const int64_t p0) {
+    CHILD_KERNEL_PROLOGUE(V, NW, D, D * NB * 64 * MT)
+    float bvs[NT];                                             // (loaded once: inside the tile loop every use was a global load + vmcnt(0))
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bvs[n] = ep.bias ? ep.bias[16 * n + mi] : 0.0f;
+    auto unit = [&](auto tag, const int64_t pu) {
         using VV = typename decltype(tag)::type;
         constexpr int HZ = VV::Z_HALF;
-        f32x4 acc[VV::T];
-        child_tile_mainloop<VV, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
+        f32x4 acc[MT][VV::T];
+        child_tile_mainloop_mt<VV, D, MT>(pnbr, n_p, pu, rs_in, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
         // staged epilogue: CH rows (CH / 8 parents) at a time through the ring's LDS
-        constexpr int W = 16 * NT, CH = (64 * W * 4 <= D * NB * 1024) ? 64 : 32, PPC = CH / 8, MQC = PPC / 4;   // MQC: lane quarters per chunk
+        constexpr int W = 16 * NT, CH = (64 * W * 4 <= D * NB * 1024 * MT) ? 64 : 32, PPC = CH / 8, MQC = PPC / 4;   // MQC: lane quarters per chunk
         float* scratch = (float*)ring;
 #pragma unroll
-        for (int h = 0; h < 128 / CH; ++h) {
-            if (mq / MQC == h) {
+        for (int m = 0; m < MT; ++m) {
+            const int64_t p0 = pu + 16 * m;
+            if (m > 0 && p0 >= n_p) break;
 #pragma unroll
-                for (int t = 0; t < VV::T; ++t) {
-                    const int j = t / NT, n = t % NT;
-                    if (HZ >= 0 && ((j >> 2) & 1) != HZ) continue;
-                    const float bv = ep.bias ? ep.bias[16 * n + mi] : 0.0f;
+            for (int h = 0; h < 128 / CH; ++h) {
+                ChildResidual<W, CH> rr;
+                child_flush_prefetch<W, CH>(rr, 8 * p0 + h * CH, 8 * n_p, ep.res, ep.res_ld, lane, HZ);
+                if (mq / MQC == h) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[t][r];
-                        if (ep.bias) v = v + bv;
-                        scratch[(8 * (4 * (mq % MQC) + r) + j) * W + 16 * n + mi] = v;
+                    for (int t = 0; t < VV::T; ++t) {
+                        const int j = t / NT, n = t % NT;
+                        if (HZ >= 0 && ((j >> 2) & 1) != HZ) continue;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = acc[m][t][r];
+                            if (ep.bias) v = v + bvs[n];
+                            scratch[(8 * (4 * (mq % MQC) + r) + j) * W + 16 * n + mi] = v;
+                        }
                     }
                 }
+                wave_lds_sync();
+                child_flush<W, CH>(scratch, rr, ep.res != nullptr, 8 * p0 + h * CH, 8 * n_p, ep.out, ep.out_ld, ep.relu, lane, HZ);
+                wave_lds_sync();
             }
-            wave_lds_sync();
-            child_flush<W>(scratch, CH, 8 * p0 + h * CH, 8 * n_p, ep.out, ep.out_ld, ep.res, ep.res_ld, ep.relu, lane, HZ);
-            wave_lds_sync();
         }
     };
-    const int64_t nunits = SPLIT ? 2 * ntiles : ntiles;
+    const int64_t nunits = (SPLIT ? 2 : 1) * ((n_p + 16 * MT - 1) / (16 * MT));
     for (int i = 0;; ++i) {
         const int64_t u = child_tile<NW>(i, wave, nunits);
         if (u < 0) break;
         CHILD_T(t_it0);
         if constexpr (SPLIT) {
-            if (u & 1) unit(child_type_tag<PlainConv<NB, NT, 1>>{}, (u >> 1) * 16);
-            else unit(child_type_tag<PlainConv<NB, NT, 0>>{}, (u >> 1) * 16);
+            if (u & 1) unit(child_type_tag<PlainConv<NB, NT, 1>>{}, (u >> 1) * (16 * MT));
+            else unit(child_type_tag<PlainConv<NB, NT, 0>>{}, (u >> 1) * (16 * MT));
         } else {
-            unit(child_type_tag<V>{}, u * 16);
+            unit(child_type_tag<V>{}, u * (16 * MT));
         }
 #ifdef PCGC_CHILD_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        { CHILD_T(t_it1); CHILD_TADD(4, t_it0, t_it1); }
+        { CHILD_T(t_dr0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHILD_T(t_it1); CHILD_TADD(5, t_dr0, t_it1); CHILD_TADD(4, t_it0, t_it1); }
 #endif
     }
+    CHILD_TFLUSH;
 }
 
 // classification head C -> 1:  acc[0][r] column j = out[8 (p0 + 4 mq + r) + j]
-template <int NB, int NW, int D>
+template <int NB, int NW, int D, int MT = 1>
 __global__ void __launch_bounds__(NW * 64)
 k_child_cls(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in, int in_ld,
             const float* __restrict__ table, int table_bytes, ChildEpi ep) {
     using V = ClsHead<NB>;
-    CHILD_KERNEL_PROLOGUE(V, NW, D, D * NB * 64)
+    CHILD_KERNEL_PROLOGUE(V, NW, D, D * NB * 64 * MT)
     const float bv = ep.bias ? ep.bias[0] : 0.0f;
+    const int64_t nunits = (n_p + 16 * MT - 1) / (16 * MT);
     for (int i = 0;; ++i) {
-        const int64_t tile = child_tile<NW>(i, wave, ntiles);
+        const int64_t tile = child_tile<NW>(i, wave, nunits);
         if (tile < 0) break;
-        const int64_t p0 = tile * 16;
+        const int64_t pu = tile * (16 * MT);
         CHILD_T(t_it0);
-        f32x4 acc[1];
-        child_tile_mainloop<V, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
+        f32x4 acc[MT][1];
+        child_tile_mainloop_mt<V, D, MT>(pnbr, n_p, pu, rs_in, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
         if (mi < 8) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t p = p0 + 4 * mq + r;
-                if (p >= n_p) continue;
-                float v = acc[0][r];
-                if (ep.bias) v = v + bv;
-                ep.out[(8 * p + mi) * ep.out_ld] = v;
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t p = pu + 16 * m + 4 * mq + r;
+                    if (p >= n_p) continue;
+                    float v = acc[m][0][r];
+                    if (ep.bias) v = v + bv;
+                    ep.out[(8 * p + mi) * ep.out_ld] = v;
+                }
             }
         }
 #ifdef PCGC_CHILD_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        { CHILD_T(t_it1); CHILD_TADD(4, t_it0, t_it1); }
+        { CHILD_T(t_dr0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHILD_T(t_it1); CHILD_TADD(5, t_dr0, t_it1); CHILD_TADD(4, t_it0, t_it1); }
 #endif
     }
+    CHILD_TFLUSH;
 }
 
 
@@ -635,75 +747,80 @@ k_child_cls(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restri
 // SPLIT (C = 64): the level is ~1.14 tiles per SIMD, and a tile is 48 us of one SIMD's MFMA pipe — whole tiles quantise to TWO tile times
 // per launch.  Half units (the four children with z bit 0 / 1 of 16 parents: half the MFMAs, 48 of the 64 cells) quantise to three
 // half-tile times.  Both halves are separate instantiations of the statically unrolled body; a wave picks one per unit.
-template <int C, int NW, int D, bool SPLIT = false>
+template <int C, int NW, int D, bool SPLIT = false, int MT = 1>
 __global__ void __launch_bounds__(NW * 64)
 k_child_irn_a(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in, int in_ld,
               const float* __restrict__ table, int table_bytes, IrnEpi ep) {
     using V = PassA<C>;
     constexpr int Q = V::Q, CPT = V::CPT, TH = V::TH;
     static_assert(!SPLIT || CPT <= 2, "half units: tiles of one or two children");
-    CHILD_KERNEL_PROLOGUE(V, NW, D, D * V::NB * 64)
+    CHILD_KERNEL_PROLOGUE(V, NW, D, D * V::NB * 64 * MT)
     const int co = mi % Q, sub = mi / Q;                       // column -> (child within the tile, output channel)
     const float b00 = ep.b0[co], b10 = ep.b1[co];
-    auto unit = [&](auto tag, const int64_t p0) {
+    auto unit = [&](auto tag, const int64_t pu) {
         using VV = typename decltype(tag)::type;
         constexpr int HZ = VV::Z_HALF;
-        f32x4 acc[VV::T];
-        child_tile_mainloop<VV, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
-        constexpr int W = 2 * Q, CH = (64 * W * 4 <= D * V::NB * 1024) ? 64 : 32, MQC = CH / 32;
+        f32x4 acc[MT][VV::T];
+        child_tile_mainloop_mt<VV, D, MT>(pnbr, n_p, pu, rs_in, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
+        constexpr int W = 2 * Q, CH = (64 * W * 4 <= D * V::NB * 1024 * MT) ? 64 : 32, MQC = CH / 32;
         float* scratch = (float*)ring;
 #pragma unroll
-        for (int h = 0; h < 128 / CH; ++h) {
-            if (mq / MQC == h) {
+        for (int m = 0; m < MT; ++m) {
+            const int64_t p0 = pu + 16 * m;
+            if (m > 0 && p0 >= n_p) break;
 #pragma unroll
-                for (int t = 0; t < TH; ++t) {
-                    if (HZ >= 0 && (((t * CPT) >> 2) & 1) != HZ) continue;     // (tile t holds children t CPT ...)
-                    const int j = t * CPT + sub;
+            for (int h = 0; h < 128 / CH; ++h) {
+                if (mq / MQC == h) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float* y = scratch + (8 * (4 * (mq % MQC) + r) + j) * W;
-                        y[co] = fmaxf(acc[t][r] + b00, 0.0f);
-                        y[Q + co] = fmaxf(acc[TH + t][r] + b10, 0.0f);
+                    for (int t = 0; t < TH; ++t) {
+                        if (HZ >= 0 && (((t * CPT) >> 2) & 1) != HZ) continue;     // (tile t holds children t CPT ...)
+                        const int j = t * CPT + sub;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* y = scratch + (8 * (4 * (mq % MQC) + r) + j) * W;
+                            y[co] = fmaxf(acc[m][t][r] + b00, 0.0f);
+                            y[Q + co] = fmaxf(acc[m][TH + t][r] + b10, 0.0f);
+                        }
                     }
                 }
+                wave_lds_sync();
+                child_flush<W, CH>(scratch, 8 * p0 + h * CH, 8 * n_p, ep.out, W, 0, lane, HZ);
+                wave_lds_sync();
             }
-            wave_lds_sync();
-            child_flush<W>(scratch, CH, 8 * p0 + h * CH, 8 * n_p, ep.out, W, nullptr, 0, 0, lane, HZ);
-            wave_lds_sync();
         }
     };
-    const int64_t nunits = SPLIT ? 2 * ntiles : ntiles;
+    const int64_t nunits = (SPLIT ? 2 : 1) * ((n_p + 16 * MT - 1) / (16 * MT));
     for (int i = 0;; ++i) {
         const int64_t u = child_tile<NW>(i, wave, nunits);
         if (u < 0) break;
         CHILD_T(t_it0);
         if constexpr (SPLIT) {
-            if (u & 1) unit(child_type_tag<PassA<C, 1>>{}, (u >> 1) * 16);
-            else unit(child_type_tag<PassA<C, 0>>{}, (u >> 1) * 16);
+            if (u & 1) unit(child_type_tag<PassA<C, 1>>{}, (u >> 1) * (16 * MT));
+            else unit(child_type_tag<PassA<C, 0>>{}, (u >> 1) * (16 * MT));
         } else {
-            unit(child_type_tag<V>{}, u * 16);
+            unit(child_type_tag<V>{}, u * (16 * MT));
         }
 #ifdef PCGC_CHILD_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        { CHILD_T(t_it1); CHILD_TADD(4, t_it0, t_it1); }
+        { CHILD_T(t_dr0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHILD_T(t_it1); CHILD_TADD(5, t_dr0, t_it1); CHILD_TADD(4, t_it0, t_it1); }
 #endif
     }
+    CHILD_TFLUSH;
 }
 
 // pass B:  out[row][0:2Q]  = (conv0_1(t[:, :Q]) + b01) + x[row][0:2Q]
 //          out[row][2Q:4Q] = (conv1_2(relu(conv1_1(t[:, Q:]) + b11)) + b12) + x[row][2Q:4Q]
 // conv1_2 (k1, Q -> 2Q) is a second, tiny MFMA product: u = relu(conv1_1 + b11) goes through a per-wave LDS scratch (the gather
 // ring, idle by then) from the accumulator layout (lane = column) into A fragments (lane = row), 16 output rows per product.
-template <int C, int NW, int D, bool SPLIT = false>
+template <int C, int NW, int D, bool SPLIT = false, int MT = 1>
 __global__ void __launch_bounds__(NW * 64)
 k_child_irn_b(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in /* t */, int in_ld,
               const float* __restrict__ table, int table_bytes, IrnEpi ep) {
     using V = PassB<C>;
     constexpr int Q = V::Q, H = 2 * Q, KQ = Q / 4, T0 = V::T0, T1 = V::T1, CPT0 = V::CPT0, CPT1 = V::CPT1;
     // epilogue scratch inside the ring's LDS: us [128 rows][Q] (u = relu(conv1_1)), then the CH-row output staging [CH][C]
-    constexpr int CH = ((128 * Q + 64 * C) * 4 <= D * 1024) ? 64 : 32, MQC = CH / 32;
+    constexpr int CH = ((128 * Q + 64 * C) * 4 <= D * 1024 * MT) ? 64 : 32, MQC = CH / 32;
     constexpr int NEEDF4 = (128 * Q + CH * C) / 4;
-    constexpr int RINGF4 = (D * 64 > NEEDF4) ? D * 64 : NEEDF4;
+    constexpr int RINGF4 = (D * 64 * MT > NEEDF4) ? D * 64 * MT : NEEDF4;
     CHILD_KERNEL_PROLOGUE(V, NW, D, RINGF4)
     float* us = (float*)ring;
     float* stage = us + 128 * Q;
@@ -713,37 +830,42 @@ k_child_irn_b(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
     for (int jj = 0; jj < KQ; ++jj) w12[jj] = ((const float*)lds_raw)[V::FRAG_W12 * frag_floats<V>() + lane * KQ + jj];
     // one unit: a whole tile, or (SPLIT) the four children with one z bit of its 16 parents — see k_child_irn_a.  In a half unit the other
     // half's rows of the scratch hold stale values: they go through conv1_2 like the rest and are never stored.
-    auto unit = [&](auto tag, const int64_t p0) {
+    // (per-lane biases, loaded once: inside the tile loop each was a global load + vmcnt(0) per tile)
+    const int c1 = mi % Q, sub1 = mi / Q, c0 = mi % H, sub0 = mi / H;
+    const float b11 = ep.b1[c1], b01 = ep.b0[c0], b12 = mi < H ? ep.b2[mi] : 0.0f;
+    auto unit = [&](auto tag, const int64_t pu) {
         using VV = typename decltype(tag)::type;
         constexpr int HZ = VV::Z_HALF;
-        f32x4 acc[VV::T];
-        child_tile_mainloop<VV, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
+        f32x4 acc[MT][VV::T];
+        child_tile_mainloop_mt<VV, D, MT>(pnbr, n_p, pu, rs_in, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+        const int64_t p0 = pu + 16 * m;
+        if (m > 0 && p0 >= n_p) break;
+        ChildResidual<C, CH> rr;                                // the first chunk's residual rows: requested before the hand-offs below
+        child_flush_prefetch<C, CH>(rr, 8 * p0, 8 * n_p, ep.x, ep.x_ld, lane, HZ);
         // ---- u = relu(conv1_1 + b11) -> scratch us [local row = 8 (4 mq + r) + child][Q]
         {
-            const int c1 = mi % Q, sub1 = mi / Q;
-            const float b11 = ep.b1[c1];
 #pragma unroll
             for (int u = 0; u < T1; ++u) {
                 if (HZ >= 0 && VV::tile_z(T0 + u) != HZ) continue;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) us[(8 * (4 * mq + r) + u * CPT1 + sub1) * Q + c1] = fmaxf(acc[T0 + u][r] + b11, 0.0f);
+                for (int r = 0; r < 4; ++r) us[(8 * (4 * mq + r) + u * CPT1 + sub1) * Q + c1] = fmaxf(acc[m][T0 + u][r] + b11, 0.0f);
             }
         }
         wave_lds_sync();
         // ---- CH rows at a time: [conv0_1 + b01 | conv1_2(u) + b12] staged row-major, then flushed with the residual x
         {
-            const int c0 = mi % H, sub0 = mi / H;
-            const float b01 = ep.b0[c0];
-            const float b12 = mi < H ? ep.b2[mi] : 0.0f;
 #pragma unroll
             for (int h = 0; h < 128 / CH; ++h) {
+                if (h > 0) child_flush_prefetch<C, CH>(rr, 8 * p0 + h * CH, 8 * n_p, ep.x, ep.x_ld, lane, HZ);
                 if (mq / MQC == h) {
 #pragma unroll
                     for (int t = 0; t < T0; ++t) {
                         if (HZ >= 0 && VV::tile_z(t) != HZ) continue;
                         const int j = t * CPT0 + sub0;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) stage[(8 * (4 * (mq % MQC) + r) + j) * C + c0] = acc[t][r] + b01;
+                        for (int r = 0; r < 4; ++r) stage[(8 * (4 * (mq % MQC) + r) + j) * C + c0] = acc[m][t][r] + b01;
                     }
                 }
 #pragma unroll
@@ -758,27 +880,28 @@ k_child_irn_b(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
                     }
                 }
                 wave_lds_sync();
-                child_flush<C>(stage, CH, 8 * p0 + h * CH, 8 * n_p, ep.out, ep.out_ld, ep.x, ep.x_ld, 0, lane, HZ);
+                child_flush<C, CH>(stage, rr, ep.x != nullptr, 8 * p0 + h * CH, 8 * n_p, ep.out, ep.out_ld, 0, lane, HZ);
                 wave_lds_sync();
             }
         }
+        }
     };
-    const int64_t nunits = SPLIT ? 2 * ntiles : ntiles;
+    const int64_t nunits = (SPLIT ? 2 : 1) * ((n_p + 16 * MT - 1) / (16 * MT));
     for (int i = 0;; ++i) {
         const int64_t u = child_tile<NW>(i, wave, nunits);
         if (u < 0) break;
         CHILD_T(t_it0);
         if constexpr (SPLIT) {
-            if (u & 1) unit(child_type_tag<PassB<C, 1>>{}, (u >> 1) * 16);
-            else unit(child_type_tag<PassB<C, 0>>{}, (u >> 1) * 16);
+            if (u & 1) unit(child_type_tag<PassB<C, 1>>{}, (u >> 1) * (16 * MT));
+            else unit(child_type_tag<PassB<C, 0>>{}, (u >> 1) * (16 * MT));
         } else {
-            unit(child_type_tag<V>{}, u * 16);
+            unit(child_type_tag<V>{}, u * (16 * MT));
         }
 #ifdef PCGC_CHILD_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        { CHILD_T(t_it1); CHILD_TADD(4, t_it0, t_it1); }
+        { CHILD_T(t_dr0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHILD_T(t_it1); CHILD_TADD(5, t_dr0, t_it1); CHILD_TADD(4, t_it0, t_it1); }
 #endif
     }
+    CHILD_TFLUSH;
 }
 
 // pass B at C = 64.  Epilogue per 16-row group g (parents 2g, 2g+1 x 8 children; held by the lanes of quarter g >> 1 in accumulator
@@ -803,9 +926,11 @@ k_child_irn_b64(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __re
         using VV = typename decltype(tag)::type;
         constexpr int HZ = VV::Z_HALF;
         f32x4 acc[VV::T];
-        child_tile_mainloop<VV, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc);
+        child_tile_mainloop<VV, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
         static_for<0, 8>([&](auto ig) {
             constexpr int g = decltype(ig)::value;
+            ChildResidual<64, 16> rr;                           // this group's residual rows: requested ahead of the hand-offs
+            child_flush_prefetch<64, 16>(rr, 8 * p0 + 16 * g, 8 * n_p, ep.x, ep.x_ld, lane, HZ);
             if (mq == (g >> 1)) {
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
@@ -830,7 +955,7 @@ k_child_irn_b64(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __re
                 for (int r = 0; r < 4; ++r) stage[(4 * mq + r) * 64 + 32 + 16 * n2 + mi] = d[r] + (n2 ? b12b : b12a);
             }
             wave_lds_sync();
-            child_flush<64>(stage, 16, 8 * p0 + 16 * g, 8 * n_p, ep.out, ep.out_ld, ep.x, ep.x_ld, 0, lane, HZ);
+            child_flush<64, 16>(stage, rr, ep.x != nullptr, 8 * p0 + 16 * g, 8 * n_p, ep.out, ep.out_ld, 0, lane, HZ);
             wave_lds_sync();
         });
     };
@@ -846,10 +971,10 @@ k_child_irn_b64(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __re
             unit(child_type_tag<V>{}, u * 16);
         }
 #ifdef PCGC_CHILD_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        { CHILD_T(t_it1); CHILD_TADD(4, t_it0, t_it1); }
+        { CHILD_T(t_dr0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHILD_T(t_it1); CHILD_TADD(5, t_dr0, t_it1); CHILD_TADD(4, t_it0, t_it1); }
 #endif
     }
+    CHILD_TFLUSH;
 }
 
 // kernels above the default dynamic-LDS limit need the attribute raised once per (kernel, device)
@@ -867,76 +992,69 @@ int child_lds_limit(K kern, size_t lds, ChildLdsGrant& granted) {
     }
     return 0;
 }
-// persistent grid: as many workgroups as stay resident (LDS-limited, at most 16 waves per CU), a multiple of 8 (one share per XCD)
-static unsigned child_grid(int64_t n_p, int nw, size_t lds, int units_per_tile = 1) {
+// persistent grid: as many workgroups as stay resident (LDS-limited, at most 16 waves per CU), a multiple of 8 (one share per XCD).
+// n_units: work items of the launch (tiles of 16 MT parents, x 2 for half units)
+static unsigned child_grid_units(int64_t n_units, int nw, size_t lds) {
     static int cus = 0;
     if (!cus) { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); cus = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
     int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
     if (per_cu > 16 / nw) per_cu = 16 / nw;
     if (per_cu < 1) per_cu = 1;
-    int64_t want = (((n_p + 15) / 16) * units_per_tile + nw - 1) / nw;
+    int64_t want = (n_units + nw - 1) / nw;
     int64_t g = (int64_t)cus * per_cu;
     if (g > want) g = want;
     g = (g + 7) / 8 * 8;
     return (unsigned)g;
 }
-#define CHILD_LAUNCH(KERN, NW, RINGBYTES, EP)                                                                                  \
+static unsigned child_grid(int64_t n_p, int nw, size_t lds, int units_per_tile = 1) {
+    return child_grid_units(((n_p + 15) / 16) * units_per_tile, nw, lds);
+}
+// KERN, waves per workgroup, ring bytes per wave, epilogue struct, M tiles per wave (MT), units per tile (2 = half units)
+#define CHILD_LAUNCH_EX(KERN, NW, RINGBYTES, EP, MT_, UPT)                                                                     \
     do {                                                                                                                       \
         const size_t lds = (size_t)table_bytes + (size_t)(NW) * (RINGBYTES);                                                   \
         auto kern = KERN;                                                                                                      \
         static ChildLdsGrant granted;                                                                                          \
         if (int rc = child_lds_limit(kern, lds, granted)) return rc;                                                           \
-        hipLaunchKernelGGL(kern, dim3(child_grid(n_p, NW, lds)), dim3((NW) * 64), lds, s, pnbr, n_p, in, in_ld, table, table_bytes, EP); \
+        const int64_t units = ((n_p + 16 * (MT_) - 1) / (16 * (MT_))) * (UPT);                                                 \
+        hipLaunchKernelGGL(kern, dim3(child_grid_units(units, NW, lds)), dim3((NW) * 64), lds, s, pnbr, n_p, in, in_ld, table, table_bytes, EP); \
         return 0;                                                                                                              \
     } while (0)
+#define CHILD_LAUNCH(KERN, NW, RINGBYTES, EP) CHILD_LAUNCH_EX(KERN, NW, RINGBYTES, EP, 1, 1)
+#define CHILD_LAUNCH_SPLIT(KERN, NW, RINGBYTES, EP) CHILD_LAUNCH_EX(KERN, NW, RINGBYTES, EP, 1, 2)      // half units: twice the work items per tile
 
-template <int NB, int NT, int NW, int D>
+template <int NB, int NT, int NW, int D, int MT = 1>
 int launch_child_conv(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
                       const ChildEpi& ep, hipStream_t s) {
-    CHILD_LAUNCH((k_child_conv<NB, NT, NW, D>), NW, D * NB * 1024, ep);
+    CHILD_LAUNCH_EX((k_child_conv<NB, NT, NW, D, false, MT>), NW, D * NB * 1024 * MT, ep, MT, 1);
 }
-// half units: twice the work items per tile
-#define CHILD_LAUNCH_SPLIT(KERN, NW, RINGBYTES, EP)                                                                            \
-    do {                                                                                                                       \
-        const size_t lds = (size_t)table_bytes + (size_t)(NW) * (RINGBYTES);                                                   \
-        auto kern = KERN;                                                                                                      \
-        static ChildLdsGrant granted;                                                                                          \
-        if (int rc = child_lds_limit(kern, lds, granted)) return rc;                                                           \
-        hipLaunchKernelGGL(kern, dim3(child_grid(n_p, NW, lds, 2)), dim3((NW) * 64), lds, s, pnbr, n_p, in, in_ld, table, table_bytes, EP); \
-        return 0;                                                                                                              \
-    } while (0)
 template <int NB, int NT, int NW, int D>
 int launch_child_conv_split(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
                             const ChildEpi& ep, hipStream_t s) {
     CHILD_LAUNCH_SPLIT((k_child_conv<NB, NT, NW, D, true>), NW, D * NB * 1024, ep);
 }
-template <int NB, int NW, int D>
+template <int NB, int NW, int D, int MT = 1>
 int launch_child_cls(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
                      const ChildEpi& ep, hipStream_t s) {
-    CHILD_LAUNCH((k_child_cls<NB, NW, D>), NW, D * NB * 1024, ep);
+    CHILD_LAUNCH_EX((k_child_cls<NB, NW, D, MT>), NW, D * NB * 1024 * MT, ep, MT, 1);
 }
-template <int C, int NW, int D>
+template <int C, int NW, int D, int MT = 1>
 int launch_child_irn_a(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
                        const IrnEpi& ep, hipStream_t s) {
-    CHILD_LAUNCH((k_child_irn_a<C, NW, D>), NW, D * (C / 16) * 1024, ep);
+    CHILD_LAUNCH_EX((k_child_irn_a<C, NW, D, false, MT>), NW, D * (C / 16) * 1024 * MT, ep, MT, 1);
 }
 template <int C, int NW, int D>
 int launch_child_irn_a_split(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
                              const IrnEpi& ep, hipStream_t s) {
-    const size_t lds = (size_t)table_bytes + (size_t)NW * (D * (C / 16) * 1024);
-    auto kern = k_child_irn_a<C, NW, D, true>;
-    static ChildLdsGrant granted;
-    if (int rc = child_lds_limit(kern, lds, granted)) return rc;
-    hipLaunchKernelGGL(kern, dim3(child_grid(n_p, NW, lds, 2)), dim3(NW * 64), lds, s, pnbr, n_p, in, in_ld, table, table_bytes, ep);
-    return 0;
+    CHILD_LAUNCH_SPLIT((k_child_irn_a<C, NW, D, true>), NW, D * (C / 16) * 1024, ep);
 }
-template <int C, int NW, int D>
+template <int C, int NW, int D, int MT = 1>
 int launch_child_irn_b(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
                        const IrnEpi& ep, hipStream_t s) {
-    constexpr int Q = C / 4, CH = ((128 * Q + 64 * C) * 4 <= D * 1024) ? 64 : 32;
+    constexpr int Q = C / 4, CH = ((128 * Q + 64 * C) * 4 <= D * 1024 * MT) ? 64 : 32;
     constexpr int need = (128 * Q + CH * C) * 4;
-    constexpr int ringb = (D * 1024 > need) ? D * 1024 : need;
-    CHILD_LAUNCH((k_child_irn_b<C, NW, D>), NW, ringb, ep);
+    constexpr int ringb = (D * 1024 * MT > need) ? D * 1024 * MT : need;
+    CHILD_LAUNCH_EX((k_child_irn_b<C, NW, D, false, MT>), NW, ringb, ep, MT, 1);
 }
 template <int C, int NW, int D>
 int launch_child_irn_b_split(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
@@ -959,12 +1077,7 @@ int launch_child_irn_b64_split(const int32_t* pnbr, int64_t n_p, const float* in
                                const IrnEpi& ep, hipStream_t s) {
     constexpr int need = (16 * 16 + 16 * 64) * 4;
     constexpr int ringb = (D * 2 * 1024 > need) ? D * 2 * 1024 : need;
-    const size_t lds = (size_t)table_bytes + (size_t)NW * ringb;
-    auto kern = k_child_irn_b64<NW, D, true>;
-    static ChildLdsGrant granted;
-    if (int rc = child_lds_limit(kern, lds, granted)) return rc;
-    hipLaunchKernelGGL(kern, dim3(child_grid(n_p, NW, lds, 2)), dim3(NW * 64), lds, s, pnbr, n_p, in, in_ld, table, table_bytes, ep);
-    return 0;
+    CHILD_LAUNCH_SPLIT((k_child_irn_b64<NW, D, true>), NW, ringb, ep);
 }
 
 }  // namespace

@@ -12,6 +12,45 @@
 #include <c10/core/InferenceMode.h>
 #include <cstdint>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+namespace {
+struct ParamOps {
+    std::vector<float> params;               // the bytes the entry was built from (the blobs below point into this copy)
+    at::Tensor sp[4], bias[4], th[4];
+};
+std::mutex g_po_mu;
+std::vector<std::shared_ptr<const ParamOps>> g_po;          // most recent last; a handful of models at most
+
+std::shared_ptr<const ParamOps> param_ops(const float* params, int C) {
+    const size_t n = (size_t)44 * C;
+    {
+        std::lock_guard<std::mutex> lk(g_po_mu);
+        for (auto it = g_po.rbegin(); it != g_po.rend(); ++it)
+            if ((*it)->params.size() == n && std::memcmp((*it)->params.data(), params, n * sizeof(float)) == 0) return *it;
+    }
+    const int F[5] = {1, 3, 3, 3, 1};
+    const auto f32 = at::TensorOptions().dtype(at::kFloat);
+    auto po = std::make_shared<ParamOps>();
+    po->params.assign(params, params + n);
+    const float* p = po->params.data();
+    for (int i = 0; i < 4; ++i) {                                               // softplus(matrix_i)   entropy_model.py:94
+        po->sp[i] = at::softplus(at::from_blob(const_cast<float*>(p), {C, F[i + 1], F[i]}, f32));
+        p += (int64_t)C * F[i + 1] * F[i];
+    }
+    for (int i = 0; i < 4; ++i) { po->bias[i] = at::from_blob(const_cast<float*>(p), {C, F[i + 1], 1}, f32); p += (int64_t)C * F[i + 1]; }
+    for (int i = 0; i < 4; ++i) {                                               // tanh(factor_i)       entropy_model.py:97
+        po->th[i] = at::tanh(at::from_blob(const_cast<float*>(p), {C, F[i + 1], 1}, f32));
+        p += (int64_t)C * F[i + 1];
+    }
+    std::lock_guard<std::mutex> lk(g_po_mu);
+    if (g_po.size() >= 8) g_po.erase(g_po.begin());
+    g_po.push_back(po);
+    return po;
+}
+}  // namespace
 
 extern "C" int pcgc_reference_table(const float* params /*[host 44*C]: matrices 0..3 | biases 0..3 | factors 0..3*/, int C, float min_v,
                                     float max_v, uint16_t* table_u16 /*[host C, L+1]*/, float* cdf_f32 /*[host C, L+1] or NULL*/) {
@@ -23,23 +62,19 @@ extern "C" int pcgc_reference_table(const float* params /*[host 44*C]: matrices 
         c10::InferenceMode guard;
         const int F[5] = {1, 3, 3, 3, 1};
         const auto f32 = at::TensorOptions().dtype(at::kFloat);
-        at::Tensor sp[4], bias[4], th[4];
-        const float* p = params;
-        for (int i = 0; i < 4; ++i) {                                           // softplus(matrix_i)   entropy_model.py:94
-            const int64_t n = (int64_t)C * F[i + 1] * F[i];
-            sp[i] = at::softplus(at::from_blob(const_cast<float*>(p), {C, F[i + 1], F[i]}, f32));
-            p += n;
-        }
-        for (int i = 0; i < 4; ++i) { bias[i] = at::from_blob(const_cast<float*>(p), {C, F[i + 1], 1}, f32); p += (int64_t)C * F[i + 1]; }
-        for (int i = 0; i < 4; ++i) {                                           // tanh(factor_i)       entropy_model.py:97
-            th[i] = at::tanh(at::from_blob(const_cast<float*>(p), {C, F[i + 1], 1}, f32));
-            p += (int64_t)C * F[i + 1];
-        }
-        // symbols = arange(min_v, max_v + 1).reshape(-1, 1).repeat(1, C); inputs = symbols.permute(1, 0).contiguous().view(C, 1, -1)
+        // softplus(matrix_i) (entropy_model.py:94) and tanh(factor_i) (:97) depend on the parameters only: evaluated once per parameter
+        // set — the same operators on the same tensors, kept like any other re-laid-out weight — not once per table
+        const std::shared_ptr<const ParamOps> po = param_ops(params, C);
+        const at::Tensor* sp = po->sp;
+        const at::Tensor* bias = po->bias;
+        const at::Tensor* th = po->th;
+        // symbols = arange(min_v, max_v + 1).reshape(-1, 1).repeat(1, C); inputs = symbols.permute(1, 0).contiguous().view(C, 1, -1):
+        // a contiguous [C, 1, L] tensor whose every row is arange's values — built here as arange -> expand -> contiguous (same values,
+        // same shape and strides; every operator below sees what it sees in the reference)
         at::Tensor sym = at::arange(at::Scalar((double)min_v), at::Scalar((double)max_v + 1), f32);
-        at::Tensor grid = sym.reshape({-1, 1}).repeat({1, C}).permute({1, 0}).contiguous();
-        const auto shape = grid.sizes().vec();
-        grid = grid.view({shape[0], 1, -1});
+        const int64_t Lsym = sym.size(0);
+        at::Tensor grid = sym.view({1, 1, Lsym}).expand({C, 1, Lsym}).contiguous();
+        const std::vector<int64_t> shape = {C, Lsym};
         at::Tensor ends[2];
         const double half[2] = {-0.5, 0.5};                                      // lower = f(v - 0.5), upper = f(v + 0.5)
         for (int e = 0; e < 2; ++e) {

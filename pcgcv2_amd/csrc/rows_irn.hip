@@ -74,14 +74,14 @@ k_rows_irn_a64(const int32_t* __restrict__ pnbr, int64_t n_p /* rows of the leve
         if (tile < 0) break;
         const int64_t row0 = tile * 16;
         f32x4 acc[V::T];
-        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc);
+        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             scratch[(4 * mq + r) * 32 + mi] = fmaxf(acc[0][r] + b00, 0.0f);
             scratch[(4 * mq + r) * 32 + 16 + mi] = fmaxf(acc[1][r] + b10, 0.0f);
         }
         wave_lds_sync();
-        child_flush<32>(scratch, 16, row0, n_p, ep.out, 32, nullptr, 0, 0, lane);
+        child_flush<32, 16>(scratch, row0, n_p, ep.out, 32, 0, lane);
         wave_lds_sync();
     }
 }
@@ -107,7 +107,9 @@ k_rows_irn_b64(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __res
         if (tile < 0) break;
         const int64_t row0 = tile * 16;
         f32x4 acc[V::T];
-        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc);
+        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
+        ChildResidual<64, 16> rr;                                  // residual rows: requested now, consumed after the staging hand-off
+        child_flush_prefetch<64, 16>(rr, row0, n_p, ep.x, ep.x_ld, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             us[(4 * mq + r) * 16 + mi] = fmaxf(acc[2][r] + b11, 0.0f);
@@ -124,7 +126,7 @@ k_rows_irn_b64(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __res
             for (int r = 0; r < 4; ++r) stage[(4 * mq + r) * 64 + 32 + 16 * n2 + mi] = d[r] + (n2 ? b12b : b12a);
         }
         wave_lds_sync();
-        child_flush<64>(stage, 16, row0, n_p, ep.out, ep.out_ld, ep.x, ep.x_ld, 0, lane);
+        child_flush<64, 16>(stage, rr, ep.x != nullptr, row0, n_p, ep.out, ep.out_ld, 0, lane);
         wave_lds_sync();
     }
 }
@@ -168,11 +170,11 @@ k_rows_irn_a32(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __res
         if (tile < 0) break;
         const int64_t row0 = tile * 16;
         f32x4 acc[V::T];
-        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc);
+        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
 #pragma unroll
         for (int r = 0; r < 4; ++r) scratch[(4 * mq + r) * 16 + mi] = fmaxf(acc[0][r] + bcol, 0.0f);
         wave_lds_sync();
-        child_flush<16>(scratch, 16, row0, n_p, ep.out, 16, nullptr, 0, 0, lane);
+        child_flush<16, 16>(scratch, row0, n_p, ep.out, 16, 0, lane);
         wave_lds_sync();
     }
 }
@@ -197,7 +199,9 @@ k_rows_irn_b32(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __res
         if (tile < 0) break;
         const int64_t row0 = tile * 16;
         f32x4 acc[V::T];
-        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc);
+        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
+        ChildResidual<32, 16> rr;                                  // residual rows: requested now, consumed after the staging hand-off
+        child_flush_prefetch<32, 16>(rr, row0, n_p, ep.x, ep.x_ld, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (mi < 8) us[(4 * mq + r) * 8 + mi] = fmaxf(acc[1][r] + b11, 0.0f);
@@ -210,7 +214,7 @@ k_rows_irn_b32(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __res
 #pragma unroll
         for (int r = 0; r < 4; ++r) stage[(4 * mq + r) * 32 + 16 + mi] = d[r] + b12;
         wave_lds_sync();
-        child_flush<32>(stage, 16, row0, n_p, ep.out, ep.out_ld, ep.x, ep.x_ld, 0, lane);
+        child_flush<32, 16>(stage, rr, ep.x != nullptr, row0, n_p, ep.out, ep.out_ld, 0, lane);
         wave_lds_sync();
     }
 }
@@ -246,7 +250,9 @@ k_rows_conv(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restri
         if (tile < 0) break;
         const int64_t row0 = tile * 16;
         f32x4 acc[V::T];
-        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc);
+        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
+        ChildResidual<W, 16> rr;                                  // residual rows: requested now, consumed after the staging hand-off
+        child_flush_prefetch<W, 16>(rr, row0, n_p, ep.res, ep.res_ld, lane);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -257,7 +263,7 @@ k_rows_conv(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restri
             }
         }
         wave_lds_sync();
-        child_flush<W>(scratch, 16, row0, n_p, ep.out, ep.out_ld, ep.res, ep.res_ld, ep.relu, lane);
+        child_flush<W, 16>(scratch, rr, ep.res != nullptr, row0, n_p, ep.out, ep.out_ld, ep.relu, lane);
         wave_lds_sync();
     }
 }
@@ -302,7 +308,9 @@ k_rows_down(const int32_t* __restrict__ pnbr /* down [8][n_p] */, int64_t n_p /*
         if (tile < 0) break;
         const int64_t row0 = tile * 16;
         f32x4 acc[V::T];
-        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_fine, in_ld, lds_raw, ring, acc);
+        child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_fine, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
+        ChildResidual<W, 16> rr;                                  // residual rows: requested now, consumed after the staging hand-off
+        child_flush_prefetch<W, 16>(rr, row0, n_p, ep.res, ep.res_ld, lane);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -313,7 +321,7 @@ k_rows_down(const int32_t* __restrict__ pnbr /* down [8][n_p] */, int64_t n_p /*
             }
         }
         wave_lds_sync();
-        child_flush<W>(scratch, 16, row0, n_p, ep.out, ep.out_ld, ep.res, ep.res_ld, ep.relu, lane);
+        child_flush<W, 16>(scratch, rr, ep.res != nullptr, row0, n_p, ep.out, ep.out_ld, ep.relu, lane);
         wave_lds_sync();
     }
 }

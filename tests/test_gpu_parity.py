@@ -1128,7 +1128,8 @@ def test_inception_resnet_child_bit_exact(name, prune, C):
     want = orc.inception_resnet(sd, 'b', orc.Level(kc, 1), x)
     params = [p for m in (blk.conv0_0, blk.conv0_1, blk.conv1_0, blk.conv1_1, blk.conv1_2) for p in (m.kernel, m.bias)]
     tables = ops.child_irn_tables(params)
-    for nw, d in ((0, 0), (4, 0)):
+    # (316: pass A with TWO M tiles per wave — 32 parents share every fragment read and wait; C = 16 only, not the product path)
+    for nw, d in ((0, 0), (4, 0)) + (((316, 0),) if C == 16 else ()):
         ops.set_child_tuning(nw, d)
         try:
             if C == 64:
@@ -1466,9 +1467,13 @@ def test_decode_batch_refuses_foreign_header_and_oversized_batches(sd, tmp_path)
     assert len(outs) == 2
     hp = tmp_path / 'b_1_H.bin'
     head = bytearray(hp.read_bytes())
-    head[4:8] = struct.pack('<i', 4096)
+    head[4:8] = struct.pack('<i', 16)                          # a plausible header of ANOTHER model (the library's probe accepts it)
     hp.write_bytes(bytes(head))
     with pytest.raises(ops.PcgcError, match='channels'):
+        coder.decode_batch(['_0', '_1'])
+    head[4:8] = struct.pack('<i', 4096)                        # an implausible one: refused by the probe itself
+    hp.write_bytes(bytes(head))
+    with pytest.raises(ops.PcgcError):
         coder.decode_batch(['_0', '_1'])
     with pytest.raises(ops.PcgcError, match='16'):
         coder.decode_batch([f'_{i}' for i in range(17)])

@@ -10,7 +10,8 @@ from pcgcv2_amd.sparse import CoordMap
 from pcgcv2_amd.autoencoder import InceptionResNet
 
 dev = torch.device('cuda:0')
-L = ctypes.CDLL(os.path.join(ROOT, 'pcgcv2_amd', 'libpcgc_hip.so'))
+from pcgcv2_amd._lib import LIB_PATH
+L = ctypes.CDLL(LIB_PATH)                  # PCGC_LIB=pcgcv2_amd/libpcgc_hip_timing.so (PCGC_BUILD_VARIANT=timing PCGC_EXTRA_HIPCC_FLAGS=-DPCGC_CHILD_TIMING python -m pcgcv2_amd._build)
 
 
 def read(fn):
@@ -48,9 +49,10 @@ def main():
         t = torch.empty((n, C // 2), device=dev); out = torch.empty((n, C), device=dev)
         pk = parent.k3
         s = torch.cuda.current_stream().cuda_stream
-        for d in (0, 1):
-            ops.set_child_tuning(0, d)
-            tag = f'C={C} {"unpipelined" if d else "pipelined"}'
+        codes = [int(a) for a in sys.argv[1:]] or [0]
+        for d in codes:
+            ops.set_child_tuning(d, 0)
+            tag = f'C={C} code {d}'
             report(f'conv {tag}', 'pcgc_child_timing', lambda: ops.conv_child(pk, x, tab, b, C))
             report(f'cls {tag}', 'pcgc_child_timing', lambda: ops.conv_child(pk, x, tc, b[:, :1].contiguous(), 1))
             report(f'irn A {tag}', 'pcgc_child_timing_irn', lambda: lib().pcgc_irn_child_pass(pk.data_ptr(), len(parent), C, 1, x.data_ptr(), C, tabs[0].data_ptr(), tabs[0].numel() * 4, P[1], P[5], None, None, 0, t.data_ptr(), C // 2, s))
