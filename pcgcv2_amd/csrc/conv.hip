@@ -476,6 +476,9 @@ k_conv_gather_mfma(const int32_t* __restrict__ nbr, int K, int64_t n_out, const 
         idx_cur = idx_nxt;
     }
     // ---- epilogue: D[row = 16m + 4*mq + r][col = 16n + mi]
+    float bias_v[NT];                                          // (once per wave: a load inside the store loop is re-issued after every store)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bias_v[n] = bias ? bias[co0 + 16 * n + mi] : 0.0f;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -486,7 +489,7 @@ k_conv_gather_mfma(const int32_t* __restrict__ nbr, int K, int64_t n_out, const 
             for (int n = 0; n < NT; ++n) {
                 const int col = co0 + 16 * n + mi;
                 float v = acc[m][n][r];
-                if (bias) v = v + bias[col];
+                if (bias) v = v + bias_v[n];
                 if (res) v = v + res[row * res_ld + col];
                 if (relu) v = fmaxf(v, 0.0f);
                 out[row * out_ld + col] = v;
@@ -592,6 +595,9 @@ k_conv_gather_mfma_wlds(const int32_t* __restrict__ nbr, int K, int64_t n_out, c
         if (cb == NB - 1) idx_cur = idx_nxt;
     }
     if (!wave_active) return;
+    float bias_v[NT];                                          // (once per wave: a load inside the store loop is re-issued after every store)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bias_v[n] = bias ? bias[16 * n + mi] : 0.0f;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -602,7 +608,7 @@ k_conv_gather_mfma_wlds(const int32_t* __restrict__ nbr, int K, int64_t n_out, c
             for (int n = 0; n < NT; ++n) {
                 const int col = 16 * n + mi;
                 float v = acc[m][n][r];
-                if (bias) v = v + bias[col];
+                if (bias) v = v + bias_v[n];
                 if (res) v = v + res[row * res_ld + col];
                 if (relu) v = fmaxf(v, 0.0f);
                 out[row * out_ld + col] = v;
@@ -772,6 +778,9 @@ k_conv_gather_mfma_pipe(const int32_t* __restrict__ nbr, int K, int64_t n_out, c
         }
     }
     if (!wave_active) return;
+    float bias_v[NT];                                          // (once per wave: a load inside the store loop is re-issued after every store)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bias_v[n] = bias ? bias[16 * n + mi] : 0.0f;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -782,7 +791,7 @@ k_conv_gather_mfma_pipe(const int32_t* __restrict__ nbr, int K, int64_t n_out, c
             for (int n = 0; n < NT; ++n) {
                 const int col = 16 * n + mi;
                 float v = acc[m][n][r];
-                if (bias) v = v + bias[col];
+                if (bias) v = v + bias_v[n];
                 if (res) v = v + res[row * res_ld + col];
                 if (relu) v = fmaxf(v, 0.0f);
                 out[row * out_ld + col] = v;

@@ -1465,14 +1465,16 @@ def test_decode_batch_refuses_foreign_header_and_oversized_batches(sd, tmp_path)
     coder.encode_batch(xb, ['_0', '_1'])
     outs = coder.decode_batch(['_0', '_1'])
     assert len(outs) == 2
-    hp = tmp_path / 'b_1_H.bin'
-    head = bytearray(hp.read_bytes())
-    head[4:8] = struct.pack('<i', 16)                          # a plausible header of ANOTHER model (the library's probe accepts it)
-    hp.write_bytes(bytes(head))
+    heads = {}
+    for b in (0, 1):                                           # plausible headers of ANOTHER model on every item (the library's probe accepts them)
+        hp = tmp_path / f'b_{b}_H.bin'
+        heads[b] = bytearray(hp.read_bytes())
+        heads[b][4:8] = struct.pack('<i', 16)
+        hp.write_bytes(bytes(heads[b]))
     with pytest.raises(ops.PcgcError, match='channels'):
         coder.decode_batch(['_0', '_1'])
-    head[4:8] = struct.pack('<i', 4096)                        # an implausible one: refused by the probe itself
-    hp.write_bytes(bytes(head))
+    heads[1][4:8] = struct.pack('<i', 4096)                    # items that disagree: refused by the probe itself
+    (tmp_path / 'b_1_H.bin').write_bytes(bytes(heads[1]))
     with pytest.raises(ops.PcgcError):
         coder.decode_batch(['_0', '_1'])
     with pytest.raises(ops.PcgcError, match='16'):
