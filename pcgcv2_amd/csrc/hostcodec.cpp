@@ -1164,9 +1164,9 @@ extern "C" int pcgc_items_encode(int n_items, const char* const* stems, const in
         const int L = (int)(max_v - min_v) + 1, Lp = L + 1;
         std::shared_ptr<const std::vector<uint16_t>> tptr;
         uint32_t table_crc = 0;
+        StageClock clk;
         if (cached_table(table_fn, eb_params, C, min_v, max_v, tptr, table_crc) != 0) { err = "CDF table evaluation failed"; return -1; }
         const std::vector<uint16_t>& table = *tptr;
-        StageClock clk;
         clk.mark("table");
         int segs = (int)std::min<int64_t>(index_segments, n / 1024);
         if (segs < 2) segs = 0;

@@ -25,9 +25,15 @@ sys.stderr.flush()
 keep = os.dup(2)
 os.dup2(log.fileno(), 2)
 try:
+    from pcgcv2_amd import entropy_model, coder as coder_mod
+    cold = os.environ.get('COLD_TABLES', '1') != '0'               # bench.py's default: every encode and every decode evaluates its table
+    coder_mod.WARM_TABLE_CODE = os.environ.get('WARM_CODE', '1') != '0'
     for i in range(N + 5):
         x.cmap.drop_caches()
-        coder.encode(x); coder.decode(); torch.cuda.synchronize()
+        if cold: entropy_model.table_cache(clear=True)
+        coder.encode(x)
+        if cold: entropy_model.table_cache(clear=True)
+        coder.decode(); torch.cuda.synchronize()
 finally:
     os.dup2(keep, 2)
 stages = collections.defaultdict(list)
