@@ -133,6 +133,10 @@ int pcgc_compact_index(const uint8_t* mask, const int32_t* prefix, int64_t n, in
 int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in /*rows of `in`*/, int Cin,
                      int in_ld, int in_coff, const float* W, const float* bias, const float* residual, int res_ld,
                      int res_coff, int relu, float* out, int Cout, int out_ld, int out_coff, void* stream);
+/* Which kernel family the calling thread's last pcgc_conv_gather launched (0 v0 VALU | 1 v1 LDS-DMA + VALU | 2 v2 MFMA | 3 v2b MFMA with
+ * LDS-shared weights, 2 M tiles | 4 v2b, 4 M tiles | 5 v1 burst | 6 row-split | 7 v2c MFMA, both operands in LDS; -1 none yet).  The policy
+ * is written down once, in pcgcv2_amd/dispatch.py; the parity tests read this back for every entry of that table.  HOST. */
+int pcgc_last_conv_impl(void);
 /* kernel selection for the gather conv: -1 auto (default), 0 = v0 direct-load kernel, 1 = v1 LDS-DMA kernel, 2 / 3 = the fp32-MFMA
  * kernels, 5 / 6 = the 16-row "burst" and row-split forms that small levels get (each where eligible).  All produce bit-identical results; the
  * switch exists for A/B measurements and tests. */

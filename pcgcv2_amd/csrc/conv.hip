@@ -1480,6 +1480,12 @@ static int g_auto_wlds = 1;         // auto: LDS-shared-weight MFMA kernel for 6
                                     // bank-conflict free, 32->32 (181 -> 168 us at 256 k rows, 400 -> 374 at 570 k)
 static int g_auto_mfma = 1;         // auto mode uses the MFMA kernel for its eligible shapes once A/B says so
 extern "C" int pcgc_set_conv_impl(int impl) { g_conv_impl = impl; return 0; }
+// Which kernel family the calling thread's last pcgc_conv_gather launched: 0 v0 (VALU, direct loads) | 1 v1 (LDS-DMA + VALU) | 2 v2 (MFMA,
+// weights from L2) | 3 v2b (MFMA, LDS-shared weights, 2 M tiles per wave) | 4 v2b with 4 M tiles | 5 v1 burst | 6 row-split | 7 v2c (MFMA,
+// both operands double-buffered in LDS).  The size / shape policy lives in ONE table, pcgcv2_amd/dispatch.py; the GPU tests read this
+// back for every entry of that table, on both sides of every gate, and compare it with the table's prediction.
+static thread_local int t_last_conv_impl = -1;
+extern "C" int pcgc_last_conv_impl(void) { return t_last_conv_impl; }
 static int64_t g_wlds_mt4_rows = 400000;   // the LDS-shared-weight MFMA kernel runs 4 M-tiles per wave (MT = 4) from this many rows on, 2 below
 extern "C" int pcgc_set_wlds_mt4_rows(int64_t min_rows) { g_wlds_mt4_rows = min_rows < 0 ? 400000 : min_rows; return 0; }
 
@@ -1509,15 +1515,19 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
         const float* res0 = residual ? residual + res_coff : nullptr;
         float* out0 = out + out_coff;
         const bool pipe = g_mfma_pipe > 0 || (g_mfma_pipe < 0 && n_out < 110000);        // 64->64: 248 -> 220 us at 71 k rows, 381 -> 395 at 150 k
-        if (Cin == 64 && pipe) launch_mfma_pipe<64, 64, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
+        if (Cin == 64 && pipe) { t_last_conv_impl = 7; launch_mfma_pipe<64, 64, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s); }
         else if (Cin == 64) {
+            t_last_conv_impl = n_out < g_wlds_mt4_rows ? 3 : 4;
             if (n_out < g_wlds_mt4_rows) launch_mfma_wlds<64, 64, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
             else launch_mfma_wlds<64, 64, 4>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         } else if (pipe && g_conv_impl < 0) {
+            t_last_conv_impl = 7;
             launch_mfma_pipe<32, 32, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         } else if (g_mfma_pipe > 0) {
+            t_last_conv_impl = 7;
             launch_mfma_pipe<32, 32, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         } else {
+            t_last_conv_impl = n_out < g_wlds_mt4_rows ? 3 : 4;
             if (n_out < g_wlds_mt4_rows) launch_mfma_wlds<32, 32, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
             else launch_mfma_wlds<32, 32, 4>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         }
@@ -1537,7 +1547,7 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
         if (Cin == 16) ok = dispatch_mfma<16>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         else if (Cin == 32) ok = dispatch_mfma<32>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         else ok = dispatch_mfma<64>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
-        if (ok) { PCGC_CHECK_LAUNCH("conv_gather_mfma"); return 0; }
+        if (ok) { t_last_conv_impl = 2; PCGC_CHECK_LAUNCH("conv_gather_mfma"); return 0; }
     }
     if (v1_eligible && K == 27 && Cin <= 32 && Cout <= 16 && (Cout & 3) == 0 && (g_conv_impl == 6 || split_first)) {
         const float* res0 = residual ? residual + res_coff : nullptr;       // (conv3 32->8 at 18.7 k rows: 71 us on v0, 42 us on the burst form)
@@ -1547,7 +1557,7 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
         else if (Cin == 16) rc = dispatch_split<16>(Cout, nbr, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         else if (Cin == 32) rc = dispatch_split<32>(Cout, nbr, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         if (rc < 0) return rc;
-        if (rc == 0) { PCGC_CHECK_LAUNCH("conv_gather_split"); return 0; }
+        if (rc == 0) { t_last_conv_impl = 6; PCGC_CHECK_LAUNCH("conv_gather_split"); return 0; }
     }
     if (v1_eligible && K == 27 && Cin <= 32 && Cout <= 16 && (g_conv_impl == 5 || (g_conv_impl < 0 && n_out < 40000))) {
         const float* res0 = residual ? residual + res_coff : nullptr;
@@ -1557,7 +1567,7 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
         else if (Cin == 16) rc = dispatch_burst<16>(Cout, nbr, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         else if (Cin == 32) rc = dispatch_burst<32>(Cout, nbr, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         if (rc < 0) return rc;
-        if (rc == 0) { PCGC_CHECK_LAUNCH("conv_gather_burst"); return 0; }
+        if (rc == 0) { t_last_conv_impl = 5; PCGC_CHECK_LAUNCH("conv_gather_burst"); return 0; }
     }
     if (v1_eligible && v1_wanted) {
         const float* res0 = residual ? residual + res_coff : nullptr;
@@ -1567,8 +1577,9 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
         else if (Cin == 16) ok = dispatch_dma_cout<16>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         else if (Cin == 32) ok = dispatch_dma_cout<32>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         else ok = dispatch_dma_cout<64>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
-        if (ok) { PCGC_CHECK_LAUNCH("conv_gather_dma"); return 0; }
+        if (ok) { t_last_conv_impl = 1; PCGC_CHECK_LAUNCH("conv_gather_dma"); return 0; }
     }
+    t_last_conv_impl = 0;
 #define PCGC_CASE(C) case C: launch_valu<C>(nbr, K, n_out, in, Cin, in_ld, in_coff, W, bias, residual, res_ld, res_coff, relu, out, out_ld, out_coff, s); break;
     switch (Cout) {
         PCGC_CASE(1) PCGC_CASE(4) PCGC_CASE(8) PCGC_CASE(16) PCGC_CASE(32) PCGC_CASE(64)

@@ -1,0 +1,160 @@
+"""ONE table: which kernel family serves which (operator, channel shape, level kind, level size).
+
+Rounds 1-3 grew six InceptionResNet implementations, eight gather-conv families and three "rows" kernels, picked by a ladder of
+`if`s spread over autoencoder.py, nn.py, ops.py and the native entry point pcgc_conv_gather.  This module is the single place where
+that policy is written down.  `select(op, ...)` returns the entry that applies; nn.MinkowskiConvolution / autoencoder.InceptionResNet
+switch on its `family` and nothing else.  For the gather family the native library still walks its own ladder (csrc/conv.hip) — the
+table PREDICTS it (`gather_impl`) and tests/test_gpu_parity.py::test_dispatch_table_* read back what was actually launched
+(pcgc_last_conv_impl, pcgc_irn_config) for every entry, on both sides of every row-count gate, and compare the output with the oracle:
+an instantiation that is reachable is an instantiation that has a parity test.
+
+Every family of one operator computes the same canonical fmaf chain: the choice affects speed, never a bit of the result.
+Gates are measured (tools/gate_ab.py, tools/rows_gate_ab.py, tools/rows_vs_child64.py; numbers in the `why` column).
+
+The A/B switches (ops.CHILD_MFMA, ops.ROWS_*, ops.MFMA_IRN, ops.FUSE_IRN, ops.UNIT_INPUT_CONV) stay what they were — module attributes
+the tests flip — and are consulted here, by name, at call time.  Nothing in the product path writes them, and nothing in the product
+path calls a process-wide `pcgc_set_*` knob: concurrent coders cannot race on the policy.
+"""
+from collections import namedtuple
+
+from . import ops
+
+LIMIT = 0xF0000000          # the LDS-DMA kernels address rows with 32-bit buffer offsets: rows * row bytes must stay below this
+
+# op:       'conv3' (k3 s1) | 'irn' (a whole InceptionResNet block) | 'down' (k2 s2) | 'conv1' (k1) | 'up' (generative transpose k2 s2)
+# shape:    (cin, cout) pairs the entry serves, or None = any
+# level:    'children' (rows 8 p + j of a generative transpose: convs can run through the PARENT level's map) | 'plain' | None = any
+# rows:     [rows_min, rows_max) of the level the operator runs on (ints, or names of ops.* attributes the tests move)
+# switch:   name of the ops.* boolean that must be on (None = always)
+# family:   what nn.py / autoencoder.py switch on
+# kernel:   the kernel template(s) behind it
+Rule = namedtuple('Rule', 'op shape level rows_min rows_max switch family kernel why')
+INF = 1 << 62
+
+TABLE = (
+    # ---- k3 s1 convolutions ---------------------------------------------------------------------------------------------------------
+    Rule('conv3', ((16, 16), (32, 32), (16, 1), (32, 1), (64, 1)), 'children', 8192, INF, 'CHILD_MFMA', 'child',
+         'k_child_conv<1,1> / k_child_conv<2,2,split> / k_child_cls<NB>',
+         'halo gather through the parent map, packed-N fp32 MFMA: conv 16->16 436 -> 259 us on 2.05 M rows, cls 16->1 209 -> 85'),
+    Rule('conv3', ((1, 4), (1, 8), (1, 16)), None, 0, INF, 'UNIT_INPUT_CONV', 'unit', 'k_conv_unit<COUT>',
+         'all-ones occupancy input (x.has_unit_features()): sum of kernel slices over the present offsets, no feature gathers: 88 -> 55 us'),
+    Rule('conv3', ((32, 32),), None, 'ROWS_CONV_MIN', INF, 'ROWS_CONV', 'rows', 'k_rows_conv<2,2>',
+         'LDS-resident fragment table, one wave per 16-row tile: 34 vs 51 us at 1-18 k rows, 127 vs 159 at 256 k'),
+    Rule('conv3', None, None, 0, INF, None, 'gather', 'pcgc_conv_gather (see GATHER below)', 'every other shape / size'),
+    # ---- InceptionResNet blocks ----------------------------------------------------------------------------------------------------
+    Rule('irn', (64,), 'children+own_map', 8192, INF, 'ROWS_IRN64_CHILD', 'rows64', 'k_rows_irn_a64<.., RowsPassA64H> + k_rows_irn_b64',
+         "the level's own map exists already (its 64->64 conv ran on the gather kernels): plain-rows form 171 vs 197 us per block at 150 k rows"),
+    Rule('irn', (64,), 'children', 8192, INF, 'CHILD_MFMA', 'child64', 'k_child_irn_a<64,split> + k_child_irn_b64<split>',
+         'both passes through the parent map in half units: 104 / 89 us at 150 k rows'),
+    Rule('irn', (16, 32), 'children', 8192, INF, 'CHILD_MFMA', 'child', 'k_child_irn_a<C> + k_child_irn_b<C> (C = 32: half units)',
+         'packed-N MFMA passes through the parent map: C = 16 212/170 -> 118/102 us on 2.05 M rows, C = 32 174/130 -> 100/81 on 570 k'),
+    Rule('irn', (64,), None, 'ROWS_IRN64_MIN', INF, 'ROWS_IRN64', 'rows64', 'k_rows_irn_a64 + k_rows_irn_b64',
+         'plain level: 65 vs 135 us per block at 1-18 k rows, 103 vs 198 at 71 k'),
+    Rule('irn', (32,), None, 'ROWS_IRN32_MIN', 'ROWS_IRN32_MAX+1', 'ROWS_IRN32', 'rows32', 'k_rows_irn_a32 + k_rows_irn_b32',
+         'plain level: 47 vs 74 us per block at 49 k rows, 119 vs 127 at 256 k'),
+    Rule('irn', (64,), None, 512, INF, 'MFMA_IRN', 'mfma64', 'k_conv_gather_mfma_wlds/pipe<64,32> + <32,48> + k_irn_tail<64>',
+         'block-sparse MFMA passes (only when the rows kernels are switched off): 117-123 us per block at 1-18 k rows against 177-220'),
+    Rule('irn', (16, 32, 64), None, 0, INF, 'FUSE_IRN', 'valu', 'k_irn_a<C,ROWS> + k_irn_b<C,ROWS> (pcgc_irn_config picks ROWS / split)',
+         'two fused gather passes on the VALU: small levels and C = 16 on plain levels'),
+    Rule('irn', None, None, 0, INF, None, 'unfused', 'five MinkowskiConvolution calls + fused epilogues', 'any other channel count'),
+    # ---- k2 s2 down convolutions -------------------------------------------------------------------------------------------------------
+    Rule('down', ((16, 32), (32, 64), (64, 32)), None, 'ROWS_DOWN_MIN', INF, 'ROWS_DOWN', 'rows_down', 'k_rows_down<NB,NT>',
+         'tile = 16 coarse rows walking the 8 child offsets: 121 -> ~65 us for the three down convs of a vox10 frame (rows = COARSE rows)'),
+    Rule('down', None, None, 0, INF, None, 'gather', 'pcgc_conv_gather, K = 8', 'other shapes / tiny levels'),
+    Rule('conv1', None, None, 0, INF, None, 'gather', 'pcgc_conv_gather, K = 1 (k_conv_gather_valu)', 'k1 convs outside fused blocks'),
+    Rule('up', None, None, 0, INF, None, 'up2', 'k_conv_up2_mfma<64,32> / <32,16>, k_conv_up2_rows otherwise', 'generative transpose, one kernel per shape'),
+)
+
+# pcgc_conv_gather's own ladder (csrc/conv.hip), restated: -> the impl code pcgc_last_conv_impl() reports.
+GATHER_IMPL_NAMES = {0: 'k_conv_gather_valu (v0)', 1: 'k_conv_gather_dma (v1)', 2: 'k_conv_gather_mfma (v2)', 3: 'k_conv_gather_mfma_wlds<..,2> (v2b)',
+                     4: 'k_conv_gather_mfma_wlds<..,4> (v2b)', 5: 'k_conv_gather_burst (v1, 16-row tiles)', 6: 'k_conv_gather_split (row-split)',
+                     7: 'k_conv_gather_mfma_pipe (v2c)'}
+GATHER_GATES = {'wide_min_rows_64': 8192, 'pipe_below': 110000, 'wlds_mt4_from': 400000, 'mfma_min_rows': 512, 'split_below_cout8': 150000,
+                'split_below_cout16': 40000, 'burst_below': 40000, 'dma_from': 30000}
+
+
+def gather_impl(K, cin, cout, rows, aligned=True):
+    """The kernel family pcgc_conv_gather launches in auto mode for a [K, cin, cout] kernel on `rows` output rows (aligned: 16-byte
+    aligned rows and weights, tensors below the 32-bit offset limit, a real kernel map)."""
+    g = GATHER_GATES
+    v1 = aligned and K <= 27 and cin in (8, 16, 32, 64)
+    if v1 and K == 27 and (cin, cout) in ((64, 64), (32, 32)) and (cin == 32 or rows >= g['wide_min_rows_64']):
+        if rows < g['pipe_below']:
+            return 7
+        return 3 if rows < g['wlds_mt4_from'] else 4
+    split_first = K == 27 and cin <= 32 and cout <= 16 and rows < (g['split_below_cout8'] if cout <= 8 else g['split_below_cout16'])
+    if v1 and cin in (16, 32, 64) and cout in (16, 32, 64) and not split_first and rows >= g['mfma_min_rows']:
+        return 2
+    if v1 and K == 27 and cin <= 32 and cout in (4, 8, 16) and split_first:
+        return 6
+    if v1 and K == 27 and cin <= 32 and cout in (1, 4, 8, 16) and rows < g['burst_below']:
+        return 5
+    if v1 and rows >= g['dma_from'] and cout in (1, 4, 8, 16, 32, 64):
+        return 1
+    return 0
+
+
+def _value(v):
+    """a gate: an int, or the name of an ops attribute (optionally '+1': an inclusive upper bound turned exclusive)"""
+    if isinstance(v, str):
+        name, plus, inc = v.partition('+')
+        return getattr(ops, name) + (int(inc) if plus else 0)
+    return v
+
+
+def _switch_on(rule):
+    if rule.switch is None:
+        return True
+    if rule.switch == 'ROWS_IRN64_CHILD':
+        return ops.ROWS_IRN64 and ops.ROWS_IRN64_CHILD and ops.CHILD_MFMA
+    return bool(getattr(ops, rule.switch))
+
+
+def select(op, shape, rows, level='plain', extent=None, own_map=False, contiguous=True, unit_input=False, plain_output=True):
+    """-> the first Rule of TABLE that applies.  shape: (cin, cout), or (C,) for 'irn'; rows: rows of the level the operator runs on
+    (the COARSE rows for 'down'); level: 'children' | 'plain'; extent: bytes of the largest tensor the kernel would address with 32-bit
+    buffer offsets (rows x leading dimension x 4; default rows x width x 4) — beyond LIMIT the generic kernels take over; own_map: the
+    children level's own k3 map has been built already; contiguous: the feature tensor is dense; unit_input: the input is the all-ones
+    occupancy indicator; plain_output: no `out=` / `residual=` (the unit and down kernels have no fused epilogue for those)."""
+    width = shape[0]
+    extent = rows * 4 * width if extent is None else extent
+    key = tuple(shape) if len(shape) > 1 else shape[0]
+    for rule in TABLE:
+        if rule.op != op or (rule.shape is not None and key not in rule.shape):
+            continue
+        if not (_value(rule.rows_min) <= rows < _value(rule.rows_max)) or not _switch_on(rule):
+            continue
+        if rule.level is not None and (level != 'children' or (rule.level == 'children+own_map' and not own_map)):
+            continue
+        fam = rule.family
+        if fam in ('child', 'child64', 'rows', 'rows64', 'rows32', 'rows_down') and extent >= LIMIT:
+            continue                                                     # beyond 32-bit buffer offsets: the generic kernels take it
+        if op == 'irn' and fam != 'unfused' and (not ops.FUSE_IRN or rows * 4 * width >= 0xFFFFFFF0):
+            continue
+        if fam in ('child', 'child64') and op == 'irn' and not contiguous:
+            continue
+        if fam == 'unit' and not (unit_input and plain_output):
+            continue
+        if fam == 'rows_down' and not plain_output:
+            continue
+        return rule
+    raise ops.PcgcError(f'dispatch: no kernel for {op} {shape} on a {level} level of {rows} rows')
+
+
+def entries():
+    """(rule, gate row counts) for the exhaustive test: every rule with the row counts just inside its window (both ends)."""
+    out = []
+    for rule in TABLE:
+        lo, hi = _value(rule.rows_min), _value(rule.rows_max)
+        out.append((rule, [r for r in (lo, hi - 1) if 0 < r < INF]))
+    return out
+
+
+def describe():
+    """The table as text (DESIGN.md §5 prints this)."""
+    lines = []
+    for r in TABLE:
+        lo, hi = _value(r.rows_min), _value(r.rows_max)
+        rng = f'{lo}..' + ('' if hi >= INF else str(hi - 1))
+        lines.append(f'{r.op:6s} {str(r.shape or "any"):48s} {str(r.level or "any"):18s} rows {rng:16s} -> {r.family:9s} {r.kernel}')
+    return '\n'.join(lines)

@@ -4,7 +4,7 @@ checkpoints (`torch.load(p)['model']`, coder.py:141-142) load with a strict load
 import math
 import torch
 
-from . import ops
+from . import dispatch, ops
 from .sparse import SparseTensor
 
 
@@ -33,42 +33,47 @@ class MinkowskiConvolution(_ConvBase):
 
     def forward(self, x, relu=False, out=None, residual=None):
         k, s = self.kernel_size, self.stride
-        if k == 3 and s == 1 and ops.child_conv_eligible(x, self.in_channels, self.out_channels):
-            # children level (output of a generative transpose): gather through the PARENT level's map, csrc/child.hip
-            stamp = (self.kernel.data_ptr(), self.kernel._version)
-            if getattr(self, '_child_stamp', None) != stamp:
-                build = ops.child_cls_table if self.out_channels == 1 else ops.child_conv_table
-                self._child_table, self._child_stamp = build(self.kernel), stamp
-            y = ops.conv_child(x.cmap.origin[1].k3, x.F, self._child_table, self.bias, self.out_channels, out=out,
-                               residual=residual, relu=relu)
-            return SparseTensor(y, coordinate_map=x.cmap)
-        elif k == 3 and s == 1 and self.in_channels == 1 and x.has_unit_features() and ops.UNIT_INPUT_CONV and out is None and residual is None \
-                and self.out_channels in (4, 8, 16):
-            # the codec's first layer on the occupancy indicator (all ones): a sum of kernel slices over the present offsets
-            return SparseTensor(ops.conv_gather_unit(x.cmap.k3, self.kernel, self.bias, relu=relu), coordinate_map=x.cmap)
-        elif k == 3 and s == 1 and ops.conv_rows_eligible(x, self.in_channels, self.out_channels):
-            # plain level, 32 -> 32 (the encoder's conv1): LDS-resident fragment table, one wave per 16-row tile (csrc/rows_irn.hip)
-            stamp = (self.kernel.data_ptr(), self.kernel._version)
-            if getattr(self, '_child_stamp', None) != stamp:
-                self._child_table, self._child_stamp = ops.child_conv_table(self.kernel), stamp
-            y = ops.conv_rows(x.cmap.k3, x.F, self._child_table, self.bias, self.out_channels, out=out, residual=residual, relu=relu)
-            return SparseTensor(y, coordinate_map=x.cmap)
-        elif k == 3 and s == 1:
+        cin, cout = self.in_channels, self.out_channels
+        plain_out = out is None and residual is None
+        if k == 3 and s == 1:
+            # which kernel family: ONE table (pcgcv2_amd/dispatch.py)
+            level = 'children' if x.cmap.origin is not None and x.cmap.origin[0] == 'children' else 'plain'
+            fam = dispatch.select('conv3', (cin, cout), x.F.shape[0], level, extent=x.F.shape[0] * x.F.stride(0) * 4,
+                                  unit_input=cin == 1 and x.has_unit_features(), plain_output=plain_out).family
+            if fam == 'child':
+                # children level (output of a generative transpose): gather through the PARENT level's map, csrc/child_kernels.h
+                table = self._table(ops.child_cls_table if cout == 1 else ops.child_conv_table)
+                y = ops.conv_child(x.cmap.origin[1].k3, x.F, table, self.bias, cout, out=out, residual=residual, relu=relu)
+                return SparseTensor(y, coordinate_map=x.cmap)
+            if fam == 'unit':
+                # the codec's first layer on the occupancy indicator (all ones): a sum of kernel slices over the present offsets
+                return SparseTensor(ops.conv_gather_unit(x.cmap.k3, self.kernel, self.bias, relu=relu), coordinate_map=x.cmap)
+            if fam == 'rows':
+                # 32 -> 32 (the encoder's conv1): LDS-resident fragment table, one wave per 16-row tile (csrc/rows_irn.hip)
+                y = ops.conv_rows(x.cmap.k3, x.F, self._table(ops.child_conv_table), self.bias, cout, out=out, residual=residual, relu=relu)
+                return SparseTensor(y, coordinate_map=x.cmap)
             cmap, nbr = x.cmap, x.cmap.k3
         elif k == 1 and s == 1:
             cmap, nbr = x.cmap, None
         elif k == 2 and s == 2:
             cmap, nbr = x.cmap.down()
-            if out is None and residual is None and ops.conv_down_rows_eligible(x, self.in_channels, self.out_channels, nbr.shape[1]):
+            fam = dispatch.select('down', (cin, cout), nbr.shape[1], extent=max(x.F.shape[0] * x.F.stride(0), nbr.shape[1] * cout) * 4,
+                                  plain_output=plain_out).family
+            if fam == 'rows_down':
                 # LDS-resident fragment table, one wave per 16 coarse rows walking the 8 child offsets (csrc/rows_irn.hip)
-                stamp = (self.kernel.data_ptr(), self.kernel._version)
-                if getattr(self, '_child_stamp', None) != stamp:
-                    self._child_table, self._child_stamp = ops.child_conv_table(self.kernel), stamp
-                return SparseTensor(ops.conv_down_rows(nbr, x.F, self._child_table, self.bias, self.out_channels, relu=relu), coordinate_map=cmap)
+                y = ops.conv_down_rows(nbr, x.F, self._table(ops.child_conv_table), self.bias, cout, relu=relu)
+                return SparseTensor(y, coordinate_map=cmap)
         else:
             raise NotImplementedError(f'MinkowskiConvolution(kernel_size={k}, stride={s}) is not on the PCGCv2 path')
         y = ops.conv_gather(nbr, x.F, self.kernel, self.bias, out=out, residual=residual, relu=relu)
         return SparseTensor(y, coordinate_map=cmap)
+
+    def _table(self, build):
+        """the layer's kernel re-laid-out as MFMA B fragments, rebuilt whenever the parameter tensor was replaced or modified"""
+        stamp = (self.kernel.data_ptr(), self.kernel._version, build.__name__)
+        if getattr(self, '_child_stamp', None) != stamp:
+            self._child_table, self._child_stamp = build(self.kernel), stamp
+        return self._child_table
 
 
 class MinkowskiGenerativeConvolutionTranspose(_ConvBase):

@@ -720,30 +720,12 @@ def irn_block_rows32(nbr, x, params, tables):
     return out
 
 
-def irn_eligible(x):
-    return FUSE_IRN and x.shape[1] in (16, 32, 64) and x.shape[0] * x.shape[1] * 4 < 0xFFFFFFF0
-
-
 # ------------------------------------------------------------------------------------------------ children-level convs
 CHILD_MFMA = True         # k3 convs on children levels go through the parent map (csrc/child.hip); A/B switch for tests
 
 
 def set_child_tuning(waves=0, depth=0):
     check(lib().pcgc_set_child_tuning(int(waves), int(depth)), 'set_child_tuning')
-
-
-def child_conv_eligible(x, cin, cout):
-    """k3 conv of a SparseTensor living on a children level, in a shape the parent-map MFMA kernels are built for."""
-    org = x.cmap.origin
-    return (CHILD_MFMA and org is not None and org[0] == 'children' and (cin, cout) in ((16, 16), (32, 32), (16, 1), (32, 1), (64, 1))
-            and x.F.shape[0] >= 8192 and x.F.shape[0] * x.F.stride(0) * 4 < 0xF0000000)
-
-
-def irn_child_eligible(x):
-    """InceptionResNet on a children level with C = 16 or 32 (the two large decoder levels)."""
-    org = x.cmap.origin
-    return (CHILD_MFMA and org is not None and org[0] == 'children' and x.F.shape[1] in (16, 32, 64) and x.F.shape[0] >= 8192
-            and x.F.is_contiguous() and x.F.shape[0] * x.F.shape[1] * 4 < 0xF0000000)
 
 
 def _halo_cells():
@@ -999,10 +981,6 @@ ROWS_CONV = _os.environ.get('PCGC_ROWS_CONV', '1') != '0'      # k3 32 -> 32 on 
 ROWS_CONV_MIN = 1024      # rows from which that path is taken (tools/rows_gate_ab.py: 34 vs 51 us at 1.1-18 k rows, 127 vs 159 at 256 k)
 
 
-def conv_rows_eligible(x, cin, cout):
-    return ROWS_CONV and cin == 32 and cout == 32 and x.F.shape[0] >= ROWS_CONV_MIN and x.F.shape[0] * x.F.shape[1] * 4 < 0xF0000000
-
-
 def conv_rows(nbr, x, table, bias, Cout, out=None, residual=None, relu=False):
     """k3 conv 32 -> 32 on a plain level through its own map (csrc/rows_irn.hip: k_rows_conv); table = child_conv_table(kernel)."""
     _f32(x, 'x')
@@ -1029,12 +1007,6 @@ def conv_rows(nbr, x, table, bias, Cout, out=None, residual=None, relu=False):
 
 ROWS_DOWN = _os.environ.get('PCGC_ROWS_DOWN', '1') != '0'      # k2 s2 down convs: LDS-resident table, one wave per 16 coarse rows; A/B switch
 ROWS_DOWN_MIN = 1024
-
-
-def conv_down_rows_eligible(x, cin, cout, n_coarse):
-    # (both tensors are addressed with 32-bit offsets: input rows through the buffer descriptor, output rows in the staged epilogue)
-    return ROWS_DOWN and (cin, cout) in ((16, 32), (32, 64), (64, 32)) and n_coarse >= ROWS_DOWN_MIN and x.F.shape[0] * x.F.stride(0) * 4 < 0xF0000000 \
-        and n_coarse * cout * 4 < 0xF0000000
 
 
 def conv_down_rows(down, x, table, bias, Cout, relu=False):

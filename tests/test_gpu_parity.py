@@ -23,7 +23,7 @@ def _t(a, dt=None):
 def _restore_path_switches():
     """the A/B switches of the rows kernels are module globals some tests flip: whatever a test leaves behind is undone"""
     names = ('ROWS_IRN64', 'ROWS_IRN64_CHILD', 'ROWS_IRN64_MIN', 'ROWS_IRN32', 'ROWS_IRN32_MIN', 'ROWS_IRN32_MAX', 'ROWS_CONV', 'ROWS_CONV_MIN',
-             'ROWS_DOWN', 'ROWS_DOWN_MIN')
+             'ROWS_DOWN', 'ROWS_DOWN_MIN', 'UNIT_INPUT_CONV', 'CHILD_MFMA', 'MFMA_IRN', 'FUSE_IRN')
     keep = {n: getattr(ops, n) for n in names}
     yield
     for n, v in keep.items():
@@ -337,7 +337,8 @@ def test_fused_inception_resnet_bit_exact(C, rows):
     xs = SparseTensor(_t(x), coordinate_map=lvl)
     sd = {'b.' + k: v.detach().cpu().numpy() for k, v in blk.state_dict().items()}
     want = orc.inception_resnet(sd, 'b', orc.Level(c4, 1), x)
-    assert ops.irn_eligible(xs.F)
+    from pcgcv2_amd import dispatch
+    assert dispatch.select('irn', (C,), len(c4)).family != 'unfused'
     if C == 32:
         # small plain levels take the rows kernels (csrc/rows_irn.hip: RowsPassA32 / B32) by default: checked here, with ragged sizes, then
         # switched off so that the rest of this test reaches the VALU forms it is about
@@ -1481,3 +1482,185 @@ def test_decode_batch_refuses_foreign_header_and_oversized_batches(sd, tmp_path)
         coder.decode_batch([f'_{i}' for i in range(17)])
     with pytest.raises(ops.PcgcError, match='16'):
         coder.encode_batch(xb, [f'_{i}' for i in range(17)])
+
+
+# ------------------------------------------------------------------------------------------------ the dispatch table, exhaustively
+def _prefix_level(n, cloud='shell10', stride=1):
+    """a plain level of exactly n rows: the first n rows (raster order: a spatially coherent piece) of a synthetic cloud"""
+    c4 = _coords(cloud)[:n].copy()
+    assert len(c4) == n
+    c4[:, 1:] *= stride
+    return np.ascontiguousarray(c4), CoordMap(_t(c4), stride, unique=True)
+
+
+def _children_prefix(n_parents, cloud='shell9'):
+    """a children level of 8 n_parents rows (rows 8 p + j) on the first n_parents rows of a cloud's stride-2 level"""
+    c4 = _coords(cloud)
+    top = CoordMap(_t(c4), 1, unique=True)
+    pc = top.down()[0].C[:n_parents].contiguous()
+    parent = CoordMap(pc, 2, unique=True)
+    kids = parent.up()
+    return parent, kids, kids.C.cpu().numpy()
+
+
+def _conv_module(cin, cout, k, stride, seed):
+    from pcgcv2_amd.nn import MinkowskiConvolution
+    rng = np.random.default_rng(seed)
+    m = MinkowskiConvolution(cin, cout, k, stride).to(DEV)
+    with torch.no_grad():
+        m.kernel.copy_(_t((rng.standard_normal(tuple(m.kernel.shape)) / np.sqrt(k ** 3 * cin)).astype(np.float32)))
+        m.bias.copy_(_t(rng.standard_normal((1, cout)).astype(np.float32)))
+    return m, m.kernel.detach().cpu().numpy(), m.bias.detach().cpu().numpy()
+
+
+GATHER_CASES = [
+    # (cin, cout, rows, switches to turn off so that the gather family is reached)       one line per side of every gate of dispatch.GATHER_GATES
+    (64, 64, 8191, ()), (64, 64, 8192, ()), (64, 64, 109999, ()), (64, 64, 110000, ()), (64, 64, 399999, ()), (64, 64, 400000, ()),
+    (64, 64, 511, ()), (64, 64, 512, ()),
+    (32, 32, 1023, ()), (32, 32, 109999, ('ROWS_CONV',)), (32, 32, 110000, ('ROWS_CONV',)), (32, 32, 400000, ('ROWS_CONV',)),
+    (32, 8, 18732, ()), (32, 8, 149999, ()), (32, 8, 150000, ()),
+    (16, 16, 39999, ()), (16, 16, 40000, ()), (16, 16, 300, ()),
+    (16, 1, 5000, ()), (32, 1, 39999, ()), (32, 1, 40000, ()), (64, 1, 29999, ()), (64, 1, 30000, ()),
+    (1, 16, 20000, ('UNIT_INPUT_CONV',)), (16, 4, 20000, ()), (64, 16, 20000, ()), (64, 32, 600, ()),
+]
+
+
+@pytest.mark.parametrize('cin,cout,rows,off', GATHER_CASES, ids=[f'{a}to{b}_{r}' for a, b, r, _ in GATHER_CASES])
+def test_dispatch_table_gather_family(cin, cout, rows, off):
+    """k3 convs that the table (pcgcv2_amd/dispatch.py) sends to pcgc_conv_gather: on both sides of every row-count gate the kernel the
+    library ACTUALLY launched (pcgc_last_conv_impl) is the one the table predicts, and its output equals the oracle's fmaf chain."""
+    from pcgcv2_amd import dispatch
+    from pcgcv2_amd._lib import lib
+    c4, lvl = _prefix_level(rows, 'shell10' if rows <= 700000 else 'shell11')
+    conv, W, b = _conv_module(cin, cout, 3, 1, cin * 1000 + cout)
+    x = np.random.default_rng(rows).standard_normal((rows, cin)).astype(np.float32)
+    for name in off:
+        setattr(ops, name, False)                      # (restored by the autouse fixture / below)
+    try:
+        assert dispatch.select('conv3', (cin, cout), rows, 'plain').family == 'gather'
+        with torch.no_grad():
+            got = conv(SparseTensor(_t(x), coordinate_map=lvl), relu=True).F.cpu().numpy()
+        launched = lib().pcgc_last_conv_impl()
+    finally:
+        for name in off:
+            setattr(ops, name, True)
+    assert launched == dispatch.gather_impl(27, cin, cout, rows), (dispatch.GATHER_IMPL_NAMES[launched], dispatch.GATHER_IMPL_NAMES[dispatch.gather_impl(27, cin, cout, rows)])
+    want = np.maximum(orc.conv_gather(orc.kmap_k3(c4, 1), x, W, b), np.float32(0))
+    np.testing.assert_array_equal(got, want)
+
+
+def test_dispatch_table_children_and_rows_conv_entries():
+    """conv3 entries other than the gather family: `child` at its 8192-row gate (1024 parents; one parent fewer falls to the level's own
+    map), `rows` (32 -> 32) at ROWS_CONV_MIN, `unit` vs the general kernel on the same input."""
+    from pcgcv2_amd import dispatch
+    from pcgcv2_amd._lib import lib
+    for cin, cout in ((16, 16), (32, 32), (16, 1), (32, 1), (64, 1)):
+        conv, W, b = _conv_module(cin, cout, 3, 1, cin + cout)
+        for n_p, fam in ((1024, 'child'), (1023, 'rows' if (cin, cout) == (32, 32) else 'gather')):
+            parent, kids, kc = _children_prefix(n_p)
+            assert dispatch.select('conv3', (cin, cout), len(kc), 'children').family == fam
+            x = np.random.default_rng(n_p + cin).standard_normal((len(kc), cin)).astype(np.float32)
+            with torch.no_grad():
+                got = conv(SparseTensor(_t(x), coordinate_map=kids)).F.cpu().numpy()
+            np.testing.assert_array_equal(got, orc.conv_gather(orc.kmap_k3(kc, 1), x, W, b))
+    conv, W, b = _conv_module(32, 32, 3, 1, 77)
+    for rows, fam in ((ops.ROWS_CONV_MIN, 'rows'), (ops.ROWS_CONV_MIN - 1, 'gather')):
+        c4, lvl = _prefix_level(rows)
+        assert dispatch.select('conv3', (32, 32), rows).family == fam
+        x = np.random.default_rng(rows).standard_normal((rows, 32)).astype(np.float32)
+        with torch.no_grad():
+            got = conv(SparseTensor(_t(x), coordinate_map=lvl)).F.cpu().numpy()
+        np.testing.assert_array_equal(got, orc.conv_gather(orc.kmap_k3(c4, 1), x, W, b))
+
+
+IRN_CASES = [
+    # (C, level kind, rows (children: parents), own map built first, expected family)
+    (16, 'children', 1024, False, 'child'), (16, 'children', 1023, False, 'valu'), (32, 'children', 1024, False, 'child'), (32, 'children', 1023, False, 'rows32'),
+    (64, 'children', 1024, False, 'child64'), (64, 'children', 1024, True, 'rows64'), (64, 'children', 1023, False, 'rows64'),
+    (64, 'plain', 1024, False, 'rows64'), (64, 'plain', 1023, False, 'mfma64'), (64, 'plain', 511, False, 'valu'),
+    (32, 'plain', 1024, False, 'rows32'), (32, 'plain', 1023, False, 'valu'),
+    (16, 'plain', 5000, False, 'valu'), (16, 'plain', 39999, False, 'valu'), (16, 'plain', 40000, False, 'valu'), (16, 'plain', 119999, False, 'valu'),
+    (16, 'plain', 120001, False, 'valu'),
+]
+
+
+@pytest.mark.parametrize('C,kind,rows,own_map,family', IRN_CASES, ids=[f'C{c}_{k}_{r}{"_ownmap" if o else ""}' for c, k, r, o, _ in IRN_CASES])
+def test_dispatch_table_inception_resnet_entries(C, kind, rows, own_map, family):
+    """every InceptionResNet entry of the table on both sides of its gates (8192 children rows, ROWS_IRN64_MIN / ROWS_IRN32_MIN, 512; the
+    VALU passes at the library's own tile-height gates, pcgc_irn_config) against the oracle's five-conv block."""
+    from pcgcv2_amd import dispatch
+    from pcgcv2_amd.autoencoder import InceptionResNet
+    rng = np.random.default_rng(C + rows)
+    blk = InceptionResNet(C).to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.from_numpy(rng.standard_normal(tuple(p.shape)).astype(np.float32) * 0.2))
+    sd = {'b.' + k: v.detach().cpu().numpy() for k, v in blk.state_dict().items()}
+    if kind == 'children':
+        parent, lvl, c4 = _children_prefix(rows)
+        if own_map:
+            lvl.k3
+    else:
+        c4, lvl = _prefix_level(rows)
+    n = len(c4)
+    assert dispatch.select('irn', (C,), n, kind, own_map=lvl._k3 is not None).family == family
+    x = rng.standard_normal((n, C)).astype(np.float32)
+    with torch.no_grad():
+        got = blk(SparseTensor(_t(x), coordinate_map=lvl)).F.cpu().numpy()
+    np.testing.assert_array_equal(got, orc.inception_resnet(sd, 'b', orc.Level(c4, 1), x))
+
+
+def test_dispatch_table_down_up_and_k1_entries():
+    """`down` (k2 s2) at ROWS_DOWN_MIN coarse rows on both sides, for the three shapes of the encoder; `up` for the decoder's three
+    shapes; a k1 conv; all against the oracle."""
+    from pcgcv2_amd import dispatch
+    from pcgcv2_amd.nn import MinkowskiGenerativeConvolutionTranspose
+    c4 = _coords('shell8')
+    fine = CoordMap(_t(c4), 1, unique=True)
+    coarse, _ = fine.down()
+    n_c = len(coarse)
+    assert n_c > ops.ROWS_DOWN_MIN
+    want_c, _ = orc.stride2_coords(c4, 2)
+    default_min = ops.ROWS_DOWN_MIN
+    for cin, cout in ((16, 32), (32, 64), (64, 32)):
+        conv, W, b = _conv_module(cin, cout, 2, 2, cin)
+        x = np.random.default_rng(cin).standard_normal((len(c4), cin)).astype(np.float32)
+        want = np.maximum(orc.conv_gather(orc.kmap_down(c4, want_c, 1), x, W, b), np.float32(0))
+        for gate, fam in ((default_min, 'rows_down'), (n_c + 1, 'gather')):
+            ops.ROWS_DOWN_MIN = gate
+            assert dispatch.select('down', (cin, cout), n_c).family == fam
+            with torch.no_grad():
+                got = conv(SparseTensor(_t(x), coordinate_map=fine), relu=True)
+            np.testing.assert_array_equal(got.C.cpu().numpy(), want_c)
+            np.testing.assert_array_equal(got.F.cpu().numpy(), want)
+    rng = np.random.default_rng(5)
+    for cin, cout in ((8, 64), (64, 32), (32, 16)):
+        up = MinkowskiGenerativeConvolutionTranspose(cin, cout, 2, 2).to(DEV)
+        with torch.no_grad():
+            up.kernel.copy_(_t((rng.standard_normal((8, cin, cout)) / np.sqrt(8 * cin)).astype(np.float32)))
+            up.bias.copy_(_t(rng.standard_normal((1, cout)).astype(np.float32)))
+        x = rng.standard_normal((n_c, cin)).astype(np.float32)
+        with torch.no_grad():
+            got = up(SparseTensor(_t(x), coordinate_map=CoordMap(_t(want_c), 2, unique=True)), relu=True)
+        want = np.maximum(orc.conv_up2(x, up.kernel.detach().cpu().numpy(), up.bias.detach().cpu().numpy()), np.float32(0))
+        np.testing.assert_array_equal(got.F.cpu().numpy(), want)
+    conv, W, b = _conv_module(64, 16, 1, 1, 9)
+    x = rng.standard_normal((len(c4), 64)).astype(np.float32)
+    assert dispatch.select('conv1', (64, 16), len(c4)).family == 'gather'
+    with torch.no_grad():
+        got = conv(SparseTensor(_t(x), coordinate_map=fine)).F.cpu().numpy()
+    np.testing.assert_array_equal(got, orc.conv_k1(x, W, b))
+
+
+def test_dispatch_table_is_the_only_policy():
+    """every family the table can name is handled by nn.py / autoencoder.py, every entry has a window, and the text of the two modules
+    holds no row-count literal of its own (the gates live in dispatch.py / ops constants)."""
+    import inspect, re
+    from pcgcv2_amd import dispatch, nn, autoencoder
+    src = inspect.getsource(nn.MinkowskiConvolution.forward) + inspect.getsource(autoencoder.InceptionResNet.forward)
+    for rule in dispatch.TABLE:
+        if rule.op in ('conv3', 'irn', 'down') and rule.family not in ('gather', 'valu', 'unfused'):
+            assert f"'{rule.family}'" in src, rule.family
+        assert dispatch._value(rule.rows_min) < dispatch._value(rule.rows_max)
+    assert not re.search(r'\b(8192|1024|512|110000|40000|150000|0xF0000000)\b', src)
+    assert len(dispatch.describe().splitlines()) == len(dispatch.TABLE)
