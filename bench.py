@@ -62,6 +62,7 @@ def parse():
     ap.add_argument('--serving-in-flight', type=int, default=4, help='frames in flight per GPU in that measurement')
     ap.add_argument('--warm-tables', action='store_true', help='keep the CDF-table caches across steps (the round-3 behaviour); default: every encode and '
                                                                'every decode evaluates its table, as the reference does')
+    ap.add_argument('--two-cpu-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--input-order', default='raster', choices=['raster', 'shuffled'], help='row order of the input cloud (frame config)')
     return ap.parse_args()
 
@@ -345,6 +346,31 @@ def main():
         del alt
         step()
 
+    # one rank on a TWO-CPU budget (eight ranks of a node that share a 16-CPU quota get exactly that): the same command in a child process
+    # whose affinity mask holds two CPUs — configure_host_threads then budgets one range-decoder thread (the lane-parallel decoder), no pools
+    two_cpu = None
+    if cfg == 'frame' and world == 1 and not args.no_extra and not args.two_cpu_child and hasattr(os, 'sched_setaffinity'):
+        import subprocess
+        cpus = sorted(os.sched_getaffinity(0))[:2]
+        if len(cpus) == 2:
+            torch.cuda.synchronize()
+            cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(args.steps), '--warmup', str(args.warmup), '--no-extra', '--no-cpu-baseline',
+                   '--no-events', '--two-cpu-child', '--input-order', args.input_order] + (['--warm-tables'] if args.warm_tables else []) + \
+                  (['--workload', args.workload] if args.workload else [])
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, preexec_fn=lambda: os.sched_setaffinity(0, set(cpus)))
+                child = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
+                if child:
+                    c = child[-1]
+                    two_cpu = {'value': c['value'], 'unit': 'Mpoints/s', 'ms_per_step': c['ms_per_step'], 'enc_ms': c['config']['enc_ms'], 'dec_ms': c['config']['dec_ms'],
+                               'host_threads': c['config']['host_threads'],
+                               'note': f'the same K steps in a child process restricted to CPUs {cpus} (sched_setaffinity): one launcher thread + one helper; '
+                                       'the feature stream is decoded by the lane-parallel decoder (eight segments per zmm register, no pool threads)'}
+                else:
+                    two_cpu = {'error': (r.stderr or r.stdout)[-300:]}
+            except (subprocess.TimeoutExpired, OSError) as e:
+                two_cpu = {'error': str(e)[:200]}
+
     one_by_one = None
     if batch is not None and not args.no_extra:
         step(one_by_one=True)
@@ -478,7 +504,7 @@ def main():
                                                                             'host-kind dependent exactly as the reference\'s are' if model.entropy_bottleneck.table_mode == 'reference' else ''),
                        'table_cache': 'warm (caches kept across steps)' if args.warm_tables else 'cold: dropped before every encode and every decode inside the timed region '
                                       '(the reference evaluates a table per compress / decompress call)',
-                       'table_cache_warm': warm_tables, 'input_order': args.input_order, 'input_order_sensitivity': order_sens,
+                       'table_cache_warm': warm_tables, 'input_order': args.input_order, 'input_order_sensitivity': order_sens, 'two_cpu_rank': two_cpu,
                        'entropy_decode': '`_F.bin` (bit-identical to the reference-format stream, decodable without it) comes with a sidecar '
                                          f'`_F.idx` of decoder states at {coder_mod.INDEX_SEGMENTS} row boundaries: its segments are decoded two per thread (two dependency chains per loop) on up to 8 threads; `_C.bin` '
                                          '(native octree, tmc3 absent) is coded as up to 8 independent groups of subtrees',

@@ -298,6 +298,10 @@ int64_t pcgc_rc_encode_indexed(const uint16_t* cdf, int C, int Lp, const int16_t
 int pcgc_rc_decode_indexed(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int64_t nbytes, int16_t* sym, int64_t n, int n_ckpt,
                            const uint32_t* ckpt);
 int pcgc_set_rc_threads(int threads);
+/* The lane-parallel form of the indexed decoder: eight segments per 512-bit register on the calling thread (AVX-512 F/BW/DQ/CD/VL) instead
+ * of one or two segments per pool thread.  -1 (default): when the thread budget (pcgc_set_rc_threads) is one or two; 0 never; 1 always.
+ * Same symbols either way.  HOST. */
+int pcgc_set_rc_lanes(int mode);
 /* decoder selection for A/B tests: 0 automatic (AVX-512 boundary count when the host CPU has it and Lp <= 64, else the
  * portable scalar search), 1 portable scalar.  Both are bit-identical. */
 int pcgc_set_rc_impl(int impl);

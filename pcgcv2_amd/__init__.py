@@ -74,13 +74,16 @@ def pin_to_gpu_numa_node(device_index):
     return allowed
 
 
-def configure_host_threads(max_threads=4, local_world=None, frames_in_flight=1, pin_device=None):
+def configure_host_threads(max_threads=1, local_world=None, frames_in_flight=1, pin_device=None):
     """The host side of the codec is a single-threaded launcher + sequential entropy coder (+ a few short-lived helper threads for the
     indexed entropy decoders); keep torch's CPU thread pool small so its workers do not spin away the container's CPU quota, and size
     the decoder pools from this process's SHARE of the CPUs: `local_world` = processes on this node that share them (one rank per GPU;
     default: LOCAL_WORLD_SIZE or 1), `frames_in_flight` = frames this process codes concurrently (shard.code_units(in_flight=F)):
     the budget is   frames x (1 launcher + 1 coordinate helper + range-decoder helpers + ATen threads)  <=  this process's CPUs.
     `pin_device` (GPU index): also pin the process to that GPU's NUMA-local CPUs (multi-rank nodes).
+    `max_threads`: ATen's intra-op threads.  The only ATen CPU work on the path is the CDF table — ~60 operators on [8, 3, ~20] tensors, far
+    below any parallel grain size; more threads only add wake-ups (measured: 0.42 ms with one thread, 0.59 with four, cold) — so 1.
+    With a budget of one or two range-decoder threads the library switches to its lane-parallel decoder by itself (pcgc_set_rc_lanes).
     -> dict of what was applied."""
     import os
     import torch

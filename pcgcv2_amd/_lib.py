@@ -88,6 +88,7 @@ SIGNATURES = {
     'pcgc_rc_encode_indexed': (i64, [vp, ci, ci, vp, i64, vp, i64, ci, vp]),
     'pcgc_rc_decode_indexed': (ci, [vp, ci, ci, vp, i64, vp, i64, ci, vp]),
     'pcgc_set_rc_threads': (ci, [ci]),
+    'pcgc_set_rc_lanes': (ci, [ci]),
     'pcgc_set_oct_tiled': (ci, [ci]),
     'pcgc_oct_encode': (i64, [vp, i64, vp, i64]),
     'pcgc_oct_decode_count': (i64, [vp, i64]),

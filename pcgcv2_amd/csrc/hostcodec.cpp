@@ -355,6 +355,95 @@ static void rc_decode_avx512_segs(const RcWideTables& tb, int C, const uint8_t* 
         for (int64_t j = both; j < left[k]; ++j) step(S[k]);
 }
 
+// Lane-parallel form (round 4): EIGHT segments of one stream advance together, one per 64-bit lane of a zmm register, on ONE thread.
+// The per-symbol dependency chain of the form above (~40 cycles, of which the core's vector units are busy for a few) becomes a
+// throughput problem: every boundary of the channel's row is broadcast and compared against all eight lanes' offsets at once
+// (segments start at row boundaries, so all lanes decode the same channel in the same step), the two table entries of the decoded
+// symbols come from one gather each, the renormalisation is the scalar formula in vplzcntq / variable shifts, and each lane reads its
+// next t bits from its own position of the stream through one 8-byte gather.  A rank whose CPU budget is one or two threads (eight
+// ranks on a 16-CPU quota: pcgcv2_amd.configure_host_threads) decodes the 150 k symbols of a vox10 frame in ~0.2 ms instead of the
+// 1.3 ms of the serial form, with no helper threads to wake.  G = 1 or 2 groups of eight lanes per loop (two: independent chains).
+// Same arithmetic per lane as rc_decode_avx512_segs (tested against it and against the bit-serial oracle).
+struct RcLaneGroup { __m512i low, span, off, pos, out; };      // out: index of the next symbol of each lane
+template <int G>
+__attribute__((target("avx512f,avx512bw,avx512dq,avx512cd,avx512vl,popcnt,lzcnt,bmi,bmi2")))
+static void rc_decode_avx512_lanes(const RcWideTables& tb, int C, int Lp, const uint8_t* padded, int64_t limit, const RcStart* st /*[8 G]*/, int16_t* sym) {
+    const int W = tb.W, RS = tb.RS, NB = Lp - 1;               // NB real boundaries per row (the last one is pinned to 2^16: never counted)
+    const uint32_t* const rows = tb.rows.data(); const uint64_t* const wide = tb.wide;
+    const __m512i m32 = _mm512_set1_epi64(0xFFFFFFFFll), m31 = _mm512_set1_epi64(0x7FFFFFFFll), one = _mm512_set1_epi64(1), c32 = _mm512_set1_epi64(32),
+                  c63 = _mm512_set1_epi64(63), c7 = _mm512_set1_epi64(7), vlimit = _mm512_set1_epi64(limit);
+    const __m512i bswap = _mm512_set_epi8(8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7,
+                                          8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7);
+    RcLaneGroup L[G];
+    int64_t steps = st[0].count;
+    for (int g = 0; g < G; ++g) {
+        alignas(64) uint64_t lo[8], sp[8], of[8], ps[8], ou[8];
+        for (int k = 0; k < 8; ++k) {
+            const RcStart& s0 = st[8 * g + k];
+            lo[k] = s0.low; sp[k] = s0.span; of[k] = s0.off; ps[k] = s0.bitpos + 32; ou[k] = (uint64_t)s0.first;
+            steps = std::min(steps, s0.count);
+        }
+        L[g] = RcLaneGroup{_mm512_load_si512(lo), _mm512_load_si512(sp), _mm512_load_si512(of), _mm512_load_si512(ps), _mm512_load_si512(ou)};
+    }
+    int ch = 0;                                                // every segment starts at a row boundary
+    for (int64_t j = 0; j < steps; ++j) {
+        const uint64_t* wr = wide + (size_t)ch * W;
+        const uint32_t* row = rows + (size_t)ch * RS;
+        if (++ch == C) ch = 0;
+        __m512i vs[G], cnt[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) { vs[g] = _mm512_sub_epi64(L[g].span, one); cnt[g] = _mm512_setzero_si512(); }
+        for (int b = 0; b < NB; ++b) {                         // cnt = s + 1 = boundaries whose scaled position is <= off
+            const __m512i r = _mm512_set1_epi64((long long)wr[b]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const __m512i cum = _mm512_srli_epi64(_mm512_add_epi64(_mm512_mul_epu32(vs[g], r), r), 16);
+                cnt[g] = _mm512_mask_add_epi64(cnt[g], _mm512_cmple_epu64_mask(cum, L[g].off), cnt[g], one);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            alignas(64) uint64_t cv[8], ov[8];
+            _mm512_store_si512(cv, cnt[g]); _mm512_store_si512(ov, L[g].out);
+            for (int k = 0; k < 8; ++k) sym[ov[k]] = (int16_t)((int)cv[k] - 1);
+            L[g].out = _mm512_add_epi64(L[g].out, one);
+            // cdf[s], cdf[s + 1] of every lane (rows carry a guard entry in front and guards behind: any count 0..W indexes inside)
+            const __m512i rlo = _mm512_cvtepu32_epi64(_mm512_i64gather_epi32(cnt[g], (const void*)row, 4));
+            const __m512i rhi = _mm512_cvtepu32_epi64(_mm512_i64gather_epi32(_mm512_add_epi64(cnt[g], one), (const void*)row, 4));
+            const __m512i c_lo = _mm512_srli_epi64(_mm512_add_epi64(_mm512_mul_epu32(vs[g], rlo), rlo), 16);
+            const __m512i c_hi = _mm512_srli_epi64(_mm512_add_epi64(_mm512_mul_epu32(vs[g], rhi), rhi), 16);
+            const __m512i lo = _mm512_and_si512(_mm512_add_epi64(L[g].low, c_lo), m32);
+            const __m512i hi = _mm512_and_si512(_mm512_sub_epi64(_mm512_add_epi64(L[g].low, c_hi), one), m32);
+            const __m512i nshare = _mm512_sub_epi64(_mm512_lzcnt_epi64(_mm512_xor_si512(lo, hi)), c32);
+            __m512i a = _mm512_or_si512(_mm512_andnot_si512(lo, m32), hi);                       // ~lo | hi  (32 bits)
+            a = _mm512_and_si512(_mm512_or_si512(_mm512_slli_epi64(a, 1), one), m32);
+            a = _mm512_and_si512(a, _mm512_srlv_epi64(m32, nshare));
+            const __m512i t = _mm512_sub_epi64(_mm512_lzcnt_epi64(a), c32);
+            // the next t bits of every lane's own stream position (big-endian bit order, as SourceBF)
+            const __m512i byte = _mm512_min_epu64(_mm512_srli_epi64(L[g].pos, 3), vlimit);
+            __m512i w = _mm512_shuffle_epi8(_mm512_i64gather_epi64(byte, (const void*)padded, 1), bswap);
+            w = _mm512_sllv_epi64(w, _mm512_and_si512(L[g].pos, c7));
+            const __m512i bits = _mm512_srlv_epi64(_mm512_srli_epi64(w, 1), _mm512_sub_epi64(c63, t));
+            L[g].low = _mm512_and_si512(_mm512_sllv_epi64(lo, t), m31);
+            L[g].span = _mm512_sllv_epi64(_mm512_sub_epi64(c_hi, c_lo), t);
+            L[g].off = _mm512_or_si512(_mm512_and_si512(_mm512_sllv_epi64(_mm512_and_si512(_mm512_sub_epi64(L[g].off, c_lo), m32), t), m32), bits);
+            L[g].pos = _mm512_add_epi64(L[g].pos, t);
+        }
+    }
+    // segments differ by a row or two: every lane finishes its own tail on the one-segment form, from the lane's state
+    for (int g = 0; g < G; ++g) {
+        alignas(64) uint64_t lo[8], sp[8], of[8], ps[8];
+        _mm512_store_si512(lo, L[g].low); _mm512_store_si512(sp, L[g].span); _mm512_store_si512(of, L[g].off); _mm512_store_si512(ps, L[g].pos);
+        for (int k = 0; k < 8; ++k) {
+            const RcStart& s0 = st[8 * g + k];
+            if (s0.count > steps) {
+                const RcStart rest{ps[k] - 32, (uint32_t)lo[k], sp[k], (uint32_t)of[k], s0.first + steps, s0.count - steps};
+                rc_decode_avx512_segs<1>(tb, C, padded, limit, &rest, 1, sym);
+            }
+        }
+    }
+}
+
 // ---- a small persistent pool for the indexed decoder (segments of one stream decoded side by side)
 namespace {
 class SegmentPool {
@@ -452,6 +541,8 @@ int rc_threads() {
     if (g_rc_threads > 0) return g_rc_threads;
     return std::min(8, effective_cpus());
 }
+int g_rc_lanes = -1;                                   // -1 automatic (thread budget <= 2), 0 never, 1 always: the lane-parallel decoder
+bool rc_lanes_wanted(int threads) { return g_rc_lanes > 0 || (g_rc_lanes < 0 && threads <= 2); }
 bool rc_use_avx512(int Lp) {
     return g_rc_impl == 0 && Lp <= 64 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq") &&
            __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("lzcnt");
@@ -470,6 +561,33 @@ int rc_decode_starts(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int6
     const bool wide = rc_use_avx512(Lp);
     RcWideTables* wt = wide ? new RcWideTables(cdf, C, Lp) : nullptr;
     RcScalarTables* stb = wide ? nullptr : new RcScalarTables(cdf, C, Lp);
+    // a thread budget of one or two (pcgc_set_rc_threads / a rank's share of a small CPU quota), or pcgc_set_rc_lanes(1): eight
+    // segments per zmm register on the calling thread (+ one helper for a second group of eight), no pool of segment threads
+    if (wide && rc_lanes_wanted(threads) && (int)starts.size() >= 8 && __builtin_cpu_supports("avx512cd") && __builtin_cpu_supports("avx512vl")) {
+        bool rows_ok = true;
+        for (const RcStart& st : starts) rows_ok = rows_ok && st.first % C == 0 && st.count > 0;
+        if (rows_ok) {
+            const int ngroups = (int)starts.size() / 8;                      // whole groups of eight; the remaining segments one by one
+            const std::function<void(int)> grp = [&](int k) {
+                if (k < ngroups / 2) rc_decode_avx512_lanes<2>(*wt, C, Lp, padded, limit, &starts[(size_t)16 * k], sym);
+                else if (k == ngroups / 2 && (ngroups & 1)) rc_decode_avx512_lanes<1>(*wt, C, Lp, padded, limit, &starts[(size_t)16 * (ngroups / 2)], sym);
+                else { const int first = 8 * ngroups + (k - (ngroups + 1) / 2); rc_decode_avx512_segs<1>(*wt, C, padded, limit, &starts[(size_t)first], 1, sym); }
+            };
+            const int tasks = (ngroups + 1) / 2 + ((int)starts.size() - 8 * ngroups);
+            if (threads >= 2 && ngroups >= 2) {
+                // two threads: one group of eight lanes each
+                const std::function<void(int)> half = [&](int k) {
+                    if (k < ngroups) rc_decode_avx512_lanes<1>(*wt, C, Lp, padded, limit, &starts[(size_t)8 * k], sym);
+                    else rc_decode_avx512_segs<1>(*wt, C, padded, limit, &starts[(size_t)(8 * ngroups + (k - ngroups))], 1, sym);
+                };
+                segment_pool().run(ngroups + ((int)starts.size() - 8 * ngroups), 1, half);
+            } else {
+                for (int k = 0; k < tasks; ++k) grp(k);
+            }
+            delete wt; delete stb;
+            return 0;
+        }
+    }
     // more segments than threads (and the vector decoder): two or four segments per task, advanced in lock step
     const int nseg = (int)starts.size();
     const int th = std::max(threads, 1);
@@ -489,6 +607,7 @@ int rc_decode_starts(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int6
 }
 }
 extern "C" int pcgc_set_rc_threads(int threads) { if (threads < 0) return -1; g_rc_threads = threads; return 0; }
+extern "C" int pcgc_set_rc_lanes(int mode) { if (mode < -1 || mode > 1) return -1; g_rc_lanes = mode; return 0; }
 
 extern "C" int pcgc_rc_decode(const uint16_t* cdf, int C, int Lp, const uint8_t* in, int64_t nbytes, int16_t* sym, int64_t n) {
     if (n <= 0) return 0;

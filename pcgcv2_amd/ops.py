@@ -1242,6 +1242,12 @@ def set_rc_threads(threads):
     check(lib().pcgc_set_rc_threads(int(threads)), 'set_rc_threads')
 
 
+def set_rc_lanes(mode):
+    """Lane-parallel indexed range decoder (eight segments per 512-bit register on the calling thread): -1 automatic (thread budget of one
+    or two), 0 never, 1 always.  Same symbols either way."""
+    check(lib().pcgc_set_rc_lanes(int(mode)), 'set_rc_lanes')
+
+
 def crc32(data, crc=0):
     """zlib.crc32(data, crc), by the library's carry-less-multiply fold (the value the native item files carry in their sidecars)"""
     src = np.frombuffer(data, np.uint8)

@@ -1188,6 +1188,23 @@ def test_bench_runs_its_collectives_over_rccl_with_one_rank():
     assert line['config']['d1_scope'].startswith('whole blocked cloud') and line['config']['d1_psnr_rank0_db'] > 20
 
 
+def test_bench_eight_ranks_blocks_dry_run_over_gloo():
+    """BASELINE config 5 as an 8-GPU node runs it — eight ranks, ONE octant block each, the decoded blocks gathered to rank 0 for the exact
+    global D1 (shard.gather_varlen: sizes, then a padded all-gather) — with the eight ranks sharing this box's one GPU and gloo carrying
+    the collectives.  The reduced figures must equal the single-process run of the same blocks: same points in and out, same rate, the
+    same global D1 (the nearest neighbours across block borders are found only if every rank's voxels arrive)."""
+    args = ['--config', 'blocks', '--steps', '1', '--warmup', '1', '--workload', 'shell10', '--no-cpu-baseline', '--no-events', '--no-extra']
+    r1, one = _run_bench(args)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r8, eight = _run_bench(['--gpus', '8'] + args, {'PCGC_DIST_BACKEND': 'gloo'}, nproc=8, timeout=900)
+    assert r8.returncode == 0, r8.stderr[-2000:]
+    assert eight['n_gpus'] == 8 and eight['scaling'] == 'strong' and eight['config']['collectives'] == 'gloo'
+    for k in ('points_in_per_step_all_gpus', 'points_coded_per_step_all_gpus', 'points_out', 'bpp', 'bpp_reference_files_only', 'd1_psnr_rank0_db'):
+        assert eight['config'][k] == one['config'][k], k
+    assert eight['config']['d1_scope'].startswith('whole blocked cloud') and eight['config']['d1_psnr_rank0_db'] > 20
+    assert eight['config']['host_threads']['cpus'] >= 1 and eight['config']['host_threads']['rc_threads'] >= 1
+
+
 def test_bench_refuses_a_world_size_mismatch():
     r, line = _run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0'])
     assert r.returncode == 2 and line is None and 'WORLD_SIZE' in r.stderr

@@ -883,3 +883,40 @@ def test_geometry_families_on_the_oracle(name, n):
 def test_full_size_geometry_families_have_the_documented_sizes():
     for name, n in (('solid_cube', 512000), ('solid_ball', 539152), ('multi10', 1022977)):
         assert len(synthetic.cloud(name)) == n, name
+
+
+@pytest.mark.parametrize('threads', [1, 2, 8])
+def test_lane_parallel_range_decoder_equals_the_serial_one(threads):
+    """pcgc_set_rc_lanes(1): eight segments of an indexed stream per zmm register on the calling thread (the decoder of ranks with a one- or
+    two-thread budget).  Alphabets of 1 ... 63 symbols, 8 / 12 / 16 checkpoints, ragged row counts, peaked / uniform / minimum-probability
+    tables: the symbols equal those of the serial decoder and the bit-serial oracle; with fewer than eight checkpoints or an alphabet
+    beyond the SIMD limit the call falls back by itself."""
+    rng = np.random.default_rng(42)
+    cases = []
+    for L, n, ck in ((21, 20000, 16), (21, 20003, 16), (2, 9000, 16), (63, 12000, 16), (5, 8001, 8), (21, 15000, 12), (40, 9999, 16), (21, 4000, 16),
+                     (100, 9000, 16), (21, 5000, 4), (1, 3000, 16)):
+        pmf = rng.random((8, L)) ** 3 + 1e-4
+        if L >= 5:
+            pmf[:, L // 2] += 3.0                                             # a peak, like real latents
+            pmf[:, 0] = 1e-7                                                  # and a minimum-probability symbol (17-bit shifts)
+        table = _table_from_pmf(pmf)
+        p = pmf / pmf.sum(1, keepdims=True)
+        sym = np.stack([rng.choice(L, size=n, p=p[c]) for c in range(8)], 1).astype(np.int16)
+        sym[0, 0], sym[-1, -1] = 0, L - 1
+        cases.append((table, sym, ck))
+    ops.set_rc_threads(threads)
+    try:
+        for table, sym, ck in cases:
+            data, index = ops.rc_encode(table, sym, checkpoints=ck)
+            assert data == orc.rc_encode(table, sym)
+            ops.set_rc_lanes(0)
+            ref = ops.rc_decode(table, data, sym.size, index=index)
+            ops.set_rc_lanes(1)
+            got = ops.rc_decode(table, data, sym.size, index=index)
+            np.testing.assert_array_equal(ref, sym.ravel())
+            np.testing.assert_array_equal(got, sym.ravel())
+            ops.set_rc_lanes(-1)
+            np.testing.assert_array_equal(ops.rc_decode(table, data, sym.size, index=index), sym.ravel())
+    finally:
+        ops.set_rc_lanes(-1)
+        ops.set_rc_threads(0)
