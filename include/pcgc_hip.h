@@ -52,6 +52,11 @@ int pcgc_hash_first_mask(const int32_t* coords, int64_t n, int32_t stride, const
  * coordinate; this library does not, so the host layer validates caller-supplied coordinates (SparseTensor ctor,
  * scale_sparse_tensor) and raises instead of silently dropping rows. */
 int pcgc_coords_check(const int32_t* coords /*[dev n,4]*/, int64_t n, int32_t* bad /*[dev 1]*/, void* stream);
+/* The same validation + how ordered the rows are: out2[0] = rows out of range, out2[1] = descents of the (batch, z, y, x) key along the
+ * rows (0: the rows are in sort_spare_tensor's order, data_utils.py:91-101).  The reference takes rows in any order (ME hashes them); here
+ * the canonical row order of every level follows the input order, so an unordered PLY would drive every encoder gather through a random
+ * row order — Coder.encode sorts such a cloud once at ingest (no output byte depends on it: the latent is sorted before coding). */
+int pcgc_coords_check_order(const int32_t* coords /*[dev n,4]*/, int64_t n, int32_t* out2 /*[dev 2]*/, void* stream);
 
 /* ---- coordinate transforms ---- */
 /* output coords of MinkowskiConvolution(kernel_size=2, stride=2): floor(c / stride_out) * stride_out per row

@@ -20,6 +20,7 @@ SIGNATURES = {
     'pcgc_set_convention': (ci, [ci, ci]),
     'pcgc_hash_first_mask': (ci, [vp, i64, i32, vp, vp, i64, vp, vp, vp]),
     'pcgc_coords_check': (ci, [vp, i64, vp, vp]),
+    'pcgc_coords_check_order': (ci, [vp, i64, vp, vp]),
     'pcgc_coords_quantize': (ci, [vp, i64, i32, vp, vp]),
     'pcgc_coords_children': (ci, [vp, i64, i32, vp, vp]),
     'pcgc_coords_scale': (ci, [vp, i64, f32, vp, vp]),

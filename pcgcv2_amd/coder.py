@@ -53,6 +53,7 @@ def _slurp(path):
 # The sidecar names the stream it belongs to by length and CRC-32 and carries a CRC over itself; one that does not match (or is
 # absent: a reference-made stream) is ignored and the stream is decoded serially, unguarded — exactly what the reference does.
 INDEX_SEGMENTS = 16                              # checkpoints per stream (two segments per decoder thread); 0 = never write or read the sidecar
+INGEST_SORT = True                               # encode: an unordered cloud is sorted once before the encoder touches it (Coder._ingest)
 WARM_TABLE_CODE = True                           # encode: a throw-away table evaluation while the host waits for the GPU (ops.table_warm)
 NATIVE_ITEMS = True                              # batches: per-item host stages on native threads (False: Python thread pool; A/B and tests)
 INDEX_SUFFIX = '_F.idx'
@@ -220,7 +221,30 @@ class Coder():
         with torch.cuda.device(x.device):                       # current device = the tensors' device (kernels, events, streams)
             return self._encode(x, postfix)
 
+    def _ingest(self, x):
+        """An UNORDERED cloud (a scanner's or a mesh sampler's PLY: rows in no particular order) is sorted once, into sort_spare_tensor's
+        (batch, z, y, x) order, before the encoder touches it.  The canonical row order of every encoder level follows the input order
+        (first occurrence), so a random input order drives every gather of every level through random rows (measured on the vox10 frame:
+        encode + decode 118 instead of 128 Mpoints/s; the per-row gather kernels alone lose 28 %, profiles/r04_order_probe.txt).  No
+        output byte depends on the input order — each output row's fmaf chain follows its neighbours by offset, and the latent is sorted
+        before it is coded (coder.py:83) — so the sort changes the speed only.  Ordered-enough input (descents of the key along the
+        rows <= n / 64: raster order, already sorted, sorted with a few stragglers) is left alone."""
+        d = getattr(x.cmap, 'descents', None)
+        if not INGEST_SORT or d is None or d * 64 <= len(x):
+            return x
+        order = ops.sort_zyx(x.C, batch_major=True)
+        cmap = CoordMap(ops.gather_coords(x.C, order), x.cmap.stride, unique=True)
+        cmap.descents = 0
+        if x.cmap._batch_rows is not None:
+            cmap._batch_rows = list(x.cmap._batch_rows)                  # (batch-major order keeps the items contiguous, in item order)
+        if x.has_unit_features():
+            y = SparseTensor(x.F, coordinate_map=cmap)                   # all ones: any permutation of it is itself
+            y.unit_features, y._unit_stamp = True, x._unit_stamp
+            return y
+        return SparseTensor(ops.gather_feats(x.F, order), coordinate_map=cmap)
+
     def _encode(self, x, postfix):
+        x = self._ingest(x)
         lvl8 = x.cmap.build_pyramid(3)                          # cached on the levels: the encoder reuses these maps
         # Side stream: the (z, y, x, batch) order of sort_spare_tensor, the sorted stride-8 coordinates and their copy into pinned
         # memory (N8 x 16 B).  None of it is needed before the latent exists, so the dozen small sort launches run beside the
@@ -420,6 +444,7 @@ class Coder():
     def _encode_batch(self, x, postfixes):
         B = len(postfixes)
         _check_batch_size(B, 'encode_batch')
+        x = self._ingest(x)
         lvl8 = x.cmap.build_pyramid(3)
         l2 = x.cmap._down[0]
         l4 = l2._down[0]

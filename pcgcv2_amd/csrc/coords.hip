@@ -89,6 +89,33 @@ __global__ void k_coords_check(const int4* __restrict__ coords, int64_t n, int32
     const unsigned long long b = __ballot(oob);
     if (b && (threadIdx.x & 63) == 0) atomicAdd(bad, (int32_t)__popcll(b));
 }
+// the same pass, plus the number of DESCENTS of the (batch, z, y, x) key along the rows (0 = the rows are in sort_spare_tensor's order,
+// data_utils.py:91-101; about n / 2 = no order at all): the encoder sorts an unordered cloud once at ingest (coder.Coder._ingest) instead
+// of dragging every gather of every encoder level through a random row order
+__global__ void k_coords_check_order(const int4* __restrict__ coords, int64_t n, int32_t* __restrict__ out2) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool oob = false, desc = false;
+    if (i < n) {
+        const int4 c = coords[i];
+        oob = !coord_in_range(c.x, c.y, c.z, c.w);
+        if (i > 0) {
+            const int4 p = coords[i - 1];
+            desc = coord_key(c.x & 15, c.y & 0xFFFFF, c.z & 0xFFFFF, c.w & 0xFFFFF) < coord_key(p.x & 15, p.y & 0xFFFFF, p.z & 0xFFFFF, p.w & 0xFFFFF);
+        }
+    }
+    const unsigned long long b = __ballot(oob), d = __ballot(desc);
+    if ((threadIdx.x & 63) == 0) {
+        if (b) atomicAdd(out2, (int32_t)__popcll(b));
+        if (d) atomicAdd(out2 + 1, (int32_t)__popcll(d));
+    }
+}
+extern "C" int pcgc_coords_check_order(const int32_t* coords, int64_t n, int32_t* out2, void* stream) {
+    PCGC_REQUIRE(out2 != nullptr, "null counters");
+    hipMemsetAsync(out2, 0, 2 * sizeof(int32_t), S(stream));
+    if (n > 0) hipLaunchKernelGGL(k_coords_check_order, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n, out2);
+    PCGC_CHECK_LAUNCH("coords_check_order");
+    return 0;
+}
 extern "C" int pcgc_coords_check(const int32_t* coords, int64_t n, int32_t* bad, void* stream) {
     PCGC_REQUIRE(bad != nullptr, "null counter");
     hipMemsetAsync(bad, 0, sizeof(int32_t), S(stream));

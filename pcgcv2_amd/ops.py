@@ -216,13 +216,15 @@ def level_prepare_children(coords, stride):
 
 
 def check_coords(coords, what='coordinates'):
-    """Raise PcgcError if any row is outside the range the coordinate key can hold (the hash kernels would skip it)."""
-    bad = torch.empty(1, dtype=torch.int32, device=coords.device)
-    check(lib().pcgc_coords_check(_p(_i32(coords)), coords.shape[0], _p(bad), _stream(coords)), 'coords_check')
-    n_bad = int(bad.item())
+    """Raise PcgcError if any row is outside the range the coordinate key can hold (the hash kernels would skip it).
+    -> descents of the (batch, z, y, x) key along the rows: 0 = sorted like sort_spare_tensor's output, ~n/2 = no order at all."""
+    out2 = torch.empty(2, dtype=torch.int32, device=coords.device)
+    check(lib().pcgc_coords_check_order(_p(_i32(coords)), coords.shape[0], _p(out2), _stream(coords)), 'coords_check_order')
+    n_bad, descents = out2.tolist()
     if n_bad:
         raise PcgcError(f'{what}: {n_bad} of {coords.shape[0]} rows are outside the supported range '
                         '(0 <= x, y, z < 2^20, 0 <= batch < 16)')
+    return int(descents)
 
 
 def first_occurrence_mask(coords, table, want_rows=False):

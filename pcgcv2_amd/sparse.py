@@ -40,6 +40,7 @@ class CoordMap:
         self._unique = unique
         self._prepared_up = None
         self._batch_rows = None
+        self.descents = None                  # (caller-built levels only: see SparseTensor)
 
     def __len__(self):
         return self.C.shape[0]
@@ -175,11 +176,11 @@ class SparseTensor:
                 raise PcgcError('coordinates must be [N,4] (batch, x, y, z)')
             if coords.shape[0] != feats.shape[0]:
                 raise PcgcError('coordinates / features length mismatch')
-            if coords.shape[0] > 0:
-                ops.check_coords(coords)                   # caller-supplied coordinates: reject what the hash cannot key
+            descents = ops.check_coords(coords) if coords.shape[0] > 0 else 0      # caller-supplied coordinates: reject what the hash cannot key
             if not assume_unique and coords.shape[0] > 0:
                 coords, feats = dedup(coords, feats, int(tensor_stride))
             self.cmap = CoordMap(coords, int(tensor_stride), unique=True)
+            self.cmap.descents = descents                  # how unordered the caller's rows are (Coder._ingest sorts an unordered cloud once)
             self.F = feats
             # (decided once, here, where the constructor synchronises anyway: the first layer then needs no feature gathers; the
             #  claim is tied to this very tensor in this very state — see has_unit_features)

@@ -1681,3 +1681,44 @@ def test_dispatch_table_is_the_only_policy():
         assert dispatch._value(rule.rows_min) < dispatch._value(rule.rows_max)
     assert not re.search(r'\b(8192|1024|512|110000|40000|150000|0xF0000000)\b', src)
     assert len(dispatch.describe().splitlines()) == len(dispatch.TABLE)
+
+
+def test_ingest_sort_changes_no_byte(sd, sd_np, tmp_path):
+    """Coder._ingest: a cloud whose rows come in no order is sorted once before the encoder runs.  The files, the sorted latent and the
+    decoded voxels are those of the unsorted run and of the oracle (which works in the INPUT order); an ordered cloud is left alone."""
+    from pcgcv2_amd import coder as coder_mod
+    from pcgcv2_amd.coder import Coder
+    m = _model(sd)
+    c4 = _cloud4('noisy_s', 'shuffled')
+    x = SparseTensor(torch.ones((len(c4), 1)), coordinates=_t(c4), tensor_stride=1, device=DEV)
+    assert x.cmap.descents > len(c4) // 4                                      # no order at all
+    ordered = SparseTensor(torch.ones((len(c4), 1)), coordinates=_t(_cloud4('noisy_s')), tensor_stride=1, device=DEV)
+    assert ordered.cmap.descents == 0
+    coder = Coder(m, str(tmp_path / 'a'))
+    assert coder._ingest(ordered) is ordered
+    y_sorted = coder._ingest(x)
+    assert y_sorted is not x and y_sorted.has_unit_features() and len(y_sorted) == len(x)
+    kz = orc.array2vector(y_sorted.C.cpu().numpy(), int(c4.max()) + 1)
+    assert np.all(np.diff(kz) > 0)
+    ref = orc.encode(sd_np, c4)
+    outs = {}
+    for flag in (True, False):
+        coder_mod.INGEST_SORT = flag
+        try:
+            c = Coder(m, str(tmp_path / f's{int(flag)}'))
+            y = c.encode(x)
+            for k in ('F', 'H', 'num_points'):
+                assert (tmp_path / f's{int(flag)}_{k}.bin').read_bytes() == ref[k], (flag, k)
+            np.testing.assert_array_equal(y.C.cpu().numpy(), ref['yC'])
+            np.testing.assert_array_equal(y.F.cpu().numpy(), ref['yF'])
+            outs[flag] = c.decode().C.cpu().numpy()
+        finally:
+            coder_mod.INGEST_SORT = True
+    np.testing.assert_array_equal(outs[True], outs[False])
+    np.testing.assert_array_equal(outs[True], orc.decode(sd_np, ref['coords8'], ref['F'], ref['H'], ref['num_points']))
+    # general (non-unit) features travel with their rows
+    f = np.random.default_rng(3).standard_normal((len(c4), 1)).astype(np.float32)
+    xf = SparseTensor(_t(f), coordinates=_t(c4), tensor_stride=1, device=DEV)
+    ys = coder._ingest(xf)
+    back = {tuple(r): v for r, v in zip(ys.C.cpu().numpy().tolist(), ys.F.cpu().numpy()[:, 0].tolist())}
+    assert all(back[tuple(r)] == v for r, v in zip(c4.tolist(), f[:, 0].tolist()))
