@@ -452,6 +452,28 @@ def main():
         coord_ms = {'encode': round((t_c1 - t_c) * 1e3, 3), 'decode': round((t_c2 - t_c1) * 1e3, 3), 'points': int(len(c8)),
                     'note': 'host octree coder alone (one unit); overlapped with GPU work inside a step'}
 
+    # `_C.bin` on geometry that is NOT the shape the octree coder's contexts were trained on (they are trained, once per process, on an
+    # integer-defined sphere shell; every bench cloud is a sphere shell too: its 1.7 bit per stride-8 point is a best case)
+    coord_rate = None
+    if cfg == 'frame' and world == 1 and not args.no_extra and not args.two_cpu_child:
+        from pcgcv2_amd import gpcc
+        from pcgcv2_amd.sparse import CoordMap
+        coord_rate = {}
+        for nm in ('shell10', 'noisy10', 'multi10', 'solid_ball'):
+            p3 = (synthetic.shell(nm, device=dev) if nm in synthetic.SHELLS else synthetic.cloud(nm).to(dev))
+            c4 = torch.cat([torch.zeros((len(p3), 1), dtype=torch.int32, device=dev), p3], 1).contiguous()
+            l8 = CoordMap(c4, 1, unique=True).build_pyramid(3)
+            c8 = (l8.C[:, 1:] // 8).cpu().numpy()
+            path = os.path.join(tmp, f'rate_{nm}_C.bin')
+            gpcc.native_encode(c8, path)
+            back = gpcc.native_decode(path)
+            assert len(back) == len(c8)
+            coord_rate[nm] = {'stride8_points': int(len(c8)), 'bits_per_stride8_point': round(os.path.getsize(path) * 8 / max(len(c8), 1), 3),
+                              'bpp_of_the_input_cloud': round(os.path.getsize(path) * 8 / max(len(p3), 1), 5)}
+            os.remove(path)
+        coord_rate['note'] = ('native octree stream (tmc3 absent) on the stride-8 level of four clouds; the coder\'s contexts are trained on a sphere shell, so '
+                              'shell10 is its best case')
+
     enc_t, dec_t = timers
     if dist_on:
         t = torch.tensor([elapsed, enc_t, dec_t], dtype=torch.float64, device=red_dev)
@@ -508,7 +530,7 @@ def main():
                        'entropy_decode': '`_F.bin` (bit-identical to the reference-format stream, decodable without it) comes with a sidecar '
                                          f'`_F.idx` of decoder states at {coder_mod.INDEX_SEGMENTS} row boundaries: its segments are decoded two per thread (two dependency chains per loop) on up to 8 threads; `_C.bin` '
                                          '(native octree, tmc3 absent) is coded as up to 8 independent groups of subtrees',
-                       'coord_codec': 'native-octree (tmc3 absent)', 'coord_coder_ms': coord_ms, 'serving_throughput': serving,
+                       'coord_codec': 'native-octree (tmc3 absent)', 'coord_coder_ms': coord_ms, 'coord_codec_rate': coord_rate, 'serving_throughput': serving,
                        'step_ms_rank0': step_ms,
                        'd1_psnr_rank0_db': None if d1 is None else round(d1['mseF,PSNR (p2point)'], 4),
                        'd1_scope': 'whole blocked cloud, decoded blocks gathered to rank 0 (shard.gather_varlen)' if cfg == 'blocks' else "this rank's first unit",

@@ -590,6 +590,14 @@ template <int W, int ROWS>
 __device__ __forceinline__ void child_flush(const float* scratch, const ChildResidual<W, ROWS>& rr, bool has_res, int64_t row0, int64_t rows_total,
                                             float* __restrict__ out, int out_ld, int relu, int lane, int half = -1) {
     constexpr int C4 = W / 4, N = (ROWS * C4 + 63) / 64;
+    ChildResidual<W, ROWS> xr = rr;
+    if (has_res) {
+        // ONE wait for every residual piece, here, before the first store is issued.  (vmcnt retires in order and counts stores too: left to
+        // the compiler, each piece's use inside the loop below waited `vmcnt(0)` — i.e. also for the PREVIOUS piece's store to be
+        // acknowledged by memory, four round trips per chunk.  The empty asm makes the registers' readiness a fact the compiler knows.)
+#pragma unroll
+        for (int it = 0; it < N; ++it) asm volatile("" : "+v"(xr.x[it].x), "+v"(xr.x[it].y), "+v"(xr.x[it].z), "+v"(xr.x[it].w));
+    }
 #pragma unroll
     for (int it = 0; it < N; ++it) {
         const int i = lane + 64 * it, lr = i / C4, c4 = i % C4;
@@ -597,7 +605,7 @@ __device__ __forceinline__ void child_flush(const float* scratch, const ChildRes
         if (i >= ROWS * C4 || row >= rows_total || (half >= 0 && ((lr >> 2) & 1) != half)) continue;
         float4 v = ((const float4*)scratch)[i];
         if (has_res) {
-            const float4 x = rr.x[it];
+            const float4 x = xr.x[it];
             v.x = v.x + x.x; v.y = v.y + x.y; v.z = v.z + x.z; v.w = v.w + x.w;
         }
         if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
@@ -607,8 +615,16 @@ __device__ __forceinline__ void child_flush(const float* scratch, const ChildRes
 template <int W, int ROWS>
 __device__ __forceinline__ void child_flush(const float* scratch, int64_t row0, int64_t rows_total, float* __restrict__ out, int out_ld,
                                             int relu, int lane, int half = -1) {
-    ChildResidual<W, ROWS> none;
-    child_flush<W, ROWS>(scratch, none, false, row0, rows_total, out, out_ld, relu, lane, half);
+    constexpr int C4 = W / 4, N = (ROWS * C4 + 63) / 64;
+#pragma unroll
+    for (int it = 0; it < N; ++it) {
+        const int i = lane + 64 * it, lr = i / C4, c4 = i % C4;
+        const int64_t row = row0 + lr;
+        if (i >= ROWS * C4 || row >= rows_total || (half >= 0 && ((lr >> 2) & 1) != half)) continue;
+        float4 v = ((const float4*)scratch)[i];
+        if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+        *(float4*)(out + row * out_ld + 4 * c4) = v;
+    }
 }
 // (runtime row count, no residual: the plain-rows kernels of rows_irn.hip whose chunk is 16 rows)
 template <int W>
@@ -643,7 +659,9 @@ __device__ __forceinline__ void child_flush(const float* scratch, int rows, int6
 
 template <class T_> struct child_type_tag { using type = T_; };
 // plain conv:  acc[t][r] = out[8 (p0 + 4 mq + r) + j][16 n + mi],  t = j * NT + n.   SPLIT: half units (see k_child_irn_a)
-template <int NB, int NT, int NW, int D, bool SPLIT = false, int MT = 1>
+// RES: the launch has residual rows (the no-residual instantiation — every conv of the decoder — carries no residual registers at all:
+// with a runtime flag their 16-32 VGPRs cost the 16 -> 16 kernel its third wave per SIMD, 241 -> 268 us)
+template <int NB, int NT, int NW, int D, bool SPLIT = false, int MT = 1, bool RES = false>
 __global__ void __launch_bounds__(NW * 64)
 k_child_conv(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in, int in_ld,
              const float* __restrict__ table, int table_bytes, ChildEpi ep) {
@@ -666,8 +684,8 @@ k_child_conv(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restr
             if (m > 0 && p0 >= n_p) break;
 #pragma unroll
             for (int h = 0; h < 128 / CH; ++h) {
-                ChildResidual<W, CH> rr;
-                child_flush_prefetch<W, CH>(rr, 8 * p0 + h * CH, 8 * n_p, ep.res, ep.res_ld, lane, HZ);
+                ChildResidual<W, RES ? CH : 1> rr;
+                if constexpr (RES) child_flush_prefetch<W, CH>(rr, 8 * p0 + h * CH, 8 * n_p, ep.res, ep.res_ld, lane, HZ);
                 if (mq / MQC == h) {
 #pragma unroll
                     for (int t = 0; t < VV::T; ++t) {
@@ -682,7 +700,8 @@ k_child_conv(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restr
                     }
                 }
                 wave_lds_sync();
-                child_flush<W, CH>(scratch, rr, ep.res != nullptr, 8 * p0 + h * CH, 8 * n_p, ep.out, ep.out_ld, ep.relu, lane, HZ);
+                if constexpr (RES) child_flush<W, CH>(scratch, rr, true, 8 * p0 + h * CH, 8 * n_p, ep.out, ep.out_ld, ep.relu, lane, HZ);
+                else child_flush<W, CH>(scratch, 8 * p0 + h * CH, 8 * n_p, ep.out, ep.out_ld, ep.relu, lane, HZ);
                 wave_lds_sync();
             }
         }
@@ -1026,12 +1045,14 @@ static unsigned child_grid(int64_t n_p, int nw, size_t lds, int units_per_tile =
 template <int NB, int NT, int NW, int D, int MT = 1>
 int launch_child_conv(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
                       const ChildEpi& ep, hipStream_t s) {
-    CHILD_LAUNCH_EX((k_child_conv<NB, NT, NW, D, false, MT>), NW, D * NB * 1024 * MT, ep, MT, 1);
+    if (ep.res) CHILD_LAUNCH_EX((k_child_conv<NB, NT, NW, D, false, MT, true>), NW, D * NB * 1024 * MT, ep, MT, 1);
+    CHILD_LAUNCH_EX((k_child_conv<NB, NT, NW, D, false, MT, false>), NW, D * NB * 1024 * MT, ep, MT, 1);
 }
 template <int NB, int NT, int NW, int D>
 int launch_child_conv_split(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
                             const ChildEpi& ep, hipStream_t s) {
-    CHILD_LAUNCH_SPLIT((k_child_conv<NB, NT, NW, D, true>), NW, D * NB * 1024, ep);
+    if (ep.res) CHILD_LAUNCH_EX((k_child_conv<NB, NT, NW, D, true, 1, true>), NW, D * NB * 1024, ep, 1, 2);
+    CHILD_LAUNCH_EX((k_child_conv<NB, NT, NW, D, true, 1, false>), NW, D * NB * 1024, ep, 1, 2);
 }
 template <int NB, int NW, int D, int MT = 1>
 int launch_child_cls(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,

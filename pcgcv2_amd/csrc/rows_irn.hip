@@ -73,6 +73,7 @@ k_rows_irn_a64(const int32_t* __restrict__ pnbr, int64_t n_p /* rows of the leve
         const int64_t tile = child_tile<NW>(i, wave, ntiles);
         if (tile < 0) break;
         const int64_t row0 = tile * 16;
+        CHILD_T(t_it0);
         f32x4 acc[V::T];
         child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
 #pragma unroll
@@ -83,7 +84,11 @@ k_rows_irn_a64(const int32_t* __restrict__ pnbr, int64_t n_p /* rows of the leve
         wave_lds_sync();
         child_flush<32, 16>(scratch, row0, n_p, ep.out, 32, 0, lane);
         wave_lds_sync();
+#ifdef PCGC_CHILD_TIMING
+        { CHILD_T(t_dr0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHILD_T(t_it1); CHILD_TADD(5, t_dr0, t_it1); CHILD_TADD(4, t_it0, t_it1); }
+#endif
     }
+    CHILD_TFLUSH;
 }
 
 // pass B:  out[row][0:32]  = (conv0_1(t[:, :16]) + b01) + x[row][0:32]
@@ -106,6 +111,7 @@ k_rows_irn_b64(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __res
         const int64_t tile = child_tile<NW>(i, wave, ntiles);
         if (tile < 0) break;
         const int64_t row0 = tile * 16;
+        CHILD_T(t_it0);
         f32x4 acc[V::T];
         child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
         ChildResidual<64, 16> rr;                                  // residual rows: requested now, consumed after the staging hand-off
@@ -128,7 +134,11 @@ k_rows_irn_b64(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __res
         wave_lds_sync();
         child_flush<64, 16>(stage, rr, ep.x != nullptr, row0, n_p, ep.out, ep.out_ld, 0, lane);
         wave_lds_sync();
+#ifdef PCGC_CHILD_TIMING
+        { CHILD_T(t_dr0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHILD_T(t_it1); CHILD_TADD(5, t_dr0, t_it1); CHILD_TADD(4, t_it0, t_it1); }
+#endif
     }
+    CHILD_TFLUSH;
 }
 
 // ---- C = 32 (Q = 8) on a plain level: the small levels (the encoder's stride-8 level: 18.7 k rows), where the row-split VALU kernels are
@@ -169,6 +179,7 @@ k_rows_irn_a32(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __res
         const int64_t tile = child_tile<NW>(i, wave, ntiles);
         if (tile < 0) break;
         const int64_t row0 = tile * 16;
+        CHILD_T(t_it0);
         f32x4 acc[V::T];
         child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
 #pragma unroll
@@ -176,7 +187,11 @@ k_rows_irn_a32(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __res
         wave_lds_sync();
         child_flush<16, 16>(scratch, row0, n_p, ep.out, 16, 0, lane);
         wave_lds_sync();
+#ifdef PCGC_CHILD_TIMING
+        { CHILD_T(t_dr0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHILD_T(t_it1); CHILD_TADD(5, t_dr0, t_it1); CHILD_TADD(4, t_it0, t_it1); }
+#endif
     }
+    CHILD_TFLUSH;
 }
 // pass B:  out[row][0:16]  = (conv0_1(t[:, :8]) + b01) + x[row][0:16]
 //          out[row][16:32] = (conv1_2(relu(conv1_1(t[:, 8:]) + b11)) + b12) + x[row][16:32]       (conv1_2 k1 8 -> 16: two MFMAs on u)
@@ -198,6 +213,7 @@ k_rows_irn_b32(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __res
         const int64_t tile = child_tile<NW>(i, wave, ntiles);
         if (tile < 0) break;
         const int64_t row0 = tile * 16;
+        CHILD_T(t_it0);
         f32x4 acc[V::T];
         child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
         ChildResidual<32, 16> rr;                                  // residual rows: requested now, consumed after the staging hand-off
@@ -216,7 +232,11 @@ k_rows_irn_b32(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __res
         wave_lds_sync();
         child_flush<32, 16>(stage, rr, ep.x != nullptr, row0, n_p, ep.out, ep.out_ld, 0, lane);
         wave_lds_sync();
+#ifdef PCGC_CHILD_TIMING
+        { CHILD_T(t_dr0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHILD_T(t_it1); CHILD_TADD(5, t_dr0, t_it1); CHILD_TADD(4, t_it0, t_it1); }
+#endif
     }
+    CHILD_TFLUSH;
 }
 
 // plain k3 conv Cin = 16 NB -> Cout = 16 NT on a plain level: tile n = output columns [16 n, 16 n + 16), fragment (k, n) = the offset's
@@ -249,6 +269,7 @@ k_rows_conv(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restri
         const int64_t tile = child_tile<NW>(i, wave, ntiles);
         if (tile < 0) break;
         const int64_t row0 = tile * 16;
+        CHILD_T(t_it0);
         f32x4 acc[V::T];
         child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_in, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
         ChildResidual<W, 16> rr;                                  // residual rows: requested now, consumed after the staging hand-off
@@ -265,7 +286,11 @@ k_rows_conv(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restri
         wave_lds_sync();
         child_flush<W, 16>(scratch, rr, ep.res != nullptr, row0, n_p, ep.out, ep.out_ld, ep.relu, lane);
         wave_lds_sync();
+#ifdef PCGC_CHILD_TIMING
+        { CHILD_T(t_dr0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHILD_T(t_it1); CHILD_TADD(5, t_dr0, t_it1); CHILD_TADD(4, t_it0, t_it1); }
+#endif
     }
+    CHILD_TFLUSH;
 }
 
 // k2 s2 down conv (autoencoder.py:78-84,97-103,116-122): tile = 16 COARSE rows, "cell" k = child offset k of the coarse row: row
@@ -307,6 +332,7 @@ k_rows_down(const int32_t* __restrict__ pnbr /* down [8][n_p] */, int64_t n_p /*
         const int64_t tile = child_tile<NW>(i, wave, ntiles);
         if (tile < 0) break;
         const int64_t row0 = tile * 16;
+        CHILD_T(t_it0);
         f32x4 acc[V::T];
         child_tile_mainloop<V, D>(pnbr, n_p, row0, rs_fine, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
         ChildResidual<W, 16> rr;                                  // residual rows: requested now, consumed after the staging hand-off
@@ -323,7 +349,11 @@ k_rows_down(const int32_t* __restrict__ pnbr /* down [8][n_p] */, int64_t n_p /*
         wave_lds_sync();
         child_flush<W, 16>(scratch, rr, ep.res != nullptr, row0, n_p, ep.out, ep.out_ld, ep.relu, lane);
         wave_lds_sync();
+#ifdef PCGC_CHILD_TIMING
+        { CHILD_T(t_dr0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHILD_T(t_it1); CHILD_TADD(5, t_dr0, t_it1); CHILD_TADD(4, t_it0, t_it1); }
+#endif
     }
+    CHILD_TFLUSH;
 }
 
 // persistent grid over 16-row tiles (child_grid counts 16-PARENT tiles: the same number here)
@@ -446,4 +476,4 @@ extern "C" int pcgc_conv_down_rows(const int32_t* down, int64_t n_coarse, const 
     PCGC_CHECK_LAUNCH("conv_down_rows");
     return 0;
 }
-
+CHILD_TIMING_READER(pcgc_child_timing_rows)

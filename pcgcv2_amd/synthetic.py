@@ -27,7 +27,11 @@ SHELLS = {
 
 def shell(name='shell10', device='cpu'):
     """-> int32 [N,3] voxel coordinates in x-fastest raster order (torch tensor on `device`)."""
-    grid, radius, amp, (la, lb) = SHELLS[name]
+    return _shell(*SHELLS[name], device=device)
+
+
+def _shell(grid, radius, amp, lobes, device='cpu'):
+    la, lb = lobes
     dev = torch.device(device)
     c = (grid - 1) / 2.0
     lo = max(0, int(math.floor(c - radius - amp - 2)))
@@ -122,20 +126,9 @@ def cloud(name, order='raster', seed=0, device='cpu'):
             grid = max(64, int(1024 * s))
             c = (grid - 1) / 2.0
             R, A = 243.0 * s, 18.0 * s
-            # a perturbed shell like shell10_b, built here so that it scales
+            # a perturbed shell like shell10_b (the same generator, so that it scales with s)
             g_lo, g_hi = int(max(0, np.floor(c - R - A - 2))), int(min(grid, np.ceil(c + R + A + 3)))
-            ax = np.arange(g_lo, g_hi) - c
-            X, Y = np.meshgrid(ax, ax, indexing='xy')
-            rxy2, phi = X * X + Y * Y, np.arctan2(Y, X)
-            parts = []
-            for zi in range(g_lo, g_hi):
-                r = np.sqrt(rxy2 + (zi - c) ** 2)
-                theta = np.arccos(np.clip((zi - c) / np.maximum(r, 1e-9), -1.0, 1.0))
-                m = np.abs(r - (R + A * np.sin(2 * theta) * np.cos(7 * phi))) < 0.5
-                if m.any():
-                    yi, xi = np.nonzero(m)
-                    parts.append(np.stack([xi + g_lo, yi + g_lo, np.full(len(xi), zi)], 1))
-            surf = np.concatenate(parts, 0).astype(np.int64)
+            surf = _shell(grid, R, A, (2, 7)).numpy().astype(np.int64)
             if family == 'sparse':
                 pts = surf[rng.random(len(surf)) >= 0.34]                      # ~0.5 M of 0.76 M voxels: most stride-2 parents survive
             else:

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/pmc_traffic
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-events --serving-frames 0 > $OUT/$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-events --serving-frames 0 --no-extra > $OUT/$C.log 2>&1
 done
 python $R/tools/pmc_traffic.py $OUT $R/profiles/pmc_traffic.json
 find $OUT -name '*.csv' -size +1M -delete      # gpurun_out/ is capped at 64 MiB
