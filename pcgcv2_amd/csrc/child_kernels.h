@@ -887,16 +887,25 @@ k_child_irn_b(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
                         for (int r = 0; r < 4; ++r) stage[(8 * (4 * (mq % MQC) + r) + j) * C + c0] = acc[m][t][r] + b01;
                     }
                 }
+                // conv1_2 on u, 16 rows per MFMA product: every A operand is read before any result is written (the compiler cannot move an
+                // LDS read across an LDS write of the same array: written group by group, each group was read -> wait -> MFMA -> wait -> write)
+                float au[CH / 16][KQ];
 #pragma unroll
-                for (int gg = 0; gg < CH / 16; ++gg) {          // conv1_2 on u, 16 rows per MFMA product
-                    const int g = h * (CH / 16) + gg;
-                    f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int gg = 0; gg < CH / 16; ++gg)
 #pragma unroll
-                    for (int jj = 0; jj < KQ; ++jj) d = __builtin_amdgcn_mfma_f32_16x16x4f32(us[(16 * g + mi) * Q + 4 * jj + mq], w12[jj], d, 0, 0, 0);
-                    if (mi < H) {
+                    for (int jj = 0; jj < KQ; ++jj) au[gg][jj] = us[(16 * (h * (CH / 16) + gg) + mi) * Q + 4 * jj + mq];
+                f32x4 d[CH / 16];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) stage[(16 * gg + 4 * mq + r) * C + H + mi] = d[r] + b12;
-                    }
+                for (int gg = 0; gg < CH / 16; ++gg) {
+                    d[gg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int jj = 0; jj < KQ; ++jj) d[gg] = __builtin_amdgcn_mfma_f32_16x16x4f32(au[gg][jj], w12[jj], d[gg], 0, 0, 0);
+                }
+                if (mi < H) {
+#pragma unroll
+                    for (int gg = 0; gg < CH / 16; ++gg)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) stage[(16 * gg + 4 * mq + r) * C + H + mi] = d[gg][r] + b12;
                 }
                 wave_lds_sync();
                 child_flush<C, CH>(stage, rr, ep.x != nullptr, 8 * p0 + h * CH, 8 * n_p, ep.out, ep.out_ld, 0, lane, HZ);
