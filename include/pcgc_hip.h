@@ -128,6 +128,9 @@ int pcgc_down_level(const int32_t* fine /*[dev n,4]*/, int64_t n, int32_t stride
 size_t pcgc_pyramid_scratch_bytes(int64_t n, int levels);
 int pcgc_pyramid(const int32_t* fine /*[dev n,4]*/, int64_t n, int32_t stride, int levels, void* scratch, size_t scratch_bytes,
                  int32_t* const* coarse, int32_t* const* parent_of, int32_t* const* down, int64_t* counts /*host*/, void* stream);
+/* A/B switch of pcgc_pyramid: 1 (default) = level l is inserted from the rows level l - 1 kept, 0 = every level from all input rows
+ * (round 3).  Same levels, parent_of and down maps either way. */
+int pcgc_set_pyramid_impl(int hierarchical);
 /* orig[prefix[i]] = i for set mask bytes (row indices that survive a compaction) */
 int pcgc_compact_index(const uint8_t* mask, const int32_t* prefix, int64_t n, int32_t* orig /*[dev total]*/, void* stream);
 

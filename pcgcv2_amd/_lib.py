@@ -41,6 +41,7 @@ SIGNATURES = {
     'pcgc_down_level': (ci, [vp, i64, i32, vp, vp, vp, i64, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),
     'pcgc_pyramid_scratch_bytes': (sz, [i64, ci]),
     'pcgc_pyramid': (ci, [vp, i64, i32, ci, vp, sz, vp, vp, vp, vp, vp]),
+    'pcgc_set_pyramid_impl': (ci, [ci]),
     'pcgc_compact_index': (ci, [vp, vp, i64, vp, vp]),
     'pcgc_conv_gather': (ci, [vp, ci, i64, vp, i64, ci, ci, ci, vp, vp, vp, ci, ci, ci, vp, ci, ci, ci, vp]),
     'pcgc_conv_gather_unit': (ci, [vp, ci, i64, vp, vp, ci, vp, ci, ci, vp]),

@@ -16,7 +16,7 @@ for cfg in frame:10:1 sweep:2:7 blocks:3:8; do
   python tools/rocprof_summary.py gpurun_out/final/kt_$c/*/*kernel_stats.csv > gpurun_out/final/kernel_stats_$c.txt 2>&1 || true
   find gpurun_out/final/kt_$c -name '*kernel_trace.csv' -delete
 done
-bash tools/fetch_calib.sh > /dev/null 2>&1; cp gpurun_out/r02_fetch_calibration.txt gpurun_out/final/fetch_calibration.txt
+bash tools/fetch_calib.sh > /dev/null 2>&1; cp gpurun_out/r02_fetch_calibration.txt gpurun_out/final/fetch_calibration.txt 2>/dev/null
 for cfg in 16:irn 16:conv 32:irn; do
   bash tools/child_pmc.sh ${cfg%%:*} 0 0 ${cfg##*:} > /dev/null 2>&1; cp gpurun_out/child_pmc/summary.txt gpurun_out/final/child_pmc_${cfg%%:*}_${cfg##*:}.txt
 done
