@@ -33,11 +33,11 @@ model = PCCModel().to(dev); model.load_state_dict(synthetic.synthetic_state_dict
 coder = Coder(model, os.path.join(tempfile.mkdtemp(dir='/dev/shm'), 'f'))
 x = SparseTensor(feats, coordinates=coords, tensor_stride=1, device=dev)
 for cls, names in ((Coder, ['encode', 'decode', '_decode_geometry', '_stage_geometry', '_sort_and_stage']), (coder_mod.FeatureCoder, ['encode', 'decode']),
-                   (coder_mod.CoordinateCoder, ['encode', 'decode']), (sparse.CoordMap, ['down', 'prepare_up']),
+                   (coder_mod.CoordinateCoder, ['encode', 'decode']), (sparse.CoordMap, ['down', 'prepare_up', 'build_pyramid']), (Coder, ['_ingest', '_stage_level', '_decode_buffers', '_upload_level']),
                    (type(model.encoder), ['forward']), (type(model.decoder), ['forward'])):
     for n in names:
         wrap(cls, n, f'{cls.__name__}.{n}')
-for n in ('rc_encode', 'rc_decode', 'quantize_symbols', 'sort_zyx', 'desymbolize', 'topk_mask', 'items_encode', 'items_probe', 'items_decode'):
+for n in ('rc_encode', 'rc_decode', 'quantize_symbols', 'sort_zyx', 'desymbolize', 'topk_mask', 'items_encode', 'items_probe', 'items_decode', 'frame_decode', 'table_warm', 'pyramid', 'level_prepare_children', 'conv_up2', 'gather_feats'):
     wrap(ops, n, 'ops.' + n)
 wrap(coder_mod, '_dump'); wrap(coder_mod, '_slurp')
 from pcgcv2_amd import entropy_model
@@ -45,7 +45,9 @@ wrap(entropy_model.EntropyBottleneck, 'host_table', 'EB.host_table')
 
 def step():
     x.cmap.drop_caches()
-    coder.encode(x); out = coder.decode(); torch.cuda.synchronize(); return out
+    entropy_model.table_cache(clear=True)
+    coder.encode(x); entropy_model.table_cache(clear=True)
+    out = coder.decode(); torch.cuda.synchronize(); return out
 for _ in range(4): step()
 LOG.clear(); torch.cuda.synchronize(); T0[0] = time.perf_counter()
 step()
