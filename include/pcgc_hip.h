@@ -369,6 +369,14 @@ int pcgc_level_prepare_children(const int32_t* coords, int64_t n, int32_t stride
  * rows needed, nothing decoded); < 0: error (-5 as above).  `_C.bin` not a native stream (tmc3): info[5] = 0, `level` untouched. */
 int pcgc_frame_decode(const char* stem, int C, const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int coord_scale,
                       int64_t cap_rows, int16_t* sym, int32_t* level, int64_t* info, float* range, int threads);
+/* The same call in two halves: `_begin` returns as soon as the coordinate level is in `level` (info / range filled; 1 = buffers too small,
+ * nothing pending) while the feature stream keeps decoding on the library's threads; the caller uploads the level and enqueues the decoder's
+ * coordinate-only kernels (pcgc_level_prepare_children), then `_end` waits for `sym` and returns pcgc_frame_decode's code.  Every
+ * successful `_begin` must be followed by `_end` on the same thread.  With fewer than three CPUs, or while another thread's frame is
+ * pending, `_begin` does everything synchronously and `_end` nothing. */
+int pcgc_frame_decode_begin(const char* stem, int C, const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int coord_scale,
+                            int64_t cap_rows, int16_t* sym, int32_t* level, int64_t* info, float* range, int threads);
+int pcgc_frame_decode_end(void);
 
 /* The CDF-table cache behind pcgc_items_encode / pcgc_items_decode / pcgc_frame_decode (a table is a pure function of the entropy
  * parameters and the symbol range; the reference evaluates it in every compress() and decompress(), entropy_model.py:165-171,185-190).

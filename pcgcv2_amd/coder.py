@@ -23,6 +23,10 @@ from .pc_error import pc_error
 from .pcc_model import PCCModel
 from .sparse import SparseTensor, CoordMap, require_gpu
 
+def _os_environ_flag(name, default='1'):
+    return os.environ.get(name, default) != '0'
+
+
 device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
 _POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix='pcgc-coord')      # helpers of up to 4 frames in flight
 
@@ -53,6 +57,7 @@ def _slurp(path):
 # The sidecar names the stream it belongs to by length and CRC-32 and carries a CRC over itself; one that does not match (or is
 # absent: a reference-made stream) is ignored and the stream is decoded serially, unguarded — exactly what the reference does.
 INDEX_SEGMENTS = 16                              # checkpoints per stream (two segments per decoder thread); 0 = never write or read the sidecar
+FRAME_SPLIT = _os_environ_flag('PCGC_FRAME_SPLIT')   # decode: coordinate-only kernels are enqueued while the feature stream is still being decoded (A/B: PCGC_FRAME_SPLIT=0)
 INGEST_SORT = True                               # encode: an unordered cloud is sorted once before the encoder touches it (Coder._ingest)
 WARM_TABLE_CODE = True                           # encode: a throw-away table evaluation while the host waits for the GPU (ops.table_warm)
 NATIVE_ITEMS = True                              # batches: per-item host stages on native threads (False: Python thread pool; A/B and tests)
@@ -401,16 +406,24 @@ class Coder():
             packed = self.feature_coder.entropy_model._host_packed()
             while True:
                 sym_np, level_np = self._decode_buffers(C)
-                n8, rng, counts, native = ops.frame_decode(stem, C, packed, sym_np, level_np, use_sidecar=bool(INDEX_SEGMENTS), level_scale=8)
+                # (round 4: in two halves — the call returns once the coordinate level is decoded; the feature stream, the longer of the
+                #  two, keeps decoding on the library's threads while this thread uploads the level and enqueues the coordinate-only kernels
+                #  of the first decoder stage: hash, kernel map, children level and its map)
+                n8, rng, counts, native = ops.frame_decode_begin(stem, C, packed, sym_np, level_np, use_sidecar=bool(INDEX_SEGMENTS), level_scale=8)
                 if rng is not None:
                     break
                 self._decode_buffers(C, rows=n8)                  # (a larger cloud than any before: grow and decode)
             n4, n2, n1 = counts
+            if not FRAME_SPLIT:
+                ops.frame_decode_end()
+            try:
+                if native:
+                    lvl8 = self._stage_level(n8, dev, stream)
+            finally:
+                ops.frame_decode_end()                           # the symbols are in the pinned buffer now (or the stream's error is raised)
             sym_d = self._pinned_sym[:n8].to(dev, non_blocking=True)          # (`stream` is this thread's current stream)
-            if native:
-                lvl8 = self._stage_level(n8, dev, stream)
-            else:                                                # tmc3 stream: the subprocess protocol (helper thread in the general path)
-                self._mark_uploads(dev)
+            self._mark_uploads(dev)
+            if not native:                                       # tmc3 stream: the subprocess protocol (helper thread in the general path)
                 lvl8 = self._decode_geometry(postfix, dev, stream)
             y_F = ops.desymbolize(sym_d, rng[0])
         else:

@@ -1364,6 +1364,7 @@ extern "C" int pcgc_items_probe(int n_items, const char* const* stems, int64_t* 
 
 // -> sym [sum rows, C] and (for items with native_coords) xyz [sum rows, 3].  use_sidecar = 0: never read <stem>_F.idx.
 // Returns -5 if a sidecar says the stream was coded with another CDF table than this host derives (see coder.py).
+namespace { thread_local std::atomic<int>* tl_frame_coords_flag = nullptr; }       // set by pcgc_frame_decode_begin's worker around its call
 extern "C" int pcgc_items_decode(int n_items, const char* const* stems, const int64_t* rows, int C, const float* ranges, const int32_t* native_coords,
                                  const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int16_t* sym, int32_t* xyz, int coord_layout,
                                  int coord_scale, int threads) {
@@ -1372,6 +1373,7 @@ extern "C" int pcgc_items_decode(int n_items, const char* const* stems, const in
         pcgc_set_error("items_decode: bad arguments"); return -2;
     }
     prewake_for_decode(n_items, threads, 300);
+    std::atomic<int>* const frame_flag = n_items == 1 ? tl_frame_coords_flag : nullptr;      // (read on the CALLING thread: either task may run on a pool thread)
     std::vector<int64_t> off((size_t)n_items + 1, 0);
     for (int i = 0; i < n_items; ++i) off[(size_t)i + 1] = off[(size_t)i] + rows[i];
     // two tasks per item — its coordinate stream and its feature stream are independent — so that ONE cloud (the single-frame path)
@@ -1381,6 +1383,9 @@ extern "C" int pcgc_items_decode(int n_items, const char* const* stems, const in
         const std::string stem = stems[i];
         const int64_t n = rows[i];
         StageClock clk;
+        // (pcgc_frame_decode_begin: the caller waits for the coordinate level only and launches the coordinate-only decoder kernels while the
+        //  feature stream is still being decoded — the flag is raised when the coordinate task of the frame ends, whatever its outcome)
+        struct CoordsDone { std::atomic<int>* f; ~CoordsDone() { if (f) f->store(1, std::memory_order_release); } } coords_done{(task & 1) == 0 ? frame_flag : nullptr};
         if ((task & 1) == 0) {                                   // (the coordinate stream is the longer task by now — 0.18 against 0.16 ms — so the
             if (native_coords[i]) {                              //  calling thread starts it at once and the feature stream pays the helper's wake-up)
                 std::vector<uint8_t> cb;
@@ -1481,3 +1486,85 @@ extern "C" int pcgc_frame_decode(const char* stem, int C, const float* eb_params
     return pcgc_items_decode(1, &stem, &rows, C, range, &native, eb_params, table_fn, use_sidecar, sym, level, 1, coord_scale > 0 ? coord_scale : 1, threads);
 }
 
+// pcgc_frame_decode in two halves (round 4).  The coordinate stream of a vox10 frame is decoded in ~0.17 ms, the feature stream (CDF table
+// + range decoder) in ~0.3 ms, side by side; the first decoder kernels — hash of the stride-8 level, its kernel map, the children level and its
+// map — need the coordinates only.  `_begin` returns as soon as the coordinate level is in `level` (the feature stream keeps decoding on the
+// library's threads), the caller uploads the level and enqueues those kernels, `_end` waits for the symbols.  Same arguments, same results
+// and error codes as pcgc_frame_decode; 1 from `_begin` = buffers too small (nothing pending).  One frame at a time per process in this
+// form: a second caller that arrives while a frame is pending is served synchronously (its `_begin` does everything, its `_end` nothing).
+namespace {
+struct FrameAsync {
+    std::mutex owner;                                    // held from a successful asynchronous _begin to its _end
+    std::thread worker; std::mutex m; std::condition_variable cv;
+    std::function<void()> job; bool has_job = false, stop = false;
+    std::atomic<int> coords{0}, finished{0};
+    std::atomic<int64_t> spin_until{0};
+    int rc = 0; std::string err;
+    static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void loop() {
+        for (;;) {
+            std::function<void()> j;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                while (!has_job && !stop) {
+                    if (now_ns() < spin_until.load(std::memory_order_relaxed)) { lk.unlock(); _mm_pause(); lk.lock(); continue; }
+                    cv.wait(lk, [&] { return has_job || stop || now_ns() < spin_until.load(std::memory_order_relaxed); });
+                }
+                if (stop) return;
+                j = std::move(job); has_job = false;
+            }
+            j();
+            finished.store(1, std::memory_order_release);
+        }
+    }
+    void ensure() { if (!worker.joinable()) worker = std::thread([this] { loop(); }); }
+    void prewake(int us) { ensure(); spin_until.store(now_ns() + (int64_t)us * 1000, std::memory_order_relaxed); cv.notify_one(); }
+    void post(std::function<void()> j) { ensure(); { std::lock_guard<std::mutex> lk(m); job = std::move(j); has_job = true; } cv.notify_one(); }
+    ~FrameAsync() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv.notify_all(); if (worker.joinable()) worker.join(); }
+};
+FrameAsync& frame_async() { static FrameAsync* f = new FrameAsync; return *f; }      // (never destroyed: its thread may outlive static destructors)
+thread_local bool tl_frame_pending = false;              // this thread owns frame_async().owner
+}  // namespace
+
+extern "C" int pcgc_frame_decode_begin(const char* stem, int C, const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int coord_scale,
+                                       int64_t cap_rows, int16_t* sym, int32_t* level, int64_t* info, float* range, int threads) {
+    if (!stem || !eb_params || !table_fn || !sym || !level || !info || !range || C < 1 || cap_rows < 0) { pcgc_set_error("frame_decode: bad arguments"); return -2; }
+    if (tl_frame_pending) { pcgc_set_error("frame_decode_begin: the previous frame of this thread was not finished (pcgc_frame_decode_end)"); return -2; }
+    FrameAsync& fa = frame_async();
+    const bool async = (threads <= 0 ? effective_cpus() : threads) >= 2 && effective_cpus() >= 3 && fa.owner.try_lock();
+    if (!async) return pcgc_frame_decode(stem, C, eb_params, table_fn, use_sidecar, coord_scale, cap_rows, sym, level, info, range, threads);
+    fa.prewake(400);                                      // (the probe reads four small files meanwhile)
+    int64_t rows = 0; int32_t channels = 0, counts[3] = {0, 0, 0}, native = 0;
+    int rc = pcgc_items_probe(1, &stem, &rows, &channels, range, counts, &native);
+    if (rc == 0) {
+        info[0] = rows; info[1] = channels; info[2] = counts[0]; info[3] = counts[1]; info[4] = counts[2]; info[5] = native;
+        if (channels != C) { pcgc_set_error("frame_decode: %s_H.bin has %d channels, the model %d", stem, (int)channels, C); rc = -2; }
+        else if (rows > cap_rows) rc = 1;
+    }
+    if (rc != 0) { fa.owner.unlock(); return rc; }
+    fa.coords.store(0); fa.finished.store(0); fa.rc = 0; fa.err.clear();
+    const std::string stem_copy = stem;
+    const float r0 = range[0], r1 = range[1];
+    fa.post([=, &fa] {
+        const char* st = stem_copy.c_str();
+        const int64_t rws = rows; const int32_t nat = native; const float rg[2] = {r0, r1};
+        tl_frame_coords_flag = &fa.coords;
+        fa.rc = pcgc_items_decode(1, &st, &rws, C, rg, &nat, eb_params, table_fn, use_sidecar, sym, level, 1, coord_scale > 0 ? coord_scale : 1, threads);
+        tl_frame_coords_flag = nullptr;
+        if (fa.rc != 0) fa.err = pcgc_last_error();
+        fa.coords.store(1, std::memory_order_release);    // (an error before the coordinate task ended must not leave the caller waiting)
+    });
+    tl_frame_pending = true;
+    while (fa.coords.load(std::memory_order_acquire) == 0 && fa.finished.load(std::memory_order_acquire) == 0) _mm_pause();
+    return 0;
+}
+extern "C" int pcgc_frame_decode_end(void) {
+    if (!tl_frame_pending) return 0;                      // (the synchronous form: everything happened in _begin)
+    FrameAsync& fa = frame_async();
+    while (fa.finished.load(std::memory_order_acquire) == 0) _mm_pause();
+    const int rc = fa.rc;
+    if (rc != 0) pcgc_set_error("%s", fa.err.c_str());
+    tl_frame_pending = false;
+    fa.owner.unlock();
+    return rc;
+}

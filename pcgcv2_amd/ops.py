@@ -1398,6 +1398,33 @@ def frame_decode(stem, C, eb_params, sym_buf, level_buf, use_sidecar=True, level
     return int(info[0]), (np.float32(rng[0]), np.float32(rng[1])), (int(info[2]), int(info[3]), int(info[4])), bool(info[5])
 
 
+def frame_decode_begin(stem, C, eb_params, sym_buf, level_buf, use_sidecar=True, level_scale=8, threads=2):
+    """frame_decode in two halves: returns as soon as the coordinate level is in level_buf (the feature stream keeps decoding on the
+    library's threads) -> the same tuple as frame_decode; the symbols in sym_buf are valid only after frame_decode_end().  When the
+    buffers are too small (rows_needed, None, None, None) nothing is pending."""
+    import ctypes
+    cap = min(sym_buf.shape[0], level_buf.shape[0])
+    if sym_buf.dtype != np.int16 or level_buf.dtype != np.int32 or sym_buf.shape[1:] != (C,) or level_buf.shape[1:] != (4,) \
+            or not sym_buf.flags.c_contiguous or not level_buf.flags.c_contiguous:
+        raise PcgcError('frame_decode: buffers must be C-contiguous int16 [cap, C] and int32 [cap, 4]')
+    info = (ctypes.c_int64 * 6)()
+    rng = (ctypes.c_float * 2)()
+    P = _np(eb_params, np.float32)
+    if P.size != 44 * int(C):
+        raise PcgcError(f'frame_decode: {P.size} entropy parameters for {C} channels (44 per channel)')
+    rc = lib().pcgc_frame_decode_begin(_os.fsencode(stem), int(C), P.ctypes.data, _table_fn(), int(bool(use_sidecar)), int(level_scale), cap,
+                                       sym_buf.ctypes.data, level_buf.ctypes.data, info, rng, int(threads))
+    if rc == 1:
+        return int(info[0]), None, None, None
+    check(rc, 'frame_decode')
+    return int(info[0]), (np.float32(rng[0]), np.float32(rng[1])), (int(info[2]), int(info[3]), int(info[4])), bool(info[5])
+
+
+def frame_decode_end():
+    """wait for the feature stream of the frame frame_decode_begin started on this thread (raises what frame_decode would have raised)"""
+    check(lib().pcgc_frame_decode_end(), 'frame_decode')
+
+
 def set_oct_tiled(on):
     """Coordinate codec: groups of subtrees coded independently (1, the default for clouds of >= 8192 points; n > 1: that many
     groups) or always one stream (0).  A/B tests."""

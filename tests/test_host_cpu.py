@@ -920,3 +920,60 @@ def test_lane_parallel_range_decoder_equals_the_serial_one(threads):
     finally:
         ops.set_rc_lanes(-1)
         ops.set_rc_threads(0)
+
+
+def test_frame_decode_in_two_halves(tmp_path):
+    """pcgc_frame_decode_begin / _end: the same symbols and level as the one-call form; the coordinate level is complete when `_begin`
+    returns; a damaged feature stream surfaces in `_end`; too-small buffers leave nothing pending; four threads at once (one is served
+    asynchronously, the others synchronously) all get their own clouds."""
+    import threading
+    from pcgcv2_amd.entropy_model import EntropyBottleneck
+    torch.manual_seed(4)
+    eb = EntropyBottleneck(8)
+    packed = eb._host_packed()
+    clouds = []
+    for t in range(4):
+        rng = np.random.default_rng(200 + t)
+        r = 5000 + 2500 * t
+        sym = np.clip(np.rint(rng.normal(7, 2.0, size=(r, 8))), 0, 14).astype(np.int16)
+        sym[0, 0], sym[-1, -1] = 0, 14
+        xyz = rng.permutation(np.unique(rng.integers(0, 80 + 10 * t, size=(4 * r, 3)), axis=0))[:r].astype(np.int32)
+        stem = str(tmp_path / f'c{t}')
+        ops.items_encode([stem], sym, xyz, [r], [(-7.0, 7.0)], [(r, 2 * r, 3 * r)], packed, 16)
+        clouds.append((stem, r, sym, xyz[np.lexsort((xyz[:, 0], xyz[:, 1], xyz[:, 2]))] * 8))
+    stem, r, sym, want = clouds[1]
+    for _ in range(5):
+        sb, lb = np.full((r + 2, 8), -5, np.int16), np.full((r + 2, 4), -5, np.int32)
+        n, rng_, counts, native = ops.frame_decode_begin(stem, 8, packed, sb, lb)
+        assert (n, native, counts) == (r, True, (r, 2 * r, 3 * r)) and tuple(float(v) for v in rng_) == (-7.0, 7.0)
+        np.testing.assert_array_equal(lb[:r, 1:], want)          # the level is complete HERE; the symbols only after _end
+        ops.frame_decode_end()
+        np.testing.assert_array_equal(sb[:r], sym)
+        assert (sb[r:] == -5).all() and (lb[r:] == -5).all()
+    ops.frame_decode_end()                                       # nothing pending: a no-op
+    assert ops.frame_decode_begin(stem, 8, packed, sb[:r - 1], lb[:r - 1]) == (r, None, None, None)
+    ops.frame_decode_end()
+    # a damaged feature stream: the error arrives in _end (or already in _begin when the call was served synchronously)
+    blob = open(stem + '_F.bin', 'rb').read()
+    os.remove(stem + '_F.bin')                                   # a missing feature stream: only the feature task can notice
+    with pytest.raises(PcgcError, match='_F.bin'):
+        ops.frame_decode_begin(stem, 8, packed, sb, lb)
+        ops.frame_decode_end()
+    ops.frame_decode_end()
+    open(stem + '_F.bin', 'wb').write(blob)
+    errors = []
+
+    def worker(t):
+        stem_t, r_t, sym_t, want_t = clouds[t]
+        sbt, lbt = np.zeros((r_t, 8), np.int16), np.zeros((r_t, 4), np.int32)
+        for _ in range(10):
+            sbt[:] = -1; lbt[:] = -1
+            n_t, _, _, nat = ops.frame_decode_begin(stem_t, 8, packed, sbt, lbt, use_sidecar=(t != 1))
+            ok_level = np.array_equal(lbt[:, 1:], want_t)
+            ops.frame_decode_end()
+            if n_t != r_t or not nat or not ok_level or not np.array_equal(sbt, sym_t):
+                errors.append(t)
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors

@@ -37,7 +37,7 @@ for cls, names in ((Coder, ['encode', 'decode', '_decode_geometry', '_stage_geom
                    (type(model.encoder), ['forward']), (type(model.decoder), ['forward'])):
     for n in names:
         wrap(cls, n, f'{cls.__name__}.{n}')
-for n in ('rc_encode', 'rc_decode', 'quantize_symbols', 'sort_zyx', 'desymbolize', 'topk_mask', 'items_encode', 'items_probe', 'items_decode', 'frame_decode', 'table_warm', 'pyramid', 'level_prepare_children', 'conv_up2', 'gather_feats'):
+for n in ('rc_encode', 'rc_decode', 'quantize_symbols', 'sort_zyx', 'desymbolize', 'topk_mask', 'items_encode', 'items_probe', 'items_decode', 'frame_decode', 'frame_decode_begin', 'frame_decode_end', 'table_warm', 'pyramid', 'level_prepare_children', 'conv_up2', 'gather_feats'):
     wrap(ops, n, 'ops.' + n)
 wrap(coder_mod, '_dump'); wrap(coder_mod, '_slurp')
 from pcgcv2_amd import entropy_model

@@ -14,8 +14,9 @@ dev = torch.device('cuda:0')
 model = PCCModel().to(dev); model.load_state_dict(synthetic.synthetic_state_dict())
 coder = Coder(model, os.path.join(tempfile.mkdtemp(dir='/dev/shm'), 'f'))
 clouds = []
-for name in ('shell10', 'shell9'):
-    pts = synthetic.shell(name, device=dev)
+from pcgcv2_amd import entropy_model
+for name, order in (('shell10', 'raster'), ('noisy_s', 'shuffled')):      # (round 4: the second cloud is unordered — ingest sort — and not a shell)
+    pts = synthetic.cloud(name, order=order, seed=2).to(dev)
     c = torch.cat([torch.zeros((len(pts), 1), dtype=torch.int32, device=dev), pts], 1).contiguous()
     clouds.append(SparseTensor(torch.ones((len(pts), 1), device=dev), coordinates=c, tensor_stride=1, device=dev))
 def rss_mb():
@@ -25,6 +26,7 @@ t0 = time.perf_counter()
 for i in range(N):
     x = clouds[i % 7 == 6]
     x.cmap.drop_caches()
+    if i % 3 == 0: entropy_model.table_cache(clear=True)      # cold and warm tables alternate
     coder.encode(x); out = coder.decode()
     n = len(out)
     key = len(x)
