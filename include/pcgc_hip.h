@@ -195,6 +195,11 @@ int pcgc_irn_config(int C, int64_t n, int* rows, int* pass_a_channels_per_subste
 /* MinkowskiGenerativeConvolutionTranspose(k=2,s=2): out[8i+k] = in[i] @ W[k] + bias (+ReLU). */
 int pcgc_conv_up2(int64_t n_in, const float* in, int Cin, int in_ld, const float* W /*[8,Cin,Cout]*/, const float* bias,
                   int relu, float* out /*[dev 8n,Cout]*/, int Cout, void* stream);
+/* the same on a pruned level read in place (autoencoder.py:247 followed by :155-161 / :182-188 of the next stage): input row p = row rows[p]
+ * of `in`, rows = the survivors' candidate rows (pcgc_topk_select's orig), so MinkowskiPruning's compacted feature tensor is never written.
+ * Returns -3 (nothing launched, no error text) for shapes other than 64 -> 32 / 32 -> 16: gather the rows, then pcgc_conv_up2. */
+int pcgc_conv_up2_gather(int64_t n_in, const float* in, int Cin, int in_ld, const int32_t* rows, const float* W /*[8,Cin,Cout]*/,
+                         const float* bias, int relu, float* out /*[dev 8n,Cout]*/, int Cout, void* stream);
 
 /* ---- k3 convolution on a CHILDREN level (the output level of a generative transpose: row 8p+j = child j of parent p) through
  *      the PARENT level's kernel map: each neighbour row is gathered once per 16-parent tile and feeds every child that
@@ -245,6 +250,25 @@ int pcgc_topk_mask(const float* logits /*[dev n], stride ld*/, int ld, int64_t n
  *      segments: seg_rows[b] rows for item b (HOST arrays; workspace as for the largest segment). ---- */
 int pcgc_topk_mask_segments(const float* logits, int ld, int nseg, const int64_t* seg_rows, const int64_t* seg_k, uint8_t* mask,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* ---- prune_voxel in one sweep (round 4): istopk (data_utils.py:77-89) + MinkowskiPruning (autoencoder.py:237,247) of a candidate level.
+ *      After the radix passes one single-pass scan keeps, per segment b, the seg_k[b] largest logits of its seg_rows[b] rows (same tie rule
+ *      and ‡ convention switch as pcgc_topk_mask) and writes the pruned level directly: out_coords [K,4] and orig [K] (the candidate row of
+ *      every surviving row, ascending), K = sum of the clamped seg_k, plus a RANK BITMAP of the candidate level for the kernel-map
+ *      derivation: bits = one bit per candidate row (row m = bit m & 7 of byte m >> 3; ((n + 63) / 64) * 8 bytes, 8-byte aligned),
+ *      wprefix [(n + 63) / 64] = survivors before row 64 w.  The candidates' coordinates are either given (`coords` [n,4]) or — a children
+ *      level, rows 8 i + j of a generative transpose that never materialised its coordinates — derived from `parent_coords` [n / 8, 4] at
+ *      tensor stride `parent_stride` (exactly one of the two is non-NULL).  seg_rows / seg_k: HOST arrays. ---- */
+size_t pcgc_topk_select_workspace_bytes(int64_t n);
+int pcgc_topk_select(const float* logits /*[dev n], stride ld*/, int ld, int nseg, const int64_t* seg_rows, const int64_t* seg_k,
+                     const int32_t* coords, const int32_t* parent_coords, int32_t parent_stride,
+                     uint8_t* bits, int32_t* wprefix, int32_t* orig, int32_t* out_coords, void* workspace, size_t workspace_bytes, void* stream);
+/* pcgc_kmap_k3_prune / _prune_parent through that rank bitmap instead of a byte mask + int32 prefix per candidate row */
+int pcgc_kmap_k3_prune_sel(const int32_t* cand_nbr /*[27,n_cand]*/, int64_t n_cand, const uint8_t* bits, const int32_t* wprefix,
+                           const int32_t* orig /*[n_out]*/, int64_t n_out, int32_t* nbr /*[dev 27,n_out]*/, void* stream);
+int pcgc_kmap_k3_prune_parent_sel(const int32_t* parent_nbr /*[dev 27,n_parent]*/, int64_t n_parent, const uint8_t* bits, const int32_t* wprefix,
+                                  const int32_t* orig, int64_t n_out, int32_t* nbr /*[dev 27,n_out]*/, void* stream);
+/* out[r] = in[orig[r]]: rows of C floats (C % 4 == 0, leading dimension in_ld) — the surviving feature rows of a pruned level */
+int pcgc_gather_rows_f32_ld(const float* in, int C, int in_ld, const int32_t* orig, int64_t n_out, float* out /*[n_out,C]*/, void* stream);
 /* rows per batch item: counts[16] (device) <- histogram of coords[:, 0]. */
 int pcgc_batch_counts(const int32_t* coords /*[dev n,4]*/, int64_t n, int32_t* counts /*[dev 16]*/, void* stream);
 

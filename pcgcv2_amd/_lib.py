@@ -65,9 +65,15 @@ SIGNATURES = {
     'pcgc_conv_rows': (ci, [vp, i64, vp, ci, ci, vp, i64, vp, vp, ci, ci, vp, ci, ci, vp]),
     'pcgc_irn_rows_pass': (ci, [vp, i64, ci, ci, vp, ci, vp, i64, vp, vp, vp, vp, ci, vp, ci, vp]),
     'pcgc_conv_up2': (ci, [i64, vp, ci, ci, vp, vp, ci, vp, ci, vp]),
+    'pcgc_conv_up2_gather': (ci, [i64, vp, ci, ci, vp, vp, vp, ci, vp, ci, vp]),
     'pcgc_topk_workspace_bytes': (sz, [i64]),
     'pcgc_topk_mask': (ci, [vp, ci, i64, i64, vp, vp, sz, vp]),
     'pcgc_topk_mask_segments': (ci, [vp, ci, ci, vp, vp, vp, vp, sz, vp]),
+    'pcgc_topk_select_workspace_bytes': (sz, [i64]),
+    'pcgc_topk_select': (ci, [vp, ci, ci, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, sz, vp]),
+    'pcgc_kmap_k3_prune_sel': (ci, [vp, i64, vp, vp, vp, i64, vp, vp]),
+    'pcgc_kmap_k3_prune_parent_sel': (ci, [vp, i64, vp, vp, vp, i64, vp, vp]),
+    'pcgc_gather_rows_f32_ld': (ci, [vp, ci, ci, vp, i64, vp, vp]),
     'pcgc_batch_counts': (ci, [vp, i64, vp, vp]),
     'pcgc_sort_bzyx': (ci, [vp, i64, vp, vp, sz, vp]),
     'pcgc_quantize_symbols_segments': (ci, [vp, ci, ci, vp, vp, vp, vp]),

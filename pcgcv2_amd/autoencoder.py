@@ -8,7 +8,7 @@ import torch
 
 from . import dispatch, ops
 from .nn import MinkowskiConvolution as Conv, MinkowskiGenerativeConvolutionTranspose as UpConv, MinkowskiPruning
-from .sparse import SparseTensor
+from .sparse import CoordMap, SparseTensor
 
 
 class InceptionResNet(torch.nn.Module):
@@ -107,16 +107,30 @@ class Decoder(torch.nn.Module):
         the item's own rows (contiguous segments, sparse.CoordMap.batch_rows)."""
         if training:
             raise NotImplementedError('training-time pruning (top-k ∪ ground truth) is outside the encode/decode path')
-        if len(nums) == 1:
-            k = int(min(len(data_cls), nums[0]))
-            mask = ops.topk_mask(data_cls.F, k)
-            return self.pruning(data, mask, n_keep=k)
-        rows = data.cmap.batch_rows
+        cand = data.cmap
+        rows = [len(data_cls)] if len(nums) == 1 else cand.batch_rows
         if len(rows) != len(nums):
             raise ValueError(f'prune_voxel: {len(nums)} budgets for a batch of {len(rows)} items')
-        keep = [int(min(r, n)) for r, n in zip(rows, nums)]
-        mask = ops.topk_mask_segments(data_cls.F, rows, keep)
-        return self.pruning(data, mask, n_keep=sum(keep), keep_per_item=keep)
+        keep = [int(min(r, max(int(n), 0))) for r, n in zip(rows, nums)]
+        if dispatch.select('prune', (data.F.shape[1],), len(data_cls)).family != 'select':
+            mask = ops.topk_mask(data_cls.F, keep[0]) if len(nums) == 1 else ops.topk_mask_segments(data_cls.F, rows, keep)
+            return self.pruning(data, mask, n_keep=sum(keep), keep_per_item=None if len(nums) == 1 else keep)
+        # one sweep (csrc/select.hip, pcgc_topk_select): thresholds by radix select, then ONE scan that decides every row, ranks genuine
+        # ties and writes the pruned level — coordinates (derived from the parent level's when the candidates are a children level whose
+        # own coordinates were never materialised), the survivors' candidate rows and the rank bitmap the kernel-map derivation reads
+        if cand._C is None and cand.origin is not None and cand.origin[0] == 'children':
+            parent = cand.origin[1]
+            bits, wprefix, orig, coords = ops.topk_select(data_cls.F, rows, keep, parent_coords=parent.C, parent_stride=parent.stride)
+        else:
+            bits, wprefix, orig, coords = ops.topk_select(data_cls.F, rows, keep, coords=cand.C)
+        cmap = CoordMap(coords, cand.stride, unique=True, origin=('selected', cand, bits, wprefix, orig))
+        if len(nums) > 1:
+            cmap._batch_rows = list(keep)
+        src = data.F
+        # (the surviving feature rows are gathered on first use: the last decoder stage only hands on coordinates)
+        out = SparseTensor(lambda: ops.gather_rows(src, orig), coordinate_map=cmap)
+        out._F_rows = (src, orig)
+        return out
 
     def forward(self, x, nums_list, ground_truth_list=(None, None, None), training=False):
         out, cls_list = x, []

@@ -1670,7 +1670,7 @@ static int launch_up2_rows(int64_t n_in, const float* in, int in_ld, const float
 // Cin*4 dependent FMAs per 16-byte store and was compute-, not write-bound (123 us for 131 MB at 32->16).
 template <int CIN, int COUT, int MT>
 __global__ void __launch_bounds__(256)
-k_conv_up2_mfma(int64_t n_in, const float* __restrict__ in, int in_ld, const float* __restrict__ W,
+k_conv_up2_mfma(int64_t n_in, const float* __restrict__ in, int in_ld, const int32_t* __restrict__ rows, const float* __restrict__ W,
                 const float* __restrict__ bias, int relu, float* __restrict__ out) {
     constexpr int NB = CIN / 16, NT = COUT / 16;
     __shared__ __attribute__((aligned(16))) float stage_all[4][2 * 16 * (COUT + 4)];
@@ -1684,9 +1684,10 @@ k_conv_up2_mfma(int64_t n_in, const float* __restrict__ in, int in_ld, const flo
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int64_t p = p0 + 16 * m + mi;
+        const int64_t src = (rows && p < n_in) ? (int64_t)rows[p] : p;        // (rows: input row p is row rows[p] of `in` — a pruned level read in place)
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
-            a[m][cb] = p < n_in ? *(const float4*)(in + p * in_ld + 16 * cb + 4 * mq) : make_float4(0.f, 0.f, 0.f, 0.f);
+            a[m][cb] = p < n_in ? *(const float4*)(in + src * in_ld + 16 * cb + 4 * mq) : make_float4(0.f, 0.f, 0.f, 0.f);
             lane_transpose4(a[m][cb]);
         }
     }
@@ -1746,24 +1747,38 @@ k_conv_up2_mfma(int64_t n_in, const float* __restrict__ in, int in_ld, const flo
     }
 }
 template <int CIN, int COUT>
-static int launch_up2_mfma(int64_t n_in, const float* in, int in_ld, const float* W, const float* bias, int relu, float* out,
+static int launch_up2_mfma(int64_t n_in, const float* in, int in_ld, const int32_t* rows, const float* W, const float* bias, int relu, float* out,
                            hipStream_t s) {
     // 16 parent rows per wave: these levels are small (71 k / 256 k parents) and a wave runs its eight k serially, so more, shorter
     // waves win (measured us for 64->32 / 32->16: 16 rows 58 / 58, 32 rows 70 / 59, 64 rows 99 / 68; VALU form 97 / 123)
-    hipLaunchKernelGGL((k_conv_up2_mfma<CIN, COUT, 1>), dim3(grid_for(n_in, 64)), dim3(256), 0, s, n_in, in, in_ld, W, bias, relu, out);
+    hipLaunchKernelGGL((k_conv_up2_mfma<CIN, COUT, 1>), dim3(grid_for(n_in, 64)), dim3(256), 0, s, n_in, in, in_ld, rows, W, bias, relu, out);
     return 0;
 }
 static int g_up2_mfma = 1;          // 0 = VALU form (A/B tests)
 extern "C" int pcgc_set_up2_impl(int mfma) { g_up2_mfma = mfma; return 0; }
 
+// the same on a PRUNED level read in place: input row p = row rows[p] of `in` (rows = the survivors' candidate rows, pcgc_topk_select) —
+// the compacted feature tensor of the pruned level is never written.  Only the shapes of the two large decoder stages; -3 = not one of them
+// (the caller gathers the rows first and calls pcgc_conv_up2).
+extern "C" int pcgc_conv_up2_gather(int64_t n_in, const float* in, int Cin, int in_ld, const int32_t* rows, const float* W, const float* bias,
+                                    int relu, float* out, int Cout, void* stream) {
+    PCGC_REQUIRE(rows != nullptr, "null row list");
+    if (n_in == 0) return 0;
+    if (!g_up2_mfma || (in_ld & 3) != 0 || (((uintptr_t)in | (uintptr_t)W | (uintptr_t)out | (uintptr_t)bias) & 15) != 0) return -3;
+    if (Cin == 64 && Cout == 32) launch_up2_mfma<64, 32>(n_in, in, in_ld, rows, W, bias, relu, out, S(stream));
+    else if (Cin == 32 && Cout == 16) launch_up2_mfma<32, 16>(n_in, in, in_ld, rows, W, bias, relu, out, S(stream));
+    else return -3;
+    PCGC_CHECK_LAUNCH("conv_up2_gather");
+    return 0;
+}
 extern "C" int pcgc_conv_up2(int64_t n_in, const float* in, int Cin, int in_ld, const float* W, const float* bias, int relu,
                              float* out, int Cout, void* stream) {
     if (n_in == 0) return 0;
     if ((in_ld & 3) == 0 && (((uintptr_t)in | (uintptr_t)W | (uintptr_t)out | (uintptr_t)bias) & 15) == 0) {
         bool done = true;
         if (Cin == 8 && Cout == 64) launch_up2_rows<8, 64>(n_in, in, in_ld, W, bias, relu, out, S(stream));
-        else if (g_up2_mfma && Cin == 64 && Cout == 32) launch_up2_mfma<64, 32>(n_in, in, in_ld, W, bias, relu, out, S(stream));
-        else if (g_up2_mfma && Cin == 32 && Cout == 16) launch_up2_mfma<32, 16>(n_in, in, in_ld, W, bias, relu, out, S(stream));
+        else if (g_up2_mfma && Cin == 64 && Cout == 32) launch_up2_mfma<64, 32>(n_in, in, in_ld, nullptr, W, bias, relu, out, S(stream));
+        else if (g_up2_mfma && Cin == 32 && Cout == 16) launch_up2_mfma<32, 16>(n_in, in, in_ld, nullptr, W, bias, relu, out, S(stream));
         else if (Cin == 64 && Cout == 32) launch_up2_rows<64, 32>(n_in, in, in_ld, W, bias, relu, out, S(stream));
         else if (Cin == 32 && Cout == 16) launch_up2_rows<32, 16>(n_in, in, in_ld, W, bias, relu, out, S(stream));
         else done = false;

@@ -300,6 +300,34 @@ __global__ void __launch_bounds__(256) k_kmap_prune_parent(const int32_t* __rest
         nbr[(int64_t)k * n_out + r] = (m >= 0 && mask[m]) ? prefix[m] : -1;
     }
 }
+// the same two derivations through the RANK BITMAP pcgc_topk_select writes (12 bytes per query from a structure of 0.19 bytes per
+// candidate row instead of 5 bytes from one of 5 bytes per row)
+__global__ void __launch_bounds__(256) k_kmap_prune_sel(const int32_t* __restrict__ cand, int64_t n_cand, const uint64_t* __restrict__ bits,
+                                                        const int32_t* __restrict__ wprefix, const int32_t* __restrict__ orig,
+                                                        int64_t n_out, int32_t* __restrict__ nbr) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_out) return;
+    int64_t o = orig[r];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        int32_t m = cand[(int64_t)k * n_cand + o];
+        nbr[(int64_t)k * n_out + r] = m >= 0 ? sel_rank(bits, wprefix, m) : -1;
+    }
+}
+__global__ void __launch_bounds__(256) k_kmap_prune_parent_sel(const int32_t* __restrict__ pnbr, int64_t np, const uint64_t* __restrict__ bits,
+                                                               const int32_t* __restrict__ wprefix, const int32_t* __restrict__ orig,
+                                                               int64_t n_out, int32_t* __restrict__ nbr) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_out) return;
+    const int64_t o = orig[r];
+    const int64_t i = o >> 3; const int j = (int)(o & 7);
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        int kp, jn; child_offset(j, k, kp, jn);
+        const int32_t pn = pnbr[(int64_t)kp * np + i];
+        nbr[(int64_t)k * n_out + r] = pn < 0 ? -1 : sel_rank(bits, wprefix, 8 * (int64_t)pn + jn);
+    }
+}
 // strided pyramid (encoder): fine row c has parent row parent_of[c]; down[j][p] = fine row at slot j of coarse row p
 __global__ void __launch_bounds__(256) k_kmap_from_coarse(const int4* __restrict__ fine, int64_t nf, int32_t stride_f,
                                                           const int32_t* __restrict__ parent_of,
@@ -359,6 +387,24 @@ extern "C" int pcgc_kmap_k3_prune_parent(const int32_t* parent_nbr, int64_t n_pa
     hipLaunchKernelGGL(k_kmap_prune_parent, dim3(grid_for(n_out, 256)), dim3(256), 0, S(stream), parent_nbr, n_parent, mask, prefix,
                        orig, n_out, nbr);
     PCGC_CHECK_LAUNCH("kmap_k3_prune_parent");
+    return 0;
+}
+extern "C" int pcgc_kmap_k3_prune_sel(const int32_t* cand_nbr, int64_t n_cand, const uint8_t* bits, const int32_t* wprefix,
+                                      const int32_t* orig, int64_t n_out, int32_t* nbr, void* stream) {
+    PCGC_REQUIRE(((uintptr_t)bits & 7) == 0, "bits must be 8-byte aligned");
+    if (n_out == 0) return 0;
+    hipLaunchKernelGGL(k_kmap_prune_sel, dim3(grid_for(n_out, 256)), dim3(256), 0, S(stream), cand_nbr, n_cand, (const uint64_t*)bits, wprefix,
+                       orig, n_out, nbr);
+    PCGC_CHECK_LAUNCH("kmap_k3_prune_sel");
+    return 0;
+}
+extern "C" int pcgc_kmap_k3_prune_parent_sel(const int32_t* parent_nbr, int64_t n_parent, const uint8_t* bits, const int32_t* wprefix,
+                                             const int32_t* orig, int64_t n_out, int32_t* nbr, void* stream) {
+    PCGC_REQUIRE(((uintptr_t)bits & 7) == 0, "bits must be 8-byte aligned");
+    if (n_out == 0) return 0;
+    hipLaunchKernelGGL(k_kmap_prune_parent_sel, dim3(grid_for(n_out, 256)), dim3(256), 0, S(stream), parent_nbr, n_parent, (const uint64_t*)bits,
+                       wprefix, orig, n_out, nbr);
+    PCGC_CHECK_LAUNCH("kmap_k3_prune_parent_sel");
     return 0;
 }
 extern "C" int pcgc_kmap_k3_from_coarse(const int32_t* fine, int64_t n_fine, int32_t stride_fine, const int32_t* parent_of,

@@ -57,3 +57,10 @@ __device__ static inline int32_t hash_lookup(const uint64_t* __restrict__ keys, 
         h = (h + 1) & cap_mask;
     }
 }
+
+// ---- rank bitmap of a pruned level (pcgc_topk_select): bit m of `bits` = candidate row m survives; wprefix[w] = survivors before row
+// 64 w.  -> the survivor's row on the pruned level, or -1
+__device__ static inline int32_t sel_rank(const uint64_t* __restrict__ bits, const int32_t* __restrict__ wprefix, int64_t m) {
+    const uint64_t w = bits[m >> 6], bit = 1ull << (m & 63);
+    return (w & bit) ? wprefix[m >> 6] + (int32_t)__popcll(w & (bit - 1)) : -1;
+}

@@ -21,7 +21,7 @@ from . import ops
 
 LIMIT = 0xF0000000          # the LDS-DMA kernels address rows with 32-bit buffer offsets: rows * row bytes must stay below this
 
-# op:       'conv3' (k3 s1) | 'irn' (a whole InceptionResNet block) | 'down' (k2 s2) | 'conv1' (k1) | 'up' (generative transpose k2 s2)
+# op:       'conv3' (k3 s1) | 'irn' (a whole InceptionResNet block) | 'down' (k2 s2) | 'conv1' (k1) | 'up' (generative transpose k2 s2) | 'prune' (top-k + pruning)
 # shape:    (cin, cout) pairs the entry serves, or None = any
 # level:    'children' (rows 8 p + j of a generative transpose: convs can run through the PARENT level's map) | 'plain' | None = any
 # rows:     [rows_min, rows_max) of the level the operator runs on (ints, or names of ops.* attributes the tests move)
@@ -62,6 +62,10 @@ TABLE = (
          'tile = 16 coarse rows walking the 8 child offsets: 121 -> ~65 us for the three down convs of a vox10 frame (rows = COARSE rows)'),
     Rule('down', None, None, 0, INF, None, 'gather', 'pcgc_conv_gather, K = 8', 'other shapes / tiny levels'),
     Rule('conv1', None, None, 0, INF, None, 'gather', 'pcgc_conv_gather, K = 1 (k_conv_gather_valu)', 'k1 convs outside fused blocks'),
+    # ---- prune_voxel: top-k + MinkowskiPruning (channel counts of the pruned features: multiples of 4 take the one-sweep form) ----------
+    Rule('prune', (8, 16, 32, 64), None, 0, INF, 'ONE_SWEEP_PRUNE', 'select', 'k_topk_init + 3 x k_topk_hist + k_topk_select',
+         'thresholds by radix select, then ONE scan writes coordinates, survivor rows and a rank bitmap: 10 -> 5 launches per decoder stage'),
+    Rule('prune', None, None, 0, INF, None, 'mask', 'pcgc_topk_mask(_segments) + pcgc_mask_scan + pcgc_compact_*', 'byte mask + int32 prefix per row'),
     Rule('up', None, None, 0, INF, None, 'up2', 'k_conv_up2_mfma<64,32> / <32,16>, k_conv_up2_rows otherwise', 'generative transpose, one kernel per shape'),
 )
 

@@ -79,7 +79,11 @@ class MinkowskiConvolution(_ConvBase):
 class MinkowskiGenerativeConvolutionTranspose(_ConvBase):
     def forward(self, x, relu=False):
         assert self.kernel_size == 2 and self.stride == 2
-        y = ops.conv_up2(x.F, self.kernel, self.bias, relu=relu)
+        src = x.pending_rows()
+        if src is not None:                       # a pruned level whose features are still "rows `orig` of the candidates' tensor"
+            y = ops.conv_up2(src[0], self.kernel, self.bias, relu=relu, rows=src[1])
+        else:
+            y = ops.conv_up2(x.F, self.kernel, self.bias, relu=relu)
         return SparseTensor(y, coordinate_map=x.cmap.up())
 
 

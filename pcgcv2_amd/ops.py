@@ -1022,9 +1022,19 @@ def conv_down_rows(down, x, table, bias, Cout, relu=False):
     return out
 
 
-def conv_up2(x, W, bias, relu=False):
+def conv_up2(x, W, bias, relu=False, rows=None):
+    """MinkowskiGenerativeConvolutionTranspose k2 s2.  rows (int32 [n]): the input level is rows `rows` of x, read in place (a pruned
+    level whose compacted features were never written); shapes without such a kernel gather the rows first."""
     _f32(x, 'x'); _f32(W, 'W')
     K, Cin, Cout = W.shape
+    if rows is not None:
+        out = torch.empty((8 * rows.shape[0], Cout), dtype=torch.float32, device=x.device)
+        rc = lib().pcgc_conv_up2_gather(rows.shape[0], _p(x), Cin, _ld(x), _p(rows), _p(W), _p(bias), int(relu), _p(out), Cout, _stream(x))
+        if rc == 0:
+            return out
+        if rc != -3:
+            check(rc, 'conv_up2_gather')
+        x = gather_rows(x, rows)
     out = torch.empty((8 * x.shape[0], Cout), dtype=torch.float32, device=x.device)
     check(lib().pcgc_conv_up2(x.shape[0], _p(x), Cin, _ld(x), _p(W), _p(bias), int(relu), _p(out), Cout, _stream(x)), 'conv_up2')
     return out
@@ -1082,6 +1092,61 @@ def topk_mask_segments(logits, seg_rows, seg_k):
     check(lib().pcgc_topk_mask_segments(_p(logits), logits.stride(0), len(seg_rows), _i64_array(seg_rows), _i64_array(seg_k), _p(mask), _p(ws),
                                         ws_bytes, _stream(logits)), 'topk_mask_segments')
     return mask
+
+
+ONE_SWEEP_PRUNE = _os.environ.get('PCGC_ONE_SWEEP_PRUNE', '1') != '0'      # prune_voxel as radix passes + one scan (csrc/select.hip, pcgc_topk_select); A/B switch
+
+
+def topk_select(logits, seg_rows, seg_k, coords=None, parent_coords=None, parent_stride=0):
+    """prune_voxel in one sweep (autoencoder.py:239-249): per item b the seg_k[b] largest logits among its seg_rows[b] rows (istopk's tie
+    rule) -> (bits uint8, wprefix int32: the rank bitmap of the candidate level; orig int32 [K]: the candidate row of every survivor;
+    out_coords int32 [K, 4]).  The candidates' coordinates are `coords`, or derived from `parent_coords` (rows 8 i + j of a children
+    level at parent_stride / 2)."""
+    _f32(logits, 'logits')
+    n = logits.shape[0]
+    if sum(seg_rows) != n:
+        raise PcgcError(f'topk_select: segments cover {sum(seg_rows)} of {n} rows')
+    if len(seg_rows) > 16:
+        raise PcgcError('topk_select: at most 16 segments')
+    K = sum(int(min(max(k, 0), r)) for r, k in zip(seg_rows, seg_k))
+    dev = logits.device
+    words = (n + 63) // 64
+    bits = torch.empty(words * 8, dtype=torch.uint8, device=dev)
+    wprefix = torch.empty(words, dtype=torch.int32, device=dev)
+    orig = torch.empty(K, dtype=torch.int32, device=dev)
+    out = torch.empty((K, 4), dtype=torch.int32, device=dev)
+    ws_bytes = int(lib().pcgc_topk_select_workspace_bytes(n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib().pcgc_topk_select(_p(logits), logits.stride(0), len(seg_rows), _i64_array(seg_rows), _i64_array(seg_k),
+                                 _p(None if coords is None else _i32(coords)), _p(None if parent_coords is None else _i32(parent_coords)),
+                                 int(parent_stride), _p(bits), _p(wprefix), _p(orig), _p(out), _p(ws), ws_bytes, _stream(logits)), 'topk_select')
+    return bits, wprefix, orig, out
+
+
+def kmap_k3_prune_sel(cand_nbr, bits, wprefix, orig):
+    n_out = orig.shape[0]
+    nbr = torch.empty((27, n_out), dtype=torch.int32, device=cand_nbr.device)
+    check(lib().pcgc_kmap_k3_prune_sel(_p(cand_nbr), cand_nbr.shape[1], _p(bits), _p(wprefix), _p(orig), n_out, _p(nbr), _stream(cand_nbr)),
+          'kmap_k3_prune_sel')
+    return nbr
+
+
+def kmap_k3_prune_parent_sel(parent_nbr, bits, wprefix, orig):
+    """k3 map of a pruned children level from the PARENT level's map and the rank bitmap of ops.topk_select."""
+    n_out = orig.shape[0]
+    nbr = torch.empty((27, n_out), dtype=torch.int32, device=parent_nbr.device)
+    check(lib().pcgc_kmap_k3_prune_parent_sel(_p(parent_nbr), parent_nbr.shape[1], _p(bits), _p(wprefix), _p(orig), n_out, _p(nbr),
+                                              _stream(parent_nbr)), 'kmap_k3_prune_parent_sel')
+    return nbr
+
+
+def gather_rows(feats, orig):
+    """out[r] = feats[orig[r]] (feats: 2-D row-major view with a leading dimension; channels % 4 == 0)."""
+    _f32(feats)
+    C = feats.shape[1]
+    out = torch.empty((orig.shape[0], C), dtype=torch.float32, device=feats.device)
+    check(lib().pcgc_gather_rows_f32_ld(_p(feats), C, _ld(feats), _p(orig), orig.shape[0], _p(out), _stream(feats)), 'gather_rows_f32_ld')
+    return out
 
 
 def gather_coords(coords, perm):

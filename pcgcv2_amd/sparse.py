@@ -27,10 +27,14 @@ class CoordMap:
          None                                  raw coordinates (root): hash if small, else via its own strided pyramid
          ('children', parent)                  rows 8*i+j of a generative transpose
          ('pruned', cand, mask, prefix)        surviving rows of `cand` (MinkowskiPruning)
+         ('selected', cand, bits, wprefix, orig)   the same, written by the one-sweep prune_voxel (ops.topk_select: rank bitmap + orig)
+    A children level's coordinates are LAZY (`lazy=(rows, device)`): its convolutions run through the parent level's map and the one-sweep
+    pruning derives the survivors' coordinates from the parent's, so the [8 n, 4] tensor only exists if somebody reads `.C`.
     """
 
-    def __init__(self, coords, stride, unique=False, origin=None):
-        self.C = coords
+    def __init__(self, coords, stride, unique=False, origin=None, lazy=None):
+        self._C = coords
+        self._n, self.device = (int(lazy[0]), lazy[1]) if coords is None else (coords.shape[0], coords.device)
         self.stride = int(stride)
         self.origin = origin
         self._table = None
@@ -43,7 +47,14 @@ class CoordMap:
         self.descents = None                  # (caller-built levels only: see SparseTensor)
 
     def __len__(self):
-        return self.C.shape[0]
+        return self._n
+
+    @property
+    def C(self):
+        if self._C is None:                                     # a children level nobody has asked the coordinates of so far
+            parent = self.origin[1]
+            self._C = ops.coords_children(parent.C, parent.stride)
+        return self._C
 
     @property
     def batch_rows(self):
@@ -66,7 +77,7 @@ class CoordMap:
         if self._k3 is None:
             kind = self.origin[0] if self.origin else None
             if len(self) == 0:
-                self._k3 = torch.empty((27, 0), dtype=torch.int32, device=self.C.device)
+                self._k3 = torch.empty((27, 0), dtype=torch.int32, device=self.device)
             elif kind == 'children':
                 self._k3 = ops.kmap_k3_children(self.origin[1].k3)
             elif kind == 'pruned':
@@ -77,6 +88,12 @@ class CoordMap:
                     self._k3 = ops.kmap_k3_prune_parent(cand.origin[1].k3, mask, prefix, orig)
                 else:
                     self._k3 = ops.kmap_k3_prune(cand.k3, mask, prefix, orig)
+            elif kind == 'selected':
+                _, cand, bits, wprefix, orig = self.origin
+                if cand._k3 is None and cand.origin is not None and cand.origin[0] == 'children':
+                    self._k3 = ops.kmap_k3_prune_parent_sel(cand.origin[1].k3, bits, wprefix, orig)
+                else:
+                    self._k3 = ops.kmap_k3_prune_sel(cand.k3, bits, wprefix, orig)
             elif len(self) > HASH_LEVEL_MAX and self.stride <= (1 << 18):
                 coarse, down = self.down()
                 self._k3 = ops.kmap_k3_from_coarse(self.C, self.stride, self._parent_of, coarse.k3, down)
@@ -115,7 +132,7 @@ class CoordMap:
         if self._prepared_up is not None:
             child, self._prepared_up = self._prepared_up, None
             return child
-        child = CoordMap(ops.coords_children(self.C, self.stride), self.stride // 2, unique=True, origin=('children', self))
+        child = CoordMap(None, self.stride // 2, unique=True, origin=('children', self), lazy=(8 * len(self), self.device))
         if self._batch_rows is not None:
             child._batch_rows = [8 * r for r in self._batch_rows]
         return child
@@ -158,10 +175,11 @@ class SparseTensor:
         if isinstance(tensor_stride, (list, tuple)):
             tensor_stride = tensor_stride[0]
         self._F_thunk = None
+        self._F_rows = None                   # (source tensor, row list): the features are rows of another tensor, not gathered yet
         self.unit_features = False            # True: one channel, every value exactly 1.0 (the occupancy indicator of a coded cloud)
         if coordinate_map is not None:
             self.cmap = coordinate_map
-            dev = coordinate_map.C.device
+            dev = coordinate_map.device
             if callable(features):                     # deferred features: produced on first access of .F (MinkowskiPruning)
                 self._F, self._F_thunk = None, features
                 return
@@ -191,12 +209,18 @@ class SparseTensor:
     @property
     def F(self):
         if self._F is None and self._F_thunk is not None:
-            self._F, self._F_thunk = self._F_thunk(), None
+            self._F, self._F_thunk, self._F_rows = self._F_thunk(), None, None
         return self._F
+
+    def pending_rows(self):
+        """(source, rows) while the features are still rows `rows` of `source` (a level pruned by the one-sweep prune_voxel whose
+        features nobody has read): a consumer that can read them in place (the next stage's transposed convolution) does so and the
+        compacted tensor is never written.  None once .F has been materialised."""
+        return self._F_rows if self._F is None else None
 
     @F.setter
     def F(self, value):
-        self._F, self._F_thunk = value, None
+        self._F, self._F_thunk, self._F_rows = value, None, None
         self.unit_features = False            # (new features: whatever was known about the old ones is void)
 
     def has_unit_features(self):
@@ -217,14 +241,14 @@ class SparseTensor:
 
     @property
     def device(self):
-        return self.cmap.C.device
+        return self.cmap.device
 
     @property
     def shape(self):
         return self.F.shape
 
     def __len__(self):
-        return self.cmap.C.shape[0]
+        return len(self.cmap)
 
     def __repr__(self):
         return f'SparseTensor(N={len(self)}, C={self.F.shape[1]}, stride={self.cmap.stride}, device={self.device})'

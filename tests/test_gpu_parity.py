@@ -23,7 +23,7 @@ def _t(a, dt=None):
 def _restore_path_switches():
     """the A/B switches of the rows kernels are module globals some tests flip: whatever a test leaves behind is undone"""
     names = ('ROWS_IRN64', 'ROWS_IRN64_CHILD', 'ROWS_IRN64_MIN', 'ROWS_IRN32', 'ROWS_IRN32_MIN', 'ROWS_IRN32_MAX', 'ROWS_CONV', 'ROWS_CONV_MIN',
-             'ROWS_DOWN', 'ROWS_DOWN_MIN', 'UNIT_INPUT_CONV', 'CHILD_MFMA', 'MFMA_IRN', 'FUSE_IRN')
+             'ROWS_DOWN', 'ROWS_DOWN_MIN', 'UNIT_INPUT_CONV', 'CHILD_MFMA', 'MFMA_IRN', 'FUSE_IRN', 'ONE_SWEEP_PRUNE')
     keep = {n: getattr(ops, n) for n in names}
     yield
     for n, v in keep.items():
@@ -437,6 +437,13 @@ def _conv_up2_case(cin, cout):
     b = rng.standard_normal((1, cout)).astype(np.float32)
     got = ops.conv_up2(_t(x), _t(W), _t(b), relu=True).cpu().numpy()
     np.testing.assert_array_equal(got, orc.relu(orc.conv_up2(x, W, b)))
+    if cin % 4 == 0:
+        # a pruned level read in place: input row p = row rows[p] of a wider tensor (the MFMA kernels follow the list themselves, the
+        # other shapes gather first)
+        rows = np.sort(rng.choice(3001, size=1777, replace=False)).astype(np.int32)
+        wide = np.concatenate([x, rng.standard_normal((3001, 8)).astype(np.float32)], 1)
+        got = ops.conv_up2(_t(wide)[:, :cin], _t(W), _t(b), relu=True, rows=_t(rows)).cpu().numpy()
+        np.testing.assert_array_equal(got, orc.relu(orc.conv_up2(x[rows], W, b)))
 
 
 # ------------------------------------------------------------------------------------------------ select / sort
@@ -448,6 +455,112 @@ def test_topk_mask_with_ties(n, k):
     got = ops.topk_mask(_t(v).reshape(-1, 1), k).cpu().numpy().astype(bool)
     np.testing.assert_array_equal(got, orc.topk_mask(v, k))
     assert got.sum() == min(n, k)
+
+
+def _unpack_bits(bits, n):
+    return np.unpackbits(bits.cpu().numpy(), bitorder='little')[:n].astype(bool)
+
+
+def _check_select(v, rows, ks, coords=None, parent=None, parent_stride=0):
+    """pcgc_topk_select against the oracle's top-k mask per segment: bitmap, rank words, survivor rows and coordinates"""
+    n = len(v)
+    want = np.zeros(n, bool)
+    off = 0
+    for r, k in zip(rows, ks):
+        want[off:off + r] = orc.topk_mask(v[off:off + r], k)
+        off += r
+    cand = coords if coords is not None else ops.coords_children(_t(parent), parent_stride).cpu().numpy()
+    bits, wprefix, orig, out = ops.topk_select(_t(v).reshape(-1, 1), rows, ks, coords=None if coords is None else _t(coords),
+                                               parent_coords=None if parent is None else _t(parent), parent_stride=parent_stride)
+    np.testing.assert_array_equal(_unpack_bits(bits, n), want)
+    assert not np.unpackbits(bits.cpu().numpy(), bitorder='little')[n:].any()                # (padding bits of the last word stay clear)
+    np.testing.assert_array_equal(orig.cpu().numpy(), np.nonzero(want)[0])
+    np.testing.assert_array_equal(out.cpu().numpy(), cand[want])
+    excl = np.concatenate([[0], np.cumsum(want)])[:-1] if n else np.zeros(0, np.int64)
+    np.testing.assert_array_equal(wprefix.cpu().numpy(), excl[::64])
+    return bits, wprefix, orig, want
+
+
+@pytest.mark.parametrize('n,k', [(1, 1), (8, 0), (100, 0), (1000, 391), (4097, 4097), (250003, 100003), (2048, 1), (2049, 2048), (70000, 35000)])
+def test_topk_select_with_ties(n, k):
+    """prune_voxel in one sweep (pcgc_topk_select): heavy ties, +-0, k = 0 / n, one to 123 scan tiles, given coordinates"""
+    rng = np.random.default_rng(n + k)
+    v = np.round(rng.standard_normal(n) * 3).astype(np.float32) / 2
+    v[rng.random(n) < 0.05] = -0.0
+    c4 = np.concatenate([np.zeros((n, 1), np.int32), rng.integers(0, 1 << 20, size=(n, 3)).astype(np.int32)], 1)
+    _check_select(v, [n], [k], coords=c4)
+
+
+def test_topk_select_segments_children_and_tie_rule(conventions_reset):
+    """several items (incl. an empty one and items that end inside a 64-row word / a scan tile), candidates = a children level whose
+    coordinates are derived from the parents', both tie rules; the rank bitmap drives the pruned level's kernel map"""
+    rng = np.random.default_rng(5)
+    rows = [1000, 8, 4096, 0, 304, 65000, 2048 * 3 + 8]
+    ks = [391, 8, 4096, 0, 0, 20000, 777]
+    n = sum(rows)
+    v = rng.standard_normal(n).astype(np.float32)
+    v[1100:1400] = 0.25                                                        # a genuine tie inside item 2
+    v[6000:30000] = np.round(v[6000:30000] * 2) / 2                            # and heavy ties in item 5
+    parent = np.concatenate([np.zeros((n // 8, 1), np.int32), 4 * rng.integers(0, 1 << 17, size=(n // 8, 3)).astype(np.int32)], 1)
+    _check_select(v, rows, ks, parent=parent, parent_stride=4)
+    conventions_reset.set_convention('topk_tie', 'high'); orc.CONVENTIONS['topk_tie'] = 'high'
+    _check_select(v, rows, ks, parent=parent, parent_stride=4)
+    _check_select(v[:5000], [5000], [1234], coords=np.zeros((5000, 4), np.int32))
+
+
+def test_selected_level_kernel_map_and_features():
+    """a level pruned by pcgc_topk_select: its k3 map (through the candidates' own map, and through the PARENT level's map when the
+    candidates are children whose map was never built) equals the oracle's; its features are the survivors' rows"""
+    c4 = _coords('shell8')
+    lvl = CoordMap(_t(c4), 1, unique=True)
+    l8 = lvl.down()[0].down()[0].down()[0]
+    rng = np.random.default_rng(1)
+    for own_map in (False, True):
+        kids = l8.up()
+        assert kids._C is None                                                 # (lazy: nobody has asked for the children's coordinates)
+        n = len(kids)
+        if own_map:
+            kids.k3
+        v = rng.standard_normal(n).astype(np.float32)
+        k = int(0.45 * n)
+        bits, wprefix, orig, coords = ops.topk_select(_t(v).reshape(-1, 1), [n], [k], parent_coords=l8.C, parent_stride=l8.stride)
+        assert kids._C is None
+        kc = kids.C.cpu().numpy()
+        want = orc.topk_mask(v, k)
+        np.testing.assert_array_equal(coords.cpu().numpy(), kc[want])
+        pruned = CoordMap(coords, kids.stride, unique=True, origin=('selected', kids, bits, wprefix, orig))
+        np.testing.assert_array_equal(pruned.k3.cpu().numpy(), orc.kmap_k3(kc[want], kids.stride))
+    f = rng.standard_normal((n, 48)).astype(np.float32)
+    ft = _t(f)
+    np.testing.assert_array_equal(ops.gather_rows(ft[:, :32], orig).cpu().numpy(), f[want][:, :32])       # (a column slice: leading dimension 48)
+    np.testing.assert_array_equal(ops.gather_rows(ft, orig[:0]).cpu().numpy(), f[:0])
+
+
+def test_one_sweep_prune_equals_mask_form(sd, tmp_path):
+    """Decoder with ops.ONE_SWEEP_PRUNE on / off: every classification output and the decoded cloud are identical (single cloud and a
+    collated batch); the children levels' coordinates are only materialised when somebody reads them"""
+    from pcgcv2_amd.coder import Coder
+    from pcgcv2_amd import dispatch
+    m = _model(sd)
+    c4 = _coords('shell8')
+    x = SparseTensor(torch.ones((len(c4), 1)), coordinates=_t(c4), tensor_stride=1, device=DEV)
+    coder = Coder(m, str(tmp_path / 'a'))
+    coder.encode(x)
+    assert dispatch.select('prune', (16,), 1000).family == 'select'
+    a = coder.decode()
+    ops.ONE_SWEEP_PRUNE = False
+    assert dispatch.select('prune', (16,), 1000).family == 'mask'
+    b = coder.decode()
+    ops.ONE_SWEEP_PRUNE = True
+    np.testing.assert_array_equal(a.C.cpu().numpy(), b.C.cpu().numpy())
+    np.testing.assert_array_equal(a.cmap.k3.cpu().numpy(), b.cmap.k3.cpu().numpy())
+    np.testing.assert_array_equal(a.F.cpu().numpy(), b.F.cpu().numpy())
+    for rho in (0.6, 2.0):
+        a = coder.decode(rho=rho)
+        ops.ONE_SWEEP_PRUNE = False
+        b = coder.decode(rho=rho)
+        ops.ONE_SWEEP_PRUNE = True
+        np.testing.assert_array_equal(a.C.cpu().numpy(), b.C.cpu().numpy())
 
 
 def test_topk_matches_reference_golden(golden_dir):
