@@ -235,6 +235,17 @@ int pcgc_conv_rows(const int32_t* nbr, int64_t n, const float* in, int Cin, int 
 int pcgc_conv_down_rows(const int32_t* down, int64_t n_coarse, const float* in, int64_t n_in, int Cin, int in_ld, const float* table,
                         int64_t table_bytes, const float* bias, int relu, float* out, int Cout, int out_ld, void* stream);
 
+/* k3 conv 64 -> 64 (the encoder's conv2, autoencoder.py:109-115, and the decoder's conv0, :162-168 — the two layers whose 442 KB of weights
+ * fit no LDS-resident table) with PRESENT-ROW PACKING: per 128-row workgroup tile and kernel offset only the rows that have the neighbour
+ * are gathered and multiplied (packed 16 at a time; accumulators in LDS), instead of zero rows for absent neighbours.  nbr [27][n] of the
+ * level itself (-1 = absent); table = ops.child_conv_table(kernel) (442 368 bytes); out = (acc + bias) (relu).  Same fmaf chain per
+ * output element as pcgc_conv_gather: bit-identical results. */
+int pcgc_conv_packed64(const int32_t* nbr, int64_t n, const float* in, int in_ld, const float* table, int64_t table_bytes,
+                       const float* bias, int relu, float* out, int out_ld, void* stream);
+/* A/B switches of pcgc_conv_packed64: rows per workgroup tile (1 .. 128; 0 = chosen per launch from the level size) and waves per
+ * workgroup (4 or 8; 0 = default).  Results do not depend on them. */
+int pcgc_set_packed_tuning(int rows, int waves);
+
 /* ‡ conventions the reference's results depend on but its sources do not pin (un-vendored MinkowskiEngine / torch.topk on ME's row
  * order): what = 0: top-k tie rule, value 0 = the lower row wins (default), 1 = the higher row wins.  The dedup policy is an argument of
  * pcgc_hash_insert_policy; the kernel-offset order is a weight permutation done by the host (pcgcv2_amd/conventions.py). */

@@ -64,6 +64,8 @@ SIGNATURES = {
     'pcgc_conv_down_rows': (ci, [vp, i64, vp, i64, ci, ci, vp, i64, vp, ci, vp, ci, ci, vp]),
     'pcgc_conv_rows': (ci, [vp, i64, vp, ci, ci, vp, i64, vp, vp, ci, ci, vp, ci, ci, vp]),
     'pcgc_irn_rows_pass': (ci, [vp, i64, ci, ci, vp, ci, vp, i64, vp, vp, vp, vp, ci, vp, ci, vp]),
+    'pcgc_conv_packed64': (ci, [vp, i64, vp, ci, vp, i64, vp, ci, vp, ci, vp]),
+    'pcgc_set_packed_tuning': (ci, [ci, ci]),
     'pcgc_conv_up2': (ci, [i64, vp, ci, ci, vp, vp, ci, vp, ci, vp]),
     'pcgc_conv_up2_gather': (ci, [i64, vp, ci, ci, vp, vp, vp, ci, vp, ci, vp]),
     'pcgc_topk_workspace_bytes': (sz, [i64]),

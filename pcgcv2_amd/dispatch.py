@@ -40,6 +40,8 @@ TABLE = (
          'all-ones occupancy input (x.has_unit_features()): sum of kernel slices over the present offsets, no feature gathers: 88 -> 55 us'),
     Rule('conv3', ((32, 32),), None, 'ROWS_CONV_MIN', INF, 'ROWS_CONV', 'rows', 'k_rows_conv<2,2>',
          'LDS-resident fragment table, one wave per 16-row tile: 34 vs 51 us at 1-18 k rows, 127 vs 159 at 256 k'),
+    Rule('conv3', ((64, 64),), None, 'PACKED_CONV64_MIN', INF, 'PACKED_CONV64', 'packed', 'k_conv_packed64',
+         'present rows packed per workgroup tile and offset, accumulators in LDS, B fragments in registers: conv2 (71 k rows) 215 -> 118 us, conv0 (150 k) 335 -> 306 (profiles/r04_conv_packed.md)'),
     Rule('conv3', None, None, 0, INF, None, 'gather', 'pcgc_conv_gather (see GATHER below)', 'every other shape / size'),
     # ---- InceptionResNet blocks ----------------------------------------------------------------------------------------------------
     Rule('irn', (64,), 'children+own_map', 8192, INF, 'ROWS_IRN64_CHILD', 'rows64', 'k_rows_irn_a64<.., RowsPassA64H> + k_rows_irn_b64',
@@ -131,7 +133,9 @@ def select(op, shape, rows, level='plain', extent=None, own_map=False, contiguou
         if rule.level is not None and (level != 'children' or (rule.level == 'children+own_map' and not own_map)):
             continue
         fam = rule.family
-        if fam in ('child', 'child64', 'rows', 'rows64', 'rows32', 'rows_down') and extent >= LIMIT:
+        if fam == 'packed' and not plain_output:
+            continue
+        if fam in ('child', 'child64', 'rows', 'rows64', 'rows32', 'rows_down', 'packed') and extent >= LIMIT:
             continue                                                     # beyond 32-bit buffer offsets: the generic kernels take it
         if op == 'irn' and fam != 'unfused' and (not ops.FUSE_IRN or rows * 4 * width >= 0xFFFFFFF0):
             continue

@@ -48,6 +48,10 @@ class MinkowskiConvolution(_ConvBase):
             if fam == 'unit':
                 # the codec's first layer on the occupancy indicator (all ones): a sum of kernel slices over the present offsets
                 return SparseTensor(ops.conv_gather_unit(x.cmap.k3, self.kernel, self.bias, relu=relu), coordinate_map=x.cmap)
+            if fam == 'packed':
+                # 64 -> 64 (conv2 of the encoder, conv0 of the decoder): present-row packing, accumulators in LDS (csrc/conv_packed.hip)
+                y = ops.conv_packed64(x.cmap.k3, x.F, self._table(ops.child_conv_table), self.bias, relu=relu)
+                return SparseTensor(y, coordinate_map=x.cmap)
             if fam == 'rows':
                 # 32 -> 32 (the encoder's conv1): LDS-resident fragment table, one wave per 16-row tile (csrc/rows_irn.hip)
                 y = ops.conv_rows(x.cmap.k3, x.F, self._table(ops.child_conv_table), self.bias, cout, out=out, residual=residual, relu=relu)

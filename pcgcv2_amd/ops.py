@@ -1007,6 +1007,20 @@ def conv_rows(nbr, x, table, bias, Cout, out=None, residual=None, relu=False):
     return out
 
 
+PACKED_CONV64 = _os.environ.get('PCGC_PACKED_CONV64', '1') != '0'      # k3 64 -> 64 with present-row packing (csrc/conv_packed.hip); A/B switch
+PACKED_CONV64_MIN = 512        # (tools/conv_packed_ab.py gate: 39 vs 86 us at 1-4 k rows, 44 vs 113 at 8 k, 75 vs 115 at 33 k, 112 vs 164 at 66 k)
+
+
+def conv_packed64(nbr, x, table, bias, relu=False):
+    """k3 conv 64 -> 64 on a level with its own map, present rows packed per 128-row tile and offset (pcgc_conv_packed64)."""
+    _f32(x, 'x')
+    n = x.shape[0]
+    out = torch.empty((n, 64), dtype=torch.float32, device=x.device)
+    check(lib().pcgc_conv_packed64(_p(nbr), n, _p(x), _ld(x), _p(table), table.numel() * 4, _p(bias), int(relu), _p(out), 64, _stream(x)),
+          'conv_packed64')
+    return out
+
+
 ROWS_DOWN = _os.environ.get('PCGC_ROWS_DOWN', '1') != '0'      # k2 s2 down convs: LDS-resident table, one wave per 16 coarse rows; A/B switch
 ROWS_DOWN_MIN = 1024
 

@@ -23,7 +23,7 @@ def _t(a, dt=None):
 def _restore_path_switches():
     """the A/B switches of the rows kernels are module globals some tests flip: whatever a test leaves behind is undone"""
     names = ('ROWS_IRN64', 'ROWS_IRN64_CHILD', 'ROWS_IRN64_MIN', 'ROWS_IRN32', 'ROWS_IRN32_MIN', 'ROWS_IRN32_MAX', 'ROWS_CONV', 'ROWS_CONV_MIN',
-             'ROWS_DOWN', 'ROWS_DOWN_MIN', 'UNIT_INPUT_CONV', 'CHILD_MFMA', 'MFMA_IRN', 'FUSE_IRN', 'ONE_SWEEP_PRUNE')
+             'ROWS_DOWN', 'ROWS_DOWN_MIN', 'UNIT_INPUT_CONV', 'CHILD_MFMA', 'MFMA_IRN', 'FUSE_IRN', 'ONE_SWEEP_PRUNE', 'PACKED_CONV64', 'PACKED_CONV64_MIN')
     keep = {n: getattr(ops, n) for n in names}
     yield
     for n, v in keep.items():
@@ -1645,8 +1645,8 @@ def _conv_module(cin, cout, k, stride, seed):
 
 GATHER_CASES = [
     # (cin, cout, rows, switches to turn off so that the gather family is reached)       one line per side of every gate of dispatch.GATHER_GATES
-    (64, 64, 8191, ()), (64, 64, 8192, ()), (64, 64, 109999, ()), (64, 64, 110000, ()), (64, 64, 399999, ()), (64, 64, 400000, ()),
-    (64, 64, 511, ()), (64, 64, 512, ()),
+    (64, 64, 8191, ('PACKED_CONV64',)), (64, 64, 8192, ('PACKED_CONV64',)), (64, 64, 109999, ('PACKED_CONV64',)), (64, 64, 110000, ('PACKED_CONV64',)), (64, 64, 399999, ('PACKED_CONV64',)), (64, 64, 400000, ('PACKED_CONV64',)),
+    (64, 64, 511, ()), (64, 64, 512, ('PACKED_CONV64',)),
     (32, 32, 1023, ()), (32, 32, 109999, ('ROWS_CONV',)), (32, 32, 110000, ('ROWS_CONV',)), (32, 32, 400000, ('ROWS_CONV',)),
     (32, 8, 18732, ()), (32, 8, 149999, ()), (32, 8, 150000, ()),
     (16, 16, 39999, ()), (16, 16, 40000, ()), (16, 16, 300, ()),
@@ -1780,6 +1780,67 @@ def test_dispatch_table_down_up_and_k1_entries():
     with torch.no_grad():
         got = conv(SparseTensor(_t(x), coordinate_map=fine)).F.cpu().numpy()
     np.testing.assert_array_equal(got, orc.conv_k1(x, W, b))
+
+
+@pytest.mark.parametrize('cloud,rows', [('shell8', None), ('shell8', 1000), ('shell8', 129), ('noisy_s', None), ('solid_ball_s', None)])
+def test_conv_packed64_bit_exact(cloud, rows):
+    """k3 64 -> 64 with present-row packing (csrc/conv_packed.hip) against the oracle: a surface, a noisy holed surface with isolated
+    voxels (offsets with no present row at all in a tile), a filled body (27 / 27 neighbourhoods: nothing to pack), ragged sizes
+    (a last tile of one row, a single tile)"""
+    c4 = _cloud4(cloud) if cloud.endswith('_s') else _coords(cloud)
+    if rows is not None:
+        c4 = c4[:rows]
+    lvl = CoordMap(_t(c4), 1, unique=True)
+    n = len(c4)
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, 64)).astype(np.float32)
+    W = (rng.standard_normal((27, 64, 64)) / 40).astype(np.float32)
+    b = rng.standard_normal((1, 64)).astype(np.float32)
+    nbr = lvl.k3
+    table = ops.child_conv_table(_t(W))
+    want = orc.conv_gather(nbr.cpu().numpy(), x, W, b)
+    for relu in (False, True):
+        got = ops.conv_packed64(nbr, _t(x), table, _t(b), relu=relu).cpu().numpy()
+        np.testing.assert_array_equal(got, orc.relu(want) if relu else want)
+    wide = _t(np.concatenate([x, x[:, :16]], 1))                                  # a leading dimension of 80 floats
+    np.testing.assert_array_equal(ops.conv_packed64(nbr, wide[:, :64], table, None).cpu().numpy(), orc.conv_gather(nbr.cpu().numpy(), x, W, None))
+
+
+@pytest.mark.parametrize('rows', [512, 8192, 110000, 400000])
+def test_dispatch_table_packed_family(rows):
+    """64 -> 64 from PACKED_CONV64_MIN rows on: the packed kernel, at the level sizes where the gather ladder changes kernels underneath it"""
+    from pcgcv2_amd import dispatch
+    c4, lvl = _prefix_level(rows, 'shell10')
+    conv, W, b = _conv_module(64, 64, 3, 1, 6464)
+    x = np.random.default_rng(rows).standard_normal((rows, 64)).astype(np.float32)
+    assert dispatch.select('conv3', (64, 64), rows, 'plain').family == 'packed'
+    with torch.no_grad():
+        got = conv(SparseTensor(_t(x), coordinate_map=lvl), relu=True).F.cpu().numpy()
+    np.testing.assert_array_equal(got, np.maximum(orc.conv_gather(orc.kmap_k3(c4, 1), x, W, b), np.float32(0)))
+
+
+def test_conv_packed64_through_the_module(sd):
+    """nn.MinkowskiConvolution(64, 64, 3) takes the packed kernel from PACKED_CONV64_MIN rows on (dispatch.py) and the gather ladder below /
+    with the switch off: same bits"""
+    from pcgcv2_amd import dispatch
+    from pcgcv2_amd.nn import MinkowskiConvolution
+    c4 = _coords('shell8')
+    lvl = CoordMap(_t(c4), 1, unique=True)
+    conv = MinkowskiConvolution(64, 64, 3).to(DEV)
+    with torch.no_grad():
+        conv.bias.normal_()
+    x = SparseTensor(torch.randn((len(c4), 64), device=DEV), coordinate_map=lvl)
+    assert dispatch.select('conv3', (64, 64), len(c4)).family == 'packed'
+    a = conv(x, relu=True).F
+    ops.PACKED_CONV64 = False
+    assert dispatch.select('conv3', (64, 64), len(c4)).family == 'gather'
+    b = conv(x, relu=True).F
+    ops.PACKED_CONV64 = True
+    assert torch.equal(a, b)
+    assert dispatch.select('conv3', (64, 64), ops.PACKED_CONV64_MIN - 1).family == 'gather'
+    res = torch.randn((len(c4), 64), device=DEV)
+    assert dispatch.select('conv3', (64, 64), len(c4), plain_output=False).family == 'gather'      # (no residual form)
+    assert torch.equal(conv(x, residual=res).F, ops.conv_gather(lvl.k3, x.F, conv.kernel, conv.bias, residual=res))
 
 
 def test_dispatch_table_is_the_only_policy():
