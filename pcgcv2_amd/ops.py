@@ -137,8 +137,9 @@ class _Profile:
                     d['compulsory_bytes'] = r['compulsory']
                     d['compulsory_GBps'] = r['compulsory'] / (us * 1e-6) / 1e9
                 if r['mfma_issued'] is not None:
-                    d['mfma_issued_flops'] = r['mfma_issued']
-                    d['mfma_issued_TFLOPs'] = r['mfma_issued'] / (us * 1e-6) / 1e12
+                    issued = r['mfma_issued'](P) if callable(r['mfma_issued']) else r['mfma_issued']      # (a packed kernel issues per present pair)
+                    d['mfma_issued_flops'] = issued
+                    d['mfma_issued_TFLOPs'] = issued / (us * 1e-6) / 1e12
             out.append(d)
         return sorted(out, key=lambda d: -d['ms'])
 
@@ -1012,12 +1013,25 @@ PACKED_CONV64_MIN = 512        # (tools/conv_packed_ab.py gate: 39 vs 86 us at 1
 
 
 def conv_packed64(nbr, x, table, bias, relu=False):
-    """k3 conv 64 -> 64 on a level with its own map, present rows packed per 128-row tile and offset (pcgc_conv_packed64)."""
+    """k3 conv 64 -> 64 on a level with its own map, present rows packed per workgroup tile and offset (pcgc_conv_packed64)."""
     _f32(x, 'x')
     n = x.shape[0]
     out = torch.empty((n, 64), dtype=torch.float32, device=x.device)
+    key = ('conv', 64, 64, n)
+    prof = PROFILE.want(key)
+    if prof:
+        # MFMA flops issued: the present pairs in packed 16-row tiles, plus about half a tile of padding per (workgroup tile of ~96 rows, offset)
+        e0, e1 = PROFILE.bracket(key, 'k_conv_packed64 (k3 64->64, present-row packing: accumulators in LDS, B fragments in registers, fp32 MFMA)', n,
+                                 lambda P, n=n: P * 64 * 4 + P * 8 + n * 64 * 4, lambda P: 2 * P * 64 * 64,
+                                 compulsory=n * 64 * 4 + 27 * n * 4 + n * 64 * 4,
+                                 mfma_issued=lambda P, n=n: 2 * (P + 8 * 27 * ((n + 95) // 96)) * 64 * 64)
+        e0.record()
     check(lib().pcgc_conv_packed64(_p(nbr), n, _p(x), _ld(x), _p(table), table.numel() * 4, _p(bias), int(relu), _p(out), 64, _stream(x)),
           'conv_packed64')
+    if prof:
+        e1.record()
+    elif PROFILE.counting:
+        PROFILE.count(nbr)
     return out
 
 

@@ -23,6 +23,8 @@ def med(f, reps=30):
         e0.record(); f(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
     return statistics.median(ts)
 for label, lvl in (('encoder conv2', l4), ('decoder conv0', kids)):
+    if len(sys.argv) > 3 and sys.argv[3] not in label:
+        continue
     n = len(lvl); nbr = lvl.k3
     x = torch.randn((n, 64), device=dev)
     present = float((nbr >= 0).float().mean()) * 27
