@@ -28,7 +28,7 @@ for label, lvl in (('encoder conv2', l4), ('decoder conv0', kids)):
     n = len(lvl); nbr = lvl.k3
     x = torch.randn((n, 64), device=dev)
     present = float((nbr >= 0).float().mean()) * 27
-    if len(sys.argv) > 2:
+    if len(sys.argv) > 2 and sys.argv[2] == 'sweep':
         for R in (128, 120, 112, 104, 98, 96, 94, 88, 80, 72, 64, 60, 56, 48):
             row = []
             for nw in (4, 8):
