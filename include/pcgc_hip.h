@@ -153,6 +153,12 @@ int pcgc_last_conv_impl(void);
  * so this IS pcgc_conv_gather's chain on that input, without the 27 feature gathers per row.  W: [K, 1, Cout]. */
 int pcgc_conv_gather_unit(const int32_t* nbr /*[dev K,n_out]*/, int K, int64_t n_out, const float* W, const float* bias, int relu,
                           float* out, int Cout, int out_ld, void* stream);
+/* the same layer on a level whose own kernel map has not been built (a level of the encoder's strided pyramid): presence of every offset
+ * is derived on the fly from the PARENT level's map + the level pair's down map + parent_of — what pcgc_kmap_k3_from_coarse would write —
+ * so the finest level's [27][n] map, which only this layer reads, is never materialised. */
+int pcgc_conv_unit_from_coarse(const int32_t* fine /*[n_fine,4]*/, int64_t n_fine, int32_t stride_fine, const int32_t* parent_of,
+                               const int32_t* coarse_nbr /*[27,n_coarse]*/, const int32_t* down /*[8,n_coarse]*/, int64_t n_coarse,
+                               const float* W /*[27,1,Cout]*/, const float* bias, int relu, float* out, int Cout, int out_ld, void* stream);
 int pcgc_set_conv_impl(int impl);
 /* the LDS-shared-weight MFMA kernels come in two schedules (v2b: 16-channel sub-steps; v2c: 32-channel steps with the next
  * step's loads in flight): -1 choose by level size (default), 0 always v2b, 1 always v2c.  Bit-identical. */

@@ -45,6 +45,7 @@ SIGNATURES = {
     'pcgc_compact_index': (ci, [vp, vp, i64, vp, vp]),
     'pcgc_conv_gather': (ci, [vp, ci, i64, vp, i64, ci, ci, ci, vp, vp, vp, ci, ci, ci, vp, ci, ci, ci, vp]),
     'pcgc_conv_gather_unit': (ci, [vp, ci, i64, vp, vp, ci, vp, ci, ci, vp]),
+    'pcgc_conv_unit_from_coarse': (ci, [vp, i64, i32, vp, vp, vp, i64, vp, vp, ci, vp, ci, ci, vp]),
     'pcgc_set_conv_impl': (ci, [ci]),
     'pcgc_last_conv_impl': (ci, []),
     'pcgc_set_mfma_pipe': (ci, [ci]),

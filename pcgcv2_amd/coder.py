@@ -256,7 +256,12 @@ class Coder():
         # encoder's convolutions instead of in front of them; the helper thread waits for the copy and runs the host coordinate coder.
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(x.device))       # the pyramid is complete after this
-        x.cmap.k3                                               # the encoder's kernel maps, coarse to fine, then its ~40 layer launches:
+        # the encoder's kernel maps, coarse to fine, then its ~40 layer launches (the finest level's own map is only read by the first layer,
+        # which on the all-ones input derives presence from the level above: sparse.CoordMap.mapless_unit_conv)
+        if x.has_unit_features() and x.cmap.mapless_unit_conv() and ops.UNIT_INPUT_CONV:
+            x.cmap.down()[0].k3
+        else:
+            x.cmap.k3
         y_list = self.model.encoder(x)                          # the GPU has 2 ms of work queued before the host turns to the side stream
         order, y_C, sorted_ev, arrived, host_C = self._sort_and_stage(lvl8.C, ready)     # (its dozen sort launches run beside the convolutions)
         coded = _POOL.submit(self._encode_geometry, arrived, host_C, lvl8.stride, postfix)     # the octree is coded while the GPU works

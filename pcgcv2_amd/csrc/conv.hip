@@ -102,6 +102,64 @@ k_conv_unit(const int32_t* __restrict__ nbr, int K, int64_t n_out, const float* 
         *(float4*)(y + co) = v;
     }
 }
+// The same layer on a level whose kernel map has not been built: presence of offset k is derived on the fly from the PARENT level's map and
+// the level pair's 8-slot down map, exactly as k_kmap_from_coarse would write it (coords.hip) — the [27][n] map of the finest encoder level
+// (85 MB for a vox10 frame: written once, read once, by this layer only) never exists.
+template <int COUT>
+__global__ void __launch_bounds__(256)
+k_conv_unit_coarse(const int4* __restrict__ fine, int64_t nf, int32_t stride_f, const int32_t* __restrict__ parent_of,
+                   const int32_t* __restrict__ pnbr, const int32_t* __restrict__ down, int64_t nc, const float* __restrict__ W,
+                   const float* __restrict__ bias, int relu, float* __restrict__ out, int out_ld) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nf) return;
+    const int4 q = fine[c];
+    const int j = ((q.y / stride_f) & 1) | (((q.z / stride_f) & 1) << 1) | (((q.w / stride_f) & 1) << 2);
+    const int64_t p = parent_of[c];
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        bool present = true;
+        if (k != 13) {
+            int kp, jn; child_offset(j, k, kp, jn);
+            const int32_t pn = pnbr[(int64_t)kp * nc + p];
+            present = pn >= 0 && down[(int64_t)jn * nc + pn] >= 0;
+        }
+        if (!present) continue;
+        const float* w = W + (int64_t)k * COUT;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = fmaf(1.0f, w[co], acc[co]);
+    }
+    float* y = out + c * out_ld;
+#pragma unroll
+    for (int co = 0; co < COUT; co += 4) {
+        float4 v;
+        v.x = acc[co] + (bias ? bias[co] : 0.0f); v.y = acc[co + 1] + (bias ? bias[co + 1] : 0.0f);
+        v.z = acc[co + 2] + (bias ? bias[co + 2] : 0.0f); v.w = acc[co + 3] + (bias ? bias[co + 3] : 0.0f);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *(float4*)(y + co) = v;
+    }
+}
+extern "C" int pcgc_conv_unit_from_coarse(const int32_t* fine, int64_t n_fine, int32_t stride_fine, const int32_t* parent_of,
+                                          const int32_t* coarse_nbr, const int32_t* down, int64_t n_coarse, const float* W, const float* bias,
+                                          int relu, float* out, int Cout, int out_ld, void* stream) {
+    PCGC_REQUIRE(fine && parent_of && coarse_nbr && down && W && out, "null argument");
+    PCGC_REQUIRE(stride_fine >= 1, "stride must be positive");
+    PCGC_REQUIRE((out_ld & 3) == 0 && (((uintptr_t)out) & 15) == 0, "output rows must be 16-byte aligned");
+    if (n_fine == 0) return 0;
+#define UNIT_COARSE(C_) hipLaunchKernelGGL((k_conv_unit_coarse<C_>), dim3(grid_for(n_fine, 256)), dim3(256), 0, S(stream), (const int4*)fine, n_fine, \
+                                           stride_fine, parent_of, coarse_nbr, down, n_coarse, W, bias, relu, out, out_ld)
+    switch (Cout) {
+        case 16: UNIT_COARSE(16); break;
+        case 8: UNIT_COARSE(8); break;
+        case 4: UNIT_COARSE(4); break;
+        default: pcgc_set_error("conv_unit_from_coarse: unsupported Cout %d (4, 8, 16)", Cout); return -2;
+    }
+#undef UNIT_COARSE
+    PCGC_CHECK_LAUNCH("conv_unit_from_coarse");
+    return 0;
+}
 extern "C" int pcgc_conv_gather_unit(const int32_t* nbr, int K, int64_t n_out, const float* W, const float* bias, int relu,
                                      float* out, int Cout, int out_ld, void* stream) {
     PCGC_REQUIRE(nbr && W && out && K >= 1, "null argument");

@@ -250,12 +250,7 @@ extern "C" int pcgc_kmap_down(const int32_t* coarse, int64_t n_coarse, int32_t s
 // A fine voxel at child slot j = (jx,jy,jz) of its parent, displaced by d in {-1,0,1}^3, lands in the parent displaced
 // by p = floor((j+d)/2) at child slot (j+d)&1 — so the fine level's 27-neighbourhood is a pure gather through the
 // coarse level's kernel map (8x smaller, cache resident).  Only the coarsest level of a pyramid probes the hash.
-__device__ static inline void child_offset(int j, int k, int& kp, int& jn) {
-    int tx = (j & 1) + (k % 3 - 1), ty = ((j >> 1) & 1) + ((k / 3) % 3 - 1), tz = (j >> 2) + (k / 9 - 1);
-    int px = tx < 0 ? -1 : (tx > 1 ? 1 : 0), py = ty < 0 ? -1 : (ty > 1 ? 1 : 0), pz = tz < 0 ? -1 : (tz > 1 ? 1 : 0);
-    kp = (px + 1) + 3 * (py + 1) + 9 * (pz + 1);
-    jn = (tx & 1) | ((ty & 1) << 1) | ((tz & 1) << 2);
-}
+// (child_offset: pcgc_common.h)
 
 // generative-transpose children (all 8 exist, rows 8*i+j): nbr[k][8i+j] = 8 * pnbr[kp][i] + j'
 __global__ void __launch_bounds__(256) k_kmap_children(const int32_t* __restrict__ pnbr, int64_t np, int32_t* __restrict__ nbr) {

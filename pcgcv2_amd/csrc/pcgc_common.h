@@ -64,3 +64,13 @@ __device__ static inline int32_t sel_rank(const uint64_t* __restrict__ bits, con
     const uint64_t w = bits[m >> 6], bit = 1ull << (m & 63);
     return (w & bit) ? wprefix[m >> 6] + (int32_t)__popcll(w & (bit - 1)) : -1;
 }
+
+// ---- hierarchical kernel maps: a fine voxel at child slot j = (jx, jy, jz) of its parent, displaced by kernel offset k, lands in the parent
+// displaced by kp at child slot jn (coords.hip; conv.hip's unit-input conv derives presence the same way)
+__device__ static inline void child_offset(int j, int k, int& kp, int& jn) {
+    int tx = (j & 1) + (k % 3 - 1), ty = ((j >> 1) & 1) + ((k / 3) % 3 - 1), tz = (j >> 2) + (k / 9 - 1);
+    int px = tx < 0 ? -1 : (tx > 1 ? 1 : 0), py = ty < 0 ? -1 : (ty > 1 ? 1 : 0), pz = tz < 0 ? -1 : (tz > 1 ? 1 : 0);
+    kp = (px + 1) + 3 * (py + 1) + 9 * (pz + 1);
+    jn = (tx & 1) | ((ty & 1) << 1) | ((tz & 1) << 2);
+}
+

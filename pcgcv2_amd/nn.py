@@ -47,7 +47,14 @@ class MinkowskiConvolution(_ConvBase):
                 return SparseTensor(y, coordinate_map=x.cmap)
             if fam == 'unit':
                 # the codec's first layer on the occupancy indicator (all ones): a sum of kernel slices over the present offsets
-                return SparseTensor(ops.conv_gather_unit(x.cmap.k3, self.kernel, self.bias, relu=relu), coordinate_map=x.cmap)
+                cm = x.cmap
+                if cm.mapless_unit_conv() and cout in (4, 8, 16) and not ops.PROFILE.counting:
+                    # ... which, on a level of the strided pyramid, are known from the PARENT level's map: this level's own [27][n] map
+                    # (read by this layer only) is not built
+                    coarse, down = cm.down()
+                    y = ops.conv_unit_from_coarse(cm.C, cm.stride, cm._parent_of, coarse.k3, down, self.kernel, self.bias, relu=relu)
+                    return SparseTensor(y, coordinate_map=cm)
+                return SparseTensor(ops.conv_gather_unit(cm.k3, self.kernel, self.bias, relu=relu), coordinate_map=cm)
             if fam == 'packed':
                 # 64 -> 64 (conv2 of the encoder, conv0 of the decoder): present-row packing, accumulators in LDS (csrc/conv_packed.hip)
                 y = ops.conv_packed64(x.cmap.k3, x.F, self._table(ops.child_conv_table), self.bias, relu=relu)

@@ -446,6 +446,7 @@ def conv_gather(nbr, x, W, bias, out=None, residual=None, relu=False, n_out=None
 
 
 UNIT_INPUT_CONV = True     # A/B switch: the first layer on an all-ones input skips the feature gathers (bit-identical)
+UNIT_CONV_MAPLESS = _os.environ.get('PCGC_UNIT_CONV_MAPLESS', '1') != '0'      # ... and, on a pyramid level, the level's own kernel map (presence from the parent level's map); A/B switch
 
 
 def conv_gather_unit(nbr, W, bias, relu=False):
@@ -469,6 +470,29 @@ def conv_gather_unit(nbr, W, bias, relu=False):
         e1.record()
     elif PROFILE.counting and K == 27:
         PROFILE.count(nbr)
+    return out
+
+
+def conv_unit_from_coarse(fine, stride_fine, parent_of, coarse_nbr, down, W, bias, relu=False):
+    """conv_gather_unit on a pyramid level whose own k3 map was never built: presence from the parent level's map + the down map
+    (pcgc_conv_unit_from_coarse); same sums, same order."""
+    _f32(W, 'W')
+    K, Cin, Cout = W.shape
+    if Cin != 1 or K != 27:
+        raise PcgcError('conv_unit_from_coarse: kernel [27, 1, Cout] expected')
+    n = fine.shape[0]
+    out = torch.empty((n, Cout), dtype=torch.float32, device=W.device)
+    key = ('conv', 1, Cout, n)
+    prof = PROFILE.want(key)
+    if prof:
+        e0, e1 = PROFILE.bracket(key, f'k3 conv 1->{Cout} on the unit input (k_conv_unit_coarse: presence from the parent level\'s map, no map of its own)', n,
+                                 lambda P, b=Cout, n=n: P * 4 + P * 8 + n * b * 4, lambda P, b=Cout: 2 * P * b,
+                                 compulsory=n * 16 + n * 4 + n * Cout * 4)
+        e0.record()
+    check(lib().pcgc_conv_unit_from_coarse(_p(_i32(fine)), n, int(stride_fine), _p(parent_of), _p(coarse_nbr), _p(down), coarse_nbr.shape[1],
+                                           _p(W), _p(bias), int(relu), _p(out), Cout, Cout, _stream(fine)), 'conv_unit_from_coarse')
+    if prof:
+        e1.record()
     return out
 
 

@@ -101,6 +101,12 @@ class CoordMap:
                 self._k3 = ops.kmap_k3(self.C, self.stride, self.table)
         return self._k3
 
+    def mapless_unit_conv(self):
+        """True when a unit-input k3 conv on this level should derive presence from the parent level's map instead of this level's own
+        (ops.conv_unit_from_coarse): a raw level that would derive its map from its strided pyramid anyway, and whose map nobody has
+        built so far."""
+        return (ops.UNIT_CONV_MAPLESS and self._k3 is None and self.origin is None and len(self) > HASH_LEVEL_MAX and self.stride <= (1 << 18))
+
     def down(self):
         """-> (coarse CoordMap at 2*stride, [8, N_coarse] kernel map): MinkowskiConvolution(kernel_size=2, stride=2).
         One hash insert + one probe per fine row (the dedup of the quantised coordinates); the map itself is a scatter."""

@@ -23,7 +23,7 @@ def _t(a, dt=None):
 def _restore_path_switches():
     """the A/B switches of the rows kernels are module globals some tests flip: whatever a test leaves behind is undone"""
     names = ('ROWS_IRN64', 'ROWS_IRN64_CHILD', 'ROWS_IRN64_MIN', 'ROWS_IRN32', 'ROWS_IRN32_MIN', 'ROWS_IRN32_MAX', 'ROWS_CONV', 'ROWS_CONV_MIN',
-             'ROWS_DOWN', 'ROWS_DOWN_MIN', 'UNIT_INPUT_CONV', 'CHILD_MFMA', 'MFMA_IRN', 'FUSE_IRN', 'ONE_SWEEP_PRUNE', 'PACKED_CONV64', 'PACKED_CONV64_MIN')
+             'ROWS_DOWN', 'ROWS_DOWN_MIN', 'UNIT_INPUT_CONV', 'CHILD_MFMA', 'MFMA_IRN', 'FUSE_IRN', 'ONE_SWEEP_PRUNE', 'PACKED_CONV64', 'PACKED_CONV64_MIN', 'UNIT_CONV_MAPLESS')
     keep = {n: getattr(ops, n) for n in names}
     yield
     for n, v in keep.items():
@@ -1841,6 +1841,29 @@ def test_conv_packed64_through_the_module(sd):
     res = torch.randn((len(c4), 64), device=DEV)
     assert dispatch.select('conv3', (64, 64), len(c4), plain_output=False).family == 'gather'      # (no residual form)
     assert torch.equal(conv(x, residual=res).F, ops.conv_gather(lvl.k3, x.F, conv.kernel, conv.bias, residual=res))
+
+
+@pytest.mark.parametrize('cloud', ['shell9', 'noisy_s'])
+def test_unit_conv_without_a_map_of_its_own(cloud, monkeypatch):
+    """the first layer on a pyramid level (all-ones input): presence derived from the parent level's map (k_conv_unit_coarse) == the
+    level's own map (k_conv_unit) == the oracle; the level's [27][n] map is not built on the way"""
+    from pcgcv2_amd import sparse
+    monkeypatch.setattr(sparse, 'HASH_LEVEL_MAX', 256)                         # (small clouds too derive their maps from the pyramid)
+    c4 = _cloud4(cloud) if cloud.endswith('_s') else _coords(cloud)
+    conv, W, b = _conv_module(1, 16, 3, 1, 116)
+    want = np.maximum(orc.conv_gather(orc.kmap_k3(c4, 1), np.ones((len(c4), 1), np.float32), W, b), np.float32(0))
+    x = SparseTensor(torch.ones((len(c4), 1)), coordinates=_t(c4), tensor_stride=1, device=DEV)
+    assert x.has_unit_features() and x.cmap.mapless_unit_conv()
+    with torch.no_grad():
+        got = conv(x, relu=True).F.cpu().numpy()
+    assert x.cmap._k3 is None                                                  # (never materialised)
+    np.testing.assert_array_equal(got, want)
+    ops.UNIT_CONV_MAPLESS = False
+    y = SparseTensor(torch.ones((len(c4), 1)), coordinates=_t(c4), tensor_stride=1, device=DEV)
+    with torch.no_grad():
+        got2 = conv(y, relu=True).F.cpu().numpy()
+    assert y.cmap._k3 is not None
+    np.testing.assert_array_equal(got2, want)
 
 
 def test_dispatch_table_is_the_only_policy():
