@@ -205,11 +205,11 @@ int pk_occ(int R, int nw) {
 }
 int pk_rows(int64_t n, int cus) {
     int best = PK_RMAX; double best_cost = 1e300;
-    auto tau = [](int c) { return c >= 3 ? 0.30 : (c == 2 ? 0.37 : 0.5); };
+    auto tau = [](int c) { return c >= 4 ? 0.219 : (c == 3 ? 0.240 : (c == 2 ? 0.276 : 0.370)); };      // (least-squares fit to the two sweeps: 4 % rms)
     for (int R = PK_RMAX; R >= 40; R -= 2) {
         const int occ = pk_occ(R, 4);
         const int64_t tiles = (n + R - 1) / R, slots = (int64_t)cus * occ;
-        const double W = R * 0.6 / 16.0 + 0.5, L = 0.94;
+        const double W = R * 0.6 / 16.0 + 0.346, L = 1.27;
         const int64_t full = tiles / slots, rem = tiles - full * slots;
         double cost = (double)full * (L + occ * W * tau(occ));
         if (rem) { const int c = (int)((rem + cus - 1) / cus); cost += L + c * W * tau(c); }
