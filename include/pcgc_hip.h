@@ -370,6 +370,15 @@ int pcgc_set_oct_tiled(int on);
 int pcgc_d1_nn(const int32_t* a /*[dev na,4]*/, int64_t na, const uint64_t* b_keys, const int32_t* b_vals, int64_t b_cap,
                const int32_t* offsets /*[dev n_offsets,4]*/, int n_offsets, double* sum /*[dev 1]*/, uint64_t* max_d2 /*[dev 1]*/,
                int32_t* unresolved /*[dev 1]*/, void* stream);
+/* The same sums through 4 x 4 x 4 cells of cloud B: cell_keys / cell_vals = coordinate hash of B's stride-4 level (vals = row), masks [n_cells] =
+ * 64-bit voxel occupancy per cell (pcgc_d1_cell_masks fills it: bit x & 3 | (y & 3) << 2 | (z & 3) << 4); offsets [n,4] = cell offsets (x, y, z) +
+ * the lower bound of the squared distance to any voxel of that cell, ascending; reach2 = squared distance from which a voxel outside the offset
+ * table could be nearer (such points count as unresolved).  A few dozen probes per point whatever the distance. */
+int pcgc_d1_cell_masks(const int32_t* b /*[dev nb,4]*/, int64_t nb, const uint64_t* cell_keys, const int32_t* cell_vals, int64_t cell_cap,
+                       uint64_t* masks /*[dev n_cells]*/, int64_t n_cells, void* stream);
+int pcgc_d1_nn_cells(const int32_t* a /*[dev na,4]*/, int64_t na, const uint64_t* cell_keys, const int32_t* cell_vals, int64_t cell_cap,
+                     const uint64_t* masks, const int32_t* offsets /*[dev n,4]*/, int n_offsets, int32_t reach2, double* sum, uint64_t* max_d2,
+                     int32_t* unresolved, void* stream);
 
 /* ---- ASCII PLY geometry I/O (data_utils.py:19-48: read_ply_ascii_geo / write_ply_ascii_geo), HOST.
  *      read: returns the number of data rows (call with xyz = NULL to size the buffer); same acceptance rule as the

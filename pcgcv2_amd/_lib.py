@@ -92,6 +92,8 @@ SIGNATURES = {
     'pcgc_quantize_symbols': (ci, [vp, i64, vp, vp, vp]),
     'pcgc_compress_prepare': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, vp, vp, vp]),
     'pcgc_cdf_table': (ci, [vp, ci, f32, f32, vp, vp, vp]),
+    'pcgc_d1_cell_masks': (ci, [vp, i64, vp, vp, i64, vp, i64, vp]),
+    'pcgc_d1_nn_cells': (ci, [vp, i64, vp, vp, i64, vp, vp, ci, i32, vp, vp, vp, vp]),
     'pcgc_d1_nn': (ci, [vp, i64, vp, vp, i64, vp, ci, vp, vp, vp, vp]),
     'pcgc_rc_encode': (i64, [vp, ci, ci, vp, i64, vp, i64]),
     'pcgc_rc_decode': (ci, [vp, ci, ci, vp, i64, vp, i64]),

@@ -1331,13 +1331,46 @@ def _d1_offsets(device, radius=12):
     return _D1_OFFSETS[key]
 
 
+D1_CELLS = _os.environ.get('PCGC_D1_CELLS', '1') != '0'       # nearest neighbours through 4 x 4 x 4 cells with occupancy masks (A/B switch: 0 = one probe per lattice offset)
+_D1_CELL_OFFSETS = {}
+
+
+def _d1_cell_offsets(device, reach_cells=4):
+    """(ox, oy, oz, lower bound of the squared distance) for every CELL offset with max|o| <= reach_cells, ascending in the bound: a voxel of the
+    query's own cell and a voxel of the cell at offset o are at least max(0, 4 |o| - 3) apart per axis."""
+    key = (str(device), reach_cells)
+    if key not in _D1_CELL_OFFSETS:
+        r = np.arange(-reach_cells, reach_cells + 1)
+        g = np.stack(np.meshgrid(r, r, r, indexing='ij'), -1).reshape(-1, 3)
+        gap = np.maximum(0, 4 * np.abs(g) - 3)
+        lb = (gap * gap).sum(1)
+        order = np.lexsort((g[:, 0], g[:, 1], g[:, 2], lb))
+        tab = np.concatenate([g[order], lb[order, None]], 1).astype(np.int32)
+        _D1_CELL_OFFSETS[key] = torch.from_numpy(np.ascontiguousarray(tab)).to(device)
+    return _D1_CELL_OFFSETS[key]
+
+
 def d1_nn(a, b, radius=12):
     """a, b: int32 [N,4] device coordinate tensors (stride 1).  -> (sum of squared NN distances a->b, max, unresolved count)."""
-    table = HashTable(_i32(b), 1)
-    off = _d1_offsets(a.device, radius)
     s = torch.empty(1, dtype=torch.float64, device=a.device)
     m = torch.empty(1, dtype=torch.int64, device=a.device)
     u = torch.empty(1, dtype=torch.int32, device=a.device)
+    if D1_CELLS and b.shape[0] > 0:
+        # cloud B as stride-4 cells: hash of the cells + a 64-bit occupancy mask per cell; reach: cells up to 4 away, i.e. every voxel nearer
+        # than 4 * 5 - 3 = 17 has been seen when the search ends
+        reach_cells = max(1, (int(radius) + 3) // 4 + 1)
+        # (the hash of the quantised rows maps a cell to the FIRST row that lies in it: that row's slot of `masks` is the cell's mask)
+        table = HashTable(coords_quantize(_i32(b), 4), 4)
+        masks = torch.empty(b.shape[0], dtype=torch.int64, device=b.device)
+        check(lib().pcgc_d1_cell_masks(_p(b), b.shape[0], _p(table.keys), _p(table.vals), table.cap, _p(masks), b.shape[0], _stream(b)),
+              'd1_cell_masks')
+        off = _d1_cell_offsets(a.device, reach_cells)
+        reach = 4 * (reach_cells + 1) - 3
+        check(lib().pcgc_d1_nn_cells(_p(_i32(a)), a.shape[0], _p(table.keys), _p(table.vals), table.cap, _p(masks), _p(off), off.shape[0],
+                                     reach * reach, _p(s), _p(m), _p(u), _stream(a)), 'd1_nn_cells')
+        return s, m, u
+    table = HashTable(_i32(b), 1)
+    off = _d1_offsets(a.device, radius)
     check(lib().pcgc_d1_nn(_p(_i32(a)), a.shape[0], _p(table.keys), _p(table.vals), table.cap, _p(off), off.shape[0], _p(s), _p(m),
                            _p(u), _stream(a)), 'd1_nn')
     return s, m, u

@@ -23,7 +23,7 @@ def _t(a, dt=None):
 def _restore_path_switches():
     """the A/B switches of the rows kernels are module globals some tests flip: whatever a test leaves behind is undone"""
     names = ('ROWS_IRN64', 'ROWS_IRN64_CHILD', 'ROWS_IRN64_MIN', 'ROWS_IRN32', 'ROWS_IRN32_MIN', 'ROWS_IRN32_MAX', 'ROWS_CONV', 'ROWS_CONV_MIN',
-             'ROWS_DOWN', 'ROWS_DOWN_MIN', 'UNIT_INPUT_CONV', 'CHILD_MFMA', 'MFMA_IRN', 'FUSE_IRN', 'ONE_SWEEP_PRUNE', 'PACKED_CONV64', 'PACKED_CONV64_MIN', 'UNIT_CONV_MAPLESS')
+             'ROWS_DOWN', 'ROWS_DOWN_MIN', 'UNIT_INPUT_CONV', 'CHILD_MFMA', 'MFMA_IRN', 'FUSE_IRN', 'ONE_SWEEP_PRUNE', 'PACKED_CONV64', 'PACKED_CONV64_MIN', 'UNIT_CONV_MAPLESS', 'D1_CELLS')
     keep = {n: getattr(ops, n) for n in names}
     yield
     for n, v in keep.items():
@@ -1088,6 +1088,28 @@ def test_device_d1_metric_matches_pc_error_d_golden(golden_dir):
         assert m['h.        (p2point)'] == pytest.approx(float(g[f'p{i}_h.(p2point)']), rel=1e-5, abs=1e-9)
         h = d1_psnr(a, b, res)
         assert m['mse1      (p2point)'] == h['mse1      (p2point)'] and m['mse2      (p2point)'] == h['mse2      (p2point)']
+
+
+@pytest.mark.parametrize('shift', [0, 2, 7, 15, 40])
+def test_device_d1_through_cells_equals_offset_probes(shift):
+    """pcgc_d1_nn_cells (stride-4 cells + occupancy masks) against pcgc_d1_nn (one probe per lattice offset) and the host KD-tree: clouds that
+    coincide, that are a few voxels apart (the codec's case), ~10 voxels apart (the bench's random-weight stand-in) and farther apart than
+    either table reaches (host finish), batch index and cloud border included"""
+    from pcgcv2_amd.pc_error import d1_psnr_device, d1_psnr
+    rng = np.random.default_rng(shift)
+    a = _coords('shell8')
+    b = a.copy()
+    b[:, 1:] = np.clip(b[:, 1:] + rng.integers(-shift, shift + 1, size=(len(b), 3)) + np.array([shift, 0, -shift // 2]), 0, None)
+    b = np.unique(b, axis=0).astype(np.int32)[: len(a) - 1000]
+    ops.D1_CELLS = True
+    m_cells = d1_psnr_device(_t(a), _t(b), 256)
+    ops.D1_CELLS = False
+    m_probe = d1_psnr_device(_t(a), _t(b), 256)
+    ops.D1_CELLS = True
+    assert m_cells == m_probe
+    h = d1_psnr(a[:, 1:], b[:, 1:], 256)
+    assert m_cells['mse1      (p2point)'] == h['mse1      (p2point)'] and m_cells['mse2      (p2point)'] == h['mse2      (p2point)']
+    assert m_cells['h.        (p2point)'] == h['h.        (p2point)']
 
 
 @pytest.mark.parametrize('case', ['single', 'pair_far', 'tiny_cluster', 'duplicates', 'line'])
