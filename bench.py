@@ -311,7 +311,8 @@ def main():
         step()                                           # leave the files of the default configuration behind
 
     def timed_steps(**kw):
-        step(**kw)
+        for _ in range(max(1, args.warmup)):                     # (the auxiliary figures get the headline's warm-up: one step left them 5-10 % noise)
+            step(**kw)
         barrier()
         t_p = time.perf_counter()
         for _ in range(args.steps):
