@@ -229,10 +229,10 @@ def main():
         torch.cuda.synchronize()
 
     outs = None
-    for _ in range(args.warmup):
-        outs = step()
+    outs = step()                                    # (first touch: allocator, tables of the dispatcher, LDS limits of the kernels)
     torch.cuda.synchronize()
-    # Untimed analysis passes (not counted as warmup): one step with EVERY sparse-conv launch bracketed by HIP events — that
+    # Untimed analysis passes (not counted as warmup; they run BEFORE the W warm-up steps, so that the warm-up is what immediately precedes
+    # the timed region — the passes below read maps back to the host and leave the GPU idle for milliseconds at a time): one step with EVERY sparse-conv launch bracketed by HIP events — that
     # finds the dominant (kernel, level) and gives the all-launch aggregate — and one that counts the kernel-map pairs per level
     # for the byte / flop formulas.  The timed region then brackets only the dominant kernel's launches, so the event overhead
     # (~0.6 ms per step with every launch bracketed) stays out of `value`.
@@ -270,9 +270,11 @@ def main():
     ops.PROFILE.reset(enabled=dominant is not None, only=dominant)
     if dominant is not None:
         ops.PROFILE.pairs = pairs
-        # third untimed analysis pass: one step under exactly the timed region's instrumentation (the pair-counting pass above reads
-        # maps back to the host and leaves allocator and caches in a state no timed step ever sees: the first timed step cost +1 ms)
+    # the W warm-up steps, under exactly the timed region's instrumentation (the pair-counting pass above leaves allocator and caches in a
+    # state no timed step ever sees: without a step in between the first timed step cost +1 ms)
+    for _ in range(args.warmup):
         step()
+    if dominant is not None:
         ops.PROFILE.reset(enabled=True, only=dominant)
         ops.PROFILE.pairs = pairs
     timers = [0.0, 0.0]
