@@ -977,3 +977,27 @@ def test_frame_decode_in_two_halves(tmp_path):
     [t.start() for t in threads]
     [t.join() for t in threads]
     assert not errors, errors
+
+
+def test_dispatch_table_rules_without_a_gpu():
+    """the policy table (pcgcv2_amd/dispatch.py) is host logic: the families of the round-4 kernels, their gates and their fall-backs
+    (32-bit offset limit, residual / out= forms the packed kernel does not have) without a device"""
+    from pcgcv2_amd import dispatch, ops
+    assert dispatch.select('prune', (16,), 2_000_000).family == 'select'
+    assert dispatch.select('prune', (1,), 1000).family == 'mask'                       # (features that are not whole 16-byte chunks)
+    assert dispatch.select('conv3', (64, 64), ops.PACKED_CONV64_MIN).family == 'packed'
+    assert dispatch.select('conv3', (64, 64), ops.PACKED_CONV64_MIN - 1).family == 'gather'
+    assert dispatch.select('conv3', (64, 64), 100_000, plain_output=False).family == 'gather'
+    assert dispatch.select('conv3', (64, 64), 100_000, extent=dispatch.LIMIT).family == 'gather'
+    assert dispatch.select('conv3', (64, 64), 100_000, 'children').family == 'packed'    # (the decoder's conv0: a children level with its own map)
+    assert dispatch.select('conv3', (32, 32), 100_000).family == 'rows'
+    assert dispatch.select('conv3', (1, 16), 100_000, unit_input=True).family == 'unit'
+    keep = {k: getattr(ops, k) for k in ('ONE_SWEEP_PRUNE', 'PACKED_CONV64')}
+    try:
+        ops.ONE_SWEEP_PRUNE = ops.PACKED_CONV64 = False
+        assert dispatch.select('prune', (16,), 2_000_000).family == 'mask'
+        assert dispatch.select('conv3', (64, 64), 100_000).family == 'gather'
+    finally:
+        for k, v in keep.items():
+            setattr(ops, k, v)
+    assert len(dispatch.describe().splitlines()) == len(dispatch.TABLE)
