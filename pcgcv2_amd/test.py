@@ -4,8 +4,8 @@ column names; `sweep(...)` is the underlying generator.
 
 What differs in execution: the input tensor — and its optional down-scaled version — is built once, and because the
 encoder's geometry pyramid and kernel maps depend only on the coordinates they are built by the first rate and reused by
-all others (they are cached on the tensor's coordinate levels).  D2 (point-to-plane) columns need normals and the external
-`pc_error_d` binary and are only produced when it is installed.  Checkpoints may be paths or in-memory state dicts."""
+all others (they are cached on the tensor's coordinate levels).  D2 (point-to-plane) columns need normals in the
+input PLY (as the reference's `pc_error(..., normal=True)` does) and are computed natively when no `pc_error_d` binary is installed.  Checkpoints may be paths or in-memory state dicts."""
 import os
 import time
 
@@ -15,7 +15,7 @@ import torch
 
 from .coder import Coder, stream_bits
 from .data_utils import load_sparse_tensor, scale_sparse_tensor, write_ply_ascii_geo
-from .pc_error import pc_error, _exe
+from .pc_error import pc_error, ply_has_normals
 from .pcc_model import PCCModel
 
 device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
@@ -47,7 +47,7 @@ def sweep(filedir, ckpts, outdir, scaling_factor=1.0, rho=1.0, res=1024):
     prefix = os.path.join(outdir, os.path.split(filedir)[-1].split('.')[0])
     x_in = scale_sparse_tensor(x, factor=scaling_factor) if scaling_factor != 1 else x
     model = PCCModel().to(device)
-    with_normals = _exe() is not None
+    with_normals = ply_has_normals(filedir)       # (test.py:74-75 always asks for D2: its test clouds carry normals; a cloud without them gets D1 only)
     for rate, ckpt in enumerate(ckpts, start=1):
         model.load_state_dict(_state_dict(ckpt))
         coder = Coder(model=model, filename=prefix)

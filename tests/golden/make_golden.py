@@ -11,6 +11,7 @@ Fixtures:
   G2 ordering.npz         array2vector keys / argsort, istopk masks            (data_utils.py:55-89)
   G3 ply_format.npz       bytes written by write_ply_ascii_geo + read-back     (data_utils.py:19-48)
   G4 d1_metric.npz        pc_error_d (mpeg-pcc-dmetric 0.13.4) outputs         (pc_error.py:27-74)
+  G6 d2_metric.npz        the same binary with `-n infile1` (normal=True): p2plane columns (pc_error.py:40-47,51-53; test.py:74-75)
   G5 state_dict_keys.txt  EntropyBottleneck state_dict names / shapes          (entropy_model.py:59-80)
 """
 import os, sys, types, shutil, subprocess, tempfile
@@ -148,8 +149,53 @@ def g4():
     np.savez_compressed(os.path.join(OUT, 'd1_metric.npz'), **out)
 
 
+def g6():
+    """point-to-plane columns: clouds with normals through the vendored binary, invoked by the imported reference pc_error(normal=True)"""
+    rng = np.random.default_rng(6)
+    out = {}
+
+    def write_with_normals(path, pts, nrm):
+        with open(path, 'w') as f:
+            f.write('ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n'
+                    'property float nx\nproperty float ny\nproperty float nz\nend_header\n' % len(pts))
+            for q, m in zip(pts, nrm):
+                f.write('%d %d %d %.6f %.6f %.6f\n' % (q[0], q[1], q[2], m[0], m[1], m[2]))
+
+    def shell(res, radius, thick):
+        g = np.stack(np.meshgrid(*[np.arange(res)] * 3, indexing='ij'), -1).reshape(-1, 3)
+        c = np.array([res / 2.0] * 3)
+        r = np.linalg.norm(g - c, axis=1)
+        a = g[np.abs(r - radius) < thick]
+        return a, (a - c) / np.linalg.norm(a - c, axis=1, keepdims=True)
+
+    cases = []
+    a, na = shell(64, 20, 0.7)                                   # thin sphere shell, analytic normals; B: jittered by one voxel, 50 points fewer
+    cases.append((a, na, np.unique(np.clip(a + rng.integers(-1, 2, size=a.shape), 0, 63), axis=0)[:len(a) - 50], 64))
+    a, na = shell(128, 44, 1.2)                                  # thicker shell; B: shifted up to three voxels (many exact distance ties)
+    cases.append((a, na, np.unique(np.clip(a + rng.integers(-3, 4, size=a.shape), 0, 127), axis=0), 128))
+    a, na = shell(64, 18, 0.6)
+    cases.append((a, na, a.copy(), 64))                          # identical clouds: zeros, infinite PSNR
+    a = np.unique(rng.integers(0, 128, size=(4000, 3)), axis=0)  # scattered points, random unit normals, B sparser than A
+    na = rng.standard_normal((len(a), 3)); na /= np.linalg.norm(na, axis=1, keepdims=True)
+    b = np.unique(np.clip(a + rng.integers(-2, 3, size=a.shape), 0, 127), axis=0)
+    cases.append((a, na, b[rng.random(len(b)) < 0.6], 128))
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, 'pc_error_d'); shutil.copy(os.path.join(REF, 'pc_error_d'), exe); os.chmod(exe, 0o755)
+        ref_pe.rootdir = d
+        for i, (a, na, b, res) in enumerate(cases):
+            pa, pb = os.path.join(d, f'a{i}.ply'), os.path.join(d, f'b{i}.ply')
+            write_with_normals(pa, a, na); ref_du.write_ply_ascii_geo(pb, b)
+            df = ref_pe.pc_error(pa, pb, res=res, normal=True)
+            out[f'p{i}_a'] = a.astype(np.int32); out[f'p{i}_b'] = b.astype(np.int32); out[f'p{i}_res'] = np.array(res)
+            out[f'p{i}_na'] = np.array([[float('%.6f' % v) for v in row] for row in na], np.float32)      # (as the file holds them)
+            for key in df.columns:
+                out[f'p{i}_' + key.replace(' ', '').replace(',', '_')] = np.array(df[key][0])
+    out['n_cases'] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT, 'd2_metric.npz'), **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g6']
     for name in which:
-        {'g1': g1, 'g2': g2, 'g3': g3, 'g4': g4}[name]()
+        {'g1': g1, 'g2': g2, 'g3': g3, 'g4': g4, 'g6': g6}[name]()
     print('golden fixtures written to', OUT)

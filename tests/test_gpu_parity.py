@@ -1075,6 +1075,33 @@ def test_rd_sweep_harness_and_cli(tmp_path):
     assert (tmp_path / 'cli' / 'shell8_dec.ply').exists()
 
 
+def test_rd_sweep_reports_point_to_plane_when_the_cloud_has_normals(tmp_path, monkeypatch):
+    """the reference's sweep asks pc_error for D2 (test.py:74-75, normal=True): a PLY with normals gets the p2plane columns of the reference's
+    results/*.csv from the native computation (no pc_error_d here), equal to d2_psnr of the input and the decoded cloud"""
+    from pcgcv2_amd.test import test as sweep
+    from pcgcv2_amd import pc_error as pe
+    monkeypatch.setattr(pe, '_exe', lambda: None)
+    pts = synthetic.shell('shell7').numpy()
+    nrm = (pts - pts.mean(0)) / np.linalg.norm(pts - pts.mean(0), axis=1, keepdims=True)
+    ply = tmp_path / 'shell7n.ply'
+    with open(ply, 'w') as f:
+        f.write('ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n'
+                'property float nx\nproperty float ny\nproperty float nz\nend_header\n' % len(pts))
+        for q, n in zip(pts, nrm):
+            f.write('%d %d %d %.6f %.6f %.6f\n' % (q[0], q[1], q[2], n[0], n[1], n[2]))
+    ck = tmp_path / 'r1.pth'
+    torch.save({'model': synthetic.synthetic_state_dict(gain=50.0)}, str(ck))
+    df = sweep(str(ply), [str(ck)], str(tmp_path / 'out'), str(tmp_path / 'res'), res=128, verbose=False)
+    for col in ['mse1      (p2plane)', 'mse1,PSNR (p2plane)', 'mse2      (p2plane)', 'mse2,PSNR (p2plane)', 'mseF      (p2plane)', 'mseF,PSNR (p2plane)',
+                'mseF,PSNR (p2point)']:
+        assert col in df.columns, col
+    assert df['num_points(input)'][0] == len(pts)
+    a, na = pe.read_ply_ascii_with_normals(str(ply))
+    b, _ = pe.read_ply_ascii_with_normals(str(tmp_path / 'out' / 'shell7n_r1_dec.ply'))
+    want = pe.d2_psnr(a, na, b, 128)
+    assert df['mseF      (p2plane)'][0] == want['mseF      (p2plane)'] and df['mseF      (p2point)'][0] == want['mseF      (p2point)']
+
+
 def test_device_d1_metric_matches_pc_error_d_golden(golden_dir):
     """GPU D1 (pcgc_d1_nn) against the stdout of the vendored mpeg-pcc-dmetric binary (golden G4) and the host KD-tree."""
     from pcgcv2_amd.pc_error import d1_psnr_device, d1_psnr

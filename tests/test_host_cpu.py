@@ -463,6 +463,41 @@ def test_native_d1_matches_pc_error_d(golden_dir, tmp_path):
     assert df['mseF,PSNR (p2point)'][0] == pytest.approx(float(g['p0_mseF_PSNR(p2point)']), abs=2e-4)
 
 
+def test_native_d2_matches_pc_error_d(golden_dir, tmp_path, monkeypatch):
+    """point-to-plane (the reference's test.py:74-75 asks pc_error for it with normal=True): the native host computation against the vendored
+    binary's stdout (golden G6: four cloud pairs with normals, distance ties, identical clouds, scattered points) — every column the reference
+    parses, to the six digits the tool prints; then through pc_error() itself on PLY files with and without normals"""
+    from pcgcv2_amd import pc_error as pe
+    from pcgcv2_amd.data_utils import write_ply_ascii_geo
+    g = np.load(os.path.join(golden_dir, 'd2_metric.npz'))
+    cols = ['mse1      (p2point)', 'mse2      (p2point)', 'mseF      (p2point)', 'mse1      (p2plane)', 'mse2      (p2plane)', 'mseF      (p2plane)',
+            'h.       1(p2point)', 'h.       2(p2point)', 'h.        (p2point)']
+    psnr = ['mse1,PSNR (p2point)', 'mse2,PSNR (p2point)', 'mseF,PSNR (p2point)', 'mse1,PSNR (p2plane)', 'mse2,PSNR (p2plane)', 'mseF,PSNR (p2plane)']
+    gk = lambda i, key: float(g[f'p{i}_' + key.replace(' ', '').replace(',', '_')])
+    for i in range(int(g['n_cases'])):
+        m = pe.d2_psnr(g[f'p{i}_a'], g[f'p{i}_na'], g[f'p{i}_b'], int(g[f'p{i}_res']))
+        for key in cols:
+            assert m[key] == pytest.approx(gk(i, key), rel=2e-5, abs=1e-9), (i, key)
+        for key in psnr:
+            if np.isinf(gk(i, key)):
+                assert np.isinf(m[key])
+            else:
+                assert m[key] == pytest.approx(gk(i, key), abs=2e-4), (i, key)
+    monkeypatch.setattr(pe, '_exe', lambda: None)                      # (no binary: the native path)
+    a, b = tmp_path / 'a.ply', tmp_path / 'b.ply'
+    with open(a, 'w') as f:
+        f.write('ply\nformat ascii 1.0\ncomment normals from a mesh\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n'
+                'property float nx\nproperty float ny\nproperty float nz\nend_header\n' % len(g['p0_a']))
+        for q, n in zip(g['p0_a'], g['p0_na']):
+            f.write('%d %d %d %.6f %.6f %.6f\n' % (q[0], q[1], q[2], n[0], n[1], n[2]))
+    write_ply_ascii_geo(str(b), g['p0_b'])
+    df = pe.pc_error(str(a), str(b), res=int(g['p0_res']), normal=True)
+    assert df['mseF,PSNR (p2plane)'][0] == pytest.approx(gk(0, 'mseF,PSNR (p2plane)'), abs=2e-4)
+    assert df['mseF,PSNR (p2point)'][0] == pytest.approx(gk(0, 'mseF,PSNR (p2point)'), abs=2e-4)
+    with pytest.raises(ValueError, match='normals'):
+        pe.pc_error(str(b), str(a), res=64, normal=True)                # infile1 without normals: as `pc_error_d -n` would fail
+
+
 def test_product_refuses_cpu_tensors():
     from pcgcv2_amd.sparse import SparseTensor
     with pytest.raises(PcgcError):
