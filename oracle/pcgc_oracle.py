@@ -470,3 +470,40 @@ def d1_metrics(a, b, res):
     peak = float(res - 1)
     psnr = lambda m: 10 * np.log10(3 * peak * peak / m) if m > 0 else float('inf')
     return dict(mse1=mse1, mse2=mse2, mseF=mse, psnr1=psnr(mse1), psnr2=psnr(mse2), psnrF=psnr(mse))
+
+
+def d2_metrics(a, na, b, res, ties_max=30):
+    """mpeg-pcc-dmetric 0.13.4 ‡ point-to-plane with `-n infile1` (pc_error.py:40-47,51-53; test.py:74-75 passes normal=True), by exhaustive
+    distance matrices (no spatial index: independent of the product's KD-tree search and of its tie order; small clouds only).
+    Normals of b: every point of a adds its normal to each of its nearest points of b (all at the minimal distance, at most ties_max), a point
+    of b takes the mean of what it received, or — if nothing — the mean normal of its own nearest points of a.  a -> b: c2p(a_i) = mean over
+    the tied nearest b_j of ((a_i - b_j) . n_bj)^2; mse = mean, PSNR = 10 log10(3 peak^2 / mse), peak = res - 1."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64); na = np.asarray(na, np.float64)
+
+    def nearest(p, q):                                   # per point of p: list of the (<= ties_max) nearest points of q, squared distance
+        out = []
+        for s0 in range(0, len(p), 512):
+            d2 = ((p[s0:s0 + 512, None, :] - q[None, :, :]) ** 2).sum(-1)
+            m = d2.min(1)
+            for r in range(len(d2)):
+                out.append((np.nonzero(d2[r] == m[r])[0][:ties_max], m[r]))
+        return out
+
+    acc = np.zeros((len(b), 3)); cnt = np.zeros(len(b), np.int64)
+    nn_ab = nearest(a, b)
+    for i, (js, _) in enumerate(nn_ab):
+        acc[js] += na[i]; cnt[js] += 1
+    nb = np.zeros((len(b), 3))
+    nn_ba = nearest(b, a)
+    for j in range(len(b)):
+        nb[j] = acc[j] / cnt[j] if cnt[j] else na[nn_ba[j][0]].mean(0)
+
+    def direction(p, q, nq, nn):
+        c2c = np.array([m for _, m in nn])
+        c2p = np.array([np.mean(((p[i] - q[js]) * nq[js]).sum(1) ** 2) for i, (js, _) in enumerate(nn)])
+        return c2c.mean(), c2p.mean()
+    mse1, pl1 = direction(a, b, nb, nn_ab)
+    mse2, pl2 = direction(b, a, na, nn_ba)
+    peak = float(res - 1)
+    psnr = lambda m: 10 * np.log10(3 * peak * peak / m) if m > 0 else float('inf')
+    return dict(mse1=mse1, mse2=mse2, mseF=max(mse1, mse2), c2p1=pl1, c2p2=pl2, c2pF=max(pl1, pl2), c2p_psnrF=psnr(max(pl1, pl2)))

@@ -120,6 +120,23 @@ def test_g4_d1_metric(golden_dir):
             assert m['psnrF'] == pytest.approx(float(g[f'p{i}_mseF_PSNR(p2point)']), abs=2e-4)
 
 
+def test_g6_d2_metric(golden_dir):
+    """the oracle's exhaustive point-to-plane restatement against the vendored binary's stdout (the cloud pairs small enough for distance
+    matrices) and against the product's KD-tree form on the same pairs"""
+    from pcgcv2_amd import pc_error as pe
+    g = _load(golden_dir, 'd2_metric.npz')
+    for i in (0, 2, 3):
+        a, na, b, res = g[f'p{i}_a'], g[f'p{i}_na'], g[f'p{i}_b'], int(g[f'p{i}_res'])
+        m = orc.d2_metrics(a, na, b, res)
+        assert m['c2p1'] == pytest.approx(float(g[f'p{i}_mse1(p2plane)']), rel=2e-5, abs=1e-9)
+        assert m['c2p2'] == pytest.approx(float(g[f'p{i}_mse2(p2plane)']), rel=2e-5, abs=1e-9)
+        assert m['mseF'] == pytest.approx(float(g[f'p{i}_mseF(p2point)']), rel=2e-5, abs=1e-9)
+        if m['c2pF'] > 0:
+            assert m['c2p_psnrF'] == pytest.approx(float(g[f'p{i}_mseF_PSNR(p2plane)']), abs=2e-4)
+        p = pe.d2_psnr(a, na, b, res)
+        assert p['mse1      (p2plane)'] == pytest.approx(m['c2p1'], rel=1e-12, abs=1e-15) and p['mse2      (p2plane)'] == pytest.approx(m['c2p2'], rel=1e-12, abs=1e-15)
+
+
 def test_range_coder_roundtrip_and_known_answer():
     rng = np.random.default_rng(0)
     params = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'entropy_tables.npz'))['c1_params']
