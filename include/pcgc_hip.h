@@ -225,6 +225,16 @@ int pcgc_set_child_tuning(int waves_per_group, int ring_depth);       /* A/B swi
 int pcgc_irn_child_pass(const int32_t* parent_nbr, int64_t n_parent, int C, int pass, const float* in, int in_ld,
                         const float* table, int64_t table_bytes, const float* b0, const float* b1, const float* b2,
                         const float* x, int x_ld, float* out, int out_ld, void* stream);
+/* The same block at C = 16 with pass 1 (A) in QUAD-BLOCK form (round 5, csrc/child_q4.h): `v_mfma_f32_4x4x1_16b_f32`, one 4 x 4 block per
+ * (4 parents, cell, child) — only the (cell, child) pairs that exist are issued, where the packed-N tiles of pcgc_irn_child_pass multiply
+ * 44 % structural zero columns.  Replaces autoencoder.py:52-57 (InceptionResNet) on the level of autoencoder.py:209-237, bit for bit the
+ * same chains.  pass 1: table = ops.child_q4_tables: [27][4 co][16 ci] = conv0_0.kernel, then [4 co][16 ci] = conv1_0.kernel (7168
+ * bytes); it writes t in the T2 layout (per parent 256 bytes = [z half][conv0_0 | conv1_0][child & 3][4 channels]: a quad of lanes stores
+ * 64 contiguous bytes).  pass 2: the packed-N pass B of pcgc_irn_child_pass gathering through the T2 layout (table =
+ * ops.child_irn_tables()[1]).  The two passes of one block must come from the same entry point.  Arguments as pcgc_irn_child_pass. */
+int pcgc_irn_child_q4(const int32_t* parent_nbr, int64_t n_parent, int C, int pass, const float* in, int in_ld,
+                      const float* table, int64_t table_bytes, const float* b0, const float* b1, const float* b2,
+                      const float* x, int x_ld, float* out, int out_ld, void* stream);
 /* The same two passes at C = 64 on a PLAIN level (the encoder's stride-4 level, autoencoder.py:104-110) through the level's own
  * k3 map nbr [27][n]: LDS-resident fragment table, one wave per 16-row tile walking the 27 offsets (csrc/rows_irn.hip); tables as
  * for the children-level C = 64 passes (ops.child_irn_tables). */

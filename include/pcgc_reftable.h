@@ -20,6 +20,10 @@ extern "C" {
  * [C, L+1] float cdf before normalisation.  Returns 0, -1 on an ATen error, -2 on bad arguments. */
 int pcgc_reference_table(const float* params /*[host 44*C]*/, int C, float min_v, float max_v, uint16_t* table_u16 /*[host]*/,
                          float* cdf_f32 /*[host] or NULL*/);
+/* The softplus / tanh of the parameter tensors (12 of the table's operators, functions of the parameters alone) are kept per
+ * parameter set; this drops them, so that the next table is evaluated operator for operator as entropy_model.py:82-101 does on every
+ * call (entropy_model.table_cache(clear=True) calls it together with pcgc_table_cache(0)).  Returns the number of sets dropped. */
+int pcgc_reference_table_clear(void);
 #ifdef __cplusplus
 }
 #endif

@@ -174,17 +174,37 @@ void orc_children_coords(const int32_t* coords, int64_t n, int32_t stride_in, in
  *   nbr [K][n_out] (int32, -1 = absent), in [n_in][in_ld] (first Cin columns used), W [K][Cin][Cout], bias [Cout] or NULL,
  *   out [n_out][out_ld] (columns out_coff .. out_coff+Cout).
  * k3: K=27 (orc_kmap_k3) · down: K=8 (orc_kmap_down) · k1: K=1, nbr[o]=o · transpose: see orc_conv_up2. */
+/* Accumulation structure (CONVENTIONS['accumulate'], round 5).  0 = 'chain': ONE fmaf chain through every offset and channel (the
+ * canonical form above, what the HIP kernels compute).  1 = 'per_offset_gemm': MinkowskiEngine's documented structure
+ * (per kernel offset a GEMM of the gathered rows with W[k], whose result is ADDED into the output rows —
+ * out[o] += in[i] @ W[k]): d_k = own fmaf chain over ci from +0, then acc = acc + d_k for k ascending.  The inner order of the
+ * library GEMM is not observable here; this form sizes what the per-offset rounding of the partial sums alone does to the latents
+ * and the top-k decisions (tools/order_sensitivity.py -> profiles/r05_order_sensitivity.md). */
+static int g_accumulate = 0;
+int orc_set_accumulate(int mode) { if (mode == 0 || mode == 1) g_accumulate = mode; return g_accumulate; }
+
 void orc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const float* in, int Cin, int in_ld, const float* W,
                      const float* bias, float* out, int Cout, int out_ld, int out_coff) {
+    const int per_offset = g_accumulate == 1;
     #pragma omp parallel for schedule(static)
     for (int64_t o = 0; o < n_out; ++o) {
-        float acc[64];
+        float acc[64], d[64];
         for (int co = 0; co < Cout; ++co) acc[co] = 0.0f;
         for (int k = 0; k < K; ++k) {
             int32_t r = nbr[(int64_t)k * n_out + o];
             if (r < 0) continue;
             const float* x = in + (int64_t)r * in_ld;
             const float* w = W + (int64_t)k * Cin * Cout;
+            if (per_offset) {
+                for (int co = 0; co < Cout; ++co) d[co] = 0.0f;
+                for (int ci = 0; ci < Cin; ++ci) {
+                    float a = x[ci];
+                    const float* wr = w + (int64_t)ci * Cout;
+                    for (int co = 0; co < Cout; ++co) d[co] = fmaf(a, wr[co], d[co]);
+                }
+                for (int co = 0; co < Cout; ++co) acc[co] = acc[co] + d[co];
+                continue;
+            }
             for (int ci = 0; ci < Cin; ++ci) {
                 float a = x[ci];
                 const float* wr = w + (int64_t)ci * Cout;

@@ -45,6 +45,8 @@ def _load():
     lib.orc_nn_sqdist_sum.argtypes = [vp, i64, vp, i64, vp]
     lib.orc_set_threads.restype = C.c_int
     lib.orc_set_threads.argtypes = [C.c_int]
+    lib.orc_set_accumulate.restype = C.c_int
+    lib.orc_set_accumulate.argtypes = [C.c_int]
     return lib
 
 
@@ -81,7 +83,7 @@ def unique_first(coords):
 
 
 # ‡ conventions, mirrored from pcgcv2_amd/conventions.py (same names, same defaults); tests flip both sides together
-CONVENTIONS = {'kernel_offset_order': 'xyz', 'topk_tie': 'low', 'dedup_keep': 'first'}
+CONVENTIONS = {'kernel_offset_order': 'xyz', 'topk_tie': 'low', 'dedup_keep': 'first', 'accumulate': 'chain'}
 
 
 def unique_keep(coords):
@@ -139,7 +141,10 @@ def children_coords(coords, stride_in):
 
 # ------------------------------------------------------------------------------------------- conv family
 def conv_gather(nbr, x, W, bias):
-    """out = fmaf-chain(k asc, ci asc) + bias.  W is ME's `kernel` [K,Cin,Cout] (2-D [Cin,Cout] for k=1)."""
+    """out = fmaf-chain(k asc, ci asc) + bias.  W is ME's `kernel` [K,Cin,Cout] (2-D [Cin,Cout] for k=1).
+    CONVENTIONS['accumulate'] = 'per_offset_gemm' (oracle only — the HIP path has no such switch): per offset an own chain from +0, whose
+    result is added into the output (ME's documented out[o] += in[i] @ W[k]); tools/order_sensitivity.py measures what that changes."""
+    lib().orc_set_accumulate(1 if CONVENTIONS['accumulate'] == 'per_offset_gemm' else 0)
     x = _c(x, np.float32)
     W = _c(W, np.float32)
     if W.ndim == 2:

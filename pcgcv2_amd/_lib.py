@@ -62,6 +62,7 @@ SIGNATURES = {
     'pcgc_conv_child': (ci, [vp, i64, vp, ci, ci, vp, i64, vp, vp, ci, ci, vp, ci, ci, vp]),
     'pcgc_set_child_tuning': (ci, [ci, ci]),
     'pcgc_irn_child_pass': (ci, [vp, i64, ci, ci, vp, ci, vp, i64, vp, vp, vp, vp, ci, vp, ci, vp]),
+    'pcgc_irn_child_q4': (ci, [vp, i64, ci, ci, vp, ci, vp, i64, vp, vp, vp, vp, ci, vp, ci, vp]),
     'pcgc_conv_down_rows': (ci, [vp, i64, vp, i64, ci, ci, vp, i64, vp, ci, vp, ci, ci, vp]),
     'pcgc_conv_rows': (ci, [vp, i64, vp, ci, ci, vp, i64, vp, vp, ci, ci, vp, ci, ci, vp]),
     'pcgc_irn_rows_pass': (ci, [vp, i64, ci, ci, vp, ci, vp, i64, vp, vp, vp, vp, ci, vp, ci, vp]),
@@ -156,6 +157,8 @@ def reftable_lib():
         l = C.CDLL(REFTABLE_PATH)
         l.pcgc_reference_table.restype = ci
         l.pcgc_reference_table.argtypes = [vp, ci, f32, f32, vp, vp]
+        l.pcgc_reference_table_clear.restype = ci
+        l.pcgc_reference_table_clear.argtypes = []
         _reftable = l
     return _reftable
 

@@ -237,6 +237,12 @@ class Coder():
         d = getattr(x.cmap, 'descents', None)
         if not INGEST_SORT or d is None or d * 64 <= len(x):
             return x
+        # one sort per cloud, not per encode: an R-D sweep (test.py) encodes the same tensor once per rate, and the sorted level carries the
+        # cached pyramid and kernel maps every rate reuses
+        key = (id(x.cmap), x.F.data_ptr(), x.F._version, tuple(x.F.shape))
+        memo = x.__dict__.get('_ingested')
+        if memo is not None and memo[0] == key:
+            return memo[1]
         order = ops.sort_zyx(x.C, batch_major=True)
         cmap = CoordMap(ops.gather_coords(x.C, order), x.cmap.stride, unique=True)
         cmap.descents = 0
@@ -245,8 +251,10 @@ class Coder():
         if x.has_unit_features():
             y = SparseTensor(x.F, coordinate_map=cmap)                   # all ones: any permutation of it is itself
             y.unit_features, y._unit_stamp = True, x._unit_stamp
-            return y
-        return SparseTensor(ops.gather_feats(x.F, order), coordinate_map=cmap)
+        else:
+            y = SparseTensor(ops.gather_feats(x.F, order), coordinate_map=cmap)
+        x.__dict__['_ingested'] = (key, y)
+        return y
 
     def _encode(self, x, postfix):
         x = self._ingest(x)

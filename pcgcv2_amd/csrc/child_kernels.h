@@ -189,8 +189,13 @@ struct PassA : HaloGeometry {
 // InceptionResNet pass B: the gathered rows are t = [relu(conv0_0) | relu(conv1_0)] (2Q wide).  conv0_1 (k3 Q -> 2Q) reads the
 // first Q channels, conv1_1 (k3 Q -> Q) the last Q: with Q = 8 (C = 32) those are K-steps {0,1} / {2,3} of the one 16-channel
 // block, with Q = 4 (C = 16) K-step 0 / 1 of a half-width block.
-template <int C, int HZ = -1>
+// T2 (C = 16, round 5): the gathered tensor t was written by the quad-block pass A (child_q4.h) in its store-friendly layout — per parent
+// 256 bytes = [z half h][conv 0 / 1][child 4 h + s][4 channels], i.e. chunk c (conv0_0 / conv1_0 half) of row 8 p + j sits at
+// 256 p + 128 (j >> 2) + 64 c + 16 (j & 3) instead of 256 p + 32 j + 16 c.  Only the gather addresses change.
+template <int C, int HZ = -1, bool T2_ = false>
 struct PassB : HaloGeometry {
+    static constexpr bool T2 = T2_;
+    static_assert(!T2_ || C == 16, "the split layout exists for C = 16");
     static constexpr int Q = C / 4, NB = 1, ROWCHUNKS = Q / 2 /*2Q floats = Q/2 chunks*/, KS = Q / 4;
     static constexpr int CPT0 = 16 / (2 * Q) /*children per conv0_1 tile: 1 or 2*/, T0 = 8 / CPT0, CPT1 = 16 / Q, T1 = 8 / CPT1, T = T0 + T1;
     static constexpr int Z_HALF = HZ;
@@ -242,6 +247,9 @@ struct PassB64 : HaloGeometry {
     static constexpr int frag_off(int c, int t, int) { return frag(c, t) * 1024; }
     static constexpr int FRAG_W12 = 81;
 };
+
+template <class V, class = void> struct child_t2_layout : std::false_type {};
+template <class V> struct child_t2_layout<V, std::enable_if_t<V::T2>> : std::true_type {};
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -363,7 +371,8 @@ __device__ __forceinline__ void child_tile_mainloop_mt(const int32_t* __restrict
 #pragma unroll
         for (int kp = 0; kp < V::NMAP; ++kp)
             rowb[m][kp] = (row_ok[m] && (int)rowb[m][kp] >= 0) ? rowb[m][kp] * ((unsigned)V::ROW_MUL * row_bytes) : ABSENT;
-    const unsigned lane_off = chunk_ok ? (unsigned)dma_chunk * 16u : ABSENT;
+    constexpr bool T2 = child_t2_layout<V>::value;             // (PassB<16> behind the quad-block pass A: chunks of a row are 64 bytes apart)
+    const unsigned lane_off = chunk_ok ? (unsigned)dma_chunk * (T2 ? 64u : 16u) : ABSENT;
     CHILD_T(t_loop0);
 
     constexpr ChildCells CL = child_cells<V>();
@@ -373,7 +382,8 @@ __device__ __forceinline__ void child_tile_mainloop_mt(const int32_t* __restrict
         float4* dst = ring + (i & (D - 1)) * (MT * NB * 64);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            unsigned voff = rowb[m][V::kp(c)] + (unsigned)V::child(c) * row_bytes + lane_off + (unsigned)V::byte_off(c);
+            unsigned voff = rowb[m][V::kp(c)] + (T2 ? (unsigned)((V::child(c) >> 2) * 128 + (V::child(c) & 3) * 16) : (unsigned)V::child(c) * row_bytes) + lane_off +
+                            (unsigned)V::byte_off(c);
             if constexpr (V::ROWCHUNKS < 4) voff = chunk_ok ? voff : 0xFFFFFFF0u;   // (ABSENT + ABSENT would wrap)
 #pragma unroll
             for (int cb = 0; cb < NB; ++cb)
@@ -830,11 +840,11 @@ k_child_irn_a(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
 //          out[row][2Q:4Q] = (conv1_2(relu(conv1_1(t[:, Q:]) + b11)) + b12) + x[row][2Q:4Q]
 // conv1_2 (k1, Q -> 2Q) is a second, tiny MFMA product: u = relu(conv1_1 + b11) goes through a per-wave LDS scratch (the gather
 // ring, idle by then) from the accumulator layout (lane = column) into A fragments (lane = row), 16 output rows per product.
-template <int C, int NW, int D, bool SPLIT = false, int MT = 1>
+template <int C, int NW, int D, bool SPLIT = false, int MT = 1, bool T2 = false>
 __global__ void __launch_bounds__(NW * 64)
 k_child_irn_b(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in /* t */, int in_ld,
               const float* __restrict__ table, int table_bytes, IrnEpi ep) {
-    using V = PassB<C>;
+    using V = PassB<C, -1, T2>;
     constexpr int Q = V::Q, H = 2 * Q, KQ = Q / 4, T0 = V::T0, T1 = V::T1, CPT0 = V::CPT0, CPT1 = V::CPT1;
     // epilogue scratch inside the ring's LDS: us [128 rows][Q] (u = relu(conv1_1)), then the CH-row output staging [CH][C]
     constexpr int CH = ((128 * Q + 64 * C) * 4 <= D * 1024 * MT) ? 64 : 32, MQC = CH / 32;
@@ -920,8 +930,8 @@ k_child_irn_b(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
         if (u < 0) break;
         CHILD_T(t_it0);
         if constexpr (SPLIT) {
-            if (u & 1) unit(child_type_tag<PassB<C, 1>>{}, (u >> 1) * (16 * MT));
-            else unit(child_type_tag<PassB<C, 0>>{}, (u >> 1) * (16 * MT));
+            if (u & 1) unit(child_type_tag<PassB<C, 1, T2>>{}, (u >> 1) * (16 * MT));
+            else unit(child_type_tag<PassB<C, 0, T2>>{}, (u >> 1) * (16 * MT));
         } else {
             unit(child_type_tag<V>{}, u * (16 * MT));
         }
@@ -1078,13 +1088,13 @@ int launch_child_irn_a_split(const int32_t* pnbr, int64_t n_p, const float* in, 
                              const IrnEpi& ep, hipStream_t s) {
     CHILD_LAUNCH_SPLIT((k_child_irn_a<C, NW, D, true>), NW, D * (C / 16) * 1024, ep);
 }
-template <int C, int NW, int D, int MT = 1>
+template <int C, int NW, int D, int MT = 1, bool T2 = false>
 int launch_child_irn_b(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
                        const IrnEpi& ep, hipStream_t s) {
     constexpr int Q = C / 4, CH = ((128 * Q + 64 * C) * 4 <= D * 1024 * MT) ? 64 : 32;
     constexpr int need = (128 * Q + CH * C) * 4;
     constexpr int ringb = (D * 1024 * MT > need) ? D * 1024 * MT : need;
-    CHILD_LAUNCH_EX((k_child_irn_b<C, NW, D, false, MT>), NW, ringb, ep, MT, 1);
+    CHILD_LAUNCH_EX((k_child_irn_b<C, NW, D, false, MT, T2>), NW, ringb, ep, MT, 1);
 }
 template <int C, int NW, int D>
 int launch_child_irn_b_split(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,

@@ -1517,6 +1517,19 @@ struct FrameAsync {
             finished.store(1, std::memory_order_release);
         }
     }
+    // the caller's side of the hand-off: spin for the ~0.1-0.3 ms a warm decode takes, then stop burning the core (a cold table, slow files or a
+    // small cgroup CPU quota shared with the segment pool): yield, then sleep in 50 us steps
+    static void wait(const std::atomic<int>& flag, const std::atomic<int>* also = nullptr) {
+        const int64_t t0 = now_ns();
+        for (int spins = 0;; ++spins) {
+            if (flag.load(std::memory_order_acquire) != 0 || (also && also->load(std::memory_order_acquire) != 0)) return;
+            if (spins < 256) { _mm_pause(); continue; }
+            const int64_t dt = now_ns() - t0;
+            if (dt < 400 * 1000) _mm_pause();
+            else if (dt < 2 * 1000 * 1000) std::this_thread::yield();
+            else std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    }
     void ensure() { if (!worker.joinable()) worker = std::thread([this] { loop(); }); }
     void prewake(int us) { ensure(); spin_until.store(now_ns() + (int64_t)us * 1000, std::memory_order_relaxed); cv.notify_one(); }
     void post(std::function<void()> j) { ensure(); { std::lock_guard<std::mutex> lk(m); job = std::move(j); has_job = true; } cv.notify_one(); }
@@ -1529,8 +1542,14 @@ thread_local bool tl_frame_pending = false;              // this thread owns fra
 extern "C" int pcgc_frame_decode_begin(const char* stem, int C, const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int coord_scale,
                                        int64_t cap_rows, int16_t* sym, int32_t* level, int64_t* info, float* range, int threads) {
     if (!stem || !eb_params || !table_fn || !sym || !level || !info || !range || C < 1 || cap_rows < 0) { pcgc_set_error("frame_decode: bad arguments"); return -2; }
-    if (tl_frame_pending) { pcgc_set_error("frame_decode_begin: the previous frame of this thread was not finished (pcgc_frame_decode_end)"); return -2; }
     FrameAsync& fa = frame_async();
+    if (tl_frame_pending) {
+        // a frame this thread began and never finished (an exception between _begin and _end on the caller's side): finish it here — wait for the
+        // worker, which may still be writing into the previous call's buffers, and release the slot — instead of refusing every later frame
+        fa.wait(fa.finished);
+        tl_frame_pending = false;
+        fa.owner.unlock();
+    }
     const bool async = (threads <= 0 ? effective_cpus() : threads) >= 2 && effective_cpus() >= 3 && fa.owner.try_lock();
     if (!async) return pcgc_frame_decode(stem, C, eb_params, table_fn, use_sidecar, coord_scale, cap_rows, sym, level, info, range, threads);
     fa.prewake(400);                                      // (the probe reads four small files meanwhile)
@@ -1545,8 +1564,12 @@ extern "C" int pcgc_frame_decode_begin(const char* stem, int C, const float* eb_
     fa.coords.store(0); fa.finished.store(0); fa.rc = 0; fa.err.clear();
     const std::string stem_copy = stem;
     const float r0 = range[0], r1 = range[1];
+    // the parameter vector is COPIED into the job: the caller's array need not outlive this call (the table is evaluated, and its cache key
+    // hashed, on the worker after _begin has returned)
+    const std::vector<float> params_copy(eb_params, eb_params + (size_t)44 * C);
     fa.post([=, &fa] {
         const char* st = stem_copy.c_str();
+        const float* eb_params = params_copy.data();
         const int64_t rws = rows; const int32_t nat = native; const float rg[2] = {r0, r1};
         tl_frame_coords_flag = &fa.coords;
         fa.rc = pcgc_items_decode(1, &st, &rws, C, rg, &nat, eb_params, table_fn, use_sidecar, sym, level, 1, coord_scale > 0 ? coord_scale : 1, threads);
@@ -1555,13 +1578,13 @@ extern "C" int pcgc_frame_decode_begin(const char* stem, int C, const float* eb_
         fa.coords.store(1, std::memory_order_release);    // (an error before the coordinate task ended must not leave the caller waiting)
     });
     tl_frame_pending = true;
-    while (fa.coords.load(std::memory_order_acquire) == 0 && fa.finished.load(std::memory_order_acquire) == 0) _mm_pause();
+    fa.wait(fa.coords, &fa.finished);
     return 0;
 }
 extern "C" int pcgc_frame_decode_end(void) {
     if (!tl_frame_pending) return 0;                      // (the synchronous form: everything happened in _begin)
     FrameAsync& fa = frame_async();
-    while (fa.finished.load(std::memory_order_acquire) == 0) _mm_pause();
+    fa.wait(fa.finished);
     const int rc = fa.rc;
     if (rc != 0) pcgc_set_error("%s", fa.err.c_str());
     tl_frame_pending = false;

@@ -52,6 +52,15 @@ std::shared_ptr<const ParamOps> param_ops(const float* params, int C) {
 }
 }  // namespace
 
+// Drops the cached parameter-only operators (softplus / tanh of the 12 parameter tensors): with them gone the next table is evaluated
+// from the raw parameters, operator for operator what the reference does on every call.  -> entries dropped
+extern "C" int pcgc_reference_table_clear(void) {
+    std::lock_guard<std::mutex> lk(g_po_mu);
+    const int n = (int)g_po.size();
+    g_po.clear();
+    return n;
+}
+
 extern "C" int pcgc_reference_table(const float* params /*[host 44*C]: matrices 0..3 | biases 0..3 | factors 0..3*/, int C, float min_v,
                                     float max_v, uint16_t* table_u16 /*[host C, L+1]*/, float* cdf_f32 /*[host C, L+1] or NULL*/) {
     if (!params || !table_u16 || C < 1 || !(max_v >= min_v)) return -2;

@@ -49,6 +49,8 @@ def table_cache(on=None, clear=False):
         dropped += lib().pcgc_table_cache(1 if on else -1)
     if clear:
         dropped += lib().pcgc_table_cache(0)
+        from ._lib import reftable_lib
+        reftable_lib().pcgc_reference_table_clear()          # ... and the parameter-only operators (softplus / tanh) kept per parameter set
         with _TABLE_LOCK:
             for m in list(_MODELS):
                 m.__dict__.pop('_table_cache', None)

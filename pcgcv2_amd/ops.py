@@ -939,7 +939,19 @@ def child_irn_tables(params):
     return _gather_table(ia, flat), (None if ib is None else _gather_table(ib, flat))
 
 
-def irn_block_child(parent_nbr, x, params, tables):
+CHILD_Q4 = _os.environ.get('PCGC_CHILD_Q4', '1') != '0'      # C = 16 InceptionResNet blocks of children levels: pass A in quad-block form (csrc/child_q4.h); A/B switch
+
+
+def child_q4_tables(params):
+    """Table of the quad-block pass A (pcgc_irn_child_q4, C = 16): [27][co 4][ci 16] = conv0_0.kernel[k][ci][co], then [co 4][ci 16] =
+    conv1_0.kernel[0][ci][co] — a lane's operands of one (cell, child) pair are its output channel's 16 input channels, contiguous."""
+    W00, W10 = params[0], params[4]
+    C = W00.shape[1]
+    return torch.cat([W00.detach().reshape(27, C, C // 4).permute(0, 2, 1).reshape(-1),
+                      W10.detach().reshape(C, C // 4).t().reshape(-1)]).contiguous()
+
+
+def irn_block_child(parent_nbr, x, params, tables, q4_table=None):
     """Fused InceptionResNet on a children level through the parent map (C = 16, 32); bit-identical to irn_block."""
     _f32(x, 'x')
     n_p = parent_nbr.shape[1]
@@ -956,11 +968,22 @@ def irn_block_child(parent_nbr, x, params, tables):
     tiles = (n_p + 15) // 16
     per_tile = {16: (416, 248), 32: (1216, 736)}[C]          # MFMA instructions per 16-parent tile (incl. the conv1_2 products of pass B)
     names = (f'k_child_irn_a<{C}>', f'k_child_irn_b<{C}>')
+    q4 = CHILD_Q4 and C == 16 and q4_table is not None
+    if q4:
+        # per 16 parents, in units of 2048 flops: 224 groups x 16 4x4x1 instructions (512 flops each) per 64 parents + the 128 transposing ones per 128
+        per_tile = ((216 + 8) * 16 // 4 // 4 + 128 // 8 // 4, per_tile[1])
+        names = ('k_child_q4_irn_a16', 'k_child_irn_b<16> (T2 gather)')
     forms = _irn_pass_formulas(n, C, 27 * n_p * 4, names)
-    calls = (lambda: lib().pcgc_irn_child_pass(_p(parent_nbr), n_p, C, 1, _p(x), _ld(x), _p(ta), ta.numel() * 4, P[1], P[5], None, None, 0,
-                                               _p(t), C // 2, s),
-             lambda: lib().pcgc_irn_child_pass(_p(parent_nbr), n_p, C, 2, _p(t), C // 2, _p(tb), tb.numel() * 4, P[3], P[7], P[9], _p(x), _ld(x),
-                                               _p(out), C, s))
+    if q4:      # pass A in quad-block form writes t in its T2 layout; pass B is the packed-N kernel with T2 gather addresses (csrc/child_q4.hip)
+        calls = (lambda: lib().pcgc_irn_child_q4(_p(parent_nbr), n_p, C, 1, _p(x), _ld(x), _p(q4_table), q4_table.numel() * 4, P[1], P[5], None,
+                                                 None, 0, _p(t), C // 2, s),
+                 lambda: lib().pcgc_irn_child_q4(_p(parent_nbr), n_p, C, 2, _p(t), C // 2, _p(tb), tb.numel() * 4, P[3], P[7], P[9], _p(x), _ld(x),
+                                                 _p(out), C, s))
+    else:
+        calls = (lambda: lib().pcgc_irn_child_pass(_p(parent_nbr), n_p, C, 1, _p(x), _ld(x), _p(ta), ta.numel() * 4, P[1], P[5], None, None, 0,
+                                                   _p(t), C // 2, s),
+                 lambda: lib().pcgc_irn_child_pass(_p(parent_nbr), n_p, C, 2, _p(t), C // 2, _p(tb), tb.numel() * 4, P[3], P[7], P[9], _p(x), _ld(x),
+                                                   _p(out), C, s))
     for (ps, name, bf, ff, comp), call, mf in zip(forms, calls, per_tile):
         prof = PROFILE.want((name, n))
         if prof:

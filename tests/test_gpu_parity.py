@@ -1304,6 +1304,63 @@ def test_inception_resnet_child_bit_exact(name, prune, C):
         np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize('name,prune', [('shell7', None), ('shell8', 7), ('shell6', 1), ('shell8', None), ('shell9', 5)])
+def test_inception_resnet_child_quad_block_bit_exact(name, prune):
+    """Round 5: the C = 16 InceptionResNet with pass A in QUAD-BLOCK form (pcgc_irn_child_q4: v_mfma_f32_4x4x1_16b_f32, one 4 x 4 block
+    per (4 parents, cell, child); t in the T2 layout, pass B gathering through it) == the oracle's five-conv block == the packed-N
+    kernels.  Levels of one partial tile (shell6), several 128-parent tiles with a ragged last one, pruned parents (absent neighbours)."""
+    from pcgcv2_amd.autoencoder import InceptionResNet
+    C = 16
+    parent, kids, kc = _children_level(name, prune)
+    n = len(kc)
+    rng = np.random.default_rng(977 + n)
+    blk = InceptionResNet(C).to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.from_numpy(rng.standard_normal(tuple(p.shape)).astype(np.float32) * 0.2))
+    x = rng.standard_normal((n, C)).astype(np.float32)
+    x[rng.random(n) < 0.05] = 0.0                              # exact-zero rows: post-ReLU zeros through the quad transposes
+    params = [p for m in (blk.conv0_0, blk.conv0_1, blk.conv1_0, blk.conv1_1, blk.conv1_2) for p in (m.kernel, m.bias)]
+    tables = ops.child_irn_tables(params)
+    q4 = ops.child_q4_tables(params)
+    assert ops.CHILD_Q4
+    got = ops.irn_block_child(parent.k3, _t(x), params, tables, q4_table=q4)
+    packed = ops.irn_block_child(parent.k3, _t(x), params, tables)               # (no quad-block table: both passes packed-N)
+    assert torch.equal(got, packed)
+    if n <= 300_000:
+        sd = {'b.' + k: v.detach().cpu().numpy() for k, v in blk.state_dict().items()}
+        want = orc.inception_resnet(sd, 'b', orc.Level(kc, 1), x)
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_quad_block_switch_reaches_both_kernel_pairs():
+    """ops.CHILD_Q4 (PCGC_CHILD_Q4) switches the decoder's C = 16 blocks between the quad-block pair and the packed-N pair: same block
+    output through the module either way, and the launch really is the kernel the switch names."""
+    from pcgcv2_amd.autoencoder import InceptionResNet
+    from pcgcv2_amd.sparse import SparseTensor
+    parent, kids, kc = _children_level('shell8', None)
+    rng = np.random.default_rng(5)
+    blk = InceptionResNet(16).to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.from_numpy(rng.standard_normal(tuple(p.shape)).astype(np.float32) * 0.2))
+    x = SparseTensor(_t(rng.standard_normal((len(kc), 16)).astype(np.float32)), coordinate_map=kids)
+    outs = {}
+    for on in (True, False):
+        old = ops.CHILD_Q4
+        ops.CHILD_Q4 = on
+        try:
+            ops.PROFILE.reset(enabled=True)
+            outs[on] = blk(x).F.clone()
+            torch.cuda.synchronize()
+            names = [d['kernel'].split(' ')[0] for d in ops.PROFILE.detail()]
+        finally:
+            ops.CHILD_Q4 = old
+            ops.PROFILE.reset(enabled=False)
+        assert ('k_child_q4_irn_a16' in names) == on, names
+    assert torch.equal(outs[True], outs[False])
+
+
 # ------------------------------------------------------------------------------------------------ bench.py, 2 ranks on one GPU
 def _run_bench(extra, env_extra=None, nproc=1, timeout=600):
     import json, subprocess, sys

@@ -28,7 +28,7 @@ def test_reftable_library_exports_its_header():
     from pcgcv2_amd._lib import reftable_lib, REFTABLE_PATH
     header = open(os.path.join(ROOT, 'include', 'pcgc_reftable.h')).read()
     declared = set(re.findall(r'\b(pcgc_\w+)\s*\(', re.sub(r'/\*.*?\*/', '', header, flags=re.S)))
-    assert declared == {'pcgc_reference_table'}
+    assert declared == {'pcgc_reference_table', 'pcgc_reference_table_clear'}
     for name in declared:
         assert hasattr(reftable_lib(), name), f'{name} not exported by {REFTABLE_PATH}'
 
