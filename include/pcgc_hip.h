@@ -235,6 +235,12 @@ int pcgc_irn_child_pass(const int32_t* parent_nbr, int64_t n_parent, int C, int 
 int pcgc_irn_child_q4(const int32_t* parent_nbr, int64_t n_parent, int C, int pass, const float* in, int in_ld,
                       const float* table, int64_t table_bytes, const float* b0, const float* b1, const float* b2,
                       const float* x, int x_ld, float* out, int out_ld, void* stream);
+/* Classification head k3 16 -> 1 on a children level (autoencoder.py:228-234 conv2_cls) in quad-block form (csrc/child_q4.h): a 4 x 4
+ * block = 4 parents x the four children of one z half; out [8 n_parent, 1] dense, a lane stores its parent's eight logits (32 bytes).
+ * table = ops.child_q4_cls_table (96 fragments [4 children][16 ci], zero where a child does not reach the cell).  Same chain as
+ * pcgc_conv_child with Cout = 1. */
+int pcgc_cls_child_q4(const int32_t* parent_nbr, int64_t n_parent, const float* in, int Cin, int in_ld, const float* table,
+                      int64_t table_bytes, const float* bias, float* out, void* stream);
 /* The same two passes at C = 64 on a PLAIN level (the encoder's stride-4 level, autoencoder.py:104-110) through the level's own
  * k3 map nbr [27][n]: LDS-resident fragment table, one wave per 16-row tile walking the 27 offsets (csrc/rows_irn.hip); tables as
  * for the children-level C = 64 passes (ops.child_irn_tables). */

@@ -63,6 +63,7 @@ SIGNATURES = {
     'pcgc_set_child_tuning': (ci, [ci, ci]),
     'pcgc_irn_child_pass': (ci, [vp, i64, ci, ci, vp, ci, vp, i64, vp, vp, vp, vp, ci, vp, ci, vp]),
     'pcgc_irn_child_q4': (ci, [vp, i64, ci, ci, vp, ci, vp, i64, vp, vp, vp, vp, ci, vp, ci, vp]),
+    'pcgc_cls_child_q4': (ci, [vp, i64, vp, ci, ci, vp, i64, vp, vp, vp]),
     'pcgc_conv_down_rows': (ci, [vp, i64, vp, i64, ci, ci, vp, i64, vp, ci, vp, ci, ci, vp]),
     'pcgc_conv_rows': (ci, [vp, i64, vp, ci, ci, vp, i64, vp, vp, ci, ci, vp, ci, ci, vp]),
     'pcgc_irn_rows_pass': (ci, [vp, i64, ci, ci, vp, ci, vp, i64, vp, vp, vp, vp, ci, vp, ci, vp]),

@@ -43,16 +43,25 @@ struct Q4Sched {
     int vm_wait[232];             // last group of cell c (c < 63): vmcnt that guarantees cell c + 1's rows have landed
     int pend[232];                // store instructions issued at the end of group n (a flush unit completed by group n - 1: see q4_flush)
 };
-template <int MT>
+constexpr int Q4_PASS_A = 0, Q4_CLS = 1;
+// KIND = Q4_CLS (k3 conv 16 -> 1, the classification head): a group = (cell, z half h): the block's four columns are the children
+// 4 h + {0..3}, column s multiplying by kernel[k(cell, 4 h + s)][ci] — zero where that child does not reach the cell (host-built table, one
+// fragment per group) — into acc[h]; `child` = h, `k` = the group's number (= its fragment).
+template <int KIND, int MT>
 constexpr Q4Sched q4_sched() {
     Q4Sched S{};
     for (int c = 0; c < 64; ++c) {
         const int n0 = S.n;
-        for (int j = 0; j < 8; ++j) {
-            if (!((cell_reach(c) >> j) & 1)) continue;
-            const int k = cell_k(c, j);
-            S.g[S.n++] = Q4Group{c, j, 0, k, false, false, k == 26};
-            if (k == 13) S.g[S.n++] = Q4Group{c, j, 1, 27, false, false, false};
+        if (KIND == Q4_CLS) {
+            for (int h = 0; h < 2; ++h)
+                if (in02(cz_of(c) - h)) { S.g[S.n] = Q4Group{c, h, 0, S.n, false, false, false}; S.n++; }
+        } else {
+            for (int j = 0; j < 8; ++j) {
+                if (!((cell_reach(c) >> j) & 1)) continue;
+                const int k = cell_k(c, j);
+                S.g[S.n++] = Q4Group{c, j, 0, k, false, false, k == 26};
+                if (k == 13) S.g[S.n++] = Q4Group{c, j, 1, 27, false, false, false};
+            }
         }
         S.g[n0].first = true;
         S.g[S.n - 1].last = true;
@@ -68,7 +77,7 @@ constexpr Q4Sched q4_sched() {
         if (G.first && G.cell + 2 < 64) { ops += 4 * MT; gather_end[G.cell + 2] = ops; }
         S.pend[n] = pending;
         ops += pending;
-        pending = (((G.kind == 1) || G.fin) && (G.child & 3) == 3) ? 4 * MT : 0;      // a flush unit: 4 parents-steps x MT stores
+        pending = (KIND == Q4_PASS_A && ((G.kind == 1) || G.fin) && (G.child & 3) == 3) ? 4 * MT : 0;      // a flush unit: 4 parents-steps x MT stores
     }
     return S;
 }
@@ -84,23 +93,28 @@ __device__ __forceinline__ void q4_store(const f32x4& v, const __amdgpu_buffer_r
 
 // InceptionResNet pass A at C = 16:  t[row][0:4] = relu(conv0_0 x + b00), t[row][4:8] = relu(conv1_0 x + b10)   (row = 8 p + j)
 // table: [k = 0..26][co = 0..3][ci = 0..15] = W00[k][ci][co], then [co][ci] = W10[ci][co]   (ops.child_q4_tables)
-template <int NW, int MT>
+//
+// Classification head at C = 16 (KIND = Q4_CLS; autoencoder.py:228-234 conv2_cls):  out[8 p + j] = conv(x)[.., 0] + bias, dense [8 n_p, 1].
+// table: one fragment per (cell, z half) group in schedule order: [s = 0..3][ci = 0..15] = kernel[k(cell, 4 h + s)][ci][0] or 0
+// (ops.child_q4_cls_table).  The lane holds its parent's eight logits (two accumulators): 32 contiguous bytes per lane, 2 KB per store pair.
+template <int KIND, int NW, int MT>
 __global__ void __launch_bounds__(NW * 64)
-k_child_q4_irn_a16(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in, int in_ld,
-                   const float* __restrict__ table, int table_bytes, IrnEpi ep) {
+k_child_q4(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in, int in_ld,
+           const float* __restrict__ table, int table_bytes, IrnEpi ep) {
     constexpr int TP = 64 * MT, SLOT_F4 = MT * 256;            // parents per tile; float4 per ring slot (MT x 4 KB)
-    constexpr Q4Sched S = q4_sched<MT>();
+    constexpr Q4Sched S = q4_sched<KIND, MT>();
+    constexpr int NACC = KIND == Q4_CLS ? 2 : 8, OUT_ROW_BYTES = KIND == Q4_CLS ? 4 : 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4* ring = (float4*)(lds_raw + table_bytes) + wave * (2 * SLOT_F4);
     child_stage_table<NW>(table, table_bytes, lds_raw);
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(8 * n_p * in_ld * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)ep.out, 0, (int)(8 * n_p * 8 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)ep.out, 0, (int)(8 * n_p * OUT_ROW_BYTES), 0x00020000);
     const int co = lane & 3;
     float b00[4], b10[4];                                      // (wave-uniform: scalar registers)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { b00[r] = ep.b0[r]; b10[r] = ep.b1[r]; }
+    for (int r = 0; r < 4; ++r) { b00[r] = KIND == Q4_CLS ? (ep.b0 ? ep.b0[0] : 0.0f) : ep.b0[r]; b10[r] = KIND == Q4_CLS ? 0.0f : ep.b1[r]; }
     const unsigned tab_lane = (unsigned)(uintptr_t)(lds_void_ptr)((const float*)lds_raw + co * 16);
     // chunk e of row `lane` sits at slot position e ^ ((row >> 2) & 3): address = a_row ^ (e << 4)  (a_row has the swizzle in bits 4-5)
     const unsigned a_row = (unsigned)(uintptr_t)(lds_void_ptr)((const float*)ring + lane * 16 + (((lane >> 2) & 3) << 2));
@@ -143,11 +157,11 @@ k_child_q4_irn_a16(const int32_t* __restrict__ pnbr, int64_t n_p, const float* _
         f32x4 sink = (f32x4){0.f, 0.f, 0.f, 0.f};
 #endif
 
-        f32x4 acc0[MT][8], c1[MT][4];                           // c1: conv1_0 of the four children of a z half (accumulators, then outputs)
+        f32x4 acc0[MT][NACC], c1[MT][KIND == Q4_CLS ? 1 : 4];   // c1 (pass A): conv1_0 of the four children of a z half (accumulators, then outputs)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc0[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NACC; ++j) acc0[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x4 a[MT][4], b[2][4];
 
         auto gather = [&](auto ic) {
@@ -279,20 +293,40 @@ k_child_q4_irn_a16(const int32_t* __restrict__ pnbr, int64_t n_p, const float* _
             });
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (G.first && G.cell + 2 < 64) gather(std::integral_constant<int, (G.cell + 2 < 64) ? G.cell + 2 : 0>{});   // this cell's slot has been read
-            if constexpr (n > 0) epi(std::integral_constant<int, (n > 0 ? n - 1 : 0)>{});
+            if constexpr (KIND == Q4_PASS_A && n > 0) epi(std::integral_constant<int, (n > 0 ? n - 1 : 0)>{});
         });
-        epi(std::integral_constant<int, S.n - 1>{});           // (child 7's last product is the tile's last group)
+        if constexpr (KIND == Q4_PASS_A) {
+            epi(std::integral_constant<int, S.n - 1>{});       // (child 7's last product is the tile's last group)
+        } else {                                               // the lane's parent: eight logits = 32 contiguous bytes
+            static_for<0, MT>([&](auto im) {
+                constexpr int m = decltype(im)::value;
+                const unsigned ov = (unsigned)((p_base + 64 * m + lane) * 32);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 v = acc0[m][h];
+                    if (ep.b0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] + b00[r];
+                    }
+#ifdef Q4_KO_STORE
+                    sink = sink + v;
+#else
+                    q4_store(v, rs_out, ov + (unsigned)(h * 16));
+#endif
+                }
+            });
+        }
 #ifdef Q4_KO_STORE
         q4_store(sink, rs_out, ovq(0));
 #endif
     }
 }
 
-template <int NW, int MT>
-int launch_child_q4_irn_a16(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
-                            const IrnEpi& ep, hipStream_t s) {
+template <int KIND, int NW, int MT>
+int launch_child_q4(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
+                    const IrnEpi& ep, hipStream_t s) {
     const size_t lds = (size_t)table_bytes + (size_t)NW * (2 * MT * 4096);
-    auto kern = k_child_q4_irn_a16<NW, MT>;
+    auto kern = k_child_q4<KIND, NW, MT>;
     static ChildLdsGrant granted;
     if (int rc = child_lds_limit(kern, lds, granted)) return rc;
     const int64_t units = (n_p + 64 * MT - 1) / (64 * MT);

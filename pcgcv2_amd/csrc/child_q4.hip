@@ -21,7 +21,7 @@ extern "C" int pcgc_irn_child_q4(const int32_t* parent_nbr, int64_t n_parent, in
     if (pass == 1) {
         PCGC_REQUIRE(out_ld == C / 2, "pass A writes a dense [rows, C/2] tensor");
         PCGC_REQUIRE(table_bytes == 28 * 64 * 4, "pass A table size");
-        rc = launch_child_q4_irn_a16<8, 2>(parent_nbr, n_parent, in, in_ld, table, (int)table_bytes, ep, s);
+        rc = launch_child_q4<Q4_PASS_A, 8, 2>(parent_nbr, n_parent, in, in_ld, table, (int)table_bytes, ep, s);
     } else {
         PCGC_REQUIRE(in_ld == C / 2, "pass B reads the dense [rows, C/2] tensor of pass A");
         PCGC_REQUIRE(table_bytes == 85 * 64 * 4, "pass B table size");
@@ -29,5 +29,20 @@ extern "C" int pcgc_irn_child_q4(const int32_t* parent_nbr, int64_t n_parent, in
     }
     if (rc) return rc;
     PCGC_CHECK_LAUNCH("irn_child_q4");
+    return 0;
+}
+
+// Classification head k3 16 -> 1 on a children level (autoencoder.py:228-234 conv2_cls; :174-180 / :201-207 at other widths stay on
+// pcgc_conv_child) in quad-block form: out [8 n_parent, 1] dense.  table: ops.child_q4_cls_table (96 fragments of 256 bytes).
+extern "C" int pcgc_cls_child_q4(const int32_t* parent_nbr, int64_t n_parent, const float* in, int Cin, int in_ld,
+                                 const float* table, int64_t table_bytes, const float* bias, float* out, void* stream) {
+    CHILD_COMMON_CHECKS(in_ld)
+    PCGC_REQUIRE(Cin == 16, "the quad-block classification head serves C = 16");
+    PCGC_REQUIRE(out && (((uintptr_t)out) & 15) == 0, "the output must be 16-byte aligned");
+    PCGC_REQUIRE(table_bytes == 96 * 64 * 4, "cls table size");
+    IrnEpi ep{bias, nullptr, nullptr, nullptr, 0, out, 1};
+    const int rc = launch_child_q4<Q4_CLS, 8, 2>(parent_nbr, n_parent, in, in_ld, table, (int)table_bytes, ep, S(stream));
+    if (rc) return rc;
+    PCGC_CHECK_LAUNCH("cls_child_q4");
     return 0;
 }

@@ -34,8 +34,8 @@ INF = 1 << 62
 TABLE = (
     # ---- k3 s1 convolutions ---------------------------------------------------------------------------------------------------------
     Rule('conv3', ((16, 16), (32, 32), (16, 1), (32, 1), (64, 1)), 'children', 8192, INF, 'CHILD_MFMA', 'child',
-         'k_child_conv<1,1> / k_child_conv<2,2,split> / k_child_cls<NB>',
-         'halo gather through the parent map, packed-N fp32 MFMA: conv 16->16 436 -> 259 us on 2.05 M rows, cls 16->1 209 -> 85'),
+         'k_child_conv<1,1> / k_child_conv<2,2,split> / k_child_cls<NB>; 16->1 with ops.CHILD_Q4: k_child_q4<cls> (quad-block 4x4x1 MFMA)',
+         'halo gather through the parent map, packed-N fp32 MFMA: conv 16->16 436 -> 259 us on 2.05 M rows, cls 16->1 209 -> 85 (quad-block form: 83)'),
     Rule('conv3', ((1, 4), (1, 8), (1, 16)), None, 0, INF, 'UNIT_INPUT_CONV', 'unit', 'k_conv_unit<COUT>',
          'all-ones occupancy input (x.has_unit_features()): sum of kernel slices over the present offsets, no feature gathers: 88 -> 55 us'),
     Rule('conv3', ((32, 32),), None, 'ROWS_CONV_MIN', INF, 'ROWS_CONV', 'rows', 'k_rows_conv<2,2>',
@@ -48,8 +48,9 @@ TABLE = (
          "the level's own map exists already (its 64->64 conv ran on the gather kernels): plain-rows form 171 vs 197 us per block at 150 k rows"),
     Rule('irn', (64,), 'children', 8192, INF, 'CHILD_MFMA', 'child64', 'k_child_irn_a<64,split> + k_child_irn_b64<split>',
          'both passes through the parent map in half units: 104 / 89 us at 150 k rows'),
-    Rule('irn', (16, 32), 'children', 8192, INF, 'CHILD_MFMA', 'child', 'k_child_irn_a<C> + k_child_irn_b<C> (C = 32: half units)',
-         'packed-N MFMA passes through the parent map: C = 16 212/170 -> 118/102 us on 2.05 M rows, C = 32 174/130 -> 100/81 on 570 k'),
+    Rule('irn', (16, 32), 'children', 8192, INF, 'CHILD_MFMA', 'child',
+         'k_child_irn_a<C> + k_child_irn_b<C> (C = 32: half units); C = 16 with ops.CHILD_Q4: k_child_q4<pass A> (quad-block 4x4x1 MFMA) + k_child_irn_b<16, T2 gather>',
+         'packed-N MFMA passes through the parent map: C = 16 212/170 -> 118/102 us on 2.05 M rows (quad-block pass A: 97/110), C = 32 174/130 -> 100/81 on 570 k'),
     Rule('irn', (64,), None, 'ROWS_IRN64_MIN', INF, 'ROWS_IRN64', 'rows64', 'k_rows_irn_a64 + k_rows_irn_b64',
          'plain level: 65 vs 135 us per block at 1-18 k rows, 103 vs 198 at 71 k'),
     Rule('irn', (32,), None, 'ROWS_IRN32_MIN', 'ROWS_IRN32_MAX+1', 'ROWS_IRN32', 'rows32', 'k_rows_irn_a32 + k_rows_irn_b32',

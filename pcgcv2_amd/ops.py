@@ -834,6 +834,60 @@ def child_cls_table(W):
     return _gather_table(_TABLE_INDEX[key], W.detach().reshape(-1))
 
 
+def _q4_cls_index(C):
+    """gather index of the quad-block classification head's table: one fragment [s 4][ci C] per (cell, z half h) group in the kernel's
+    schedule order (cells ascending; h = 0 if the cell's z plane is reached by the children with z bit 0, then h = 1): column s =
+    kernel[k(cell, 4 h + s)][:, 0] where child 4 h + s reaches the cell, zero elsewhere."""
+    W = np.arange(27 * C, dtype=np.int64).reshape(27, C)
+    frags = []
+    for c, (kp, jc, reach) in enumerate(_halo_cells()):
+        cz = c >> 4
+        kof = dict(reach)
+        for h in range(2):
+            if not 0 <= cz - h <= 2:
+                continue
+            f = np.full((4, C), -1, np.int64)
+            for sidx in range(4):
+                if 4 * h + sidx in kof:
+                    f[sidx] = W[kof[4 * h + sidx]]
+            frags.append(f.reshape(-1))
+    assert len(frags) == 96
+    return np.concatenate(frags)
+
+
+def child_q4_cls_table(W):
+    """Table of pcgc_cls_child_q4 (k3 conv 16 -> 1 on a children level, quad-block form)."""
+    C = W.shape[1]
+    key = ('q4cls', C, W.device)
+    if key not in _TABLE_INDEX:
+        _TABLE_INDEX[key] = torch.from_numpy(_q4_cls_index(C)).to(W.device)
+    return _gather_table(_TABLE_INDEX[key], W.detach().reshape(-1))
+
+
+def cls_child_q4(parent_nbr, x, table, bias):
+    """Classification head k3 16 -> 1 on the children level of `parent_nbr`'s level in quad-block form (csrc/child_q4.h): -> [8 n_parent, 1]."""
+    _f32(x, 'x')
+    n_p = parent_nbr.shape[1]
+    if x.shape[0] != 8 * n_p:
+        raise PcgcError('cls_child_q4: feature rows must be 8 x the parent level')
+    Cin = x.shape[1]
+    n = 8 * n_p
+    out = torch.empty((n, 1), dtype=torch.float32, device=x.device)
+    key = ('child_conv', Cin, 1, n)
+    prof = PROFILE.want(key)
+    if prof:
+        e0, e1 = PROFILE.bracket(key, f'k_child_q4<cls> (k3 {Cin}->1 on a children level, parent-map halo gather + quad-block 4x4x1 fp32 MFMA)', n,
+                                 lambda P, a=Cin: P * a * 4 + P * 8 + n * 4, lambda P, a=Cin: 2 * P * a,
+                                 compulsory=n * Cin * 4 + 27 * n_p * 4 + n * 4, mfma_issued=((n_p + 63) // 64) * 96 * 16 * 512)
+        e0.record()
+    check(lib().pcgc_cls_child_q4(_p(parent_nbr), n_p, _p(x), Cin, _ld(x), _p(table), table.numel() * 4, _p(bias), _p(out), _stream(x)), 'cls_child_q4')
+    if prof:
+        e1.record()
+    elif PROFILE.counting:
+        PROFILE.count_children(parent_nbr)
+    return out
+
+
 def _irn_index(C):
     """Gather indices (into cat(W00, W01, W10, W11, W12) flattened) of the two pass tables; the fragment order is the one
     csrc/child_kernels.h's PassA / PassB variants index (frag())."""

@@ -1272,6 +1272,11 @@ def test_cls_head_child_bit_exact(name, prune, cin):
         finally:
             ops.set_child_tuning(0, 0)
         np.testing.assert_array_equal(got.cpu().numpy(), want)
+    if cin == 16:        # round 5: the same head in quad-block form (pcgc_cls_child_q4: a 4 x 4 block = 4 parents x the four children of a z half)
+        got = ops.cls_child_q4(parent.k3, _t(x), ops.child_q4_cls_table(_t(W)), _t(b))
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        got = ops.cls_child_q4(parent.k3, _t(x), ops.child_q4_cls_table(_t(W)), None)          # (no bias)
+        np.testing.assert_array_equal(got.cpu().numpy(), orc.conv_gather(orc.kmap_k3(kc, 1), x, W, None))
 
 
 @pytest.mark.parametrize('C', [16, 32, 64])
