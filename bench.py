@@ -349,6 +349,51 @@ def main():
         del alt
         step()
 
+    # the same K steps on geometry that is NOT a smooth closed surface: holes / drop-outs / salt (noisy10), intersecting
+    # shells + one-voxel sheets + a rod + a solid block (multi10), a filled body with 27 / 27 neighbourhoods and whole regions of tied
+    # logits (solid_ball); cold tables, the headline's warm-up
+    geom_sens = None
+    if cfg == 'frame' and world == 1 and not args.no_extra and not args.two_cpu_child and not args.workload:
+        geom_sens = {}
+        for nm in ('noisy10', 'multi10', 'solid_ball'):
+            alt = [(nm, cloud(nm))]
+            dt_p = timed_steps(these=alt)
+            geom_sens[nm] = {'points': int(len(alt[0][1])), 'Mpoints_s': round(len(alt[0][1]) * args.steps / dt_p / 1e6, 4),
+                             'ms_per_step': round(dt_p / args.steps * 1e3, 3)}
+            del alt
+        geom_sens['note'] = ('this rank, the same K steps (cold tables) on synthetic.CLOUDS; the headline cloud (shell10) is `value`; every figure codes '
+                             'ONE frame at a time, so smaller clouds pay the same ~1.3 ms host-serial window over fewer points')
+        step()
+
+    # where a step's wall-clock goes: five untimed steps with two host marks inside the coder — after the encoder's
+    # symbols have reached the host (nothing is queued on the GPU any more) and before the decoder's first device work is enqueued.  Between
+    # the two the GPU idles behind the sequential host stages (range encoder, files, file read, coordinate decode, table); outside them the
+    # host launches and the GPU executes concurrently.
+    windows = None
+    if cfg == 'frame' and not args.no_extra and batch is None and rate_sds is None:
+        spans = []
+        for _ in range(5):
+            coder_mod.TIMELINE = marks = []
+            torch.cuda.synchronize()
+            t_a = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            t_b = time.perf_counter()
+            coder_mod.TIMELINE = None
+            m = dict(marks)
+            if 'enc_gpu_done' in m and 'dec_gpu_first' in m:
+                spans.append(((m['enc_gpu_done'] - t_a) * 1e3, (m['dec_gpu_first'] - m['enc_gpu_done']) * 1e3, (t_b - m['dec_gpu_first']) * 1e3))
+        if spans:
+            med = lambda i: round(sorted(sp[i] for sp in spans)[len(spans) // 2], 3)
+            windows = {'enc_gpu_window_ms': med(0), 'host_serial_ms': med(1), 'dec_gpu_window_ms': med(2),
+                       'gpu_conv_ms': None if warm_all is None else warm_all['all_launches']['ms_per_step'],
+                       'note': 'medians of 5 untimed steps (host clock, no extra device synchronisation inside the step).  enc_gpu_window: step start -> '
+                               "the latent's symbols are on the host (pyramid, maps, encoder convolutions, sort, quantisation; the host enqueues ahead of the "
+                               'GPU).  host_serial: -> the decoder\'s first device work is enqueued: range encoder, table, files, file read, coordinate-stream '
+                               'decode — the GPU has NOTHING queued in this window.  dec_gpu_window: -> decode complete (level upload, feature-stream decode '
+                               'finishing beside it, decoder convolutions, top-k / pruning).  gpu_conv_ms = sum of the sparse-conv launches of one step (HIP '
+                               'events, analysis pass); the GPU-busy total incl. the non-conv kernels is in profiles/r05_kernel_trace.txt'}
+
     # one rank on a TWO-CPU budget (eight ranks of a node that share a 16-CPU quota get exactly that): the same command in a child process
     # whose affinity mask holds two CPUs — configure_host_threads then budgets one range-decoder thread (the lane-parallel decoder), no pools
     two_cpu = None
@@ -530,10 +575,11 @@ def main():
                        'table_cache': 'warm (caches kept across steps)' if args.warm_tables else 'cold: dropped before every encode and every decode inside the timed region '
                                       '(the reference evaluates a table per compress / decompress call)',
                        'table_cache_warm': warm_tables, 'input_order': args.input_order, 'input_order_sensitivity': order_sens, 'two_cpu_rank': two_cpu,
+                       'geometry_sensitivity': geom_sens, 'step_windows': windows,
                        'entropy_decode': '`_F.bin` (bit-identical to the reference-format stream, decodable without it) comes with a sidecar '
                                          f'`_F.idx` of decoder states at {coder_mod.INDEX_SEGMENTS} row boundaries: its segments are decoded two per thread (two dependency chains per loop) on up to 8 threads; `_C.bin` '
                                          '(native octree, tmc3 absent) is coded as up to 8 independent groups of subtrees',
-                       'path_switches': {k: bool(getattr(ops, k)) for k in ('ONE_SWEEP_PRUNE', 'PACKED_CONV64', 'UNIT_CONV_MAPLESS', 'ROWS_IRN64', 'ROWS_IRN32', 'ROWS_CONV', 'ROWS_DOWN', 'CHILD_MFMA')},
+                       'path_switches': {k: bool(getattr(ops, k)) for k in ('ONE_SWEEP_PRUNE', 'PACKED_CONV64', 'UNIT_CONV_MAPLESS', 'ROWS_IRN64', 'ROWS_IRN32', 'ROWS_CONV', 'ROWS_DOWN', 'CHILD_MFMA', 'CHILD_Q4')},
                        'coord_codec': 'native-octree (tmc3 absent)', 'coord_coder_ms': coord_ms, 'coord_codec_rate': coord_rate, 'serving_throughput': serving,
                        'step_ms_rank0': step_ms,
                        'd1_psnr_rank0_db': None if d1 is None else round(d1['mseF,PSNR (p2point)'], 4),
@@ -571,6 +617,17 @@ def attach_pmc_traffic(roof):
     try:
         table = json.load(open(path))
     except ValueError:
+        return
+    # the collection is only replayed while the kernel sources are the ones it was collected on (tools/pmc_traffic.py stamps their hash)
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'pcgcv2_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h', '.cpp')):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), 'rb').read())
+    if table.get('kernel_sources_sha16') != h.hexdigest()[:16]:
+        roof['traffic_source'] = ('profiles/pmc_traffic.json was collected on other kernel sources (stamp %s, now %s): not replayed; re-run tools/pmc_traffic.sh'
+                                  % (table.get('kernel_sources_sha16'), h.hexdigest()[:16]))
         return
     short = roof['kernel'].split(' (')[0].rstrip('>')                     # e.g. "k_child_irn_a<16" or "k_conv_gather_mfma_wlds<64, 32, 2"
     import math

@@ -59,6 +59,7 @@ def _slurp(path):
 INDEX_SEGMENTS = 16                              # checkpoints per stream (two segments per decoder thread); 0 = never write or read the sidecar
 FRAME_SPLIT = _os_environ_flag('PCGC_FRAME_SPLIT')   # decode: coordinate-only kernels are enqueued while the feature stream is still being decoded (A/B: PCGC_FRAME_SPLIT=0)
 INGEST_SORT = True                               # encode: an unordered cloud is sorted once before the encoder touches it (Coder._ingest)
+TIMELINE = None                                  # measurement hook (bench.py): a list -> (mark, perf_counter) of the points between which the GPU has nothing queued
 WARM_TABLE_CODE = True                           # encode: a throw-away table evaluation while the host waits for the GPU (ops.table_warm)
 NATIVE_ITEMS = True                              # batches: per-item host stages on native threads (False: Python thread pool; A/B and tests)
 INDEX_SUFFIX = '_F.idx'
@@ -286,6 +287,8 @@ class Coder():
             if WARM_TABLE_CODE:
                 ops.table_warm(self.feature_coder.entropy_model._host_packed(), self.feature_coder.entropy_model._channels)
             min_v, max_v, sym_h = ops.quantize_symbols(y.F)
+            if TIMELINE is not None:
+                TIMELINE.append(('enc_gpu_done', time.perf_counter()))      # the symbols are on the host: nothing is queued on the GPU from here on
             ops.items_encode([self.filename + postfix], sym_h, np.zeros((0, 3), np.int32), [len(sym_h)], [(min_v, max_v)], [budgets],
                              self.feature_coder.entropy_model._host_packed(), INDEX_SEGMENTS, write_coords=False, threads=1)
         else:
@@ -429,6 +432,8 @@ class Coder():
             n4, n2, n1 = counts
             if not FRAME_SPLIT:
                 ops.frame_decode_end()
+            if TIMELINE is not None:
+                TIMELINE.append(('dec_gpu_first', time.perf_counter()))     # the first device work of the decode (level upload) is enqueued next
             try:
                 if native:
                     lvl8 = self._stage_level(n8, dev, stream)

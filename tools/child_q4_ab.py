@@ -30,6 +30,10 @@ t = torch.empty((n, C // 2), device=dev); t2 = torch.full((n, C // 2), -7.0, dev
 def pass_a(): ops.check(lib().pcgc_irn_child_pass(pk.data_ptr(), n_p, C, 1, x.data_ptr(), C, tabs[0].data_ptr(), tabs[0].numel() * 4, P[1], P[5], None, None, 0, t.data_ptr(), C // 2, s), 'a')
 def pass_q(): ops.check(lib().pcgc_irn_child_q4(pk.data_ptr(), n_p, C, 1, x.data_ptr(), C, tq.data_ptr(), tq.numel() * 4, P[1], P[5], None, None, 0, t2.data_ptr(), C // 2, s), 'q')
 def pass_b(): ops.check(lib().pcgc_irn_child_pass(pk.data_ptr(), n_p, C, 2, t.data_ptr(), C // 2, tabs[1].data_ptr(), tabs[1].numel() * 4, P[3], P[7], P[9], x.data_ptr(), C, out.data_ptr(), C, s), 'b')
+Wc = (torch.randn((27, C, 1), generator=g) * 0.05).to(dev); bc = torch.randn((1, 1), generator=g).to(dev)
+tcp, tcq = ops.child_cls_table(Wc), ops.child_q4_cls_table(Wc)
+def cls_p(): return ops.conv_child(pk, x, tcp, bc, 1)
+def cls_q(): return ops.cls_child_q4(pk, x, tcq, bc)
 def med(f, reps=15):
     for _ in range(3): f()
     ts = []
@@ -49,4 +53,4 @@ if not eq:
 for _ in range(200): pass_a(); pass_b()
 torch.cuda.synchronize()
 for rnd in range(3):
-    print('  '.join(f'{nm} {med(f)[0]:7.1f} us (min {med(f)[1]:6.1f})' for nm, f in (('packedA', pass_a), ('quadA', pass_q), ('passB', pass_b))), flush=True)
+    print('  '.join(f'{nm} {med(f)[0]:7.1f} us (min {med(f)[1]:6.1f})' for nm, f in (('packedA', pass_a), ('quadA', pass_q), ('passB', pass_b), ('packedCls', cls_p), ('quadCls', cls_q))), flush=True)

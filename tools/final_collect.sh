@@ -16,7 +16,15 @@ for cfg in frame:10:1 sweep:2:7 blocks:3:8; do
   python tools/rocprof_summary.py gpurun_out/final/kt_$c/*/*kernel_stats.csv > gpurun_out/final/kernel_stats_$c.txt 2>&1 || true
   find gpurun_out/final/kt_$c -name '*kernel_trace.csv' -delete
 done
-bash tools/fetch_calib.sh > /dev/null 2>&1; cp gpurun_out/r02_fetch_calibration.txt gpurun_out/final/fetch_calibration.txt 2>/dev/null
+bash tools/fetch_calib.sh > /dev/null 2>&1; cp gpurun_out/fetch_calibration.txt gpurun_out/final/fetch_calibration.txt 2>/dev/null
+# a second geometry family: kernel trace of the frame config on noisy10
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/kt_noisy10 -- python $R/bench.py --workload noisy10 --steps 10 --warmup 2 --no-cpu-baseline --no-events --serving-frames 0 --no-extra > $R/gpurun_out/final/kt_noisy10.log 2>&1
+cd $R
+python tools/trace_window_summary.py gpurun_out/final/kt_noisy10/*/*kernel_trace.csv 10 1 > gpurun_out/final/kernel_trace_noisy10.txt 2>&1 || true
+find gpurun_out/final/kt_noisy10 -name '*kernel_trace.csv' -delete
+python bench.py --workload noisy10 --steps 20 --warmup 5 --no-cpu-baseline --no-extra --detail gpurun_out/final/detail_noisy10.json > gpurun_out/final/bench_noisy10.json 2>> gpurun_out/final/bench.err
+bash tools/q4_pmc.sh shell10 > /dev/null 2>&1; cp gpurun_out/q4_pmc/summary.txt gpurun_out/final/child_q4_pmc.txt
 for cfg in 16:irn 16:conv 32:irn; do
   bash tools/child_pmc.sh ${cfg%%:*} 0 0 ${cfg##*:} > /dev/null 2>&1; cp gpurun_out/child_pmc/summary.txt gpurun_out/final/child_pmc_${cfg%%:*}_${cfg##*:}.txt
 done

@@ -5,7 +5,7 @@ byte counts, profiles/r02_fetch_calibration.txt): wide streaming reads and gathe
 requests and read back HALF their bytes (correction x2, as MI355X_MICROARCH.md says); gathers of 64-byte rows read back exactly their
 bytes (x1); 32-byte rows read back 2x their bytes, which is true traffic (64-byte sectors).  So kernels whose traffic is dominated by
 gathers of rows of at most 64 bytes (the C = 16 level) take x1, everything else x2; mixed kernels lie in between."""
-import csv, glob, json, re, sys, collections
+import csv, glob, hashlib, json, os, re, sys, collections
 src, dst = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(src + '/**/*counter_collection.csv', recursive=True):
@@ -21,7 +21,7 @@ for (k, grid), d in acc.items():
         continue
     fetch = sum(d['FETCH_SIZE']) / len(d['FETCH_SIZE']) * 1024
     write = sum(d['WRITE_SIZE']) / len(d['WRITE_SIZE']) * 1024
-    narrow = bool(re.match(r'k_(irn_[ab]<16|child_irn_[ab]<16|child_conv<1, 1|child_cls<1,|conv_gather_\w+<16,)', k))
+    narrow = bool(re.match(r'k_(irn_[ab]<16|child_irn_[ab]<16|child_q4<|child_conv<1, 1|child_cls<1,|conv_gather_\w+<16,)', k))
     f = 1.0 if narrow else 2.0
     out.append({'kernel': k, 'grid_size': grid, 'grid_rows': grid, 'launches_sampled': len(d['FETCH_SIZE']),
                 'fetch_bytes_raw': round(fetch), 'fetch_correction': f, 'fetch_bytes_corrected': round(f * fetch), 'write_bytes': round(write),
@@ -29,6 +29,20 @@ for (k, grid), d in acc.items():
                 'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py; FETCH_SIZE x%g (calibrated: 64 B tallied per '
                           'request; %s)' % (f, '64-byte row gathers read back their bytes' if narrow else '128-byte requests read back half')})
 out.sort(key=lambda e: -e['hbm_bytes_per_launch'])
-json.dump({'kernels': out}, open(dst, 'w'), indent=1)
+
+
+def kernel_sources_sha16(root):
+    """hash of every kernel source of the library: bench.py replays this file only while it matches the sources it runs"""
+    h = hashlib.sha256()
+    d = os.path.join(root, 'pcgcv2_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h', '.cpp')):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+json.dump({'kernel_sources_sha16': kernel_sources_sha16(root), 'collected_by': 'tools/pmc_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)',
+           'kernels': out}, open(dst, 'w'), indent=1)
 for e in out[:12]:
     print(e['kernel'], e['grid_size'], 'fetch(raw) %.1f MB  write %.1f MB' % (e['fetch_bytes_raw'] / 1e6, e['write_bytes'] / 1e6))
