@@ -380,6 +380,11 @@ int pcgc_oct_decode(const uint8_t* in, int64_t nbytes, int32_t* xyz /*[host n,3]
  * the threads of pcgc_set_rc_threads; 0 = always the single-stream form (version 2); n > 1 = that many groups (A/B tests).  The
  * decoder reads both versions. */
 int pcgc_set_oct_tiled(int on);
+/* Context model the ENCODER uses (the decoder reads every version): 1 (default, round 5) = stream versions 4 / 5 — every stream starts from
+ * contexts trained on a mix of integer-defined shapes (sphere, ellipsoid, tilted plane, ragged noisy shell: none of them a bench cloud) and
+ * a context adapts fast on its first visits; 0 = the round-3 versions 2 / 3 (p = 1/2 / sphere-trained prior), kept so that files written
+ * by earlier builds stay covered by the format tests.  Replaces nothing in the reference (gpcc.py:6-41 hands `_C.bin` to tmc3). */
+int pcgc_set_oct_model(int model);
 
 /* ---- D1 point-to-point distortion (pc_error.py:27-74 -> mpeg-pcc-dmetric ‡): sum and max over A of the squared distance to
  *      the nearest point of B, B given by its coordinate hash (stride 1).  offsets: int32 [n,4] = (dx,dy,dz,d2) sorted by d2. ---- */

@@ -125,7 +125,18 @@ k_child_q4(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restric
     const int64_t ntiles = (n_p + TP - 1) / TP;
 
     for (int it = 0;; ++it) {
+#ifdef Q4_EXP_TILE_ORDER
+        // (experiment) the waves of a workgroup take CONSECUTIVE tiles of their XCD's slab instead of tiles a workgroup-count apart
+        int64_t tile;
+        {
+            const int64_t S = (ntiles + 7) >> 3;
+            const int64_t l = ((int64_t)(blockIdx.x >> 3) + (int64_t)(gridDim.x >> 3) * it) * NW + wave;
+            tile = (blockIdx.x & 7) * S + l;
+            if (!(l < S && tile < ntiles)) tile = -1;
+        }
+#else
         const int64_t tile = child_tile<NW>(it, wave, ntiles);
+#endif
         if (tile < 0) break;
         const int64_t p_base = tile * TP;
         // the parent map entries of row 16 (L & 3) + (L >> 2) of each M tile: quad L >> 2 holds rows (L >> 2) + 16 {0, 1, 2, 3}, and gather

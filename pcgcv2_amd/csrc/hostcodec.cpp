@@ -660,10 +660,10 @@ struct BinEnc {
         ++cache_size;
         low = (uint32_t)low << 8;
     }
-    void encode(uint16_t& p, int bit) {
+    void encode(uint16_t& p, int bit, int shift = 4) {
         uint32_t bound = (range >> 12) * p;
-        if (bit == 0) { range = bound; p += (4096 - p) >> 4; }
-        else { low += bound; range -= bound; p -= p >> 4; }
+        if (bit == 0) { range = bound; p += (4096 - p) >> shift; }
+        else { low += bound; range -= bound; p -= p >> shift; }
         while (range < (1u << 24)) { range <<= 8; shift_low(); }
     }
     void finish() { for (int i = 0; i < 5; ++i) shift_low(); }
@@ -672,11 +672,11 @@ struct BinDec {
     const uint8_t* in; int64_t len; int64_t pos = 0; uint32_t range = 0xFFFFFFFFu, code = 0;
     uint8_t next() { return pos < len ? in[pos++] : 0; }
     void init() { next(); for (int i = 0; i < 4; ++i) code = (code << 8) | next(); }
-    int decode(uint16_t& p) {
+    int decode(uint16_t& p, int shift = 4) {
         uint32_t bound = (range >> 12) * p;
         int bit;
-        if (code < bound) { range = bound; p += (4096 - p) >> 4; bit = 0; }
-        else { code -= bound; range -= bound; p -= p >> 4; bit = 1; }
+        if (code < bound) { range = bound; p += (4096 - p) >> shift; bit = 0; }
+        else { code -= bound; range -= bound; p -= p >> shift; bit = 1; }
         while (range < (1u << 24)) { range <<= 8; code = (code << 8) | next(); }
         return bit;
     }
@@ -810,8 +810,23 @@ struct OctCoder {
     }
     inline uint16_t& ctx(int j, int occupied_before) {
         const int axis = child.use_bitmap ? (int)axis_of[j] : ((int)outward(j, 0) | ((int)outward(j, 1) << 1) | ((int)outward(j, 2) << 2));
-        return prob[(((size_t)bucket * kAxis + axis) * kPos + (j * 9 + occupied_before)) * kNb + nb_class];
+        last = (((size_t)bucket * kAxis + axis) * kPos + (j * 9 + occupied_before)) * kNb + nb_class;
+        return prob[last];
     }
+    // Model 1 (stream versions 4 / 5, round 5): every stream starts from contexts trained on a MIX of shapes (oct_prior_mixed: none of them a
+    // bench cloud) and a context adapts FAST on its first visits within the stream — update shifts 2, 3, 3, then the usual 4 — so that a
+    // group of a few thousand points re-centres a prior that does not fit its cloud in three visits instead of sixteen.
+    bool fast = false;
+    size_t last = 0;
+    std::vector<uint8_t> seen;
+    void enable_fast_start() { fast = true; seen.assign(prob.size(), 0); }
+    inline int shift_of_last() {                                  // update shift of the context ctx() returned last
+        if (!fast) return 4;
+        uint8_t& c = seen[last];
+        if (c >= 3) return 4;
+        return c++ == 0 ? 2 : 3;
+    }
+    inline void clamp_last() { if (fast) { uint16_t& p = prob[last]; p = p < 32 ? 32 : (p > 4064 ? 4064 : p); } }
 };
 
 constexpr uint8_t kMagic[4] = {'P', 'C', 'G', 'O'};
@@ -822,9 +837,10 @@ constexpr uint8_t kMagic[4] = {'P', 'C', 'G', 'O'};
 namespace {
 // `leaves`: the Morton-sorted leaf codes that lie below `roots` (a contiguous run of the cloud's sorted leaves)
 std::vector<uint8_t> oct_encode_part(const std::vector<uint64_t>& roots, int lvl0, int depth, const uint64_t* leaves, size_t n_leaves,
-                                     const std::vector<uint16_t>* prior = nullptr, std::vector<uint16_t>* trained = nullptr) {
+                                     const std::vector<uint16_t>* prior = nullptr, std::vector<uint16_t>* trained = nullptr, bool fast = false) {
     BinEnc enc; OctCoder oc;
     if (prior) oc.prob = *prior;
+    if (fast) oc.enable_fast_start();
     std::vector<uint64_t> level_nodes = roots, next;
     for (int lvl = lvl0; lvl < depth && !level_nodes.empty(); ++lvl) {
         const int shift = 3 * (depth - 1 - lvl);                     // leaves >> shift = child code at level lvl+1
@@ -839,7 +855,9 @@ std::vector<uint8_t> oct_encode_part(const std::vector<uint64_t>& roots, int lvl
             int before = 0;
             for (int j = 0; j < 8; ++j) {
                 const int bit = (occ >> j) & 1;
-                enc.encode(oc.ctx(j, before), bit);
+                uint16_t& p = oc.ctx(j, before);
+                enc.encode(p, bit, oc.shift_of_last());
+                oc.clamp_last();
                 if (bit) { const uint64_t c = (node << 3) | (uint64_t)j; next.push_back(c); oc.child.mark(c); ++before; }
             }
         }
@@ -868,12 +886,44 @@ const std::vector<uint16_t>& oct_prior() {
     }();
     return prior;
 }
+// Model 1: the prior is the state the context model reaches after coding FOUR integer-defined training shapes in a 128^3 grid one after
+// the other (plain shift-4 updates) — a sphere shell, an ellipsoid shell (semi-axes 54 / 36 / 27), a tilted plane slab and a sphere shell
+// with hashed drop-outs and volume salt: curved, flat and ragged neighbourhoods, none of them one of the clouds the bench or the tests
+// code ("train / adapt on something that is not the benchmark shape").  tools/experiments/oct/ctx_probe.py is the offline
+// evaluation behind the choice (profiles/r05_coord_codec.md).
+const std::vector<uint16_t>& oct_prior_mixed() {
+    static const std::vector<uint16_t> prior = [] {
+        std::vector<uint16_t> state;
+        for (int shape = 0; shape < 4; ++shape) {
+            std::vector<uint64_t> leaves;
+            for (int z = 0; z < 128; ++z) for (int y = 0; y < 128; ++y) for (int x = 0; x < 128; ++x) {
+                bool in = false;
+                if (shape == 0) { const int d2 = (x - 64) * (x - 64) + (y - 64) * (y - 64) + (z - 64) * (z - 64); in = d2 >= 45 * 45 && d2 < 46 * 46; }
+                else if (shape == 1) { const int e = 4 * (x - 64) * (x - 64) + 9 * (y - 64) * (y - 64) + 16 * (z - 64) * (z - 64); in = e >= 108 * 108 && e < 112 * 112; }
+                else if (shape == 2) { const int pl = 3 * x + 5 * y + 7 * z; in = pl >= 960 && pl < 969 && x > 8 && x < 120 && y > 8 && y < 120 && z > 8 && z < 120; }
+                else {
+                    const uint64_t h = (((uint64_t)x * 73856093ull) ^ ((uint64_t)y * 19349663ull) ^ ((uint64_t)z * 83492791ull)) & 1023ull;
+                    const int d3 = (x - 60) * (x - 60) + (y - 66) * (y - 66) + (z - 62) * (z - 62);
+                    in = (d3 >= 38 * 38 && d3 < 39 * 39 && h >= 100) || (h < 2 && d3 < 50 * 50);
+                }
+                if (in) leaves.push_back(morton3((uint32_t)x, (uint32_t)y, (uint32_t)z));
+            }
+            std::sort(leaves.begin(), leaves.end());
+            std::vector<uint16_t> next;
+            (void)oct_encode_part(std::vector<uint64_t>(1, 0), 0, 7, leaves.data(), leaves.size(), state.empty() ? nullptr : &state, &next);
+            state.swap(next);
+        }
+        return state;
+    }();
+    return prior;
+}
 // -> 0, or -2 on a corrupt stream; `out` = the nodes of level `depth_to` below `roots`, Morton-sorted
 int oct_decode_part(const uint8_t* in, int64_t nbytes, const std::vector<uint64_t>& roots, int lvl0, int depth_to, int depth, int64_t max_nodes,
-                    std::vector<uint64_t>& out, const std::vector<uint16_t>* prior = nullptr) {
+                    std::vector<uint64_t>& out, const std::vector<uint16_t>* prior = nullptr, bool fast = false) {
     BinDec dec{in, nbytes}; dec.init();
     OctCoder oc;
     if (prior) oc.prob = *prior;
+    if (fast) oc.enable_fast_start();
     std::vector<uint64_t> level_nodes = roots, next;
     for (int lvl = lvl0; lvl < depth_to && !level_nodes.empty(); ++lvl) {
         next.clear();
@@ -883,7 +933,9 @@ int oct_decode_part(const uint8_t* in, int64_t nbytes, const std::vector<uint64_
             oc.begin_node(node);
             int before = 0;
             for (int j = 0; j < 8; ++j) {
-                const int bit = dec.decode(oc.ctx(j, before));
+                uint16_t& p = oc.ctx(j, before);
+                const int bit = dec.decode(p, oc.shift_of_last());
+                oc.clamp_last();
                 if (bit) { const uint64_t c = (node << 3) | (uint64_t)j; next.push_back(c); oc.child.mark(c); ++before; }
             }
             if ((int64_t)next.size() > max_nodes) { oc.end_level(); return -2; }          // corrupt stream
@@ -901,10 +953,16 @@ int kOctGroups = 8;
 #define PCGC_OCT_NODES_PER_GROUP 2
 #endif
 int g_oct_tiled = 1;                                   // 0 = always one stream (A/B tests)
+int g_oct_model = 1;                                   // what the ENCODER writes: 1 = versions 4 / 5 (mixed prior + fast start), 0 = the round-3 versions 2 / 3
+constexpr uint8_t kOctVersion1 = 4, kOctTiled1 = 5;    // model 1: one stream / groups of subtrees (the decoder reads all four versions)
 }  // namespace
+extern "C" int pcgc_set_oct_model(int model) { if (model != 0 && model != 1) return -1; g_oct_model = model; return 0; }
 // 0 = one stream, 1 = the default 8 groups, n > 1 = n groups (clamped to the 255 the one-byte group count of the stream can hold)
 extern "C" int pcgc_set_oct_tiled(int on) { g_oct_tiled = on ? 1 : 0; kOctGroups = on > 1 ? (on > 255 ? 255 : on) : 8; return 0; }
 
+// stream versions 4 / 5 (round 5, what the encoder writes): the layouts of versions 2 / 3 below with context MODEL 1 — every stream starts from
+// the mixed-shape prior (oct_prior_mixed) and contexts adapt fast on their first visits; 2 / 3 (p = 1/2 or the sphere-trained prior, shift-4
+// updates) are still decoded, and written when pcgc_set_oct_model(0) asks for them (format tests).
 // stream, version 2: "PCGO" | 2 | depth u8 | n u32 | range-coded occupancy bits of the whole tree
 // stream, version 3 (clouds of >= 8192 points): "PCGO" | 3 | depth u8 | n u32 | split level d u8 | groups G u8 | top bytes u32 |
 //     G x (roots u32, points u32, bytes u32) | the occupancy stream of levels [0, d) | G occupancy streams of levels [d, depth)
@@ -939,11 +997,12 @@ extern "C" int64_t pcgc_oct_encode(const int32_t* xyz, int64_t n, uint8_t* out, 
     }
     if (d == 0) {
         std::vector<uint64_t> root; if (n_unique > 0) root.push_back(0);
-        const std::vector<uint8_t> body = oct_encode_part(root, 0, depth, leaves.data(), leaves.size());
+        const std::vector<uint8_t> body = g_oct_model ? oct_encode_part(root, 0, depth, leaves.data(), leaves.size(), &oct_prior_mixed(), nullptr, true)
+                                                      : oct_encode_part(root, 0, depth, leaves.data(), leaves.size());
         const int64_t total = 4 + 2 + 4 + (int64_t)body.size();
         if (total > cap) return -total;
         std::memcpy(out, kMagic, 4);
-        out[4] = kOctVersion; out[5] = (uint8_t)depth;
+        out[4] = g_oct_model ? kOctVersion1 : kOctVersion; out[5] = (uint8_t)depth;
         std::memcpy(out + 6, &n32, 4);
         std::memcpy(out + 10, body.data(), body.size());
         return total;
@@ -964,12 +1023,13 @@ extern "C" int64_t pcgc_oct_encode(const int32_t* xyz, int64_t n, uint8_t* out, 
     std::vector<std::vector<uint8_t>> bodies((size_t)G);
     // the top of the tree: levels [0, d), with the level-d nodes as its "leaves"
     std::vector<uint64_t> root(1, 0);
-    const std::vector<uint16_t>& prior = oct_prior();
-    const std::vector<uint8_t> top = oct_encode_part(root, 0, d, split_nodes.data(), split_nodes.size(), &prior);
+    const bool m1 = g_oct_model != 0;
+    const std::vector<uint16_t>& prior = m1 ? oct_prior_mixed() : oct_prior();
+    const std::vector<uint8_t> top = oct_encode_part(root, 0, d, split_nodes.data(), split_nodes.size(), &prior, nullptr, m1);
     const std::function<void(int)> one = [&](int g) {
         const std::vector<uint64_t> roots(split_nodes.begin() + group_begin[(size_t)g], split_nodes.begin() + group_begin[(size_t)g + 1]);
         const int64_t lo = split_first[(size_t)group_begin[(size_t)g]], hi = split_first[(size_t)group_begin[(size_t)g + 1]];
-        bodies[(size_t)g] = oct_encode_part(roots, d, depth, leaves.data() + lo, (size_t)(hi - lo), &prior);
+        bodies[(size_t)g] = oct_encode_part(roots, d, depth, leaves.data() + lo, (size_t)(hi - lo), &prior, nullptr, m1);
     };
     const int threads = rc_threads();
     if (threads <= 1) { for (int g = 0; g < G; ++g) one(g); } else octree_pool().run(G, std::min(threads, G) - 1, one);
@@ -978,7 +1038,7 @@ extern "C" int64_t pcgc_oct_encode(const int32_t* xyz, int64_t n, uint8_t* out, 
     if (total > cap) return -total;
     uint8_t* p = out;
     std::memcpy(p, kMagic, 4); p += 4;
-    *p++ = kOctTiled; *p++ = (uint8_t)depth;
+    *p++ = m1 ? kOctTiled1 : kOctTiled; *p++ = (uint8_t)depth;
     std::memcpy(p, &n32, 4); p += 4;
     *p++ = (uint8_t)d; *p++ = (uint8_t)G;
     { const uint32_t tb = (uint32_t)top.size(); std::memcpy(p, &tb, 4); p += 4; }
@@ -994,7 +1054,7 @@ extern "C" int64_t pcgc_oct_encode(const int32_t* xyz, int64_t n, uint8_t* out, 
 }
 
 extern "C" int64_t pcgc_oct_decode_count(const uint8_t* in, int64_t nbytes) {
-    if (nbytes < 10 || std::memcmp(in, kMagic, 4) != 0 || (in[4] != kOctVersion && in[4] != kOctTiled)) return -1;
+    if (nbytes < 10 || std::memcmp(in, kMagic, 4) != 0 || (in[4] != kOctVersion && in[4] != kOctTiled && in[4] != kOctVersion1 && in[4] != kOctTiled1)) return -1;
     uint32_t n32; std::memcpy(&n32, in + 6, 4);
     return (int64_t)n32;
 }
@@ -1006,9 +1066,10 @@ int oct_decode_leaves(const uint8_t* in, int64_t nbytes, int64_t n, std::vector<
     const int depth = in[5];
     if (depth < 1 || depth > 21) { pcgc_set_error("oct_decode: bad depth %d", depth); return -1; }
     leaves.clear();
-    if (in[4] == kOctVersion) {
+    const bool m1 = in[4] == kOctVersion1 || in[4] == kOctTiled1;                  // model 1: mixed prior + fast start (versions 4 / 5)
+    if (in[4] == kOctVersion || in[4] == kOctVersion1) {
         std::vector<uint64_t> root; if (n > 0) root.push_back(0);
-        if (oct_decode_part(in + 10, nbytes - 10, root, 0, depth, depth, n, leaves)) { pcgc_set_error("oct_decode: corrupt or truncated stream (line %d)", __LINE__); return -2; }
+        if (oct_decode_part(in + 10, nbytes - 10, root, 0, depth, depth, n, leaves, m1 ? &oct_prior_mixed() : nullptr, m1)) { pcgc_set_error("oct_decode: corrupt or truncated stream (line %d)", __LINE__); return -2; }
     } else {
         if (nbytes < 16) { pcgc_set_error("oct_decode: corrupt or truncated stream (line %d)", __LINE__); return -2; }
         const int d = in[10], G = in[11];
@@ -1016,8 +1077,8 @@ int oct_decode_leaves(const uint8_t* in, int64_t nbytes, int64_t n, std::vector<
         const int64_t table = 16, payload = table + 12 * (int64_t)G;
         if (d < 1 || d >= depth || G < 1 || payload + (int64_t)top_bytes > nbytes) { pcgc_set_error("oct_decode: corrupt or truncated stream (line %d)", __LINE__); return -2; }
         std::vector<uint64_t> split_nodes, root(1, 0);
-        const std::vector<uint16_t>& prior = oct_prior();
-        if (oct_decode_part(in + payload, top_bytes, root, 0, d, d, n, split_nodes, &prior)) { pcgc_set_error("oct_decode: corrupt or truncated stream (line %d)", __LINE__); return -2; }      // (the top is a tree of depth d of its own)
+        const std::vector<uint16_t>& prior = m1 ? oct_prior_mixed() : oct_prior();
+        if (oct_decode_part(in + payload, top_bytes, root, 0, d, d, n, split_nodes, &prior, m1)) { pcgc_set_error("oct_decode: corrupt or truncated stream (line %d)", __LINE__); return -2; }      // (the top is a tree of depth d of its own)
         std::vector<int64_t> root_at((size_t)G + 1, 0), leaf_at((size_t)G + 1, 0), byte_at((size_t)G + 1, payload + top_bytes);
         for (int g = 0; g < G; ++g) {
             uint32_t rec[3]; std::memcpy(rec, in + table + 12 * g, 12);
@@ -1031,7 +1092,7 @@ int oct_decode_leaves(const uint8_t* in, int64_t nbytes, int64_t n, std::vector<
             const std::vector<uint64_t> roots(split_nodes.begin() + root_at[(size_t)g], split_nodes.begin() + root_at[(size_t)g + 1]);
             const int64_t want = leaf_at[(size_t)g + 1] - leaf_at[(size_t)g];
             std::vector<uint64_t> got;
-            if (oct_decode_part(in + byte_at[(size_t)g], byte_at[(size_t)g + 1] - byte_at[(size_t)g], roots, d, depth, depth, want, got, &prior) || (int64_t)got.size() != want) { status[(size_t)g] = -2; return; }
+            if (oct_decode_part(in + byte_at[(size_t)g], byte_at[(size_t)g + 1] - byte_at[(size_t)g], roots, d, depth, depth, want, got, &prior, m1) || (int64_t)got.size() != want) { status[(size_t)g] = -2; return; }
             std::memcpy(leaves.data() + leaf_at[(size_t)g], got.data(), (size_t)want * sizeof(uint64_t));
         };
         const int threads = rc_threads();

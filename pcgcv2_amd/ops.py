@@ -1658,6 +1658,11 @@ def set_oct_tiled(on):
     check(lib().pcgc_set_oct_tiled(int(on)), 'set_oct_tiled')
 
 
+def set_oct_model(model):
+    """context model of the octree ENCODER: 1 = stream versions 4 / 5 (mixed-shape prior, fast start; default), 0 = versions 2 / 3"""
+    check(lib().pcgc_set_oct_model(int(model)), 'set_oct_model')
+
+
 def oct_encode(xyz):
     xyz = _np(xyz, np.int32)
     if xyz.ndim != 2 or xyz.shape[1] != 3:

@@ -261,28 +261,46 @@ def test_octree_codec_roundtrip(case):
     np.testing.assert_array_equal(key(back), key(pts))
     if case == 'shell':
         bits_per_point = 8 * len(data) / len(pts)
-        assert bits_per_point < 2.1, bits_per_point              # neighbour-context model: 1.88 bit/pt here, 1.47 on the vox10 frame
+        assert bits_per_point < 1.6, bits_per_point              # neighbour contexts from the mixed-shape prior: 1.45 bit/pt here (1.88 from p = 1/2), 1.26 on the vox10 frame's level
 
 
 def test_octree_stream_bytes_are_pinned():
     """The `_C.bin` container is a FORMAT: files written by one build must decode with the next.  The streams of the bench frame's
-    stride-8 level (version 2 = one stream, version 3 = groups of subtrees) are pinned by hash — a faster coder (round 3: Morton-space
-    neighbour steps, radix sort, per-thread occupancy buffers) must reproduce them bit for bit."""
+    stride-8 level are pinned by hash per version: 2 = one stream / 3 = groups of subtrees (round 3: p = 1/2 / sphere-trained prior; written
+    on request, pcgc_set_oct_model(0)), 4 / 5 = the same layouts with context model 1 (round 5: mixed-shape prior + fast start; the
+    default).  A faster coder must reproduce them bit for bit; the decoder reads all four."""
     import hashlib
     pts = np.unique(synthetic.shell('shell10').numpy() // 8, axis=0).astype(np.int32)
-    want = {0: (3434, 2, '7ff1c2c56af7cd67446d0d0aae2b0752effeb22291bac33a3fc289364b1bfb35'),
-            1: (3949, 3, '43d8e8e41bcdbf50c0573deb0f7b228ae004a9bed2e1c9bba9f25e2f237870db')}
+    small_pts = np.unique(synthetic.shell('shell9').numpy() // 8, axis=0).astype(np.int32)      # below 8192 points: always one stream
+    want = {(0, 0): (3434, 2, '7ff1c2c56af7cd67446d0d0aae2b0752effeb22291bac33a3fc289364b1bfb35'),
+            (0, 1): (3949, 3, '43d8e8e41bcdbf50c0573deb0f7b228ae004a9bed2e1c9bba9f25e2f237870db'),
+            (1, 0): (2952, 4, 'bbc009f395b7744422b16705f51788445e42d190b7ef2b77936e712173d8f118'),
+            (1, 1): (3580, 5, '11a722af42a253f990abeca36aba826df0df00836aadc06d57ecda01a88d1328')}
+    small_want = {0: (1076, 2, '9e803865eb61dcd08fb477e287cf146577effc8ebbc111a9ddbed875aeb5ae64'),
+                  1: (830, 4, 'b0d8cbb443d365a693e92fc08cbddeef654e41992c5f790d27f988a06ebaf95e')}
+    key = lambda a: a[np.lexsort((a[:, 0], a[:, 1], a[:, 2]))]
+    streams = []
     try:
-        for tiled, (size, version, digest) in want.items():
+        for (model, tiled), (size, version, digest) in want.items():
+            ops.set_oct_model(model)
             ops.set_oct_tiled(tiled)
             data = ops.oct_encode(pts)
             assert (len(data), data[4]) == (size, version)
             assert hashlib.sha256(data).hexdigest() == digest
+            streams.append(data)
+        for model, (size, version, digest) in small_want.items():
+            ops.set_oct_model(model)
+            ops.set_oct_tiled(1)
+            small = ops.oct_encode(small_pts)
+            assert (len(small), small[4]) == (size, version)
+            assert hashlib.sha256(small).hexdigest() == digest
+            np.testing.assert_array_equal(key(ops.oct_decode(small)), key(small_pts))
     finally:
         ops.set_oct_tiled(1)
-    small = ops.oct_encode(np.unique(synthetic.shell('shell9').numpy() // 8, axis=0).astype(np.int32))       # below 8192 points: version 2
-    assert (len(small), small[4]) == (1076, 2)
-    assert hashlib.sha256(small).hexdigest() == '9e803865eb61dcd08fb477e287cf146577effc8ebbc111a9ddbed875aeb5ae64'
+        ops.set_oct_model(1)
+    for data in streams:                                         # whatever the encoder is set to, the decoder reads every version
+        np.testing.assert_array_equal(key(ops.oct_decode(data)), key(pts))
+    assert 8 * len(streams[3]) / len(pts) < 1.55 and 8 * len(streams[2]) / len(pts) < 1.30      # model 1: 1.53 (groups) / 1.26 (one stream) bit per point
 
 
 @pytest.mark.parametrize('groups', [0, 1, 3, 12])
@@ -290,25 +308,27 @@ def test_octree_codec_groups_of_subtrees(groups):
     """Stream version 3 (independent groups of subtrees, coded and decoded side by side) against version 2 on the stride-8 level
     of the vox10 bench frame: same voxels, in the same (Morton) order, for every group count and thread count."""
     pts = np.unique(synthetic.shell('shell10').numpy() // 8, axis=0).astype(np.int32)              # 18 732 voxels
-    ops.set_oct_tiled(0)
-    plain = ops.oct_encode(pts)
     try:
-        ops.set_oct_tiled(groups)
-        data = ops.oct_encode(pts)
-        assert data[4] == (2 if groups == 0 else 3)
-        for threads in (1, 4):
-            ops.set_rc_threads(threads)
-            np.testing.assert_array_equal(ops.oct_decode(data), ops.oct_decode(plain))
-        assert 8 * len(data) / len(pts) < (1.5 if groups == 0 else 2.0)
-        if groups:                                                 # damage in one group is detected, not decoded into garbage silently
-            bad = bytearray(data); bad[len(bad) // 2] ^= 0x55; bad[len(bad) // 2 + 1] ^= 0xAA
-            try:
-                back = ops.oct_decode(bytes(bad))
-                assert len(back) == len(pts)
-            except PcgcError:
-                pass
+        for model in (0, 1):                                       # the round-3 streams (versions 2 / 3) and the round-5 ones (4 / 5)
+            ops.set_oct_model(model)
+            ops.set_oct_tiled(0)
+            plain = ops.oct_encode(pts)
+            ops.set_oct_tiled(groups)
+            data = ops.oct_encode(pts)
+            assert data[4] == ((2 if groups == 0 else 3) if model == 0 else (4 if groups == 0 else 5))
+            for threads in (1, 4):
+                ops.set_rc_threads(threads)
+                np.testing.assert_array_equal(ops.oct_decode(data), ops.oct_decode(plain))
+            assert 8 * len(data) / len(pts) < (1.5 if groups == 0 else 2.0)
+            if groups:                                             # damage in one group is detected, not decoded into garbage silently
+                bad = bytearray(data); bad[len(bad) // 2] ^= 0x55; bad[len(bad) // 2 + 1] ^= 0xAA
+                try:
+                    back = ops.oct_decode(bytes(bad))
+                    assert len(back) == len(pts)
+                except PcgcError:
+                    pass
     finally:
-        ops.set_oct_tiled(1); ops.set_oct_tiled(8); ops.set_rc_threads(0)
+        ops.set_oct_tiled(1); ops.set_oct_tiled(8); ops.set_rc_threads(0); ops.set_oct_model(1)
 
 
 def test_octree_rejects_foreign_stream():

@@ -43,6 +43,9 @@ print(f'{cloud}: {n} rows ({n_p} parents)')
 for _ in range(200): pass_a(); pass_b()
 torch.cuda.synchronize()
 print(f'packed-N (product)          pass A {med(pass_a)[0]:7.1f} us   pass B {med(pass_b)[0]:7.1f} us')
+Wc = (torch.randn((27, C, 1), generator=g) * 0.05).to(dev); bc = torch.randn((1, 1), generator=g).to(dev)
+tcq = ops.child_q4_cls_table(Wc); oc = torch.empty((n, 1), device=dev)
+ref_cls = ops.conv_child(pk, x, ops.child_cls_table(Wc), bc, 1)
 for nm in names:
     L = ctypes.CDLL(os.path.join(R, f'tools/ubench/_bin/libq4_{nm}.so'))
     fn = L.pcgc_irn_child_q4
@@ -53,6 +56,12 @@ for nm in names:
     def pass_qb():
         rc = fn(pk.data_ptr(), n_p, C, 2, t2.data_ptr(), C // 2, tabs[1].data_ptr(), tabs[1].numel() * 4, P[3], P[7], P[9], x.data_ptr(), C, out2.data_ptr(), C, s)
         assert rc == 0, rc
+    fc = L.pcgc_cls_child_q4; fc.restype, fc.argtypes = ci, [vp, i64, vp, ci, ci, vp, i64, vp, vp, vp]
+    def cls_q():
+        rc = fc(pk.data_ptr(), n_p, x.data_ptr(), C, C, tcq.data_ptr(), tcq.numel() * 4, bc.data_ptr(), oc.data_ptr(), s)
+        assert rc == 0, rc
+    cls_q()
     t2.fill_(-7.0); out2.fill_(-7.0); pass_q(); pass_qb(); torch.cuda.synchronize()
     m, lo = med(pass_q); mb, lob = med(pass_qb)
-    print(f'quad-block {nm:16s} pass A {m:7.1f} us (min {lo:6.1f})   pass B (T2 gather) {mb:7.1f} us   block == packed-N: {torch.equal(out, out2)}', flush=True)
+    mc, _ = med(cls_q)
+    print(f'quad-block {nm:16s} pass A {m:7.1f} us (min {lo:6.1f})   pass B (T2 gather) {mb:7.1f} us   block == packed-N: {torch.equal(out, out2)}   cls {mc:7.1f} us == {torch.equal(ref_cls, oc)}', flush=True)

@@ -13,6 +13,7 @@ extern "C" int pcgc_set_rc_threads(int);
 extern "C" int64_t pcgc_oct_encode(const int32_t* xyz, int64_t n, uint8_t* out, int64_t cap);
 extern "C" int pcgc_oct_decode(const uint8_t* in, int64_t nbytes, int32_t* xyz, int64_t n);
 void pcgc_set_error(const char* fmt, ...) { }
+extern "C" const char* pcgc_last_error(void) { return ""; }                      // (coords.hip in the library)
 int main() {
     std::mt19937 rng(5);
     int bad = 0;

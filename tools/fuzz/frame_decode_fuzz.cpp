@@ -9,6 +9,7 @@
 #include <fstream>
 #include "../../include/pcgc_hip.h"
 void pcgc_set_error(const char* fmt, ...) { }
+extern "C" const char* pcgc_last_error(void) { return ""; }                      // (coords.hip in the library)
 static int table_fn(const float* params, int C, float min_v, float max_v, uint16_t* t, float* cdf) {
     if (min_v != std::floor(min_v) || max_v != std::floor(max_v)) return -2;
     const int L = (int)(max_v - min_v) + 1, Lp = L + 1;

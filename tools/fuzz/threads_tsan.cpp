@@ -9,6 +9,7 @@
 #include <thread>
 #include "../../include/pcgc_hip.h"
 void pcgc_set_error(const char* fmt, ...) { }
+extern "C" const char* pcgc_last_error(void) { return ""; }                      // (coords.hip in the library)
 static int table_fn(const float* params, int C, float min_v, float max_v, uint16_t* t, float* cdf) {
     const int L = (int)(max_v - min_v) + 1, Lp = L + 1;
     for (int c = 0; c < C; ++c) {
