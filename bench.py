@@ -634,7 +634,7 @@ def attach_pmc_traffic(roof):
     cands = []
     for e in table.get('kernels', []):
         name = e['kernel'].replace('(anonymous namespace)::', '').replace('void ', '')
-        if name.startswith(short + ',') or name.startswith(short + '>'):
+        if name.startswith(short + ',') or name.startswith(short + '>') or name.startswith(short + '<'):
             cands.append(e)
     # the same template may run on several levels: take the launch geometry closest to this level (grid threads ~ 1-2 x rows;
     # the persistent children-level kernels have one entry each)

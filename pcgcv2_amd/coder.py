@@ -240,8 +240,9 @@ class Coder():
             return x
         # one sort per cloud, not per encode: an R-D sweep (test.py) encodes the same tensor once per rate, and the sorted level carries the
         # cached pyramid and kernel maps every rate reuses
-        key = (id(x.cmap), x.F.data_ptr(), x.F._version, tuple(x.F.shape))
-        memo = x.__dict__.get('_ingested')
+        # (kept on the coordinate map, so that CoordMap.drop_caches() — "no geometry survives" — drops it with everything else)
+        key = (x.F.data_ptr(), x.F._version, tuple(x.F.shape))
+        memo = x.cmap.__dict__.get('_ingested')
         if memo is not None and memo[0] == key:
             return memo[1]
         order = ops.sort_zyx(x.C, batch_major=True)
@@ -254,7 +255,7 @@ class Coder():
             y.unit_features, y._unit_stamp = True, x._unit_stamp
         else:
             y = SparseTensor(ops.gather_feats(x.F, order), coordinate_map=cmap)
-        x.__dict__['_ingested'] = (key, y)
+        x.cmap.__dict__['_ingested'] = (key, y)
         return y
 
     def _encode(self, x, postfix):

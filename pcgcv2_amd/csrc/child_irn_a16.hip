@@ -3,10 +3,8 @@
 
 #define DEF_IRN_LAUNCH(NAME) int NAME(int nw, const int32_t* parent_nbr, int64_t n_parent, const float* in, int in_ld, const float* table, \
                                       int table_bytes, const IrnEpi& ep, hipStream_t s)
-DEF_IRN_LAUNCH(pcgc_irn_child_a16_mt2);
 // <C, waves per group, ring depth>; the 52 KB table leaves room for shallow rings only
 DEF_IRN_LAUNCH(pcgc_irn_child_a16) {
-    if (nw >= 200) return pcgc_irn_child_a16_mt2(nw, parent_nbr, n_parent, in, in_ld, table, table_bytes, ep, s);
     return (nw == 4) ? launch_child_irn_a<16, 4, 4>(parent_nbr, n_parent, in, in_ld, table, table_bytes, ep, s)
                      : launch_child_irn_a<16, 16, 4>(parent_nbr, n_parent, in, in_ld, table, table_bytes, ep, s);
 }

@@ -876,7 +876,7 @@ def cls_child_q4(parent_nbr, x, table, bias):
     key = ('child_conv', Cin, 1, n)
     prof = PROFILE.want(key)
     if prof:
-        e0, e1 = PROFILE.bracket(key, f'k_child_q4<cls> (k3 {Cin}->1 on a children level, parent-map halo gather + quad-block 4x4x1 fp32 MFMA)', n,
+        e0, e1 = PROFILE.bracket(key, f'k_child_q4<1, 8, 2> (k3 {Cin}->1 on a children level, parent-map halo gather + quad-block 4x4x1 fp32 MFMA)', n,
                                  lambda P, a=Cin: P * a * 4 + P * 8 + n * 4, lambda P, a=Cin: 2 * P * a,
                                  compulsory=n * Cin * 4 + 27 * n_p * 4 + n * 4, mfma_issued=((n_p + 63) // 64) * 96 * 16 * 512)
         e0.record()
@@ -1026,7 +1026,7 @@ def irn_block_child(parent_nbr, x, params, tables, q4_table=None):
     if q4:
         # per 16 parents, in units of 2048 flops: 224 groups x 16 4x4x1 instructions (512 flops each) per 64 parents + the 128 transposing ones per 128
         per_tile = ((216 + 8) * 16 // 4 // 4 + 128 // 8 // 4, per_tile[1])
-        names = ('k_child_q4_irn_a16', 'k_child_irn_b<16> (T2 gather)')
+        names = ('k_child_q4<0, 8, 2>', 'k_child_irn_b<16>')            # (pass B: the T2-gather instantiation of the packed-N kernel)
     forms = _irn_pass_formulas(n, C, 27 * n_p * 4, names)
     if q4:      # pass A in quad-block form writes t in its T2 layout; pass B is the packed-N kernel with T2 gather addresses (csrc/child_q4.hip)
         calls = (lambda: lib().pcgc_irn_child_q4(_p(parent_nbr), n_p, C, 1, _p(x), _ld(x), _p(q4_table), q4_table.numel() * 4, P[1], P[5], None,

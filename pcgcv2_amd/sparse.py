@@ -160,6 +160,7 @@ class CoordMap:
 
     def drop_caches(self):
         self._table = self._k3 = self._down = self._parent_of = self._prepared_up = None
+        self.__dict__.pop('_ingested', None)                   # (coder.Coder._ingest: the sorted copy of an unordered cloud carries caches of its own)
 
 
 def dedup(coords, feats, stride):

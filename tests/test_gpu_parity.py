@@ -1296,8 +1296,7 @@ def test_inception_resnet_child_bit_exact(name, prune, C):
     want = orc.inception_resnet(sd, 'b', orc.Level(kc, 1), x)
     params = [p for m in (blk.conv0_0, blk.conv0_1, blk.conv1_0, blk.conv1_1, blk.conv1_2) for p in (m.kernel, m.bias)]
     tables = ops.child_irn_tables(params)
-    # (316: pass A with TWO M tiles per wave — 32 parents share every fragment read and wait; C = 16 only, not the product path)
-    for nw, d in ((0, 0), (4, 0)) + (((316, 0),) if C == 16 else ()):
+    for nw, d in ((0, 0), (4, 0)):
         ops.set_child_tuning(nw, d)
         try:
             if C == 64:
@@ -1362,7 +1361,7 @@ def test_quad_block_switch_reaches_both_kernel_pairs():
         finally:
             ops.CHILD_Q4 = old
             ops.PROFILE.reset(enabled=False)
-        assert ('k_child_q4_irn_a16' in names) == on, names
+        assert any(nm.startswith('k_child_q4<0') for nm in names) == on, names
     assert torch.equal(outs[True], outs[False])
 
 

@@ -15,7 +15,7 @@ from pcgcv2_amd.autoencoder import InceptionResNet
 dev = torch.device('cuda:0')
 L = ctypes.CDLL(LIB_PATH)
 C = 16
-codes = [int(a) for a in sys.argv[1:]] or [0, 316]
+codes = [int(a) for a in sys.argv[1:]] or [0]
 
 
 def read(fn):
