@@ -36,7 +36,9 @@ class InceptionResNet(torch.nn.Module):
             elif fam == 'child64':       # children level: both passes through the PARENT level's map, packed-N fp32 MFMA (csrc/child_kernels.h)
                 y = ops.irn_block_child64(x.cmap.origin[1].k3, x.F, params, self._tables('child', ops.child_irn_tables, params))
             elif fam == 'child':
-                q4 = self._tables('q4', ops.child_q4_tables, params) if (c == 16 and ops.CHILD_Q4) else None    # pass A in quad-block form
+                # the stride-1 level of a vox10+ frame: pass A in quad-block form (csrc/child_q4.h; smaller levels do not fill its wave slots)
+                big = x.F.shape[0] >= 8 * ops.CHILD_Q4_MIN_PARENTS
+                q4 = self._tables('q4', ops.child_q4_tables, params) if (c == 16 and ops.CHILD_Q4 and big) else None
                 y = ops.irn_block_child(x.cmap.origin[1].k3, x.F, params, self._tables('child', ops.child_irn_tables, params), q4_table=q4)
             elif fam == 'rows32':        # plain level, C = 32: the rows kernels instead of the VALU passes
                 y = ops.irn_block_rows32(x.cmap.k3, x.F, params, self._tables('rows32', ops.rows_irn32_tables, params))

@@ -47,7 +47,7 @@ constexpr int Q4_PASS_A = 0, Q4_CLS = 1;
 // KIND = Q4_CLS (k3 conv 16 -> 1, the classification head): a group = (cell, z half h): the block's four columns are the children
 // 4 h + {0..3}, column s multiplying by kernel[k(cell, 4 h + s)][ci] — zero where that child does not reach the cell (host-built table, one
 // fragment per group) — into acc[h]; `child` = h, `k` = the group's number (= its fragment).
-template <int KIND, int MT>
+template <int KIND, int MT, int D = 2>
 constexpr Q4Sched q4_sched() {
     Q4Sched S{};
     for (int c = 0; c < 64; ++c) {
@@ -66,15 +66,14 @@ constexpr Q4Sched q4_sched() {
         S.g[n0].first = true;
         S.g[S.n - 1].last = true;
     }
-    // VMEM instruction order: [gather 0][gather 1] then per group: (last: wait for cell + 1) ... (first: gather cell + 2) (stores of group n - 1)
+    // VMEM instruction order: [gathers 0 .. D - 1] then per group: (last: wait for cell + 1) ... (first: gather cell + D) (stores of group n - 1)
     int ops = 0, pending = 0;
-    int gather_end[66] = {};
-    ops += 4 * MT; gather_end[0] = ops;
-    ops += 4 * MT; gather_end[1] = ops;
+    int gather_end[64 + 16] = {};
+    for (int c = 0; c < D; ++c) { ops += 4 * MT; gather_end[c] = ops; }
     for (int n = 0; n < S.n; ++n) {
         const Q4Group& G = S.g[n];
         if (G.last && G.cell + 1 < 64) S.vm_wait[n] = ops - gather_end[G.cell + 1];
-        if (G.first && G.cell + 2 < 64) { ops += 4 * MT; gather_end[G.cell + 2] = ops; }
+        if (G.first && G.cell + D < 64) { ops += 4 * MT; gather_end[G.cell + D] = ops; }
         S.pend[n] = pending;
         ops += pending;
         pending = (KIND == Q4_PASS_A && ((G.kind == 1) || G.fin) && (G.child & 3) == 3) ? 4 * MT : 0;      // a flush unit: 4 parents-steps x MT stores
@@ -97,17 +96,17 @@ __device__ __forceinline__ void q4_store(const f32x4& v, const __amdgpu_buffer_r
 // Classification head at C = 16 (KIND = Q4_CLS; autoencoder.py:228-234 conv2_cls):  out[8 p + j] = conv(x)[.., 0] + bias, dense [8 n_p, 1].
 // table: one fragment per (cell, z half) group in schedule order: [s = 0..3][ci = 0..15] = kernel[k(cell, 4 h + s)][ci][0] or 0
 // (ops.child_q4_cls_table).  The lane holds its parent's eight logits (two accumulators): 32 contiguous bytes per lane, 2 KB per store pair.
-template <int KIND, int NW, int MT>
+template <int KIND, int NW, int MT, int D = 2>
 __global__ void __launch_bounds__(NW * 64)
 k_child_q4(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in, int in_ld,
            const float* __restrict__ table, int table_bytes, IrnEpi ep) {
     constexpr int TP = 64 * MT, SLOT_F4 = MT * 256;            // parents per tile; float4 per ring slot (MT x 4 KB)
-    constexpr Q4Sched S = q4_sched<KIND, MT>();
+    constexpr Q4Sched S = q4_sched<KIND, MT, D>();
     constexpr int NACC = KIND == Q4_CLS ? 2 : 8, OUT_ROW_BYTES = KIND == Q4_CLS ? 4 : 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float4* ring = (float4*)(lds_raw + table_bytes) + wave * (2 * SLOT_F4);
+    float4* ring = (float4*)(lds_raw + table_bytes) + wave * (D * SLOT_F4);
     child_stage_table<NW>(table, table_bytes, lds_raw);
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(8 * n_p * in_ld * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)ep.out, 0, (int)(8 * n_p * OUT_ROW_BYTES), 0x00020000);
@@ -176,7 +175,7 @@ k_child_q4(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restric
         f32x4 a[MT][4], b[2][4];
 
         auto gather = [&](auto ic) {
-            constexpr int c = decltype(ic)::value, kp = cell_kp(c), ch = cell_child(c), slot = c & 1;
+            constexpr int c = decltype(ic)::value, kp = cell_kp(c), ch = cell_child(c), slot = c % D;
             const unsigned cell_off = (unsigned)ch * row_bytes + lane_off;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -194,7 +193,7 @@ k_child_q4(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restric
             asm volatile("" ::: "memory");
         };
         auto load_a = [&](auto ic, auto ie) {                  // quarter e (channels 4 e .. 4 e + 3) of the lane's row of cell c, every M tile
-            constexpr int c = decltype(ic)::value, e = decltype(ie)::value, slot = c & 1;
+            constexpr int c = decltype(ic)::value, e = decltype(ie)::value, slot = c % D;
             static_for<0, MT>([&](auto im) {
                 constexpr int m = decltype(im)::value;
                 a[m][e] = lds_ld128_off<(slot * MT + m) * 4096>(a_row ^ (unsigned)(e << 4));
@@ -259,10 +258,8 @@ k_child_q4(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restric
         };
 
         using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        gather(I0{});
-        gather(I1{});
-        wait_vmcnt<4 * MT>();
+        static_for<0, D>(gather);
+        wait_vmcnt<4 * MT * (D - 1)>();
         load_b(I0{}, I0{});
         static_for<0, 4>([&](auto ie) { load_a(I0{}, ie); });
 
@@ -303,7 +300,7 @@ k_child_q4(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restric
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (G.first && G.cell + 2 < 64) gather(std::integral_constant<int, (G.cell + 2 < 64) ? G.cell + 2 : 0>{});   // this cell's slot has been read
+            if constexpr (G.first && G.cell + D < 64) gather(std::integral_constant<int, (G.cell + D < 64) ? G.cell + D : 0>{});   // this cell's slot has been read
             if constexpr (KIND == Q4_PASS_A && n > 0) epi(std::integral_constant<int, (n > 0 ? n - 1 : 0)>{});
         });
         if constexpr (KIND == Q4_PASS_A) {
@@ -333,11 +330,11 @@ k_child_q4(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restric
     }
 }
 
-template <int KIND, int NW, int MT>
+template <int KIND, int NW, int MT, int D = 2>
 int launch_child_q4(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
                     const IrnEpi& ep, hipStream_t s) {
-    const size_t lds = (size_t)table_bytes + (size_t)NW * (2 * MT * 4096);
-    auto kern = k_child_q4<KIND, NW, MT>;
+    const size_t lds = (size_t)table_bytes + (size_t)NW * (D * MT * 4096);
+    auto kern = k_child_q4<KIND, NW, MT, D>;
     static ChildLdsGrant granted;
     if (int rc = child_lds_limit(kern, lds, granted)) return rc;
     const int64_t units = (n_p + 64 * MT - 1) / (64 * MT);

@@ -25,7 +25,7 @@ extern "C" int pcgc_irn_child_q4(const int32_t* parent_nbr, int64_t n_parent, in
     } else {
         PCGC_REQUIRE(in_ld == C / 2, "pass B reads the dense [rows, C/2] tensor of pass A");
         PCGC_REQUIRE(table_bytes == 85 * 64 * 4, "pass B table size");
-        rc = launch_child_irn_b<16, 16, 8, 1, true>(parent_nbr, n_parent, in, in_ld, table, (int)table_bytes, ep, s);
+        rc = launch_child_irn_b<16, 16, 8, 1, true>(parent_nbr, n_parent, in, in_ld, table, (int)table_bytes, ep, s);   // packed-N pass B with T2 gather addresses
     }
     if (rc) return rc;
     PCGC_CHECK_LAUNCH("irn_child_q4");

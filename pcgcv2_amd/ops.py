@@ -1005,6 +1005,12 @@ def child_q4_tables(params):
                       W10.detach().reshape(C, C // 4).t().reshape(-1)]).contiguous()
 
 
+# the quad-block kernels are one 128-parent tile per wave on 2 048 wave slots: below ~1 600 tiles the slots are not filled twice and a lone
+# wave's tile time (78 us at two cells of gather in flight) is what the launch takes — 64 k parents: 78 us against the packed-N pass A's 37,
+# 225 k: 97 against 100, 256 k: 97 against 114 (tools/child_q4_variants.py) — so the module path takes them from this many parents on
+CHILD_Q4_MIN_PARENTS = 200_000
+
+
 def irn_block_child(parent_nbr, x, params, tables, q4_table=None):
     """Fused InceptionResNet on a children level through the parent map (C = 16, 32); bit-identical to irn_block."""
     _f32(x, 'x')

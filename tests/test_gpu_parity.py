@@ -1351,15 +1351,16 @@ def test_quad_block_switch_reaches_both_kernel_pairs():
     x = SparseTensor(_t(rng.standard_normal((len(kc), 16)).astype(np.float32)), coordinate_map=kids)
     outs = {}
     for on in (True, False):
-        old = ops.CHILD_Q4
+        old, old_min = ops.CHILD_Q4, ops.CHILD_Q4_MIN_PARENTS
         ops.CHILD_Q4 = on
+        ops.CHILD_Q4_MIN_PARENTS = 0                          # (the module path takes the quad-block kernels from 200 k parents on)
         try:
             ops.PROFILE.reset(enabled=True)
             outs[on] = blk(x).F.clone()
             torch.cuda.synchronize()
             names = [d['kernel'].split(' ')[0] for d in ops.PROFILE.detail()]
         finally:
-            ops.CHILD_Q4 = old
+            ops.CHILD_Q4, ops.CHILD_Q4_MIN_PARENTS = old, old_min
             ops.PROFILE.reset(enabled=False)
         assert any(nm.startswith('k_child_q4<0') for nm in names) == on, names
     assert torch.equal(outs[True], outs[False])

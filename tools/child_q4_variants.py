@@ -53,8 +53,8 @@ for nm in names:
     def pass_q(): 
         rc = fn(pk.data_ptr(), n_p, C, 1, x.data_ptr(), C, tq.data_ptr(), tq.numel() * 4, P[1], P[5], None, None, 0, t2.data_ptr(), C // 2, s)
         assert rc == 0, rc
-    def pass_qb():
-        rc = fn(pk.data_ptr(), n_p, C, 2, t2.data_ptr(), C // 2, tabs[1].data_ptr(), tabs[1].numel() * 4, P[3], P[7], P[9], x.data_ptr(), C, out2.data_ptr(), C, s)
+    def pass_qb(tab=tabs[1]):
+        rc = fn(pk.data_ptr(), n_p, C, 2, t2.data_ptr(), C // 2, tab.data_ptr(), tab.numel() * 4, P[3], P[7], P[9], x.data_ptr(), C, out2.data_ptr(), C, s)
         assert rc == 0, rc
     fc = L.pcgc_cls_child_q4; fc.restype, fc.argtypes = ci, [vp, i64, vp, ci, ci, vp, i64, vp, vp, vp]
     def cls_q():
