@@ -30,6 +30,11 @@ __host__ __device__ constexpr int pk_lds(int R, int NW) { return pk_acc_bytes(R)
 
 // NW = 4 or 8 waves: wave w multiplies against column tile w & 3; with eight waves the packed tiles of an offset alternate between the two
 // waves of a column tile (group = w >> 2) — different rows inside an offset, and the barriers between offsets order the rest
+// Operand roles (round 5): A = the weight fragment, B = the gathered rows, so that D = [column][row]: lane (row slot mi, quarter mq) holds
+// the FOUR CONSECUTIVE columns 4 mq .. 4 mq + 3 of its row, and a packed tile's C / D traffic is one ds_read_b128 + one ds_write_b128 per
+// lane (2 LDS instructions per 16 MFMAs, one accumulator row per lane; rows start 4 banks apart: contiguous row slots are conflict-free).
+// Round 4 had the roles the other way round — four b32 reads and writes to four rows per lane: 289 -> 280 us on the 149 856-row level,
+// 126 -> 117 on the 71 216-row one, same bits (fma(a, b, c) = fma(b, a, c); profiles/r05_conv_packed_roles.txt).
 template <int NW>
 __global__ void __launch_bounds__(NW * 64)
 k_conv_packed64(const int32_t* __restrict__ nbr, int64_t n, const float* __restrict__ in, int in_ld, const float* __restrict__ table,
@@ -117,17 +122,13 @@ k_conv_packed64(const int32_t* __restrict__ nbr, int64_t n, const float* __restr
         const float* abase = abuf + (mi * 4) * 4 + mq;
         // two packed tiles at a time: two independent accumulator chains (a dependent fp32 MFMA issues every ~40 cycles, an independent
         // one every 32) and both tiles' LDS reads in flight before the first MFMA
-        auto tile_rows = [&](int i, int (&rows)[4]) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rows[r] = rowl[16 * i + 4 * mq + r];
-        };
+        // C / D of a packed tile: lane (row slot mi, quarter mq) owns columns 4 mq .. 4 mq + 3 of its row — one 16-byte LDS read and write
+        auto cd = [&](int t) { return (f32x4*)(accf + rowl[16 * t + mi] * PK_ACC_LD + 16 * nt + 4 * mq); };
         int i = group;
         for (; i + NG < T_cur; i += 2 * NG) {
-            int rows0[4], rows1[4];
-            tile_rows(i, rows0); tile_rows(i + NG, rows1);
-            f32x4 acc0, acc1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { acc0[r] = accf[rows0[r] * PK_ACC_LD + 16 * nt + mi]; acc1[r] = accf[rows1[r] * PK_ACC_LD + 16 * nt + mi]; }
+            f32x4* const c0 = cd(i);
+            f32x4* const c1 = cd(i + NG);
+            f32x4 acc0 = *c0, acc1 = *c1;
             const float* img0 = abase + i * 1024;
             const float* img1 = abase + (i + NG) * 1024;
 #pragma unroll
@@ -135,37 +136,29 @@ k_conv_packed64(const int32_t* __restrict__ nbr, int64_t n, const float* __restr
                 float a0[4], a1[4];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) { a0[jj] = img0[cb * 256 + (jj ^ f_a) * 4]; a1[jj] = img1[cb * 256 + (jj ^ f_a) * 4]; }
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0], b_cur[cb].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0], b_cur[cb].x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[1], b_cur[cb].y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[1], b_cur[cb].y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[2], b_cur[cb].z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[2], b_cur[cb].z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[3], b_cur[cb].w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[3], b_cur[cb].w, acc1, 0, 0, 0);
-            }
+                const float bw[4] = {b_cur[cb].x, b_cur[cb].y, b_cur[cb].z, b_cur[cb].w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { accf[rows0[r] * PK_ACC_LD + 16 * nt + mi] = acc0[r]; accf[rows1[r] * PK_ACC_LD + 16 * nt + mi] = acc1[r]; }
+                for (int jj = 0; jj < 4; ++jj) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[jj], a0[jj], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[jj], a1[jj], acc1, 0, 0, 0);
+                }
+            }
+            *c0 = acc0; *c1 = acc1;
         }
         if (i < T_cur) {
-            int rows[4];
-            tile_rows(i, rows);
-            f32x4 acc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = accf[rows[r] * PK_ACC_LD + 16 * nt + mi];
+            f32x4* const c = cd(i);
+            f32x4 acc = *c;
             const float* img = abase + i * 1024;
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
                 float a[4];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) a[jj] = img[cb * 256 + (jj ^ f_a) * 4];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b_cur[cb].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b_cur[cb].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b_cur[cb].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b_cur[cb].w, acc, 0, 0, 0);
-            }
+                const float bw[4] = {b_cur[cb].x, b_cur[cb].y, b_cur[cb].z, b_cur[cb].w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) accf[rows[r] * PK_ACC_LD + 16 * nt + mi] = acc[r];
+                for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[jj], a[jj], acc, 0, 0, 0);
+            }
+            *c = acc;
         }
         e0 = e0n; e1 = e1n;
 #pragma unroll

@@ -1278,11 +1278,12 @@ typedef int (*pcgc_table_fn)(const float* params, int C, float min_v, float max_
 namespace {
 // The decode of n_items is about to need its pools: wake their threads now (they spin for the announced work for up to `us`).
 // One item: its two tasks run on the caller + one helper, each with the segment / group pool; more items: one thread per task.
+thread_local bool tl_frame_path = false;               // set by pcgc_frame_decode_begin around its probe
 void prewake_for_decode(int n_items, int threads, int us) {
     if (n_items <= 0) return;
     if (threads <= 0) threads = effective_cpus();
     if (n_items > 1 && threads > 1) { items_pool().prewake(std::min(threads, 2 * n_items) - 1, us); return; }      // (for_items: nested pools idle)
-    if (threads > 1) items_pool().prewake(1, us);
+    if (threads > 1 && !tl_frame_path) items_pool().prewake(1, us);        // (the frame path has its own worker for the second task)
     const int inner = rc_threads();
     if (inner > 1) { segment_pool().prewake(inner - 1, us); octree_pool().prewake(inner - 1, us); }
 }
@@ -1423,9 +1424,96 @@ extern "C" int pcgc_items_probe(int n_items, const char* const* stems, int64_t* 
     return 0;
 }
 
+// The two independent tasks of one item's decode: its coordinate stream (-> xyz: [n, 3] voxels in stream order for coord_layout 0, the sorted
+// coordinate level [n, 4] for coord_layout 1) and its feature stream (-> out [n, C] symbols).  -> 0 or an error code with `err` set.
+namespace {
+int decode_item_coords(const std::string& stem, int i, int64_t n, bool native, int32_t* xyz, int coord_layout, int coord_scale, std::string& err) {
+    StageClock clk;
+    if (native) {
+        std::vector<uint8_t> cb;
+        if (!read_file(stem + "_C.bin", cb)) { err = "cannot read " + stem + "_C.bin"; return -1; }
+        clk.mark("read");
+        if (coord_layout == 0) {
+            if (pcgc_oct_decode(cb.data(), (int64_t)cb.size(), xyz, n) != 0) { err = "corrupt " + stem + "_C.bin"; return -2; }
+            clk.mark("octree");
+        } else {
+            // the coordinate LEVEL the decoder starts from (coder.py:97-102): rows (item, scale x, scale y, scale z) in (z, y, x) order —
+            // sorted here, on the thread that has the voxels in cache, instead of by a dozen launches after an upload
+            static thread_local std::vector<uint64_t> leaves, keys;
+            if (oct_decode_leaves(cb.data(), (int64_t)cb.size(), n, leaves) != 0) { err = "corrupt " + stem + "_C.bin"; return -2; }
+            clk.mark("octree");
+            const int d = cb[5];                                          // bits per coordinate (the tree's depth; checked by the decoder)
+            keys.resize((size_t)n);
+            zyx_keys(leaves.data(), n, d, keys.data());
+            const uint64_t m = (1ull << d) - 1;
+            int32_t* L = xyz;
+            auto row = [&](int64_t r, uint64_t k) {
+                L[4 * r] = i; L[4 * r + 1] = (int32_t)(k & m) * coord_scale;
+                L[4 * r + 2] = (int32_t)((k >> d) & m) * coord_scale; L[4 * r + 3] = (int32_t)(k >> (2 * d)) * coord_scale;
+            };
+            if (3 * d <= 22 && n >= 512) {
+                // two 11-bit radix passes with both histograms from one sweep, the second pass scattering the finished rows
+                static thread_local std::vector<uint64_t> tmp;
+                if (tmp.size() < (size_t)n) tmp.resize((size_t)n);
+                uint32_t c0[2048] = {0}, c1[2048] = {0};
+                for (int64_t r = 0; r < n; ++r) { const uint64_t k = keys[(size_t)r]; ++c0[k & 2047]; ++c1[(k >> 11) & 2047]; }
+                uint32_t a0 = 0, a1 = 0;
+                for (int b = 0; b < 2048; ++b) { const uint32_t x0 = c0[b], x1 = c1[b]; c0[b] = a0; c1[b] = a1; a0 += x0; a1 += x1; }
+                for (int64_t r = 0; r < n; ++r) { const uint64_t k = keys[(size_t)r]; tmp[c0[k & 2047]++] = k; }
+                for (int64_t r = 0; r < n; ++r) { const uint64_t k = tmp[(size_t)r]; row((int64_t)c1[(k >> 11) & 2047]++, k); }
+            } else {
+                sort_codes(keys, 3 * d);
+                for (int64_t r = 0; r < n; ++r) row(r, keys[(size_t)r]);
+            }
+            clk.mark("level");
+        }
+    }
+    clk.done("decode coords", i);
+    return 0;
+}
+int decode_item_features(const std::string& stem, int i, int64_t n, int C, float min_v, float max_v, const float* eb_params, pcgc_table_fn table_fn,
+                         int use_sidecar, int16_t* out, std::string& err) {
+    StageClock clk;
+    if (n == 0) return 0;
+    // (a header's range must be two integral values, as compress() writes them: the table callback sizes its output from the same
+    //  two numbers in ITS arithmetic — a fractional bound from a damaged `_H.bin` made it write one row entry past this allocation)
+    if (!(min_v <= max_v) || min_v != std::floor(min_v) || max_v != std::floor(max_v) || max_v - min_v > 65000.0f) { err = "symbol range"; return -2; }
+    const int L = (int)(max_v - min_v) + 1, Lp = L + 1;
+    std::shared_ptr<const std::vector<uint16_t>> tptr;
+    uint32_t mine = 0;
+    if (cached_table(table_fn, eb_params, C, min_v, max_v, tptr, mine) != 0) { err = "CDF table evaluation failed"; return -1; }
+    const std::vector<uint16_t>& table = *tptr;
+    clk.mark("table");
+    std::vector<uint8_t> stream, side;
+    if (!read_file(stem + "_F.bin", stream)) { err = "cannot read " + stem + "_F.bin"; return -1; }
+    clk.mark("read");
+    int n_ck = 0; const uint32_t* ck = nullptr;
+    if (use_sidecar && read_file(stem + "_F.idx", side) && side.size() >= kSidecarHead && std::memcmp(side.data(), "PCG2", 4) == 0) {
+        const uint32_t nbytes = get32(side.data() + 4), scrc = get32(side.data() + 8), count = get32(side.data() + 12), tcrc = get32(side.data() + 16), self = get32(side.data() + 20);
+        uLong c = crc32(0L, side.data(), 20);
+        if (side.size() > kSidecarHead) c = crc32(c, side.data() + kSidecarHead, (uInt)(side.size() - kSidecarHead));
+        if (nbytes == stream.size() && side.size() == kSidecarHead + (size_t)count * 4 * PCGC_RC_CKPT_WORDS && self == (uint32_t)c &&
+            scrc == pcgc_crc32(0, stream.data(), (int64_t)stream.size())) {
+            if (tcrc != mine) {
+                char b[160]; std::snprintf(b, sizeof b, "the CDF table derived on this host (CRC-32 %08x) is not the one the stream was coded with (%08x)", mine, tcrc);
+                err = b; return -5;
+            }
+            if (count >= 2) { n_ck = (int)count; ck = (const uint32_t*)(side.data() + kSidecarHead); }
+        }
+    }
+    clk.mark("sidecar");
+        int rc;
+    if (n_ck) rc = pcgc_rc_decode_indexed(table.data(), C, Lp, stream.data(), (int64_t)stream.size(), out, n * C, n_ck, ck);
+    else rc = pcgc_rc_decode(table.data(), C, Lp, stream.data(), (int64_t)stream.size(), out, n * C);
+    if (rc != 0) { err = "range decoder refused " + stem + "_F.bin"; return rc; }
+    clk.mark("range");
+    clk.done("decode features", i);
+    return 0;
+}
+}  // namespace
+
 // -> sym [sum rows, C] and (for items with native_coords) xyz [sum rows, 3].  use_sidecar = 0: never read <stem>_F.idx.
 // Returns -5 if a sidecar says the stream was coded with another CDF table than this host derives (see coder.py).
-namespace { thread_local std::atomic<int>* tl_frame_coords_flag = nullptr; }       // set by pcgc_frame_decode_begin's worker around its call
 extern "C" int pcgc_items_decode(int n_items, const char* const* stems, const int64_t* rows, int C, const float* ranges, const int32_t* native_coords,
                                  const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int16_t* sym, int32_t* xyz, int coord_layout,
                                  int coord_scale, int threads) {
@@ -1434,99 +1522,16 @@ extern "C" int pcgc_items_decode(int n_items, const char* const* stems, const in
         pcgc_set_error("items_decode: bad arguments"); return -2;
     }
     prewake_for_decode(n_items, threads, 300);
-    std::atomic<int>* const frame_flag = n_items == 1 ? tl_frame_coords_flag : nullptr;      // (read on the CALLING thread: either task may run on a pool thread)
     std::vector<int64_t> off((size_t)n_items + 1, 0);
     for (int i = 0; i < n_items; ++i) off[(size_t)i + 1] = off[(size_t)i] + rows[i];
-    // two tasks per item — its coordinate stream and its feature stream are independent — so that ONE cloud (the single-frame path)
-    // decodes both side by side as well, each on its own pool of segment / group threads
+    // two tasks per item — its coordinate stream and its feature stream are independent — so that ONE cloud decodes both side by side as
+    // well, each on its own pool of segment / group threads (the coordinate stream is the longer task by now — 0.18 against 0.16 ms — so
+    // the calling thread starts it at once and the feature stream pays the helper's wake-up)
     return for_items(2 * n_items, threads, [&](int task, std::string& err) -> int {
         const int i = task >> 1;
-        const std::string stem = stems[i];
-        const int64_t n = rows[i];
-        StageClock clk;
-        // (pcgc_frame_decode_begin: the caller waits for the coordinate level only and launches the coordinate-only decoder kernels while the
-        //  feature stream is still being decoded — the flag is raised when the coordinate task of the frame ends, whatever its outcome)
-        struct CoordsDone { std::atomic<int>* f; ~CoordsDone() { if (f) f->store(1, std::memory_order_release); } } coords_done{(task & 1) == 0 ? frame_flag : nullptr};
-        if ((task & 1) == 0) {                                   // (the coordinate stream is the longer task by now — 0.18 against 0.16 ms — so the
-            if (native_coords[i]) {                              //  calling thread starts it at once and the feature stream pays the helper's wake-up)
-                std::vector<uint8_t> cb;
-                if (!read_file(stem + "_C.bin", cb)) { err = "cannot read " + stem + "_C.bin"; return -1; }
-                clk.mark("read");
-                if (coord_layout == 0) {
-                    if (pcgc_oct_decode(cb.data(), (int64_t)cb.size(), xyz + off[(size_t)i] * 3, n) != 0) { err = "corrupt " + stem + "_C.bin"; return -2; }
-                    clk.mark("octree");
-                } else {
-                    // the coordinate LEVEL the decoder starts from (coder.py:97-102): rows (item, scale x, scale y, scale z) in (z, y, x) order —
-                    // sorted here, on the thread that has the voxels in cache, instead of by a dozen launches after an upload
-                    static thread_local std::vector<uint64_t> leaves, keys;
-                    if (oct_decode_leaves(cb.data(), (int64_t)cb.size(), n, leaves) != 0) { err = "corrupt " + stem + "_C.bin"; return -2; }
-                    clk.mark("octree");
-                    const int d = cb[5];                                          // bits per coordinate (the tree's depth; checked by the decoder)
-                    keys.resize((size_t)n);
-                    zyx_keys(leaves.data(), n, d, keys.data());
-                    const uint64_t m = (1ull << d) - 1;
-                    int32_t* L = xyz + off[(size_t)i] * 4;
-                    auto row = [&](int64_t r, uint64_t k) {
-                        L[4 * r] = i; L[4 * r + 1] = (int32_t)(k & m) * coord_scale;
-                        L[4 * r + 2] = (int32_t)((k >> d) & m) * coord_scale; L[4 * r + 3] = (int32_t)(k >> (2 * d)) * coord_scale;
-                    };
-                    if (3 * d <= 22 && n >= 512) {
-                        // two 11-bit radix passes with both histograms from one sweep, the second pass scattering the finished rows
-                        static thread_local std::vector<uint64_t> tmp;
-                        if (tmp.size() < (size_t)n) tmp.resize((size_t)n);
-                        uint32_t c0[2048] = {0}, c1[2048] = {0};
-                        for (int64_t r = 0; r < n; ++r) { const uint64_t k = keys[(size_t)r]; ++c0[k & 2047]; ++c1[(k >> 11) & 2047]; }
-                        uint32_t a0 = 0, a1 = 0;
-                        for (int b = 0; b < 2048; ++b) { const uint32_t x0 = c0[b], x1 = c1[b]; c0[b] = a0; c1[b] = a1; a0 += x0; a1 += x1; }
-                        for (int64_t r = 0; r < n; ++r) { const uint64_t k = keys[(size_t)r]; tmp[c0[k & 2047]++] = k; }
-                        for (int64_t r = 0; r < n; ++r) { const uint64_t k = tmp[(size_t)r]; row((int64_t)c1[(k >> 11) & 2047]++, k); }
-                    } else {
-                        sort_codes(keys, 3 * d);
-                        for (int64_t r = 0; r < n; ++r) row(r, keys[(size_t)r]);
-                    }
-                    clk.mark("level");
-                }
-            }
-            clk.done("decode coords", i);
-            return 0;
-        }
-        if (n == 0) return 0;
-        const float min_v = ranges[2 * i], max_v = ranges[2 * i + 1];
-        // (a header's range must be two integral values, as compress() writes them: the table callback sizes its output from the same
-        //  two numbers in ITS arithmetic — a fractional bound from a damaged `_H.bin` made it write one row entry past this allocation)
-        if (!(min_v <= max_v) || min_v != std::floor(min_v) || max_v != std::floor(max_v) || max_v - min_v > 65000.0f) { err = "symbol range"; return -2; }
-        const int L = (int)(max_v - min_v) + 1, Lp = L + 1;
-        std::shared_ptr<const std::vector<uint16_t>> tptr;
-        uint32_t mine = 0;
-        if (cached_table(table_fn, eb_params, C, min_v, max_v, tptr, mine) != 0) { err = "CDF table evaluation failed"; return -1; }
-        const std::vector<uint16_t>& table = *tptr;
-        clk.mark("table");
-        std::vector<uint8_t> stream, side;
-        if (!read_file(stem + "_F.bin", stream)) { err = "cannot read " + stem + "_F.bin"; return -1; }
-        clk.mark("read");
-        int n_ck = 0; const uint32_t* ck = nullptr;
-        if (use_sidecar && read_file(stem + "_F.idx", side) && side.size() >= kSidecarHead && std::memcmp(side.data(), "PCG2", 4) == 0) {
-            const uint32_t nbytes = get32(side.data() + 4), scrc = get32(side.data() + 8), count = get32(side.data() + 12), tcrc = get32(side.data() + 16), self = get32(side.data() + 20);
-            uLong c = crc32(0L, side.data(), 20);
-            if (side.size() > kSidecarHead) c = crc32(c, side.data() + kSidecarHead, (uInt)(side.size() - kSidecarHead));
-            if (nbytes == stream.size() && side.size() == kSidecarHead + (size_t)count * 4 * PCGC_RC_CKPT_WORDS && self == (uint32_t)c &&
-                scrc == pcgc_crc32(0, stream.data(), (int64_t)stream.size())) {
-                if (tcrc != mine) {
-                    char b[160]; std::snprintf(b, sizeof b, "the CDF table derived on this host (CRC-32 %08x) is not the one the stream was coded with (%08x)", mine, tcrc);
-                    err = b; return -5;
-                }
-                if (count >= 2) { n_ck = (int)count; ck = (const uint32_t*)(side.data() + kSidecarHead); }
-            }
-        }
-        clk.mark("sidecar");
-        int16_t* out = sym + off[(size_t)i] * C;
-        int rc;
-        if (n_ck) rc = pcgc_rc_decode_indexed(table.data(), C, Lp, stream.data(), (int64_t)stream.size(), out, n * C, n_ck, ck);
-        else rc = pcgc_rc_decode(table.data(), C, Lp, stream.data(), (int64_t)stream.size(), out, n * C);
-        if (rc != 0) { err = "range decoder refused " + stem + "_F.bin"; return rc; }
-        clk.mark("range");
-        clk.done("decode features", i);
-        return 0;
+        if ((task & 1) == 0)
+            return decode_item_coords(stems[i], i, rows[i], native_coords[i] != 0, xyz + off[(size_t)i] * (coord_layout == 0 ? 3 : 4), coord_layout, coord_scale, err);
+        return decode_item_features(stems[i], i, rows[i], C, ranges[2 * i], ranges[2 * i + 1], eb_params, table_fn, use_sidecar, sym + off[(size_t)i] * C, err);
     }, 2);
 }
 
@@ -1558,9 +1563,9 @@ struct FrameAsync {
     std::mutex owner;                                    // held from a successful asynchronous _begin to its _end
     std::thread worker; std::mutex m; std::condition_variable cv;
     std::function<void()> job; bool has_job = false, stop = false;
-    std::atomic<int> coords{0}, finished{0};
+    std::atomic<int> finished{0};
     std::atomic<int64_t> spin_until{0};
-    int rc = 0; std::string err;
+    int rc = 0, coords_rc = 0; std::string err, coords_err;
     static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     void loop() {
         for (;;) {
@@ -1580,16 +1585,24 @@ struct FrameAsync {
     }
     // the caller's side of the hand-off: spin for the ~0.1-0.3 ms a warm decode takes, then stop burning the core (a cold table, slow files or a
     // small cgroup CPU quota shared with the segment pool): yield, then sleep in 50 us steps
-    static void wait(const std::atomic<int>& flag, const std::atomic<int>* also = nullptr) {
+    static void wait(const std::atomic<int>& flag) {
         const int64_t t0 = now_ns();
         for (int spins = 0;; ++spins) {
-            if (flag.load(std::memory_order_acquire) != 0 || (also && also->load(std::memory_order_acquire) != 0)) return;
+            if (flag.load(std::memory_order_acquire) != 0) return;
             if (spins < 256) { _mm_pause(); continue; }
             const int64_t dt = now_ns() - t0;
             if (dt < 400 * 1000) _mm_pause();
             else if (dt < 2 * 1000 * 1000) std::this_thread::yield();
             else std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
+    }
+    // the posted job is complete when this returns.  A worker that has not even TAKEN the job yet (its wake-up is late: a busy host — 2-8 ms
+    // were measured on a shared box, profiles/r05_step_outliers.md) loses it to the caller, which runs it on its own thread instead of waiting.
+    void finish() {
+        std::function<void()> j;
+        { std::lock_guard<std::mutex> lk(m); if (has_job) { j = std::move(job); has_job = false; } }
+        if (j) { j(); finished.store(1, std::memory_order_release); }
+        else wait(finished);
     }
     void ensure() { if (!worker.joinable()) worker = std::thread([this] { loop(); }); }
     void prewake(int us) { ensure(); spin_until.store(now_ns() + (int64_t)us * 1000, std::memory_order_relaxed); cv.notify_one(); }
@@ -1607,7 +1620,7 @@ extern "C" int pcgc_frame_decode_begin(const char* stem, int C, const float* eb_
     if (tl_frame_pending) {
         // a frame this thread began and never finished (an exception between _begin and _end on the caller's side): finish it here — wait for the
         // worker, which may still be writing into the previous call's buffers, and release the slot — instead of refusing every later frame
-        fa.wait(fa.finished);
+        fa.finish();
         tl_frame_pending = false;
         fa.owner.unlock();
     }
@@ -1615,39 +1628,40 @@ extern "C" int pcgc_frame_decode_begin(const char* stem, int C, const float* eb_
     if (!async) return pcgc_frame_decode(stem, C, eb_params, table_fn, use_sidecar, coord_scale, cap_rows, sym, level, info, range, threads);
     fa.prewake(400);                                      // (the probe reads four small files meanwhile)
     int64_t rows = 0; int32_t channels = 0, counts[3] = {0, 0, 0}, native = 0;
+    tl_frame_path = true;
     int rc = pcgc_items_probe(1, &stem, &rows, &channels, range, counts, &native);
+    tl_frame_path = false;
     if (rc == 0) {
         info[0] = rows; info[1] = channels; info[2] = counts[0]; info[3] = counts[1]; info[4] = counts[2]; info[5] = native;
         if (channels != C) { pcgc_set_error("frame_decode: %s_H.bin has %d channels, the model %d", stem, (int)channels, C); rc = -2; }
         else if (rows > cap_rows) rc = 1;
     }
     if (rc != 0) { fa.owner.unlock(); return rc; }
-    fa.coords.store(0); fa.finished.store(0); fa.rc = 0; fa.err.clear();
+    fa.finished.store(0); fa.rc = fa.coords_rc = 0; fa.err.clear(); fa.coords_err.clear();
     const std::string stem_copy = stem;
     const float r0 = range[0], r1 = range[1];
-    // the parameter vector is COPIED into the job: the caller's array need not outlive this call (the table is evaluated, and its cache key
-    // hashed, on the worker after _begin has returned)
+    // the feature stream goes to the frame worker (which spins for it since the prewake above) with the segment pool under it.  The
+    // parameter vector is COPIED into the job: the caller's array need not outlive this call (the table is evaluated, and its cache key
+    // hashed, after _begin has returned)
     const std::vector<float> params_copy(eb_params, eb_params + (size_t)44 * C);
     fa.post([=, &fa] {
-        const char* st = stem_copy.c_str();
-        const float* eb_params = params_copy.data();
-        const int64_t rws = rows; const int32_t nat = native; const float rg[2] = {r0, r1};
-        tl_frame_coords_flag = &fa.coords;
-        fa.rc = pcgc_items_decode(1, &st, &rws, C, rg, &nat, eb_params, table_fn, use_sidecar, sym, level, 1, coord_scale > 0 ? coord_scale : 1, threads);
-        tl_frame_coords_flag = nullptr;
-        if (fa.rc != 0) fa.err = pcgc_last_error();
-        fa.coords.store(1, std::memory_order_release);    // (an error before the coordinate task ended must not leave the caller waiting)
+        std::string e;
+        const int r = decode_item_features(stem_copy, 0, rows, C, r0, r1, params_copy.data(), table_fn, use_sidecar, sym, e);
+        if (r != 0) { fa.rc = r; fa.err = e; }
     });
     tl_frame_pending = true;
-    fa.wait(fa.coords, &fa.finished);
+    // the coordinate stream is decoded HERE, on the calling thread (round 5; round 4 handed both tasks to the worker and spun for a flag): the
+    // caller needs this result before it can do anything else, so no other thread's wake-up is on its path — only the octree pool's helpers,
+    // which the calling thread never waits for before it has run out of groups itself
+    fa.coords_rc = decode_item_coords(stem_copy, 0, rows, native != 0, level, 1, coord_scale > 0 ? coord_scale : 1, fa.coords_err);
     return 0;
 }
 extern "C" int pcgc_frame_decode_end(void) {
     if (!tl_frame_pending) return 0;                      // (the synchronous form: everything happened in _begin)
     FrameAsync& fa = frame_async();
-    fa.wait(fa.finished);
-    const int rc = fa.rc;
-    if (rc != 0) pcgc_set_error("%s", fa.err.c_str());
+    fa.finish();
+    const int rc = fa.coords_rc ? fa.coords_rc : fa.rc;   // (the order of pcgc_items_decode: the first failing task's code and message)
+    if (rc != 0) pcgc_set_error("item 0: %s", (fa.coords_rc ? fa.coords_err : fa.err).c_str());
     tl_frame_pending = false;
     fa.owner.unlock();
     return rc;
