@@ -54,7 +54,6 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', default='', help='cloud for the CPU oracle (default: the bench workload itself)')
     ap.add_argument('--no-events', action='store_true', help='do not bracket the dominant kernel with HIP events')
-    ap.add_argument('--irn-rows', type=int, default=0, help='force the fused-IRN tile height (A/B); 0 = automatic')
     ap.add_argument('--detail', default='', help='optional path for a per-kernel-shape JSON breakdown')
     ap.add_argument('--no-extra', action='store_true', help='skip the auxiliary measurements after the timed region (reference-format-only / one-by-one / serving): profiler runs')
     ap.add_argument('--no-batch', action='store_true', help='blocks config: code the blocks one by one instead of as ONE collated batch')
@@ -108,8 +107,6 @@ def main():
     from pcgcv2_amd.data_utils import scale_sparse_tensor
     from pcgcv2_amd.sparse import SparseTensor
     from pcgcv2_amd import entropy_model
-    if args.irn_rows:
-        ops.set_irn_rows(args.irn_rows)
 
     def cloud(name, order='raster'):
         if name in synthetic.SHELLS and order == 'raster':

@@ -159,45 +159,20 @@ int pcgc_conv_gather_unit(const int32_t* nbr /*[dev K,n_out]*/, int K, int64_t n
 int pcgc_conv_unit_from_coarse(const int32_t* fine /*[n_fine,4]*/, int64_t n_fine, int32_t stride_fine, const int32_t* parent_of,
                                const int32_t* coarse_nbr /*[27,n_coarse]*/, const int32_t* down /*[8,n_coarse]*/, int64_t n_coarse,
                                const float* W /*[27,1,Cout]*/, const float* bias, int relu, float* out, int Cout, int out_ld, void* stream);
+/* force a family of pcgc_conv_gather: -1 auto (default) | 0 VALU | 2 MFMA | 6 row-split (A/B tests; bit-identical) */
 int pcgc_set_conv_impl(int impl);
-/* the LDS-shared-weight MFMA kernels come in two schedules (v2b: 16-channel sub-steps; v2c: 32-channel steps with the next
- * step's loads in flight): -1 choose by level size (default), 0 always v2b, 1 always v2c.  Bit-identical. */
-int pcgc_set_mfma_pipe(int mode);
 /* generative transpose 64->32 / 32->16: 1 fp32-MFMA kernel (default), 0 VALU kernel.  Bit-identical. */
 int pcgc_set_up2_impl(int mfma);
-/* rows per wave of the fused InceptionResNet passes: 0 = by level size (default), or force 64 / 32 / 16 (A/B tests). */
-int pcgc_set_irn_rows(int rows);
-/* 16-row tiles at C <= 32: 1 = row-split kernels (lanes split the output channels, weights staged in LDS; default),
- * 0 = lane-per-row kernels.  Bit-identical (A/B tests). */
-int pcgc_set_irn_split(int on);
-/* C = 32 pass A gathers 16 instead of 32 channels per sub-step on levels of at least `min_rows` rows (default 400 000; 0 =
- * always, negative = default).  Bit-identical; a speed/occupancy trade measured per level size. */
-int pcgc_set_irn_cb16_rows(int64_t min_rows);
-/* The LDS-shared-weight MFMA gather conv (k3 64->64 / 32->32, autoencoder.py:109-115,162-168) runs four 16-row M tiles per
- * wave on levels of at least `min_rows` rows (default 400 000: the vox11 / vox12 levels of configs 4 and 5), two below
- * (0 = always four, negative = default).  Bit-identical; the switch lets tests reach the large-level instantiation on small clouds. */
-int pcgc_set_wlds_mt4_rows(int64_t min_rows);
 /* Fused InceptionResNet block (autoencoder.py:7-57):  out = cat(conv0_1(relu(conv0_0 x)), conv1_2(relu(conv1_1(relu(conv1_0 x))))) + x
  * in two gather passes.  params[10] = {conv0_0.kernel, .bias, conv0_1.kernel, .bias, conv1_0.kernel, .bias, conv1_1.kernel,
  * .bias, conv1_2.kernel, .bias} (ME layouts).  t_scratch: [n, C/2] fp32 workspace.  Bit-identical to the five
  * pcgc_conv_gather calls it replaces. */
 int pcgc_irn_block(const int32_t* nbr /*[27,n]*/, int64_t n, const float* x /*[n,C], ld x_ld*/, int C, int x_ld,
                    const float* const* params, float* t_scratch, float* out, int out_ld, void* stream);
-/* Block-sparse k3 gather conv on the fp32 MFMA kernel with workgroup-shared weights (shapes 64->32 and 32->48, the two
- * passes of the C=64 InceptionResNet with fused weights).  W [27,Cin,Cout] dense (zeros where sparse); tile_mask [27*Cin/16]
- * uint32: bit n set = column tile n (16 columns) of that 16-row weight slice is non-zero; NULL = all tiles active. */
-int pcgc_conv_gather_masked(const int32_t* nbr, int64_t n_out, const float* in, int64_t n_in, int Cin, int in_ld, const float* W,
-                            int Cout, const uint32_t* tile_mask, const float* bias, int relu, float* out, int out_ld, void* stream);
-/* pointwise tail of the fused C=64 InceptionResNet: out = [u[:, :32] + x[:, :32] | relu(u[:, 32:48]) @ W12 + b12 + x[:, 32:]] */
-int pcgc_irn_tail(const float* u /*[n,48]*/, const float* x, int C, int x_ld, const float* W12 /*[16,32]*/, const float* b12,
-                  float* out, int out_ld, int64_t n, void* stream);
 /* the two gather passes of pcgc_irn_block separately (pass 1 = A: x -> t_scratch, pass 2 = B: t_scratch, x -> out);
  * same arguments; used to time the passes individually. */
 int pcgc_irn_pass(const int32_t* nbr, int64_t n, const float* x, int C, int x_ld, const float* const* params,
                   float* t_scratch, float* out, int out_ld, int pass, void* stream);
-/* which instantiation pcgc_irn_block / pcgc_irn_pass run for (C, n): rows per wave tile and channels per sub-step of pass A (profiling
- * records name the kernel; the policy lives in the library only). */
-int pcgc_irn_config(int C, int64_t n, int* rows, int* pass_a_channels_per_substep);
 /* MinkowskiGenerativeConvolutionTranspose(k=2,s=2): out[8i+k] = in[i] @ W[k] + bias (+ReLU). */
 int pcgc_conv_up2(int64_t n_in, const float* in, int Cin, int in_ld, const float* W /*[8,Cin,Cout]*/, const float* bias,
                   int relu, float* out /*[dev 8n,Cout]*/, int Cout, void* stream);
@@ -217,7 +192,6 @@ int pcgc_conv_child(const int32_t* parent_nbr /*[dev 27,n_parent]*/, int64_t n_p
                     const float* bias, const float* residual, int res_ld, int relu, float* out, int Cout, int out_ld, void* stream);
 /* Cout == 1 (the classification heads conv0/1/2_cls, autoencoder.py:169-175,196-202,223-229) is served by the same entry with a
  * 64-fragment table (ops.child_cls_table): the 8 children are the 8 used columns of one accumulator tile. */
-int pcgc_set_child_tuning(int waves_per_group, int ring_depth);       /* A/B switches; 0 = defaults */
 /* Fused InceptionResNet (autoencoder.py:52-57) on a children level, C = 16 or 32, as two parent-map passes:
  *   pass 1 (A): in = x [8 n_parent, C]      -> out = t [8 n_parent, C/2] = [relu(conv0_0 x + b0) | relu(conv1_0 x + b1)]
  *   pass 2 (B): in = t [8 n_parent, C/2]    -> out [.., C] = [conv0_1(t[:, :Q]) + b0 | conv1_2(relu(conv1_1(t[:, Q:]) + b1)) + b2] + x

@@ -48,19 +48,10 @@ SIGNATURES = {
     'pcgc_conv_unit_from_coarse': (ci, [vp, i64, i32, vp, vp, vp, i64, vp, vp, ci, vp, ci, ci, vp]),
     'pcgc_set_conv_impl': (ci, [ci]),
     'pcgc_last_conv_impl': (ci, []),
-    'pcgc_set_mfma_pipe': (ci, [ci]),
     'pcgc_set_up2_impl': (ci, [ci]),
-    'pcgc_set_irn_rows': (ci, [ci]),
-    'pcgc_set_irn_split': (ci, [ci]),
-    'pcgc_set_irn_cb16_rows': (ci, [i64]),
-    'pcgc_set_wlds_mt4_rows': (ci, [i64]),
     'pcgc_irn_block': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, ci, vp]),
-    'pcgc_conv_gather_masked': (ci, [vp, i64, vp, i64, ci, ci, vp, ci, vp, vp, ci, vp, ci, vp]),
-    'pcgc_irn_tail': (ci, [vp, vp, ci, ci, vp, vp, vp, ci, i64, vp]),
-    'pcgc_irn_config': (ci, [ci, i64, vp, vp]),
     'pcgc_irn_pass': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, ci, ci, vp]),
     'pcgc_conv_child': (ci, [vp, i64, vp, ci, ci, vp, i64, vp, vp, ci, ci, vp, ci, ci, vp]),
-    'pcgc_set_child_tuning': (ci, [ci, ci]),
     'pcgc_irn_child_pass': (ci, [vp, i64, ci, ci, vp, ci, vp, i64, vp, vp, vp, vp, ci, vp, ci, vp]),
     'pcgc_irn_child_q4': (ci, [vp, i64, ci, ci, vp, ci, vp, i64, vp, vp, vp, vp, ci, vp, ci, vp]),
     'pcgc_cls_child_q4': (ci, [vp, i64, vp, ci, ci, vp, i64, vp, vp, vp]),

@@ -28,13 +28,11 @@ class InceptionResNet(torch.nn.Module):
         children = x.cmap.origin is not None and x.cmap.origin[0] == 'children'
         # which of the implementations: ONE table (pcgcv2_amd/dispatch.py); every family computes the same fmaf chains
         fam = dispatch.select('irn', (c,), x.F.shape[0], 'children' if children else 'plain', extent=x.F.shape[0] * max(c, x.F.stride(0)) * 4,
-                              own_map=x.cmap._k3 is not None, contiguous=x.F.is_contiguous()).family
+                              contiguous=x.F.is_contiguous()).family
         if fam != 'unfused':
             params = [p for m in (self.conv0_0, self.conv0_1, self.conv1_0, self.conv1_1, self.conv1_2) for p in (m.kernel, m.bias)]
             if fam == 'rows64':          # C = 64, LDS-resident fragment table, one wave per 16-row tile through the level's own map (csrc/rows_irn.hip)
                 y = ops.irn_block_rows64(x.cmap.k3, x.F, params, self._tables('child', ops.child_irn_tables, params))
-            elif fam == 'child64':       # children level: both passes through the PARENT level's map, packed-N fp32 MFMA (csrc/child_kernels.h)
-                y = ops.irn_block_child64(x.cmap.origin[1].k3, x.F, params, self._tables('child', ops.child_irn_tables, params))
             elif fam == 'child':
                 # the stride-1 level of a vox10+ frame: pass A in quad-block form (csrc/child_q4.h; smaller levels do not fill its wave slots)
                 big = x.F.shape[0] >= 8 * ops.CHILD_Q4_MIN_PARENTS
@@ -42,8 +40,6 @@ class InceptionResNet(torch.nn.Module):
                 y = ops.irn_block_child(x.cmap.origin[1].k3, x.F, params, self._tables('child', ops.child_irn_tables, params), q4_table=q4)
             elif fam == 'rows32':        # plain level, C = 32: the rows kernels instead of the VALU passes
                 y = ops.irn_block_rows32(x.cmap.k3, x.F, params, self._tables('rows32', ops.rows_irn32_tables, params))
-            elif fam == 'mfma64':        # block-sparse MFMA passes on the gather kernels
-                y = ops.irn_block_mfma64(x.cmap.k3, x.F, self._tables('fused', ops.fuse_irn64, params))
             else:                        # 'valu': two fused gather passes
                 y = ops.irn_block(x.cmap.k3, x.F, params)
             return SparseTensor(y, coordinate_map=x.cmap)

@@ -1,8 +1,8 @@
 // One instantiation unit of the children-level fused InceptionResNet passes (kernels: child_kernels.h; entry point: child_irn.hip).
 #include "child_kernels.h"
 
-#define DEF_IRN_LAUNCH(NAME) int NAME(int nw, const int32_t* parent_nbr, int64_t n_parent, const float* in, int in_ld, const float* table, \
+#define DEF_IRN_LAUNCH(NAME) int NAME(const int32_t* parent_nbr, int64_t n_parent, const float* in, int in_ld, const float* table, \
                                       int table_bytes, const IrnEpi& ep, hipStream_t s)
 // 76 KB table; half units (4451 tiles of the 570 k-row level on 3072 waves were two rounds: see k_child_irn_a; 181.7 -> 173.2 us per block)
-DEF_IRN_LAUNCH(pcgc_irn_child_a32) { (void)nw; return launch_child_irn_a_split<32, 12, 2>(parent_nbr, n_parent, in, in_ld, table, table_bytes, ep, s); }
+DEF_IRN_LAUNCH(pcgc_irn_child_a32) { return launch_child_irn_a_split<32, 12, 2>(parent_nbr, n_parent, in, in_ld, table, table_bytes, ep, s); }
 CHILD_TIMING_READER(pcgc_child_timing_a32)

@@ -127,8 +127,6 @@ struct PlainConv : HaloGeometry {                     // k3 conv Cin = 16 NB -> 
     static constexpr bool active(int c, int t) { return (HZ < 0 || (((t / NT) >> 2) & 1) == HZ) && ((cell_reach(c) >> (t / NT)) & 1); }
     static constexpr int frag(int c, int t) { return cell_k(c, t / NT) * NT + t % NT; }
     static constexpr bool uses_block(int, int) { return true; }
-    static constexpr int NBATCH = 1;
-    static constexpr int batch(int) { return 0; }
     static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 64 * KS * 4; }      // byte offset in the table
 };
 template <int NB_>
@@ -139,16 +137,15 @@ struct ClsHead : HaloGeometry {                       // k3 conv C -> 1: one til
     static constexpr bool active(int, int) { return true; }
     static constexpr int frag(int c, int) { return c; }
     static constexpr bool uses_block(int, int) { return true; }
-    static constexpr int NBATCH = 1;
-    static constexpr int batch(int) { return 0; }
     static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 32 * KS * 4; }
 };
 // InceptionResNet pass A (autoencoder.py:52-57 first half): conv0_0 (k3 C -> Q) and conv1_0 (k1 C -> Q), Q = C/4.
 // Columns pack (child, output channel): 16/Q children per tile.  Tiles [0, T/2) = conv0_0, [T/2, T) = conv1_0 (fed only by the
 // cell that IS the child: offset k = 13).
-// HZ (C = 64 only): -1 = all eight children; 0 / 1 = only the four children with that z bit (a half unit: see k_child_irn_a)
+// HZ: -1 = all eight children; 0 / 1 = only the four children with that z bit (a half unit: see k_child_irn_a)
 template <int C, int HZ = -1>
 struct PassA : HaloGeometry {
+    static_assert(C == 16 || C == 32, "children-level passes: C = 16, 32 (C = 64 runs on the rows kernels through the level's own map)");
     static constexpr int Q = C / 4, NB = C / 16, ROWCHUNKS = 4, CPT = 16 / Q /*children per tile: 4, 2 or 1*/, TH = 8 / CPT, T = 2 * TH, KS = 4;
     static_assert(HZ < 0 || CPT <= 2, "half units: tiles of one or two children (a z-half tile holds both halves' columns)");
     static constexpr int Z_HALF = HZ;
@@ -158,11 +155,6 @@ struct PassA : HaloGeometry {
     static constexpr int tz(int t) { return CPT == 4 ? (t % TH) : (t % TH) >> 1; }
     static constexpr int ty(int t) { return (t % TH) & 1; }
     static constexpr bool active(int c, int t) {
-        if (CPT == 1) {                                         // C = 64: one child per tile; conv1_0 is fed only by the cell that IS the child
-            if (HZ >= 0 && (((t < TH ? t : t - TH) >> 2) & 1) != HZ) return false;
-            if (t < TH) return (cell_reach(c) >> t) & 1;
-            return ((cell_reach(c) >> (t - TH)) & 1) && cell_k(c, t - TH) == 13;
-        }
         const int kz = cz_of(c) - tz(t);
         if (HZ >= 0 && tz(t) != HZ) return false;               // (CPT == 2: tile = (jz, jy) quarter)
         if (CPT == 4) {
@@ -175,15 +167,12 @@ struct PassA : HaloGeometry {
     }
     static constexpr int N0 = CPT == 4 ? 48 : (CPT == 2 ? 36 : 27);                 // conv0_0 fragments
     static constexpr int frag(int c, int t) {
-        if (CPT == 1) return t < TH ? cell_k(c, t) : N0;
         const int kz = cz_of(c) - tz(t);
         if (CPT == 4) return t < TH ? kz * 16 + (c & 15) : N0 + (cy_of(c) - 1) * 2 + (cx_of(c) - 1);
         const int ky = cy_of(c) - ty(t);
         return t < TH ? (kz * 3 + ky) * 4 + cx_of(c) : N0 + (cx_of(c) - 1);
     }
     static constexpr bool uses_block(int, int) { return true; }
-    static constexpr int NBATCH = 1;
-    static constexpr int batch(int) { return 0; }
     static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 64 * KS * 4; }
 };
 // InceptionResNet pass B: the gathered rows are t = [relu(conv0_0) | relu(conv1_0)] (2Q wide).  conv0_1 (k3 Q -> 2Q) reads the
@@ -226,26 +215,7 @@ struct PassB : HaloGeometry {
         return N0 + (cz_of(c) - u) * 16 + (c & 15);
     }
     static constexpr bool uses_block(int, int) { return true; }
-    static constexpr int NBATCH = 1;
-    static constexpr int batch(int) { return 0; }
     static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 64 * KS * 4; }
-};
-// pass B at C = 64 (Q = 16): t is 32 wide = two 16-channel blocks; block 0 feeds conv0_1 (k3 16 -> 32: two column tiles per child),
-// block 1 feeds conv1_1 (k3 16 -> 16: one tile per child).  Fragments: conv0_1 (k, n) = 54, conv1_1 k = 27, conv1_2 (k1 16 -> 32) = 2.
-template <int HZ = -1>
-struct PassB64 : HaloGeometry {
-    static constexpr int Q = 16, NB = 2, ROWCHUNKS = 4, KS = 4, T0 = 16, T1 = 8, T = 24;
-    static constexpr int Z_HALF = HZ;                      // -1 = all eight children; 0 / 1 = the four children with that z bit (half units)
-    static constexpr bool HALF = false;
-    static constexpr int kfirst(int) { return 0; }
-    static constexpr int child_of(int t) { return t < T0 ? t / 2 : t - T0; }
-    static constexpr bool active(int c, int t) { return (HZ < 0 || ((child_of(t) >> 2) & 1) == HZ) && ((cell_reach(c) >> child_of(t)) & 1); }
-    static constexpr bool uses_block(int t, int cb) { return t < T0 ? cb == 0 : cb == 1; }
-    static constexpr int NBATCH = 2;                       // B fragments of a block in two batches (16 at once would not fit the registers)
-    static constexpr int batch(int t) { return t < T0 ? (t & 1) : 0; }
-    static constexpr int frag(int c, int t) { return t < T0 ? cell_k(c, t / 2) * 2 + (t & 1) : 54 + cell_k(c, t - T0); }
-    static constexpr int frag_off(int c, int t, int) { return frag(c, t) * 1024; }
-    static constexpr int FRAG_W12 = 81;
 };
 
 template <class V, class = void> struct child_t2_layout : std::false_type {};
@@ -406,85 +376,7 @@ __device__ __forceinline__ void child_tile_mainloop_mt(const int32_t* __restrict
     for (int jj = 0; jj < 4; ++jj) a_addr[jj] = (unsigned)(uintptr_t)(lds_void_ptr)((const float*)ring + (mi * 4 + (jj ^ f_a)) * 4 + mq);
     constexpr unsigned ksteps_used = [] { unsigned m = 0; for (int t = 0; t < T; ++t) for (int j = 0; j < KS; ++j) m |= 1u << (V::kfirst(t) + j); return m; }();
 
-    constexpr bool BLOCKWISE = NB * T > 32;                                    // wide layers: B fragments one 16-channel block (and batch) at a time
-    static_assert(BLOCKWISE || V::NBATCH == 1, "batches only exist in the block-wise form");
-    if constexpr (BLOCKWISE) {
-        static_assert(!BLOCKWISE || MT == 1, "the block-wise (C = 64) form keeps one M tile per wave");
-        // C = 64 variants: one or two waves per SIMD and one tile per wave, so little but the wave itself covers an LDS round trip.
-        // Every LDS read is requested one step ahead of its use: the B fragments of the next block / batch, and — during a cell's last
-        // step — the A operand and the first B fragments of the next cell (two register sets each).  A step is: wait for what was
-        // requested a step ago; request the next step's operands; MFMAs.  (Worth 1-3 % only: SQ counters show the wave waiting on the
-        // MFMA pipe, not on memory.  A tile is 3584 MFMAs = 48 us of one SIMD's pipe; the 150 k-row level is 1171 tiles on 1024 SIMDs,
-        // so 147 SIMDs run two tiles and the launch takes two tile times — only finer work units than 16 parents x 8 children would
-        // change that.)
-        constexpr int STEPS = NB * V::NBATCH;
-        static_assert(STEPS % 2 == 0, "the register sets alternate per step: an even number of steps per cell");
-        static_assert(D >= 2, "the next cell's rows must have been requested a cell earlier");
-        BFrag<KS> bp[2][T];
-        float ap[2][NB][4];
-        auto load_b = [&](auto icell, auto icb, auto ibt, auto ibuf) {
-            constexpr int cell = decltype(icell)::value, cb = decltype(icb)::value, bt = decltype(ibt)::value, buf = decltype(ibuf)::value;
-            static_for<0, T>([&](auto it) {
-                constexpr int t = decltype(it)::value;
-                if constexpr (V::active(cell, t) && V::uses_block(t, cb) && V::batch(t) == bt) {
-                    constexpr int off = V::frag_off(cell, t, cb);                                // byte offset of the fragment in the table
-                    if constexpr (off < 65536) bp[buf][t].template load<off>(tab_lane);
-                    else bp[buf][t].template load<off - 65536>(tab_lane + 65536);
-                }
-            });
-        };
-        auto load_a = [&](auto ii) {                                           // once the cell's rows have landed in its ring slot
-            constexpr int i = decltype(ii)::value;
-            constexpr int younger = (NC - 1 - i) < (D - 1) ? (NC - 1 - i) : (D - 1);
-            wait_vmcnt<younger * NB>();
-            static_for<0, NB>([&](auto icb) {
-                constexpr int cb = decltype(icb)::value;
-                static_for<0, 4>([&](auto ij) {
-                    constexpr int jj = decltype(ij)::value;
-                    if constexpr ((ksteps_used >> jj) & 1) ap[i & 1][cb][jj] = lds_ld32_off<((i & (D - 1)) * NB + cb) * 1024>(a_addr[jj]);
-                });
-            });
-        };
-        using I0 = std::integral_constant<int, 0>;
-        static_for<0, (D < NC ? D : NC)>(issue);
-        load_a(I0{});
-        load_b(std::integral_constant<int, CL.c[0]>{}, I0{}, I0{}, I0{});
-        static_for<0, NC>([&](auto ii) {
-            constexpr int i = decltype(ii)::value, c = CL.c[i];
-            using IC = std::integral_constant<int, c>;
-            static_for<0, STEPS>([&](auto is) {
-                constexpr int s = decltype(is)::value, cb = s / V::NBATCH, bt = s % V::NBATCH, cur = s & 1;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // requested one step ago
-                if constexpr (s == 0) {
-                    static_for<0, NB>([&](auto icb2) {
-                        static_for<0, 4>([&](auto ij) {
-                            constexpr int jj = decltype(ij)::value;
-                            if constexpr ((ksteps_used >> jj) & 1) lds_tie(ap[i & 1][decltype(icb2)::value][jj]);
-                        });
-                    });
-                    if constexpr (i + D < NC) issue(std::integral_constant<int, i + D>{});    // the ring slot of this cell has been read: refill it
-                }
-                static_for<0, T>([&](auto it) {
-                    constexpr int t = decltype(it)::value;
-                    if constexpr (V::active(c, t) && V::uses_block(t, cb) && V::batch(t) == bt) bp[cur][t].tie();
-                });
-                if constexpr (s + 1 < STEPS) {
-                    load_b(IC{}, std::integral_constant<int, (s + 1) / V::NBATCH>{}, std::integral_constant<int, (s + 1) % V::NBATCH>{}, std::integral_constant<int, cur ^ 1>{});
-                } else if constexpr (i + 1 < NC) {
-                    load_a(std::integral_constant<int, i + 1>{});
-                    load_b(std::integral_constant<int, CL.c[i + 1 < NC ? i + 1 : i]>{}, I0{}, I0{}, std::integral_constant<int, cur ^ 1>{});
-                }
-                static_for<0, 4>([&](auto ij) {
-                    constexpr int jj = decltype(ij)::value;
-                    static_for<0, T>([&](auto it) {
-                        constexpr int t = decltype(it)::value;
-                        if constexpr (V::active(c, t) && V::uses_block(t, cb) && V::batch(t) == bt && jj >= V::kfirst(t) && jj < V::kfirst(t) + KS)
-                            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i & 1][cb][jj], bp[cur][t].get(jj - V::kfirst(t)), acc[0][t], 0, 0, 0);
-                    });
-                });
-            });
-        });
-    } else {
+    static_assert(NB * T <= 32, "all B fragments of a cell are held in registers at once");
     // (A two-deep register pipeline — LDS reads of cell c+1 issued before the MFMAs of cell c — was measured and dropped on these
     // variants: no gain, 8-30 more registers; with 3-4 waves per SIMD the other waves already cover the LDS latency.)
     static_for<0, (D < NC ? D : NC)>(issue);
@@ -544,7 +436,6 @@ __device__ __forceinline__ void child_tile_mainloop_mt(const int32_t* __restrict
             });
         });
     });
-    }
 #ifdef PCGC_CHILD_TIMING
     asm volatile("s_nop 0" : "+v"(acc[0][0]));                  // (keeps the stamp behind the last MFMA's issue)
     CHILD_T(t_loop1);
@@ -942,79 +833,6 @@ k_child_irn_b(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __rest
     CHILD_TFLUSH;
 }
 
-// pass B at C = 64.  Epilogue per 16-row group g (parents 2g, 2g+1 x 8 children; held by the lanes of quarter g >> 1 in accumulator
-// elements r = 2 (g & 1) + {0, 1}): u = relu(conv1_1 + b11) and conv0_1 + b01 go to the scratch, conv1_2 (k1 16 -> 32) is 8 MFMAs on u,
-// then the 16 rows x 64 columns leave coalesced with the residual x added.
-template <int NW, int D, bool SPLIT = false>
-__global__ void __launch_bounds__(NW * 64)
-k_child_irn_b64(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __restrict__ in /* t [.., 32] */, int in_ld,
-                const float* __restrict__ table, int table_bytes, IrnEpi ep) {
-    using V = PassB64<>;
-    constexpr int NEEDF4 = (16 * 16 + 16 * 64) / 4;                                        // us [16][16] + stage [16][64]
-    constexpr int RINGF4 = (D * V::NB * 64 > NEEDF4) ? D * V::NB * 64 : NEEDF4;
-    CHILD_KERNEL_PROLOGUE(V, NW, D, RINGF4)
-    float* us = (float*)ring;
-    float* stage = us + 16 * 16;
-    f32x4 w12[2];                                                                          // conv1_2 B fragments: W12[4 jj + mq][16 n + mi]
-#pragma unroll
-    for (int n2 = 0; n2 < 2; ++n2) w12[n2] = *((const f32x4*)(lds_raw + (V::FRAG_W12 + n2) * 1024) + lane);
-    const float b01a = ep.b0[mi], b01b = ep.b0[16 + mi], b11 = ep.b1[mi], b12a = ep.b2[mi], b12b = ep.b2[16 + mi];
-    // one unit: a whole tile, or (SPLIT) the four children with one z bit of its 16 parents — see k_child_irn_a
-    auto unit = [&](auto tag, const int64_t p0) {
-        using VV = typename decltype(tag)::type;
-        constexpr int HZ = VV::Z_HALF;
-        f32x4 acc[VV::T];
-        child_tile_mainloop<VV, D>(pnbr, n_p, p0, rs_in, in_ld, lds_raw, ring, acc CHILD_DBG_ARG);
-        static_for<0, 8>([&](auto ig) {
-            constexpr int g = decltype(ig)::value;
-            ChildResidual<64, 16> rr;                           // this group's residual rows: requested ahead of the hand-offs
-            child_flush_prefetch<64, 16>(rr, 8 * p0 + 16 * g, 8 * n_p, ep.x, ep.x_ld, lane, HZ);
-            if (mq == (g >> 1)) {
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    constexpr int r0 = 2 * (g & 1);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if (HZ >= 0 && ((j >> 2) & 1) != HZ) continue;                     // (the other half's rows: computed below from stale
-                        const int lr = 8 * rr + j;                                         //  scratch, never stored)
-                        us[lr * 16 + mi] = fmaxf(acc[16 + j][r0 + rr] + b11, 0.0f);
-                        stage[lr * 64 + mi] = acc[2 * j][r0 + rr] + b01a;
-                        stage[lr * 64 + 16 + mi] = acc[2 * j + 1][r0 + rr] + b01b;
-                    }
-                }
-            }
-            wave_lds_sync();
-#pragma unroll
-            for (int n2 = 0; n2 < 2; ++n2) {
-                f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) d = __builtin_amdgcn_mfma_f32_16x16x4f32(us[mi * 16 + 4 * jj + mq], w12[n2][jj], d, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) stage[(4 * mq + r) * 64 + 32 + 16 * n2 + mi] = d[r] + (n2 ? b12b : b12a);
-            }
-            wave_lds_sync();
-            child_flush<64, 16>(stage, rr, ep.x != nullptr, 8 * p0 + 16 * g, 8 * n_p, ep.out, ep.out_ld, 0, lane, HZ);
-            wave_lds_sync();
-        });
-    };
-    const int64_t nunits = SPLIT ? 2 * ntiles : ntiles;
-    for (int i = 0;; ++i) {
-        const int64_t u = child_tile<NW>(i, wave, nunits);
-        if (u < 0) break;
-        CHILD_T(t_it0);
-        if constexpr (SPLIT) {
-            if (u & 1) unit(child_type_tag<PassB64<1>>{}, (u >> 1) * 16);
-            else unit(child_type_tag<PassB64<0>>{}, (u >> 1) * 16);
-        } else {
-            unit(child_type_tag<V>{}, u * 16);
-        }
-#ifdef PCGC_CHILD_TIMING
-        { CHILD_T(t_dr0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHILD_T(t_it1); CHILD_TADD(5, t_dr0, t_it1); CHILD_TADD(4, t_it0, t_it1); }
-#endif
-    }
-    CHILD_TFLUSH;
-}
-
 // kernels above the default dynamic-LDS limit need the attribute raised once per (kernel, device)
 struct ChildLdsGrant { size_t bytes[16] = {0}; };
 template <typename K>
@@ -1064,13 +882,11 @@ static unsigned child_grid(int64_t n_p, int nw, size_t lds, int units_per_tile =
 template <int NB, int NT, int NW, int D, int MT = 1>
 int launch_child_conv(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
                       const ChildEpi& ep, hipStream_t s) {
-    if (ep.res) CHILD_LAUNCH_EX((k_child_conv<NB, NT, NW, D, false, MT, true>), NW, D * NB * 1024 * MT, ep, MT, 1);
     CHILD_LAUNCH_EX((k_child_conv<NB, NT, NW, D, false, MT, false>), NW, D * NB * 1024 * MT, ep, MT, 1);
 }
 template <int NB, int NT, int NW, int D>
 int launch_child_conv_split(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
                             const ChildEpi& ep, hipStream_t s) {
-    if (ep.res) CHILD_LAUNCH_EX((k_child_conv<NB, NT, NW, D, true, 1, true>), NW, D * NB * 1024, ep, 1, 2);
     CHILD_LAUNCH_EX((k_child_conv<NB, NT, NW, D, true, 1, false>), NW, D * NB * 1024, ep, 1, 2);
 }
 template <int NB, int NW, int D, int MT = 1>
@@ -1105,24 +921,7 @@ int launch_child_irn_b_split(const int32_t* pnbr, int64_t n_p, const float* in, 
     CHILD_LAUNCH_SPLIT((k_child_irn_b<C, NW, D, true>), NW, ringb, ep);
 }
 
-template <int NW, int D>
-int launch_child_irn_b64(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
-                         const IrnEpi& ep, hipStream_t s) {
-    constexpr int need = (16 * 16 + 16 * 64) * 4;
-    constexpr int ringb = (D * 2 * 1024 > need) ? D * 2 * 1024 : need;
-    CHILD_LAUNCH((k_child_irn_b64<NW, D>), NW, ringb, ep);
-}
-template <int NW, int D>
-int launch_child_irn_b64_split(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
-                               const IrnEpi& ep, hipStream_t s) {
-    constexpr int need = (16 * 16 + 16 * 64) * 4;
-    constexpr int ringb = (D * 2 * 1024 > need) ? D * 2 * 1024 : need;
-    CHILD_LAUNCH_SPLIT((k_child_irn_b64<NW, D, true>), NW, ringb, ep);
-}
-
 }  // namespace
-
-extern int g_child_nw, g_child_depth;                       // A/B switches (pcgc_set_child_tuning); 0 = defaults
 
 #define CHILD_COMMON_CHECKS(ROWS_LD)                                                                                           \
     PCGC_REQUIRE(parent_nbr && in && table, "null argument");                                                                  \

@@ -151,10 +151,8 @@ extern "C" int pcgc_conv_unit_from_coarse(const int32_t* fine, int64_t n_fine, i
 #define UNIT_COARSE(C_) hipLaunchKernelGGL((k_conv_unit_coarse<C_>), dim3(grid_for(n_fine, 256)), dim3(256), 0, S(stream), (const int4*)fine, n_fine, \
                                            stride_fine, parent_of, coarse_nbr, down, n_coarse, W, bias, relu, out, out_ld)
     switch (Cout) {
-        case 16: UNIT_COARSE(16); break;
-        case 8: UNIT_COARSE(8); break;
-        case 4: UNIT_COARSE(4); break;
-        default: pcgc_set_error("conv_unit_from_coarse: unsupported Cout %d (4, 8, 16)", Cout); return -2;
+        case 16: UNIT_COARSE(16); break;                    // (autoencoder.py:88-94: the encoder's 1 -> 16 layer is the only unit-input conv)
+        default: pcgc_set_error("conv_unit_from_coarse: unsupported Cout %d (16)", Cout); return -2;
     }
 #undef UNIT_COARSE
     PCGC_CHECK_LAUNCH("conv_unit_from_coarse");
@@ -167,9 +165,7 @@ extern "C" int pcgc_conv_gather_unit(const int32_t* nbr, int K, int64_t n_out, c
     if (n_out == 0) return 0;
     switch (Cout) {
         case 16: hipLaunchKernelGGL((k_conv_unit<16>), dim3(grid_for(n_out, 256)), dim3(256), 0, S(stream), nbr, K, n_out, W, bias, relu, out, out_ld); break;
-        case 8: hipLaunchKernelGGL((k_conv_unit<8>), dim3(grid_for(n_out, 256)), dim3(256), 0, S(stream), nbr, K, n_out, W, bias, relu, out, out_ld); break;
-        case 4: hipLaunchKernelGGL((k_conv_unit<4>), dim3(grid_for(n_out, 256)), dim3(256), 0, S(stream), nbr, K, n_out, W, bias, relu, out, out_ld); break;
-        default: pcgc_set_error("conv_gather_unit: unsupported Cout %d (4, 8, 16)", Cout); return -2;
+        default: pcgc_set_error("conv_gather_unit: unsupported Cout %d (16)", Cout); return -2;
     }
     PCGC_CHECK_LAUNCH("conv_gather_unit");
     return 0;
@@ -235,207 +231,6 @@ __device__ static inline void fma4(float (&acc)[NO], const float4& x, const floa
 #pragma unroll
     for (int co = 0; co < NO; ++co) acc[co] = fmaf(x.w, w[3 * ldw + co], acc[co]);
 }
-
-template <int CIN, int CT>
-__global__ void __launch_bounds__(256)
-k_conv_gather_dma(const int32_t* __restrict__ nbr, int K, int64_t n_out, const float* __restrict__ in, int64_t n_in,
-                  int in_ld, const float* __restrict__ W, int Cout, const float* __restrict__ bias,
-                  const float* __restrict__ res, int res_ld, int relu, float* __restrict__ out, int out_ld) {
-    constexpr int CB = CIN < 32 ? CIN : 32;        // channels per sub-step
-    constexpr int NB = CIN / CB;                   // sub-steps per kernel offset
-    constexpr int CH = CB / 4;                     // 16-byte chunks per row per sub-step: 2, 4, 8
-    constexpr int RPI = 64 / CH;                   // rows covered by one DMA instruction
-    constexpr int SH = (CH == 2) ? 3 : (CH == 4 ? 2 : 1);      // s(r) = (r >> SH) & (CH-1)
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float4* rowbuf = (float4*)lds_raw + (size_t)wave * (64 * CH);      // [64][CH] 16-byte slots, private to the wave
-
-    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * 64;
-    if (row0 >= n_out) return;                                         // wave-uniform
-    const int co0 = blockIdx.y * CT;
-    const int64_t my_row = row0 + lane;
-    const bool valid = my_row < n_out;
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(n_in * in_ld * 4), 0x00020000);
-
-    const int dma_row_lo = lane / CH, dma_p = lane % CH;
-    const int my_swz = (lane >> SH) & (CH - 1);
-
-    __attribute__((aligned(8))) float acc[CT];
-#pragma unroll
-    for (int co = 0; co < CT; ++co) acc[co] = 0.0f;
-
-    int idx_cur = valid ? nbr[my_row] : -1;
-    for (int k = 0; k < K; ++k) {
-        int idx_nxt = -1;
-#pragma unroll
-        for (int cb = 0; cb < NB; ++cb) {
-            // ---- gather: CH DMA instructions, each fetching RPI rows as CH adjacent 16-byte chunks
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const int r = i * RPI + dma_row_lo;
-                const int rid = __shfl(idx_cur, r, 64);
-                const int chunk = dma_p ^ ((r >> SH) & (CH - 1));
-                const unsigned voff = rid >= 0 ? (unsigned)(((int64_t)rid * in_ld + cb * CB + chunk * 4) * 4) : 0xFFFFFFF0u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_ptr)(rowbuf + i * 64), 16, (int)voff, 0, 0, 0);
-            }
-            asm volatile("" ::: "memory");                       // keep the map prefetch BEHIND the DMA in the VMEM queue
-            if (cb == NB - 1 && k + 1 < K) {
-                if (valid) idx_nxt = nbr[(int64_t)(k + 1) * n_out + my_row];   // newest VMEM op: stays in flight
-                asm volatile("" ::: "memory");
-                wait_vmcnt<1>();                                                // everything older (the DMA) has landed
-            } else wait_vmcnt<0>();
-            float4 x[CH];
-#pragma unroll
-            for (int c = 0; c < CH; ++c) x[c] = rowbuf[lane * CH + (c ^ my_swz)];
-            if (idx_cur >= 0) {
-                const float* w = W + ((int64_t)k * CIN + cb * CB) * Cout + co0;
-#pragma unroll
-                for (int c = 0; c < CH; ++c) fma4<CT>(acc, x[c], w + (int64_t)(4 * c) * Cout, Cout);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // row buffer fully read before the next DMA overwrites it
-        }
-        idx_cur = idx_nxt;
-    }
-    if (!valid) return;
-    float* y = out + my_row * out_ld + co0;
-    const float* rr = res ? res + my_row * res_ld + co0 : nullptr;
-#pragma unroll
-    for (int co = 0; co < CT; ++co) {
-        float v = acc[co];
-        if (bias) v = v + bias[co0 + co];
-        if (rr) v = v + rr[co];
-        if (relu) v = fmaxf(v, 0.0f);
-        y[co] = v;
-    }
-}
-
-template <int CIN, int CT>
-static void launch_dma(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int in_ld, const float* W,
-                       int Cout, const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld,
-                       hipStream_t s) {
-    constexpr int CB = CIN < 32 ? CIN : 32;
-    constexpr size_t lds = 4 * (size_t)(64 * (CB / 4) * 16);
-    hipLaunchKernelGGL((k_conv_gather_dma<CIN, CT>), dim3(grid_for(n_out, 256), Cout / CT), dim3(256), lds, s, nbr, K, n_out, in,
-                       n_in, in_ld, W, Cout, bias, res, res_ld, relu, out, out_ld);
-}
-
-// ----------------------------------------------------------------------------------------------------------------
-// v1 for levels of a few ten thousand rows ("burst"): 16 output rows per wave and KG = 9 kernel offsets gathered per wait.
-// Such a level is 1-2 workgroups per CU, so nothing hides the gather latency: three waits per row instead of 27 (the
-// LDS the 9 row buffers take is free there).  Same fmaf chain: offsets ascending inside and across the groups.
-// ----------------------------------------------------------------------------------------------------------------
-template <int CIN, int CT, int ROWS, int KG>
-__global__ void __launch_bounds__(256)
-k_conv_gather_burst(const int32_t* __restrict__ nbr, int64_t n_out, const float* __restrict__ in, int64_t n_in, int in_ld,
-                    const float* __restrict__ W, int Cout, const float* __restrict__ bias, const float* __restrict__ res,
-                    int res_ld, int relu, float* __restrict__ out, int out_ld) {
-    static_assert(CIN <= 32 && 27 % KG == 0, "one sub-step per offset; offset groups tile the 27 offsets");
-    constexpr int CH = CIN / 4;
-    using RG = RowGather<CH, ROWS>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float4* rowbuf = (float4*)lds_raw + (size_t)wave * (KG * RG::SLOTS);
-    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * ROWS;
-    if (row0 >= n_out) return;
-    const int co0 = blockIdx.y * CT;
-    const int64_t my_row = row0 + lane;
-    const bool valid = lane < ROWS && my_row < n_out;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(n_in * in_ld * 4), 0x00020000);
-    __attribute__((aligned(8))) float acc[CT];
-#pragma unroll
-    for (int co = 0; co < CT; ++co) acc[co] = 0.0f;
-    int idx[KG];
-#pragma unroll
-    for (int g = 0; g < KG; ++g) idx[g] = valid ? nbr[(int64_t)g * n_out + my_row] : -1;
-    for (int k0 = 0; k0 < 27; k0 += KG) {
-#pragma unroll
-        for (int g = 0; g < KG; ++g) RG::fetch(rs, rowbuf + g * RG::SLOTS, idx[g], in_ld, 0, lane);
-        int idx_n[KG];
-#pragma unroll
-        for (int g = 0; g < KG; ++g) idx_n[g] = (valid && k0 + KG + g < 27) ? nbr[(int64_t)(k0 + KG + g) * n_out + my_row] : -1;
-        asm volatile("" ::: "memory");
-        if (k0 + KG < 27) wait_vmcnt<KG>(); else wait_vmcnt<0>();        // only the map prefetches (issued after the DMAs) stay in flight
-#pragma unroll
-        for (int g = 0; g < KG; ++g) {
-            float4 xv[CH];
-            RG::read(rowbuf + g * RG::SLOTS, lane, xv);
-            if (idx[g] >= 0) {
-                const float* w = W + (int64_t)(k0 + g) * CIN * Cout + co0;
-#pragma unroll
-                for (int c = 0; c < CH; ++c) fma4<CT>(acc, xv[c], w + (int64_t)(4 * c) * Cout, Cout);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int g = 0; g < KG; ++g) idx[g] = idx_n[g];
-    }
-    if (!valid) return;
-    float* y = out + my_row * out_ld + co0;
-    const float* rr = res ? res + my_row * res_ld + co0 : nullptr;
-#pragma unroll
-    for (int co = 0; co < CT; ++co) {
-        float v = acc[co];
-        if (bias) v = v + bias[co0 + co];
-        if (rr) v = v + rr[co];
-        if (relu) v = fmaxf(v, 0.0f);
-        y[co] = v;
-    }
-}
-template <int CIN, int CT>
-static int launch_burst(const int32_t* nbr, int64_t n_out, const float* in, int64_t n_in, int in_ld, const float* W, int Cout,
-                        const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld, hipStream_t s) {
-    constexpr int ROWS = 16, KG = 9;
-    constexpr size_t lds = 4 * (size_t)(KG * RowGather<CIN / 4, ROWS>::SLOTS * 16);
-    static size_t granted[16] = {0};
-    auto kern = k_conv_gather_burst<CIN, CT, ROWS, KG>;
-    if (lds > 48 * 1024) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (lds > granted[dev & 15]) {
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-                pcgc_set_error("conv_gather burst: cannot raise the LDS limit to %zu", lds); return -1;
-            }
-            granted[dev & 15] = lds;
-        }
-    }
-    hipLaunchKernelGGL(kern, dim3(grid_for(n_out, 4 * ROWS), Cout / CT), dim3(256), lds, s, nbr, n_out, in, n_in, in_ld, W, Cout,
-                       bias, res, res_ld, relu, out, out_ld);
-    return 0;
-}
-// -> 0 launched, 1 shape not covered, < 0 error
-template <int CIN>
-static int dispatch_burst(int Cout, const int32_t* nbr, int64_t n_out, const float* in, int64_t n_in, int in_ld, const float* W,
-                          const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld, hipStream_t s) {
-    switch (Cout) {
-        case 1: return launch_burst<CIN, 1>(nbr, n_out, in, n_in, in_ld, W, Cout, bias, res, res_ld, relu, out, out_ld, s);
-        case 4: return launch_burst<CIN, 4>(nbr, n_out, in, n_in, in_ld, W, Cout, bias, res, res_ld, relu, out, out_ld, s);
-        case 8: return launch_burst<CIN, 8>(nbr, n_out, in, n_in, in_ld, W, Cout, bias, res, res_ld, relu, out, out_ld, s);
-        case 16: return launch_burst<CIN, 16>(nbr, n_out, in, n_in, in_ld, W, Cout, bias, res, res_ld, relu, out, out_ld, s);
-    }
-    return 1;
-}
-
-// output-channel tile per wave: whole Cout up to 16; 16 or 32 beyond (smaller tiles on small levels = more waves)
-template <int CIN>
-static bool dispatch_dma_cout(int Cout, const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int in_ld,
-                              const float* W, const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld,
-                              hipStream_t s) {
-#define PCGC_DMA(CTILE) launch_dma<CIN, CTILE>(nbr, K, n_out, in, n_in, in_ld, W, Cout, bias, res, res_ld, relu, out, out_ld, s); return true;
-    switch (Cout) {
-        case 1: PCGC_DMA(1)
-        case 4: PCGC_DMA(4)
-        case 8: PCGC_DMA(8)
-        case 16: PCGC_DMA(16)
-        case 32: if (n_out < 200000) { PCGC_DMA(16) } else { PCGC_DMA(32) }
-        case 64: if (n_out < 200000) { PCGC_DMA(16) } else { PCGC_DMA(32) }
-    }
-#undef PCGC_DMA
-    return false;
-}
-
 
 // ----------------------------------------------------------------------------------------------------------------
 // v2 kernel: LDS-DMA gather + fp32 MFMA channel GEMM, for Cin in {16,32,64} and Cout a multiple of 16.
@@ -555,384 +350,6 @@ k_conv_gather_mfma(const int32_t* __restrict__ nbr, int K, int64_t n_out, const 
         }
 }
 
-// ----------------------------------------------------------------------------------------------------------------
-// v2b: the same MFMA gather conv with the weight (B) tiles shared by the workgroup through LDS.
-// PMC on v2 (64->64, 150 k rows): 3.7 GB fetched per launch against 0.74 GB algorithmic — every wave streams its share of
-// the 442 KB weight set from L2, and with 16-column tiles (gridDim.y = 4) every row is gathered four times.  Here a
-// workgroup of 4 waves x (16*MT) rows computes ALL output columns: the 16 x COUT weight slice of a sub-step is staged once
-// per workgroup into a double-buffered LDS tile (one __syncthreads per sub-step; the slice for sub-step t+1 is fetched
-// while t is computed), and every wave reads its B fragments from LDS.
-// ----------------------------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int MT>
-__global__ void __launch_bounds__(256)
-k_conv_gather_mfma_wlds(const int32_t* __restrict__ nbr, int K, int64_t n_out, const float* __restrict__ in, int64_t n_in,
-                        int in_ld, const float* __restrict__ W, const uint32_t* __restrict__ tile_mask,
-                        const float* __restrict__ bias,
-                        const float* __restrict__ res, int res_ld, int relu, float* __restrict__ out, int out_ld) {
-    constexpr int NB = CIN / 16, NT = COUT / 16, ROWS = 16 * MT;
-    // weight rows are padded to WLD floats in LDS: lane quarter q reads row 4j+q, so the row stride decides the banks of the
-    // four quarters — 32 floats puts two of them on the same 16 banks and 64 all four (PMC: 25 % of the LDS cycles of
-    // wlds<64,32,2> were bank conflicts, none in <32,48,2>); 48 / 80 keep the quarters apart
-    constexpr int WLD = (COUT % 32 == 0) ? COUT + 16 : COUT;
-    constexpr int WSLICE = 16 * WLD;                                   // floats per (k, cb) weight slice in LDS
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* wbuf = (float*)lds_raw;                                      // [2][16][WLD]
-    float4* rowbuf = (float4*)(lds_raw + 2 * WSLICE * 4) + (size_t)wave * (ROWS * 4);   // [ROWS][4] slots per wave
-    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * ROWS;
-    const bool wave_active = row0 < n_out;                              // idle waves still take part in staging + barriers
-    const int64_t my_row = row0 + lane;
-    const bool valid = wave_active && lane < ROWS && my_row < n_out;
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(n_in * in_ld * 4), 0x00020000);
-    const int mi = lane & 15, mq = lane >> 4;
-    const int f_a = (0x78 >> (2 * (mi >> 2))) & 3;
-    const int dma_row_lo = lane >> 2, dma_p = lane & 3;
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int T = K * NB;
-    // stage slice t (k = t / NB, cb = t % NB) into wbuf[t & 1]: WSLICE/4 float4, one or fewer per thread
-    auto stage_w = [&](int t) {
-        const int k = t / NB, cb = t % NB;
-        const float4* src = (const float4*)(W + ((int64_t)k * CIN + cb * 16) * COUT);
-        float4* dst = (float4*)(wbuf + (t & 1) * WSLICE);
-        for (int i = threadIdx.x; i < 16 * COUT / 4; i += 256) dst[(i / (COUT / 4)) * (WLD / 4) + i % (COUT / 4)] = src[i];
-    };
-    stage_w(0);
-    int idx_cur = valid ? nbr[my_row] : -1;
-    for (int t = 0; t < T; ++t) {
-        const int k = t / NB, cb = t % NB;
-        __syncthreads();                                                // slice t staged; everyone done with sub-step t-1
-        if (t + 1 < T) stage_w(t + 1);
-        int idx_nxt = -1;
-        if (cb == NB - 1 && k + 1 < K && valid) idx_nxt = nbr[(int64_t)(k + 1) * n_out + my_row];
-        if (wave_active) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int r = i * 16 + dma_row_lo;
-                const int rid = __shfl(idx_cur, r, 64);
-                const int chunk = dma_p ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3);
-                const unsigned voff = rid >= 0 ? (unsigned)(((int64_t)rid * in_ld + cb * 16 + chunk * 4) * 4) : 0xFFFFFFF0u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_ptr)(rowbuf + i * 64), 16, (int)voff, 0, 0, 0);
-            }
-            asm volatile("" ::: "memory");
-            wait_vmcnt<0>();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            float4 a[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                a[m] = rowbuf[(16 * m + mi) * 4 + (mq ^ f_a)];
-                lane_transpose4(a[m]);
-            }
-            const float* wb = wbuf + (t & 1) * WSLICE + mq * WLD + mi;      // B[j][n] = wb[(4j)*WLD + 16n]
-            // block-sparse weights: bit n of tile_mask[t] = "column tile n has a non-zero weight in slice t"; an all-zero tile
-            // would only add fma(x, 0, acc) = acc, so it is skipped (wave-uniform branch)
-            const uint32_t tmask = tile_mask ? __builtin_amdgcn_readfirstlane(tile_mask[t]) : 0xFFFFFFFFu;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float b[NT];
-#pragma unroll
-                for (int n = 0; n < NT; ++n) b[n] = wb[(4 * j) * WLD + 16 * n];
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    if (tmask & (1u << n)) {
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            const float av = j == 0 ? a[m].x : (j == 1 ? a[m].y : (j == 2 ? a[m].z : a[m].w));
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[n], acc[m][n], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        }
-        if (cb == NB - 1) idx_cur = idx_nxt;
-    }
-    if (!wave_active) return;
-    float bias_v[NT];                                          // (once per wave: a load inside the store loop is re-issued after every store)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) bias_v[n] = bias ? bias[16 * n + mi] : 0.0f;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t row = row0 + 16 * m + 4 * mq + r;
-            if (row >= n_out) continue;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int col = 16 * n + mi;
-                float v = acc[m][n][r];
-                if (bias) v = v + bias_v[n];
-                if (res) v = v + res[row * res_ld + col];
-                if (relu) v = fmaxf(v, 0.0f);
-                out[row * out_ld + col] = v;
-            }
-        }
-}
-
-template <int CIN, int COUT, int MT>
-static void launch_mfma_wlds(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int in_ld, const float* W,
-                             const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld, hipStream_t s,
-                             const uint32_t* tile_mask = nullptr) {
-    constexpr size_t lds = 2 * 16 * ((COUT % 32 == 0) ? COUT + 16 : COUT) * 4 + 4 * (size_t)(16 * MT * 64);
-    hipLaunchKernelGGL((k_conv_gather_mfma_wlds<CIN, COUT, MT>), dim3(grid_for(n_out, 4 * 16 * MT)), dim3(256), lds, s, nbr, K,
-                       n_out, in, n_in, in_ld, W, tile_mask, bias, res, res_ld, relu, out, out_ld);
-}
-
-// ----------------------------------------------------------------------------------------------------------------
-// v2c: v2b with 32-channel steps and the next step's loads in flight during the current step's MFMAs.
-// On the C = 64 levels (71 k / 150 k rows) there are only 2-5 row tiles per SIMD and v2b runs each tile as 108 dependent
-// sub-steps of "stage weights (global -> VGPR -> LDS) -> barrier -> gather -> wait -> 8..16 MFMAs": ~1.7 us per sub-step of
-// which ~0.15 us is MFMA work (wlds<64,32,2> on 150 k rows: 186 us = 108 x 1.7 us; the MFMA pipe is 28 % busy).  Here
-//   * a step is one kernel offset x 32 input channels (54 / 27 steps for Cin = 64 / 32): twice the MFMA work per barrier;
-//   * both operand streams are double-buffered in LDS and filled by LDS-DMA: the gathered rows ([ROWS][8] 16-byte slots per
-//     wave, 8 adjacent lanes per 128-byte row segment) and the 32 x COUT weight slice (thread i copies float4 i; no VGPR
-//     round trip, so nothing waits at issue).  Order per step: wait for step s -> s_barrier (slice s visible to all waves,
-//     everyone done with s-1) -> issue step s+1 into the other buffers -> MFMAs of step s;
-//   * the LDS reads of a step are hidden from the compiler (lds_ld*_raw): a visible read of a DMA destination makes hipcc
-//     wait vmcnt(0) first, which would serialise the prefetch again.
-// LDS image of the rows: slot (r, u) holds 16-byte chunk u ^ ((r >> 1) & 7) of row r (source-side swizzle): a b128 read of
-// one chunk index over 16 consecutive rows then touches 16 distinct bank groups.  MFMA operand layouts, lane transposes,
-// tile masks and the accumulation order are those of v2b: bit-identical results.
-// ----------------------------------------------------------------------------------------------------------------
-// b[j][n] = wb[(4j) * COUT + 16n] for one 16-channel block, compile-time LDS offsets
-template <int COUT, int NT, int J = 0, int N = 0>
-__device__ static inline void pipe_load_b(const float* wb, float (&b)[4][NT]) {
-    if constexpr (J < 4) {
-        b[J][N] = lds_ld32_raw<((4 * J) * COUT + 16 * N) * 4>(wb);
-        if constexpr (N + 1 < NT) pipe_load_b<COUT, NT, J, N + 1>(wb, b);
-        else pipe_load_b<COUT, NT, J + 1, 0>(wb, b);
-    }
-}
-
-template <int CIN, int COUT, int MT>
-__global__ void __launch_bounds__(256)
-k_conv_gather_mfma_pipe(const int32_t* __restrict__ nbr, int K, int64_t n_out, const float* __restrict__ in, int64_t n_in,
-                        int in_ld, const float* __restrict__ W, const uint32_t* __restrict__ tile_mask,
-                        const float* __restrict__ bias,
-                        const float* __restrict__ res, int res_ld, int relu, float* __restrict__ out, int out_ld) {
-    constexpr int NB2 = CIN / 32, NB = CIN / 16, NT = COUT / 16, ROWS = 16 * MT;
-    constexpr int WLD = (COUT == 32) ? 48 : COUT;                      // padded LDS row of the weight slice (see v2b: bank spread); 64 stays
-                                                                       // unpadded: 80 would cost a third DMA per step and the third block per CU
-    constexpr int WSLICE = 32 * WLD;                                   // floats per (k, 32-channel block) weight slice in LDS
-    constexpr int WI = (WSLICE / 4 + 255) / 256;                       // weight DMA instructions per wave and step
-    constexpr int WBUF = WI * 256 * 4;                                 // floats per weight buffer: whole DMA instructions (an out-of-range
-                                                                       // lane still owns its 16-byte LDS slot, which must not be live data)
-    constexpr int ASLOTS = ROWS * 8;                                   // float4 slots of one row tile (32 channels)
-    constexpr int AI = ROWS / 8;                                       // row DMA instructions per wave and step
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* wring = (float*)lds_raw;                                                              // [2][32][COUT]
-    float4* aring = (float4*)(lds_raw + (size_t)2 * WBUF * 4) + (size_t)wave * (2 * ASLOTS);       // [2][ROWS][8] per wave
-    const int64_t row0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave) * ROWS;
-    const bool wave_active = row0 < n_out;                              // idle waves still copy weights and take the barriers
-    const int64_t my_row = row0 + lane;
-    const bool valid = wave_active && lane < ROWS && my_row < n_out;
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(n_in * in_ld * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)((int64_t)K * CIN * COUT * 4), 0x00020000);
-    const int mi = lane & 15, mq = lane >> 4;
-    const int dma_row_lo = lane >> 3, dma_p = lane & 7;                 // 8 lanes per 128-byte row segment, 8 rows per instruction
-    const int S = K * NB2;
-
-    // step u = (k, c2): rows of offset k (map entries `idx`, one per lane = tile row), channels [32 c2, 32 c2 + 32)
-    auto issue = [&](int u, int idx) {
-        const int k = u / NB2, c2 = u % NB2, buf = u & 1;
-        float4* abase = aring + buf * ASLOTS;
-#pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const int r = i * 8 + dma_row_lo;
-            const int rid = __shfl(idx, r, 64);
-            const int chunk = dma_p ^ ((r >> 1) & 7);
-            const unsigned voff = rid >= 0 ? (unsigned)(((int64_t)rid * in_ld + c2 * 32 + chunk * 4) * 4) : 0xFFFFFFF0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_ptr)(abase + i * 64), 16, (int)voff, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const int e = i * 256 + threadIdx.x;                       // float4 slot of the LDS image: row e / (WLD/4), column e % (WLD/4)
-            const int wr = e / (WLD / 4), wc = e % (WLD / 4);
-            const unsigned woff = (wr < 32 && wc < COUT / 4) ? (unsigned)((((int64_t)k * CIN + c2 * 32 + wr) * COUT + wc * 4) * 4) : 0xFFFFFFF0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_ptr)((float4*)(wring + buf * WBUF) + i * 256 + wave * 64), 16,
-                                                     (int)woff, 0, 0, 0);
-        }
-        asm volatile("" ::: "memory");
-    };
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    int idx_cur = valid ? nbr[my_row] : -1;                             // offset of the step being issued next
-    int idx_nxt = (valid && K > 1) ? nbr[n_out + my_row] : -1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // after issuing step u: if it was the last 32-channel block of its offset, the next step gathers the next offset's rows
-    auto advance = [&](int u) {
-        if (u % NB2 == NB2 - 1) {
-            const int kn = u / NB2 + 2;
-            idx_cur = idx_nxt;
-            idx_nxt = (valid && kn < K) ? nbr[(int64_t)kn * n_out + my_row] : -1;
-        }
-    };
-    issue(0, idx_cur);
-    advance(0);
-    for (int s = 0; s < S; ++s) {
-        wait_vmcnt<0>();                                                // step s has landed (and the map entry fetched below)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // own LDS reads of step s-1 retired
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (s + 1 < S) {
-            issue(s + 1, idx_cur);
-            advance(s + 1);
-        }
-        if (wave_active) {
-            const int buf = s & 1;
-            const float4* abase = aring + buf * ASLOTS;
-            const float* wsl = wring + buf * WBUF;
-#pragma unroll
-            for (int cq = 0; cq < 2; ++cq) {                            // the two 16-channel blocks of the step
-                f32x4 araw[MT];
-                float b[4][NT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int r = 16 * m + mi;
-                    araw[m] = lds_ld128_raw(abase + r * 8 + ((cq * 4 + mq) ^ ((r >> 1) & 7)));
-                }
-                pipe_load_b<WLD, NT>(wsl + (cq * 16 + mq) * WLD + mi, b);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int m = 0; m < MT; ++m) lds_tie(araw[m]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) lds_tie(b[j][n]);
-                float4 a[MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    a[m] = make_float4(araw[m][0], araw[m][1], araw[m][2], araw[m][3]);
-                    lane_transpose4(a[m]);
-                }
-                const int t16 = (s / NB2) * NB + (s % NB2) * 2 + cq;    // (k, 16-channel block) index of the tile mask
-                const uint32_t tmask = tile_mask ? __builtin_amdgcn_readfirstlane(tile_mask[t16]) : 0xFFFFFFFFu;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        if (tmask & (1u << n)) {
-#pragma unroll
-                            for (int m = 0; m < MT; ++m) {
-                                const float av = j == 0 ? a[m].x : (j == 1 ? a[m].y : (j == 2 ? a[m].z : a[m].w));
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j][n], acc[m][n], 0, 0, 0);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (!wave_active) return;
-    float bias_v[NT];                                          // (once per wave: a load inside the store loop is re-issued after every store)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) bias_v[n] = bias ? bias[16 * n + mi] : 0.0f;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t row = row0 + 16 * m + 4 * mq + r;
-            if (row >= n_out) continue;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int col = 16 * n + mi;
-                float v = acc[m][n][r];
-                if (bias) v = v + bias_v[n];
-                if (res) v = v + res[row * res_ld + col];
-                if (relu) v = fmaxf(v, 0.0f);
-                out[row * out_ld + col] = v;
-            }
-        }
-}
-
-template <int CIN, int COUT, int MT>
-static void launch_mfma_pipe(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int in_ld, const float* W,
-                             const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld, hipStream_t s,
-                             const uint32_t* tile_mask = nullptr) {
-    constexpr int wld = (COUT == 32) ? 48 : COUT;
-    constexpr size_t lds = (size_t)2 * (((32 * wld / 4 + 255) / 256) * 256 * 16) + 4 * (size_t)(2 * 16 * MT * 8 * 16);
-    static_assert(lds <= 64 * 1024, "stays under the default dynamic LDS limit");
-    hipLaunchKernelGGL((k_conv_gather_mfma_pipe<CIN, COUT, MT>), dim3(grid_for(n_out, 4 * 16 * MT)), dim3(256), lds, s, nbr, K,
-                       n_out, in, n_in, in_ld, W, tile_mask, bias, res, res_ld, relu, out, out_ld);
-}
-
-static int g_mfma_pipe = -1;        // v2c (32-channel steps, double-buffered): -1 by level size, 0 never, 1 always (A/B tests)
-extern "C" int pcgc_set_mfma_pipe(int mode) { g_mfma_pipe = mode; return 0; }
-
-// Block-sparse k3 gather conv on the LDS-shared-weight MFMA kernels (used by the fused C=64 InceptionResNet passes).
-extern "C" int pcgc_conv_gather_masked(const int32_t* nbr, int64_t n_out, const float* in, int64_t n_in, int Cin, int in_ld,
-                                       const float* W, int Cout, const uint32_t* tile_mask, const float* bias, int relu,
-                                       float* out, int out_ld, void* stream) {
-    PCGC_REQUIRE(nbr && in && W && out, "null argument");
-    PCGC_REQUIRE((in_ld & 3) == 0 && (((uintptr_t)in | (uintptr_t)W) & 15) == 0, "unaligned input");
-    PCGC_REQUIRE(n_in * (int64_t)in_ld * 4 < (int64_t)0xFFFFFFF0, "tensor too large for 32-bit buffer offsets");
-    if (n_out == 0) return 0;
-    hipStream_t s = S(stream);
-    // v2c below ~110 k rows (measured us, v2b -> v2c: 64->32 at 71 k rows 140 -> 103, at 150 k 175 -> 180; 32->48 86 -> 70 / 114 -> 124)
-    const bool pipe = g_mfma_pipe > 0 || (g_mfma_pipe < 0 && n_out < 110000);
-    if (pipe && Cin == 64 && Cout == 32) launch_mfma_pipe<64, 32, 2>(nbr, 27, n_out, in, n_in, in_ld, W, bias, nullptr, 0, relu, out, out_ld, s, tile_mask);
-    else if (pipe && Cin == 32 && Cout == 48) launch_mfma_pipe<32, 48, 2>(nbr, 27, n_out, in, n_in, in_ld, W, bias, nullptr, 0, relu, out, out_ld, s, tile_mask);
-    else if (Cin == 64 && Cout == 32) launch_mfma_wlds<64, 32, 2>(nbr, 27, n_out, in, n_in, in_ld, W, bias, nullptr, 0, relu, out, out_ld, s, tile_mask);
-    else if (Cin == 32 && Cout == 48) launch_mfma_wlds<32, 48, 2>(nbr, 27, n_out, in, n_in, in_ld, W, bias, nullptr, 0, relu, out, out_ld, s, tile_mask);
-    else { pcgc_set_error("conv_gather_masked: unsupported shape %d -> %d (64->32, 32->48)", Cin, Cout); return -2; }
-    PCGC_CHECK_LAUNCH("conv_gather_masked");
-    return 0;
-}
-
-// Tail of the fused C=64 InceptionResNet: u = [conv0_1 + b01 (2Q) | conv1_1 + b11 (Q)] ->
-//   out[:, 0:2Q] = u[:, 0:2Q] + x[:, 0:2Q] ;  out[:, 2Q:4Q] = (relu(u[:, 2Q:3Q]) @ W12 + b12) + x[:, 2Q:4Q]      (Q = C/4)
-template <int C>
-__global__ void __launch_bounds__(256) k_irn_tail(const float* __restrict__ u, const float* __restrict__ x, int x_ld,
-                                                  const float* __restrict__ W12, const float* __restrict__ b12,
-                                                  float* __restrict__ out, int out_ld, int64_t n) {
-    // one thread per (row, 4 output columns): consecutive lanes touch consecutive 16-byte chunks (coalesced loads/stores)
-    constexpr int Q = C / 4, H = C / 2, UW = 3 * Q, CHUNKS = C / 4;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t row = t / CHUNKS;
-    const int c = (int)(t % CHUNKS);
-    if (row >= n) return;
-    const float* ur = u + row * UW;
-    const float4 xr = *(const float4*)(x + row * x_ld + 4 * c);
-    float4 y;
-    if (c < H / 4) {                                              // cat slot 0: conv0_1 (+bias, already in u) + residual
-        const float4 uv = *(const float4*)(ur + 4 * c);
-        y = make_float4(uv.x + xr.x, uv.y + xr.y, uv.z + xr.z, uv.w + xr.w);
-    } else {                                                      // cat slot 1: conv1_2(relu(conv1_1)) + bias + residual
-        const int co = 4 * (c - H / 4);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-        for (int ci = 0; ci < Q; ++ci) {
-            const float v = fmaxf(ur[H + ci], 0.0f);
-            const float4 w = *(const float4*)(W12 + ci * H + co);
-            a0 = fmaf(v, w.x, a0); a1 = fmaf(v, w.y, a1); a2 = fmaf(v, w.z, a2); a3 = fmaf(v, w.w, a3);
-        }
-        const float4 bb = *(const float4*)(b12 + co);
-        y = make_float4((a0 + bb.x) + xr.x, (a1 + bb.y) + xr.y, (a2 + bb.z) + xr.z, (a3 + bb.w) + xr.w);
-    }
-    *(float4*)(out + row * out_ld + 4 * c) = y;
-}
-extern "C" int pcgc_irn_tail(const float* u, const float* x, int C, int x_ld, const float* W12, const float* b12, float* out,
-                             int out_ld, int64_t n, void* stream) {
-    PCGC_REQUIRE(C == 64, "irn_tail: only C = 64 is built");
-    if (n == 0) return 0;
-    PCGC_REQUIRE((x_ld & 3) == 0 && (out_ld & 3) == 0, "leading dimensions must be multiples of 4");
-    hipLaunchKernelGGL((k_irn_tail<64>), dim3(grid_for(n * 16, 256)), dim3(256), 0, S(stream), u, x, x_ld, W12, b12, out, out_ld, n);
-    PCGC_CHECK_LAUNCH("irn_tail");
-    return 0;
-}
-
 template <int CIN, int NT>
 static void launch_mfma(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int in_ld, const float* W,
                         int Cout, const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld,
@@ -944,13 +361,8 @@ template <int CIN>
 static bool dispatch_mfma(int Cout, const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int in_ld,
                           const float* W, const float* bias, const float* res, int res_ld, int relu, float* out, int out_ld,
                           hipStream_t s) {
-#define PCGC_MF(NTILES) launch_mfma<CIN, NTILES>(nbr, K, n_out, in, n_in, in_ld, W, Cout, bias, res, res_ld, relu, out, out_ld, s); return true;
-    switch (Cout) {
-        case 16: PCGC_MF(1)
-        case 32: if (n_out < 200000) { PCGC_MF(1) } else { PCGC_MF(2) }
-        case 64: if (n_out < 200000) { PCGC_MF(1) } else { PCGC_MF(2) }
-    }
-#undef PCGC_MF
+    // (one 16-column tile per wave at every size: the 32-column form only paid from 200 k rows on, where the rows / packed / children kernels run)
+    if (Cout == 16 || Cout == 32 || Cout == 64) { launch_mfma<CIN, 1>(nbr, K, n_out, in, n_in, in_ld, W, Cout, bias, res, res_ld, relu, out, out_ld, s); return true; }
     return false;
 }
 
@@ -963,14 +375,10 @@ static bool dispatch_mfma(int Cout, const int32_t* nbr, int K, int64_t n_out, co
 //       ONE gather of the 2Q-wide rows of t feeds both k3 convs (the unfused form gathers two Q-wide tensors).
 // 5 launches / 3 gathers / 2 pointwise passes become 2 launches / 2 gathers; every fmaf chain is unchanged.
 // ----------------------------------------------------------------------------------------------------------------
-static int g_irn_rows = 0;          // 0 = choose the tile height from the level size; 64/32/16 force (A/B tests)
-static int64_t g_irn_cb16_rows = 400000;   // C = 32 pass A: 16-channel sub-steps from this many rows on (0 = always, for tests)
-extern "C" int pcgc_set_irn_cb16_rows(int64_t min_rows) { g_irn_cb16_rows = min_rows < 0 ? 400000 : min_rows; return 0; }
-extern "C" int pcgc_set_irn_rows(int rows) { g_irn_rows = rows; return 0; }
-static int g_irn_split = 1;         // 16-row tiles at C <= 32: row-split kernels (1, default) or the lane = row kernels (0; A/B tests)
-extern "C" int pcgc_set_irn_split(int on) { g_irn_split = on ? 1 : 0; return 0; }
-static int irn_rows_for(int64_t n) { return g_irn_rows > 0 ? g_irn_rows : (n < 40000 ? 16 : (n < 120000 ? 32 : 64)); }   // (measurements: launch_irn_rows; 64-71 k rows at C = 32: 32-row tiles 62-72 us, 64-row 74-84)
-
+// Tile height: 16 rows per wave (round 5).  This pair serves what the rows / children kernels leave: levels below 1024 rows, children levels below
+// 8192 rows — where the extra waves of short tiles win (18.7 k rows at C = 32: 64-row tiles 62.7 / 45.8 us, 16-row 43.7 / 32.8) — and, with
+// the A/B switches off, any level as the comparison baseline.  The 32- / 64-row instantiations and the 16-channel sub-step form went with
+// the levels they were tuned for.
 // kernel offsets gathered per wait (27 = 9 x 3): more gathers in flight per wave.  Pays only while the extra row buffers do
 // not cut occupancy: measured irn_b<16> 194 -> 167 us, but irn_b<32> 127 -> 160 us and irn_b<64> 196 -> 433 us with 3.
 template <int C> struct IrnKG { static constexpr int value = (C == 16) ? 3 : 1; };       // pass B
@@ -1436,69 +844,45 @@ template <int C, int ROWS> struct IrnBurst {
     static constexpr int A = (ROWS == 16 && C <= 32) ? 9 : IrnKGA<C>::value;      // pass A needs the whole row in one sub-step
     static constexpr int B = (ROWS == 16) ? 9 : IrnKG<C>::value;
 };
-template <int C, int ROWS>
+template <int C>
 static int launch_irn(const int32_t* nbr, int64_t n, const float* x, int x_ld, const float* const* P, float* t, float* out,
                        int out_ld, int phase, hipStream_t s) {
-    constexpr int CBA = C < 32 ? C : 32;
-    constexpr int KGA = IrnBurst<C, ROWS>::A, KGB = IrnBurst<C, ROWS>::B;
-    const size_t lds_a = 4 * (size_t)(KGA * RowGather<CBA / 4, ROWS>::SLOTS * 16);
-    const size_t lds_b = 4 * (size_t)(KGB * RowGather<C / 8, ROWS>::SLOTS * 16);
+    constexpr int ROWS = 16;
     const dim3 grid(grid_for(n, 4 * ROWS));
-    if constexpr (ROWS == 16 && C <= 32) {
-        if (g_irn_split) {                               // lane = (row, output-channel part), weights in LDS
-            if (phase & 1) {
-                static size_t granted[16] = {0};
-                auto kern = k_irn_a_split<C>;
-                if (irn_lds_limit((const void*)kern, IrnSplit<C>::LDS_A, granted)) { pcgc_set_error("irn pass A: cannot raise the LDS limit"); return -1; }
-                hipLaunchKernelGGL(kern, grid, dim3(256), IrnSplit<C>::LDS_A, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
-            }
-            if (phase & 2) {
-                static size_t granted[16] = {0};
-                auto kern = k_irn_b_split<C>;
-                if (irn_lds_limit((const void*)kern, IrnSplit<C>::LDS_B, granted)) { pcgc_set_error("irn pass B: cannot raise the LDS limit"); return -1; }
-                hipLaunchKernelGGL(kern, grid, dim3(256), IrnSplit<C>::LDS_B, s, nbr, n, t, x, x_ld, P[2], P[3], P[6], P[7], P[8], P[9], out, out_ld);
-            }
-            return 0;
+    if constexpr (C <= 32) {                             // lane = (row, output-channel part), weights in LDS
+        if (phase & 1) {
+            static size_t granted[16] = {0};
+            auto kern = k_irn_a_split<C>;
+            if (irn_lds_limit((const void*)kern, IrnSplit<C>::LDS_A, granted)) { pcgc_set_error("irn pass A: cannot raise the LDS limit"); return -1; }
+            hipLaunchKernelGGL(kern, grid, dim3(256), IrnSplit<C>::LDS_A, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
         }
+        if (phase & 2) {
+            static size_t granted[16] = {0};
+            auto kern = k_irn_b_split<C>;
+            if (irn_lds_limit((const void*)kern, IrnSplit<C>::LDS_B, granted)) { pcgc_set_error("irn pass B: cannot raise the LDS limit"); return -1; }
+            hipLaunchKernelGGL(kern, grid, dim3(256), IrnSplit<C>::LDS_B, s, nbr, n, t, x, x_ld, P[2], P[3], P[6], P[7], P[8], P[9], out, out_ld);
+        }
+        return 0;
+    } else {                                             // C = 64: lane = row, weights as scalar operands
+        constexpr int KGA = IrnBurst<C, ROWS>::A, KGB = IrnBurst<C, ROWS>::B;
+        const size_t lds_a = 4 * (size_t)(KGA * RowGather<32 / 4, ROWS>::SLOTS * 16);
+        const size_t lds_b = 4 * (size_t)(KGB * RowGather<C / 8, ROWS>::SLOTS * 16);
+        if (phase & 1) {
+            static size_t granted[16] = {0};
+            auto kern = k_irn_a<C, ROWS, 32, KGA>;
+            if (irn_lds_limit((const void*)kern, lds_a, granted)) { pcgc_set_error("irn pass A: cannot raise the LDS limit to %zu", lds_a); return -1; }
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds_a, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
+        }
+        if (phase & 2) {
+            static size_t granted[16] = {0};
+            auto kern = k_irn_b<C, ROWS, KGB>;
+            if (irn_lds_limit((const void*)kern, lds_b, granted)) { pcgc_set_error("irn pass B: cannot raise the LDS limit to %zu", lds_b); return -1; }
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds_b, s, nbr, n, t, x, x_ld, P[2], P[3], P[6], P[7], P[8], P[9], out, out_ld);
+        }
+        return 0;
     }
-    if ((phase & 1) && C == 32 && ROWS == 64 && n >= g_irn_cb16_rows) {
-        const size_t lds16 = 4 * (size_t)(IrnKGA<C>::value * RowGather<4, ROWS>::SLOTS * 16);
-        hipLaunchKernelGGL((k_irn_a<C, ROWS, 16>), grid, dim3(256), lds16, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
-    } else if (phase & 1) {
-        static size_t granted[16] = {0};
-        auto kern = k_irn_a<C, ROWS, 32, KGA>;
-        if (irn_lds_limit((const void*)kern, lds_a, granted)) { pcgc_set_error("irn pass A: cannot raise the LDS limit to %zu", lds_a); return -1; }
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds_a, s, nbr, n, x, x_ld, P[0], P[1], P[4], P[5], t);
-    }
-    if (phase & 2) {
-        static size_t granted[16] = {0};
-        auto kern = k_irn_b<C, ROWS, KGB>;
-        if (irn_lds_limit((const void*)kern, lds_b, granted)) { pcgc_set_error("irn pass B: cannot raise the LDS limit to %zu", lds_b); return -1; }
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds_b, s, nbr, n, t, x, x_ld, P[2], P[3], P[6], P[7], P[8], P[9],
-                           out, out_ld);
-    }
-    return 0;
-}
-template <int C>
-static int launch_irn_rows(const int32_t* nbr, int64_t n, const float* x, int x_ld, const float* const* P, float* t, float* out,
-                            int out_ld, int phase, hipStream_t s) {
-    // measured per level (bench.py --irn-rows, us for pass A / pass B at C = 32): 18.7 k rows: 64 -> 62.7 / 45.8, 32 -> 51.8 / 38.0,
-    // 16 -> 43.7 / 32.8 (a level that small is 73 tiles of 64 rows: the extra waves win); 256 k rows: 68.5 / 54.3, 93.1 / 66.3,
-    // 141.7 / 100.4 and likewise above (shorter tiles lose more DMA efficiency than the extra waves gain).
-    const int rows = irn_rows_for(n);
-    if (rows == 64) return launch_irn<C, 64>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
-    if (rows == 32) return launch_irn<C, 32>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
-    return launch_irn<C, 16>(nbr, n, x, x_ld, P, t, out, out_ld, phase, s);
 }
 
-// the tile height / channel sub-step the dispatcher below picks for (C, n): the single source of that policy, also for the host's
-// profile records (which name the exact kernel instantiation)
-extern "C" int pcgc_irn_config(int C, int64_t n, int* rows, int* pass_a_channels_per_substep) {
-    const int r = irn_rows_for(n);
-    if (rows) *rows = r;
-    if (pass_a_channels_per_substep) *pass_a_channels_per_substep = (C == 32 && r == 64 && n >= g_irn_cb16_rows) ? 16 : 32;
-    return 0;
-}
 // params: {W00,b00, W01,b01, W10,b10, W11,b11, W12,b12} = conv0_0, conv0_1, conv1_0, conv1_1, conv1_2 (kernel, bias)
 static int irn_launch(const int32_t* nbr, int64_t n, const float* x, int C, int x_ld, const float* const* params,
                       float* t_scratch, float* out, int out_ld, int phase, void* stream);
@@ -1521,84 +905,47 @@ static int irn_launch(const int32_t* nbr, int64_t n, const float* x, int C, int 
     PCGC_REQUIRE((((uintptr_t)x | (uintptr_t)t_scratch | (uintptr_t)out) & 15) == 0, "buffers must be 16-byte aligned");
     if (n == 0) return 0;
     int rc;
-    if (C == 16) rc = launch_irn_rows<16>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
-    else if (C == 32) rc = launch_irn_rows<32>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
-    else rc = launch_irn_rows<64>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
+    if (C == 16) rc = launch_irn<16>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
+    else if (C == 32) rc = launch_irn<32>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
+    else rc = launch_irn<64>(nbr, n, x, x_ld, params, t_scratch, out, out_ld, phase, S(stream));
     if (rc) return rc;
     PCGC_CHECK_LAUNCH("irn_block");
     return 0;
 }
 
-// kernel selection for pcgc_conv_gather (all variants are bit-identical; tests run every one of them):
-//   -1 auto | 0 v0 direct loads + VALU | 1 v1 LDS-DMA + VALU | 2 v2 LDS-DMA + MFMA | 3 v2b MFMA with LDS-shared weights | 5 v1 burst (16-row tiles, 9 offsets per wait) | 6 row-split (16-row tiles, lanes split the output channels, weights in LDS)
-// auto policy (measured per shape, tools/conv_ab.py, tools/conv32_ab.py): >= 30 k rows: 64->64 and 32->32 -> v2b (v2c below 110 k rows for 64->64); Cin in {16,32,64} & Cout in {16,32,64} -> v2;
-// other gathered shapes with Cin in {8,16,32,64} -> v1; everything else (Cin 1/4, k1 convs, tiny levels) -> v0.
+// kernel selection for pcgc_conv_gather (all families are bit-identical; tests run every one of them): -1 auto | 0 direct loads + VALU |
+// 2 LDS-DMA + MFMA | 6 row-split
 static int g_conv_impl = -1;
-static int g_auto_wlds = 1;         // auto: LDS-shared-weight MFMA kernel for 64->64 (591 -> 403 us at 150 k rows) and, since the weight rows are
-                                    // bank-conflict free, 32->32 (181 -> 168 us at 256 k rows, 400 -> 374 at 570 k)
-static int g_auto_mfma = 1;         // auto mode uses the MFMA kernel for its eligible shapes once A/B says so
 extern "C" int pcgc_set_conv_impl(int impl) { g_conv_impl = impl; return 0; }
-// Which kernel family the calling thread's last pcgc_conv_gather launched: 0 v0 (VALU, direct loads) | 1 v1 (LDS-DMA + VALU) | 2 v2 (MFMA,
-// weights from L2) | 3 v2b (MFMA, LDS-shared weights, 2 M tiles per wave) | 4 v2b with 4 M tiles | 5 v1 burst | 6 row-split | 7 v2c (MFMA,
-// both operands double-buffered in LDS).  The size / shape policy lives in ONE table, pcgcv2_amd/dispatch.py; the GPU tests read this
-// back for every entry of that table, on both sides of every gate, and compare it with the table's prediction.
+// Which kernel family the calling thread's last pcgc_conv_gather launched: 0 = VALU, direct loads | 2 = MFMA, LDS-DMA row gather, weights
+// from L2 | 6 = row-split (16-row tiles, lanes split the output channels).  (Round 5 removed the LDS-DMA + VALU forms 1 / 5 and the
+// LDS-shared-weight MFMA forms 3 / 4 / 7: every level they were tuned for runs on the rows / packed / children kernels)
+// The size / shape policy lives in ONE table, pcgcv2_amd/dispatch.py; the GPU tests read this back for every entry of that table, on
+// both sides of every gate, and compare it with the table's prediction.
 static thread_local int t_last_conv_impl = -1;
 extern "C" int pcgc_last_conv_impl(void) { return t_last_conv_impl; }
-static int64_t g_wlds_mt4_rows = 400000;   // the LDS-shared-weight MFMA kernel runs 4 M-tiles per wave (MT = 4) from this many rows on, 2 below
-extern "C" int pcgc_set_wlds_mt4_rows(int64_t min_rows) { g_wlds_mt4_rows = min_rows < 0 ? 400000 : min_rows; return 0; }
 
 extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const float* in, int64_t n_in, int Cin, int in_ld,
                                 int in_coff, const float* W, const float* bias, const float* residual, int res_ld, int res_coff,
                                 int relu, float* out, int Cout, int out_ld, int out_coff, void* stream) {
     PCGC_REQUIRE(K >= 1 && Cin >= 1, "bad K / Cin");
     PCGC_REQUIRE(nbr != nullptr || K == 1, "identity map only for K == 1");
+    PCGC_REQUIRE(g_conv_impl == -1 || g_conv_impl == 0 || g_conv_impl == 2 || g_conv_impl == 6, "conv_gather: forced family must be -1 (auto), 0, 2 or 6");
     if (n_out == 0) return 0;
     hipStream_t s = S(stream);
-    // v1 (LDS-DMA gather) eligibility: gathered maps, 8..64 input channels, 16-byte aligned rows, 32-bit buffer offsets
+    // the LDS-DMA row gather: gathered maps, 8..64 input channels, 16-byte aligned rows, 32-bit buffer offsets
     const float* in0 = in + in_coff;
     const bool aligned = (((uintptr_t)in0 | (uintptr_t)W) & 15) == 0 && (in_ld & 3) == 0;
     const bool small = n_in * in_ld * 4 < (int64_t)0xFFFFFFF0 && (int64_t)K * n_out * 4 < (int64_t)0xFFFFFFF0;
-    const bool v1_eligible = nbr != nullptr && K <= 27 && aligned && small && (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64);
-    const bool v1_wanted = g_conv_impl == 1 || (g_conv_impl < 0 && n_out >= 30000);
-    const bool wlds_shape = (Cin == 64 && Cout == 64) || (Cin == 32 && Cout == 32);
-    // Size policy of the two wide k3 shapes (tools/gate_ab.py, us per launch; every family is a chain of barrier-separated steps whose
-    // length barely depends on the row count below ~20 k rows):
-    //   64 -> 64   rows 1-18 k: v0 367-480, v2 81-118, v2b 137-141, v2c 109-112;  64 k: v2 198, v2b 196, v2c 161;  71 k: 233 / 231 / 208;  150 k: v2b 378
-    //              -> v2 (MFMA, weights from L2) below 8 k rows, v2c up to 110 k, v2b above
-    //   32 -> 32   rows 1-18 k: v0 96, v2 45, v2b 52, v2c 41;  64-71 k: v2 69-86, v2b 64-77, v2c 56-70;  256 k: v2b 171 (v2c 178)
-    //              -> v2c up to 110 k rows, v2b above
-    // (round 2 sent everything below 30 k rows to the one-thread-per-row v0 kernel: 334 us for the 64 -> 64 conv of a 117 k-point block)
-    const bool wide_auto = g_conv_impl < 0 && g_auto_wlds && K == 27 && (Cin == 32 || n_out >= 8192);
-    if (v1_eligible && wlds_shape && (((uintptr_t)W) & 15) == 0 && (g_conv_impl == 3 || wide_auto)) {
-        const float* res0 = residual ? residual + res_coff : nullptr;
-        float* out0 = out + out_coff;
-        const bool pipe = g_mfma_pipe > 0 || (g_mfma_pipe < 0 && n_out < 110000);        // 64->64: 248 -> 220 us at 71 k rows, 381 -> 395 at 150 k
-        if (Cin == 64 && pipe) { t_last_conv_impl = 7; launch_mfma_pipe<64, 64, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s); }
-        else if (Cin == 64) {
-            t_last_conv_impl = n_out < g_wlds_mt4_rows ? 3 : 4;
-            if (n_out < g_wlds_mt4_rows) launch_mfma_wlds<64, 64, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
-            else launch_mfma_wlds<64, 64, 4>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
-        } else if (pipe && g_conv_impl < 0) {
-            t_last_conv_impl = 7;
-            launch_mfma_pipe<32, 32, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
-        } else if (g_mfma_pipe > 0) {
-            t_last_conv_impl = 7;
-            launch_mfma_pipe<32, 32, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
-        } else {
-            t_last_conv_impl = n_out < g_wlds_mt4_rows ? 3 : 4;
-            if (n_out < g_wlds_mt4_rows) launch_mfma_wlds<32, 32, 2>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
-            else launch_mfma_wlds<32, 32, 4>(nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
-        }
-        PCGC_CHECK_LAUNCH("conv_gather_mfma_wlds");
-        return 0;
-    }
-    const bool mfma_eligible = v1_eligible && (Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 16 || Cout == 32 || Cout == 64);
-    // narrow outputs on small levels: the row-split kernel (16 -> 16 at 1-18 k rows: 12-16 us against 27 on v2; 32 -> 8: 16-20 against 40;
-    // 32 -> 8 at 64-71 k rows: 38-49 against 68-73)
-    const bool split_first = g_conv_impl < 0 && K == 27 && Cin <= 32 && Cout <= 16 && n_out < (Cout <= 8 ? 150000 : 40000);
-    // everything else with MFMA-sized channels: v2 from 512 rows on (64 -> 32 at 1-18 k rows: v0 178-220 us, v2 81; the k2 s2 down convs
-    // 64 -> 32 / 32 -> 64 on an octant block's 3-10 k rows: v0 93 us)
-    if (mfma_eligible && !split_first && (g_conv_impl == 2 || (g_conv_impl < 0 && g_auto_mfma && n_out >= 512))) {      // (down2 64->32 at 18.7 k rows: 58 -> 38 us)
+    const bool dma_eligible = nbr != nullptr && K <= 27 && aligned && small && (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64);
+    const bool mfma_eligible = dma_eligible && (Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 16 || Cout == 32 || Cout == 64);
+    // narrow outputs: the row-split kernel (16 -> 16 at 1-18 k rows: 12-16 us against 27 on the MFMA form; 32 -> 8: 16-20 against 40;
+    // 32 -> 8 at 64-71 k rows: 38-49 against 68-73).  Cout <= 8 has no MFMA form: row-split at every size.
+    const bool split_shape = dma_eligible && K == 27 && Cin <= 32 && Cout <= 16 && (Cout & 3) == 0;
+    const bool split_first = g_conv_impl < 0 && split_shape && (Cout <= 8 || n_out < 40000);
+    // MFMA-sized channels from 512 rows on (64 -> 32 at 1-18 k rows: VALU 178-220 us, MFMA 81; the k2 s2 down convs 64 -> 32 / 32 -> 64
+    // on an octant block's 3-10 k rows: VALU 93 us, down2 64 -> 32 at 18.7 k rows: 58 -> 38)
+    if (mfma_eligible && !split_first && (g_conv_impl == 2 || (g_conv_impl < 0 && n_out >= 512))) {
         const float* res0 = residual ? residual + res_coff : nullptr;
         float* out0 = out + out_coff;
         bool ok = false;
@@ -1607,8 +954,8 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
         else ok = dispatch_mfma<64>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         if (ok) { t_last_conv_impl = 2; PCGC_CHECK_LAUNCH("conv_gather_mfma"); return 0; }
     }
-    if (v1_eligible && K == 27 && Cin <= 32 && Cout <= 16 && (Cout & 3) == 0 && (g_conv_impl == 6 || split_first)) {
-        const float* res0 = residual ? residual + res_coff : nullptr;       // (conv3 32->8 at 18.7 k rows: 71 us on v0, 42 us on the burst form)
+    if (split_shape && (g_conv_impl == 6 || split_first)) {
+        const float* res0 = residual ? residual + res_coff : nullptr;
         float* out0 = out + out_coff;
         int rc = 1;
         if (Cin == 8) rc = dispatch_split<8>(Cout, nbr, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
@@ -1616,26 +963,6 @@ extern "C" int pcgc_conv_gather(const int32_t* nbr, int K, int64_t n_out, const 
         else if (Cin == 32) rc = dispatch_split<32>(Cout, nbr, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
         if (rc < 0) return rc;
         if (rc == 0) { t_last_conv_impl = 6; PCGC_CHECK_LAUNCH("conv_gather_split"); return 0; }
-    }
-    if (v1_eligible && K == 27 && Cin <= 32 && Cout <= 16 && (g_conv_impl == 5 || (g_conv_impl < 0 && n_out < 40000))) {
-        const float* res0 = residual ? residual + res_coff : nullptr;
-        float* out0 = out + out_coff;
-        int rc = 1;
-        if (Cin == 8) rc = dispatch_burst<8>(Cout, nbr, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
-        else if (Cin == 16) rc = dispatch_burst<16>(Cout, nbr, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
-        else if (Cin == 32) rc = dispatch_burst<32>(Cout, nbr, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
-        if (rc < 0) return rc;
-        if (rc == 0) { t_last_conv_impl = 5; PCGC_CHECK_LAUNCH("conv_gather_burst"); return 0; }
-    }
-    if (v1_eligible && v1_wanted) {
-        const float* res0 = residual ? residual + res_coff : nullptr;
-        float* out0 = out + out_coff;
-        bool ok = false;
-        if (Cin == 8) ok = dispatch_dma_cout<8>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
-        else if (Cin == 16) ok = dispatch_dma_cout<16>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
-        else if (Cin == 32) ok = dispatch_dma_cout<32>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
-        else ok = dispatch_dma_cout<64>(Cout, nbr, K, n_out, in0, n_in, in_ld, W, bias, res0, res_ld, relu, out0, out_ld, s);
-        if (ok) { t_last_conv_impl = 1; PCGC_CHECK_LAUNCH("conv_gather_dma"); return 0; }
     }
     t_last_conv_impl = 0;
 #define PCGC_CASE(C) case C: launch_valu<C>(nbr, K, n_out, in, Cin, in_ld, in_coff, W, bias, residual, res_ld, res_coff, relu, out, out_ld, out_coff, s); break;

@@ -19,18 +19,7 @@ struct RowsGeometry {
     static constexpr int child(int) { return 0; }
     static constexpr int byte_off(int) { return 0; }
 };
-// pass A: x rows (64 wide, four 16-channel blocks) -> tile 0 = conv0_0 (k3 64 -> 16), tile 1 = conv1_0 (k1 64 -> 16: the centre offset only)
-struct RowsPassA64 : RowsGeometry {
-    static constexpr int NB = 4, ROWCHUNKS = 4, T = 2, KS = 4, Z_HALF = -1, NBATCH = 1;
-    static constexpr bool HALF = false;
-    static constexpr int kfirst(int) { return 0; }
-    static constexpr bool active(int c, int t) { return t == 0 || c == 13; }
-    static constexpr int frag(int c, int t) { return t == 0 ? c : 27; }
-    static constexpr bool uses_block(int, int) { return true; }
-    static constexpr int batch(int) { return 0; }
-    static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 1024; }
-};
-// pass A in HALF-row cells: cell 2 k + h = channels [32 h, 32 h + 32) of offset k's rows (two 16-channel blocks, 2 KB per 16 rows), so that
+// pass A (C = 64): tile 0 = conv0_0 (k3 64 -> 16), tile 1 = conv1_0 (k1 64 -> 16: the centre offset only), in HALF-row cells: cell 2 k + h = channels [32 h, 32 h + 32) of offset k's rows (two 16-channel blocks, 2 KB per 16 rows), so that
 // twelve waves can each keep TWO gathers in flight in the 48 KB the 112 KB table leaves (whole-row cells: one 4 KB slot per wave — nothing in
 // flight behind a wave's own MFMAs): 54.5 -> 51 us on 71 k rows, 103 -> 93 on 150 k.  (Quarter-row cells, four in flight: no further gain.)
 // Same chain: ascending offset, then ascending channel.
@@ -39,30 +28,28 @@ struct RowsPassA64H {
     static constexpr int kp(int c) { return c >> 1; }
     static constexpr int child(int) { return 0; }
     static constexpr int byte_off(int c) { return (c & 1) * 128; }
-    static constexpr int NB = 2, ROWCHUNKS = 4, T = 2, KS = 4, Z_HALF = -1, NBATCH = 1;
+    static constexpr int NB = 2, ROWCHUNKS = 4, T = 2, KS = 4, Z_HALF = -1;
     static constexpr bool HALF = false;
     static constexpr int kfirst(int) { return 0; }
     static constexpr bool active(int c, int t) { return t == 0 || (c >> 1) == 13; }
     static constexpr int frag(int c, int t) { return t == 0 ? (c >> 1) : 27; }
     static constexpr bool uses_block(int, int) { return true; }
-    static constexpr int batch(int) { return 0; }
     static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * 4 + 2 * (c & 1) + cb) * 1024; }
 };
 // pass B: t rows (32 wide: block 0 = relu(conv0_0), block 1 = relu(conv1_0)) -> tiles 0, 1 = conv0_1 (k3 16 -> 32) from block 0,
 // tile 2 = conv1_1 (k3 16 -> 16) from block 1.  Fragments: conv0_1 (k, n) = 2 k + n, conv1_1 k = 54 + k, conv1_2 (k1 16 -> 32) n = 81 + n.
 struct RowsPassB64 : RowsGeometry {
-    static constexpr int NB = 2, ROWCHUNKS = 4, T = 3, KS = 4, Z_HALF = -1, NBATCH = 1, FRAG_W12 = 81;
+    static constexpr int NB = 2, ROWCHUNKS = 4, T = 3, KS = 4, Z_HALF = -1, FRAG_W12 = 81;
     static constexpr bool HALF = false;
     static constexpr int kfirst(int) { return 0; }
     static constexpr bool active(int, int) { return true; }
     static constexpr int frag(int c, int t) { return t < 2 ? 2 * c + t : 54 + c; }
     static constexpr bool uses_block(int t, int cb) { return t < 2 ? cb == 0 : cb == 1; }
-    static constexpr int batch(int) { return 0; }
     static constexpr int frag_off(int c, int t, int) { return frag(c, t) * 1024; }
 };
 
 // pass A:  t[row][0:16] = relu(conv0_0 + b00), t[row][16:32] = relu(conv1_0 + b10)        acc[t][r] = row 4 mq + r of the tile, column mi
-template <int NW, int D, class V = RowsPassA64>
+template <int NW, int D, class V = RowsPassA64H>
 __global__ void __launch_bounds__(NW * 64)
 k_rows_irn_a64(const int32_t* __restrict__ pnbr, int64_t n_p /* rows of the level */, const float* __restrict__ in, int in_ld,
                const float* __restrict__ table, int table_bytes, IrnEpi ep) {
@@ -147,23 +134,21 @@ k_rows_irn_b64(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __res
 // relu(conv0_0)) feed tile 0 = conv0_1 (k3 8 -> 16), K-steps {2, 3} (relu(conv1_0)) feed tile 1 = conv1_1 (k3 8 -> 8, columns 8-15 zero).
 // Tables: ops.rows_irn32_tables.
 struct RowsPassA32 : RowsGeometry {
-    static constexpr int NB = 2, ROWCHUNKS = 4, T = 1, KS = 4, Z_HALF = -1, NBATCH = 1;
+    static constexpr int NB = 2, ROWCHUNKS = 4, T = 1, KS = 4, Z_HALF = -1;
     static constexpr bool HALF = false;
     static constexpr int kfirst(int) { return 0; }
     static constexpr bool active(int, int) { return true; }
     static constexpr int frag(int c, int) { return c; }
     static constexpr bool uses_block(int, int) { return true; }
-    static constexpr int batch(int) { return 0; }
     static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 1024; }
 };
 struct RowsPassB32 : RowsGeometry {
-    static constexpr int NB = 1, ROWCHUNKS = 4, T = 2, KS = 2, Z_HALF = -1, NBATCH = 1, FRAG_W12 = 54;
+    static constexpr int NB = 1, ROWCHUNKS = 4, T = 2, KS = 2, Z_HALF = -1, FRAG_W12 = 54;
     static constexpr bool HALF = false;
     static constexpr int kfirst(int t) { return t == 0 ? 0 : 2; }
     static constexpr bool active(int, int) { return true; }
     static constexpr int frag(int c, int t) { return t == 0 ? c : 27 + c; }
     static constexpr bool uses_block(int, int) { return true; }
-    static constexpr int batch(int) { return 0; }
     static constexpr int frag_off(int c, int t, int) { return frag(c, t) * 512; }
 };
 // pass A:  t[row][0:8] = relu(conv0_0 + b00), t[row][8:16] = relu(conv1_0 + b10)
@@ -243,13 +228,12 @@ k_rows_irn_b32(const int32_t* __restrict__ pnbr, int64_t n_p, const float* __res
 // weight slice (ops.child_conv_table: [k][n][cb])
 template <int NB_, int NT>
 struct RowsConv : RowsGeometry {
-    static constexpr int NB = NB_, ROWCHUNKS = 4, T = NT, KS = 4, Z_HALF = -1, NBATCH = 1;
+    static constexpr int NB = NB_, ROWCHUNKS = 4, T = NT, KS = 4, Z_HALF = -1;
     static constexpr bool HALF = false;
     static constexpr int kfirst(int) { return 0; }
     static constexpr bool active(int, int) { return true; }
     static constexpr int frag(int c, int t) { return c * NT + t; }
     static constexpr bool uses_block(int, int) { return true; }
-    static constexpr int batch(int) { return 0; }
     static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 1024; }
 };
 template <int NB, int NT, int NW, int D>
@@ -304,13 +288,12 @@ struct DownGeometry {
 };
 template <int NB_, int NT>
 struct RowsDown : DownGeometry {
-    static constexpr int NB = NB_, ROWCHUNKS = 4, T = NT, KS = 4, Z_HALF = -1, NBATCH = 1;
+    static constexpr int NB = NB_, ROWCHUNKS = 4, T = NT, KS = 4, Z_HALF = -1;
     static constexpr bool HALF = false;
     static constexpr int kfirst(int) { return 0; }
     static constexpr bool active(int, int) { return true; }
     static constexpr int frag(int c, int t) { return c * NT + t; }
     static constexpr bool uses_block(int, int) { return true; }
-    static constexpr int batch(int) { return 0; }
     static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 1024; }
 };
 template <int NB, int NT, int NW, int D>
@@ -389,24 +372,12 @@ extern "C" int pcgc_irn_rows_pass(const int32_t* nbr, int64_t n, int C, int pass
     int rc;
     static ChildLdsGrant granted[8];
 #define ROWS_GO(SLOT, KERN, NW_, RINGBYTES) launch_rows(KERN, NW_, (size_t)table_bytes + (size_t)(NW_) * (RINGBYTES), nbr, n, in, in_ld, table, (int)table_bytes, ep, s, granted[SLOT])
-    const int nw = g_child_nw, depth = g_child_depth;          // A/B switches (pcgc_set_child_tuning); 0 = defaults
     if (C == 32) {                                             // 54 KB / 27.5 KB tables; 16 waves, ring slots of 2 KB / 1 KB (pass B: scratch 2.5 KB)
-        static ChildLdsGrant granted32[4];
-#define ROWS_GO32(SLOT, KERN, NW_, RINGBYTES) launch_rows(KERN, NW_, (size_t)table_bytes + (size_t)(NW_) * (RINGBYTES), nbr, n, in, in_ld, table, (int)table_bytes, ep, s, granted32[SLOT])
-        if (pass == 1) rc = (nw == 8) ? ROWS_GO32(0, (k_rows_irn_a32<8, 2>), 8, 2 * 2048) : ROWS_GO32(1, (k_rows_irn_a32<16, 2>), 16, 2 * 2048);
-        else rc = (nw == 8) ? ROWS_GO32(2, (k_rows_irn_b32<8, 4>), 8, 4 * 1024) : ROWS_GO32(3, (k_rows_irn_b32<16, 4>), 16, 4 * 1024);
-#undef ROWS_GO32
-    } else
-    if (pass == 1) {                                           // 112 KB table: 48 KB for the rings (4 KB per slot)
-        if (nw == 6 && depth == 2) rc = ROWS_GO(0, (k_rows_irn_a64<6, 2>), 6, 2 * 4096);
-        else if (nw == 12 && depth == 1) rc = ROWS_GO(1, (k_rows_irn_a64<12, 1>), 12, 1 * 4096);
-        else if (nw == 8 && depth == 2) rc = ROWS_GO(2, (k_rows_irn_a64<8, 2, RowsPassA64H>), 8, 2 * 2048);
-        else rc = ROWS_GO(3, (k_rows_irn_a64<12, 2, RowsPassA64H>), 12, 2 * 2048);
+        rc = pass == 1 ? ROWS_GO(0, (k_rows_irn_a32<16, 2>), 16, 2 * 2048) : ROWS_GO(1, (k_rows_irn_b32<16, 4>), 16, 4 * 1024);
+    } else if (pass == 1) {                                    // 112 KB table: 48 KB for the rings (12 waves, two 2 KB slots each)
+        rc = ROWS_GO(2, (k_rows_irn_a64<12, 2, RowsPassA64H>), 12, 2 * 2048);
     } else {                                                   // 83 KB table: 8 KB per wave (ring slots of 2 KB; the epilogue scratch needs 5 KB)
-        if (nw == 15 && depth == 1) rc = ROWS_GO(4, (k_rows_irn_b64<15, 1>), 15, 5120);
-        else if (nw == 12 && depth == 1) rc = ROWS_GO(5, (k_rows_irn_b64<12, 1>), 12, 5120);
-        else if (nw == 8 && depth == 4) rc = ROWS_GO(6, (k_rows_irn_b64<8, 4>), 8, 4 * 2048);
-        else rc = ROWS_GO(7, (k_rows_irn_b64<12, 2>), 12, 5120);
+        rc = ROWS_GO(3, (k_rows_irn_b64<12, 2>), 12, 5120);
     }
 #undef ROWS_GO
     if (rc) return rc;
@@ -430,13 +401,9 @@ extern "C" int pcgc_conv_rows(const int32_t* nbr, int64_t n, const float* in, in
     hipStream_t s = S(stream);
     ChildEpi ep{bias, residual, res_ld, relu, out, out_ld, Cout / 16};
     static ChildLdsGrant granted[4];
-    const int nw = g_child_nw, depth = g_child_depth;          // A/B switches; 0 = default
     int rc;
 #define ROWS_GO(SLOT, KERN, NW_, RINGBYTES) launch_rows(KERN, NW_, (size_t)table_bytes + (size_t)(NW_) * (RINGBYTES), nbr, n, in, in_ld, table, (int)table_bytes, ep, s, granted[SLOT])
-    if (nw == 8 && depth == 2) rc = ROWS_GO(0, (k_rows_conv<2, 2, 8, 2>), 8, 2 * 2048);
-    else if (nw == 16 && depth == 1) rc = ROWS_GO(1, (k_rows_conv<2, 2, 16, 1>), 16, 2048);
-    else if (nw == 12 && depth == 1) rc = ROWS_GO(2, (k_rows_conv<2, 2, 12, 1>), 12, 2048);
-    else rc = ROWS_GO(3, (k_rows_conv<2, 2, 12, 2>), 12, 2 * 2048);
+    rc = ROWS_GO(3, (k_rows_conv<2, 2, 12, 2>), 12, 2 * 2048);
 #undef ROWS_GO
     if (rc) return rc;
     PCGC_CHECK_LAUNCH("conv_rows");

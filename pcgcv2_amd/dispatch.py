@@ -2,16 +2,17 @@
 
 Rounds 1-3 grew six InceptionResNet implementations, eight gather-conv families and three "rows" kernels, picked by a ladder of
 `if`s spread over autoencoder.py, nn.py, ops.py and the native entry point pcgc_conv_gather.  This module is the single place where
-that policy is written down.  `select(op, ...)` returns the entry that applies; nn.MinkowskiConvolution / autoencoder.InceptionResNet
+that policy is written down.  (Round 5 pruned the library to what this table reaches with its default switches plus ONE comparison
+family per operator: three gather families — VALU, MFMA, row-split — and one VALU InceptionResNet pair remain of those.)  `select(op, ...)` returns the entry that applies; nn.MinkowskiConvolution / autoencoder.InceptionResNet
 switch on its `family` and nothing else.  For the gather family the native library still walks its own ladder (csrc/conv.hip) — the
 table PREDICTS it (`gather_impl`) and tests/test_gpu_parity.py::test_dispatch_table_* read back what was actually launched
-(pcgc_last_conv_impl, pcgc_irn_config) for every entry, on both sides of every row-count gate, and compare the output with the oracle:
+(pcgc_last_conv_impl) for every entry, on both sides of every row-count gate, and compare the output with the oracle:
 an instantiation that is reachable is an instantiation that has a parity test.
 
 Every family of one operator computes the same canonical fmaf chain: the choice affects speed, never a bit of the result.
-Gates are measured (tools/gate_ab.py, tools/rows_gate_ab.py, tools/rows_vs_child64.py; numbers in the `why` column).
+Gates are measured (tools/rows_gate_ab.py; numbers in the `why` column).
 
-The A/B switches (ops.CHILD_MFMA, ops.ROWS_*, ops.MFMA_IRN, ops.FUSE_IRN, ops.UNIT_INPUT_CONV) stay what they were — module attributes
+The A/B switches (ops.CHILD_MFMA, ops.ROWS_*, ops.FUSE_IRN, ops.UNIT_INPUT_CONV) stay what they were — module attributes
 the tests flip — and are consulted here, by name, at call time.  Nothing in the product path writes them, and nothing in the product
 path calls a process-wide `pcgc_set_*` knob: concurrent coders cannot race on the policy.
 """
@@ -36,7 +37,7 @@ TABLE = (
     Rule('conv3', ((16, 16), (32, 32), (16, 1), (32, 1), (64, 1)), 'children', 8192, INF, 'CHILD_MFMA', 'child',
          'k_child_conv<1,1> / k_child_conv<2,2,split> / k_child_cls<NB>; 16->1 with ops.CHILD_Q4: k_child_q4<cls> (quad-block 4x4x1 MFMA)',
          'halo gather through the parent map, packed-N fp32 MFMA: conv 16->16 436 -> 259 us on 2.05 M rows, cls 16->1 209 -> 85 (quad-block form: 83)'),
-    Rule('conv3', ((1, 4), (1, 8), (1, 16)), None, 0, INF, 'UNIT_INPUT_CONV', 'unit', 'k_conv_unit<COUT>',
+    Rule('conv3', ((1, 16),), None, 0, INF, 'UNIT_INPUT_CONV', 'unit', 'k_conv_unit<16> / k_conv_unit_coarse<16>',
          'all-ones occupancy input (x.has_unit_features()): sum of kernel slices over the present offsets, no feature gathers: 88 -> 55 us'),
     Rule('conv3', ((32, 32),), None, 'ROWS_CONV_MIN', INF, 'ROWS_CONV', 'rows', 'k_rows_conv<2,2>',
          'LDS-resident fragment table, one wave per 16-row tile: 34 vs 51 us at 1-18 k rows, 127 vs 159 at 256 k'),
@@ -44,21 +45,16 @@ TABLE = (
          'present rows packed per workgroup tile and offset, accumulators in LDS, B fragments in registers: conv2 (71 k rows) 215 -> 118 us, conv0 (150 k) 335 -> 306 (profiles/r04_conv_packed.md)'),
     Rule('conv3', None, None, 0, INF, None, 'gather', 'pcgc_conv_gather (see GATHER below)', 'every other shape / size'),
     # ---- InceptionResNet blocks ----------------------------------------------------------------------------------------------------
-    Rule('irn', (64,), 'children+own_map', 8192, INF, 'ROWS_IRN64_CHILD', 'rows64', 'k_rows_irn_a64<.., RowsPassA64H> + k_rows_irn_b64',
-         "the level's own map exists already (its 64->64 conv ran on the gather kernels): plain-rows form 171 vs 197 us per block at 150 k rows"),
-    Rule('irn', (64,), 'children', 8192, INF, 'CHILD_MFMA', 'child64', 'k_child_irn_a<64,split> + k_child_irn_b64<split>',
-         'both passes through the parent map in half units: 104 / 89 us at 150 k rows'),
     Rule('irn', (16, 32), 'children', 8192, INF, 'CHILD_MFMA', 'child',
          'k_child_irn_a<C> + k_child_irn_b<C> (C = 32: half units); C = 16 with ops.CHILD_Q4: k_child_q4<pass A> (quad-block 4x4x1 MFMA) + k_child_irn_b<16, T2 gather>',
          'packed-N MFMA passes through the parent map: C = 16 212/170 -> 118/102 us on 2.05 M rows (quad-block pass A: 97/110), C = 32 174/130 -> 100/81 on 570 k'),
-    Rule('irn', (64,), None, 'ROWS_IRN64_MIN', INF, 'ROWS_IRN64', 'rows64', 'k_rows_irn_a64 + k_rows_irn_b64',
-         'plain level: 65 vs 135 us per block at 1-18 k rows, 103 vs 198 at 71 k'),
+    Rule('irn', (64,), None, 'ROWS_IRN64_MIN', INF, 'ROWS_IRN64', 'rows64', 'k_rows_irn_a64<.., RowsPassA64H> + k_rows_irn_b64',
+         "through the level's own map, plain or children level (the decoder's 64 -> 64 conv has built it): 65 vs 135 us per block at 1-18 k rows, 103 vs 198 at 71 k; "
+         'on the 150 k-row children level 171 vs 197 us for the parent-map form (removed in round 5)'),
     Rule('irn', (32,), None, 'ROWS_IRN32_MIN', 'ROWS_IRN32_MAX+1', 'ROWS_IRN32', 'rows32', 'k_rows_irn_a32 + k_rows_irn_b32',
          'plain level: 47 vs 74 us per block at 49 k rows, 119 vs 127 at 256 k'),
-    Rule('irn', (64,), None, 512, INF, 'MFMA_IRN', 'mfma64', 'k_conv_gather_mfma_wlds/pipe<64,32> + <32,48> + k_irn_tail<64>',
-         'block-sparse MFMA passes (only when the rows kernels are switched off): 117-123 us per block at 1-18 k rows against 177-220'),
-    Rule('irn', (16, 32, 64), None, 0, INF, 'FUSE_IRN', 'valu', 'k_irn_a<C,ROWS> + k_irn_b<C,ROWS> (pcgc_irn_config picks ROWS / split)',
-         'two fused gather passes on the VALU: small levels and C = 16 on plain levels'),
+    Rule('irn', (16, 32, 64), None, 0, INF, 'FUSE_IRN', 'valu', 'k_irn_a_split<C> + k_irn_b_split<C> (C = 16, 32), k_irn_a<64,16> + k_irn_b<64,16>',
+         'two fused gather passes on the VALU, 16-row tiles: levels below 1024 rows, children levels below 8192'),
     Rule('irn', None, None, 0, INF, None, 'unfused', 'five MinkowskiConvolution calls + fused epilogues', 'any other channel count'),
     # ---- k2 s2 down convolutions -------------------------------------------------------------------------------------------------------
     Rule('down', ((16, 32), (32, 64), (64, 32)), None, 'ROWS_DOWN_MIN', INF, 'ROWS_DOWN', 'rows_down', 'k_rows_down<NB,NT>',
@@ -73,31 +69,21 @@ TABLE = (
 )
 
 # pcgc_conv_gather's own ladder (csrc/conv.hip), restated: -> the impl code pcgc_last_conv_impl() reports.
-GATHER_IMPL_NAMES = {0: 'k_conv_gather_valu (v0)', 1: 'k_conv_gather_dma (v1)', 2: 'k_conv_gather_mfma (v2)', 3: 'k_conv_gather_mfma_wlds<..,2> (v2b)',
-                     4: 'k_conv_gather_mfma_wlds<..,4> (v2b)', 5: 'k_conv_gather_burst (v1, 16-row tiles)', 6: 'k_conv_gather_split (row-split)',
-                     7: 'k_conv_gather_mfma_pipe (v2c)'}
-GATHER_GATES = {'wide_min_rows_64': 8192, 'pipe_below': 110000, 'wlds_mt4_from': 400000, 'mfma_min_rows': 512, 'split_below_cout8': 150000,
-                'split_below_cout16': 40000, 'burst_below': 40000, 'dma_from': 30000}
+GATHER_IMPL_NAMES = {0: 'k_conv_gather_valu', 2: 'k_conv_gather_mfma', 6: 'k_conv_gather_split (row-split)'}
+GATHER_GATES = {'mfma_min_rows': 512, 'split_below_cout16': 40000}
 
 
 def gather_impl(K, cin, cout, rows, aligned=True):
     """The kernel family pcgc_conv_gather launches in auto mode for a [K, cin, cout] kernel on `rows` output rows (aligned: 16-byte
     aligned rows and weights, tensors below the 32-bit offset limit, a real kernel map)."""
     g = GATHER_GATES
-    v1 = aligned and K <= 27 and cin in (8, 16, 32, 64)
-    if v1 and K == 27 and (cin, cout) in ((64, 64), (32, 32)) and (cin == 32 or rows >= g['wide_min_rows_64']):
-        if rows < g['pipe_below']:
-            return 7
-        return 3 if rows < g['wlds_mt4_from'] else 4
-    split_first = K == 27 and cin <= 32 and cout <= 16 and rows < (g['split_below_cout8'] if cout <= 8 else g['split_below_cout16'])
-    if v1 and cin in (16, 32, 64) and cout in (16, 32, 64) and not split_first and rows >= g['mfma_min_rows']:
+    dma = aligned and K <= 27 and cin in (8, 16, 32, 64)
+    split_shape = dma and K == 27 and cin <= 32 and cout in (4, 8, 16)
+    split_first = split_shape and (cout <= 8 or rows < g['split_below_cout16'])
+    if dma and cin in (16, 32, 64) and cout in (16, 32, 64) and not split_first and rows >= g['mfma_min_rows']:
         return 2
-    if v1 and K == 27 and cin <= 32 and cout in (4, 8, 16) and split_first:
+    if split_first:
         return 6
-    if v1 and K == 27 and cin <= 32 and cout in (1, 4, 8, 16) and rows < g['burst_below']:
-        return 5
-    if v1 and rows >= g['dma_from'] and cout in (1, 4, 8, 16, 32, 64):
-        return 1
     return 0
 
 
@@ -112,16 +98,14 @@ def _value(v):
 def _switch_on(rule):
     if rule.switch is None:
         return True
-    if rule.switch == 'ROWS_IRN64_CHILD':
-        return ops.ROWS_IRN64 and ops.ROWS_IRN64_CHILD and ops.CHILD_MFMA
     return bool(getattr(ops, rule.switch))
 
 
-def select(op, shape, rows, level='plain', extent=None, own_map=False, contiguous=True, unit_input=False, plain_output=True):
+def select(op, shape, rows, level='plain', extent=None, contiguous=True, unit_input=False, plain_output=True):
     """-> the first Rule of TABLE that applies.  shape: (cin, cout), or (C,) for 'irn'; rows: rows of the level the operator runs on
     (the COARSE rows for 'down'); level: 'children' | 'plain'; extent: bytes of the largest tensor the kernel would address with 32-bit
-    buffer offsets (rows x leading dimension x 4; default rows x width x 4) — beyond LIMIT the generic kernels take over; own_map: the
-    children level's own k3 map has been built already; contiguous: the feature tensor is dense; unit_input: the input is the all-ones
+    buffer offsets (rows x leading dimension x 4; default rows x width x 4) — beyond LIMIT the generic kernels take over;
+    contiguous: the feature tensor is dense; unit_input: the input is the all-ones
     occupancy indicator; plain_output: no `out=` / `residual=` (the unit and down kernels have no fused epilogue for those)."""
     width = shape[0]
     extent = rows * 4 * width if extent is None else extent
@@ -131,16 +115,16 @@ def select(op, shape, rows, level='plain', extent=None, own_map=False, contiguou
             continue
         if not (_value(rule.rows_min) <= rows < _value(rule.rows_max)) or not _switch_on(rule):
             continue
-        if rule.level is not None and (level != 'children' or (rule.level == 'children+own_map' and not own_map)):
+        if rule.level is not None and level != 'children':
             continue
         fam = rule.family
-        if fam == 'packed' and not plain_output:
+        if fam in ('packed', 'child') and op == 'conv3' and not plain_output:     # (neither has a residual / `out=` form)
             continue
-        if fam in ('child', 'child64', 'rows', 'rows64', 'rows32', 'rows_down', 'packed') and extent >= LIMIT:
+        if fam in ('child', 'rows', 'rows64', 'rows32', 'rows_down', 'packed') and extent >= LIMIT:
             continue                                                     # beyond 32-bit buffer offsets: the generic kernels take it
         if op == 'irn' and fam != 'unfused' and (not ops.FUSE_IRN or rows * 4 * width >= 0xFFFFFFF0):
             continue
-        if fam in ('child', 'child64') and op == 'irn' and not contiguous:
+        if fam == 'child' and op == 'irn' and not contiguous:
             continue
         if fam == 'unit' and not (unit_input and plain_output):
             continue

@@ -405,7 +405,7 @@ def kmap_down(coarse, stride_fine, fine_table):
 
 # ------------------------------------------------------------------------------------------------ conv family
 def set_conv_impl(impl):
-    """-1 auto, 0 = v0 direct-load gather kernel, 1 = v1 LDS-DMA gather kernel (bit-identical results)."""
+    """family of pcgc_conv_gather: -1 auto, 0 = direct-load VALU kernel, 2 = LDS-DMA + MFMA, 6 = row-split (bit-identical results)."""
     check(lib().pcgc_set_conv_impl(int(impl)), 'set_conv_impl')
 
 
@@ -501,39 +501,6 @@ def set_up2_impl(mfma):
     check(lib().pcgc_set_up2_impl(int(mfma)), 'set_up2_impl')
 
 
-def set_mfma_pipe(mode):
-    """schedule of the LDS-shared-weight MFMA kernels: -1 by level size, 0 v2b (16-channel sub-steps), 1 v2c (pipelined 32-channel steps)."""
-    check(lib().pcgc_set_mfma_pipe(int(mode)), 'set_mfma_pipe')
-
-
-def set_irn_split(on):
-    """16-row InceptionResNet passes at C <= 32: row-split kernels (default) or lane-per-row kernels (A/B tests)."""
-    check(lib().pcgc_set_irn_split(int(on)), 'set_irn_split')
-
-
-def set_irn_rows(rows):
-    """rows per wave of the fused InceptionResNet passes: 0 = by level size (default), or force 64 / 32 / 16."""
-    check(lib().pcgc_set_irn_rows(int(rows)), 'set_irn_rows')
-
-
-def set_irn_cb16_rows(min_rows):
-    """C = 32 pass A uses 16-channel sub-steps on levels of at least `min_rows` rows (negative = default 400 000, 0 = always)."""
-    check(lib().pcgc_set_irn_cb16_rows(int(min_rows)), 'set_irn_cb16_rows')
-
-
-def set_wlds_mt4_rows(min_rows):
-    """k3 64->64 / 32->32 gather conv: 4 M-tiles per wave on levels of at least `min_rows` rows (negative = default 400 000, 0 = always)."""
-    check(lib().pcgc_set_wlds_mt4_rows(int(min_rows)), 'set_wlds_mt4_rows')
-
-
-def _irn_config(C, n):
-    """(rows per wave tile, pass-A channels per sub-step) the library picks for this level: asked, not re-derived."""
-    import ctypes
-    rows, cb = ctypes.c_int(0), ctypes.c_int(0)
-    check(lib().pcgc_irn_config(int(C), int(n), ctypes.addressof(rows), ctypes.addressof(cb)), 'irn_config')
-    return rows.value, cb.value
-
-
 FUSE_IRN = True           # tests flip this to compare the fused block against its five-conv composition
 
 
@@ -557,13 +524,12 @@ def irn_block(nbr, x, params):
     arr = (ctypes.c_void_p * 10)(*[p.data_ptr() for p in params])
     if PROFILE.counting:
         PROFILE.count(nbr)
-    R, cb_a = _irn_config(C, n)
-    name_a = f'k_irn_a<{C}, {R}, {cb_a}>'
-    if not (PROFILE.want((name_a, n)) or PROFILE.want((f'k_irn_b<{C}, {R}>', n))):
+    name_a, name_b = (f'k_irn_a<{C}, 16>', f'k_irn_b<{C}, 16>') if C == 64 else (f'k_irn_a_split<{C}>', f'k_irn_b_split<{C}>')
+    if not (PROFILE.want((name_a, n)) or PROFILE.want((name_b, n))):
         check(lib().pcgc_irn_block(_p(nbr), n, _p(x), C, _ld(x), arr, _p(t), _p(out), C, _stream(nbr)), 'irn_block')
         return out
     Q = C // 4
-    passes = _irn_pass_formulas(n, C, 27 * n * 4, (name_a, f'k_irn_b<{C}, {R}>'))
+    passes = _irn_pass_formulas(n, C, 27 * n * 4, (name_a, name_b))
     for ps, name, bf, ff, comp in passes:
         prof = PROFILE.want((name, n))
         if prof:
@@ -575,100 +541,13 @@ def irn_block(nbr, x, params):
     return out
 
 
-MFMA_IRN = True           # C = 64 blocks run on the block-sparse MFMA kernel (A/B switch)
-
-
-def fuse_irn64(params):
-    """Fused weights of a C=64 InceptionResNet for the block-sparse MFMA path.  params as in irn_block.
-    pass A: Wa [27,64,32] = [conv0_0 | conv1_0 embedded at the centre offset, zero elsewhere], mask: tile 1 only at k = 13
-    pass B: Wb [27,32,48] = block diagonal [conv0_1 on channels 0:16 -> cols 0:32 | conv1_1 on channels 16:32 -> cols 32:48]."""
-    W00, b00, W01, b01, W10, b10, W11, b11, W12, b12 = [p.detach() for p in params]
-    dev = W00.device
-    Wa = torch.zeros((27, 64, 32), dtype=torch.float32, device=dev)
-    Wa[:, :, :16] = W00
-    Wa[13, :, 16:] = W10
-    ba = torch.cat([b00.reshape(-1), b10.reshape(-1)]).contiguous()
-    mask_a = torch.tensor([(1 | (2 if k == 13 else 0)) for k in range(27) for _ in range(4)], dtype=torch.int32, device=dev)
-    Wb = torch.zeros((27, 32, 48), dtype=torch.float32, device=dev)
-    Wb[:, :16, :32] = W01
-    Wb[:, 16:, 32:] = W11
-    bb = torch.cat([b01.reshape(-1), b11.reshape(-1)]).contiguous()
-    mask_b = torch.tensor([3, 4] * 27, dtype=torch.int32, device=dev)
-    return {'Wa': Wa, 'ba': ba, 'mask_a': mask_a, 'Wb': Wb, 'bb': bb, 'mask_b': mask_b,
-            'W12': W12.contiguous(), 'b12': b12.reshape(-1).contiguous()}
-
-
-def irn_block_mfma64(nbr, x, f):
-    """C = 64 InceptionResNet: two block-sparse MFMA gather convs + a pointwise tail; bit-identical to irn_block."""
-    _f32(x, 'x')
-    n = x.shape[0]
-    t = torch.empty((n, 32), dtype=torch.float32, device=x.device)
-    u = torch.empty((n, 48), dtype=torch.float32, device=x.device)
-    out = torch.empty((n, 64), dtype=torch.float32, device=x.device)
-    if PROFILE.counting:
-        PROFILE.count(nbr)
-    Q, C = 16, 64
-    steps = (
-        ('k_conv_gather_mfma_wlds<64, 32, 2>', lambda P: (P * C * 4 + P * 8 + n * Q * 4) + n * (C + Q) * 4, lambda P: 2 * P * C * Q + 2 * n * C * Q,
-         lambda: lib().pcgc_conv_gather_masked(_p(nbr), n, _p(x), n, 64, _ld(x), _p(f['Wa']), 32, _p(f['mask_a']), _p(f['ba']), 1, _p(t), 32, _stream(nbr))),
-        ('k_conv_gather_mfma_wlds<32, 48, 2>', lambda P: (P * Q * 4 + P * 8 + n * 2 * Q * 4) + (P * Q * 4 + P * 8 + n * Q * 4) + n * 3 * Q * 4,
-         lambda P: 2 * P * Q * 2 * Q + 2 * P * Q * Q + 2 * n * Q * 2 * Q,
-         lambda: lib().pcgc_conv_gather_masked(_p(nbr), n, _p(t), n, 32, 32, _p(f['Wb']), 48, _p(f['mask_b']), _p(f['bb']), 0, _p(u), 48, _stream(nbr))),
-    )
-    comp = {'k_conv_gather_mfma_wlds<64, 32, 2>': n * 64 * 4 + 27 * n * 4 + n * 32 * 4, 'k_conv_gather_mfma_wlds<32, 48, 2>': n * 32 * 4 + 27 * n * 4 + n * 48 * 4}
-    n16 = (n + 15) // 16 * 16                                 # MFMAs issued: pass A 4 blocks x (1 tile, +1 at the centre offset), pass B 2 blocks x (2 + 1 tiles)
-    issued = {'k_conv_gather_mfma_wlds<64, 32, 2>': 2 * n16 * 16 * 16 * 4 * (27 + 1), 'k_conv_gather_mfma_wlds<32, 48, 2>': 2 * n16 * 16 * 16 * 27 * 3}
-    for name, bf, ff, call in steps:
-        prof = PROFILE.want((name, n))
-        if prof:
-            e0, e1 = PROFILE.bracket((name, n), name + ' (block-sparse per-row gather)', n, bf, ff, compulsory=comp[name], mfma_issued=issued[name])
-            e0.record()
-        check(call(), 'conv_gather_masked')
-        if prof:
-            e1.record()
-    check(lib().pcgc_irn_tail(_p(u), _p(x), 64, _ld(x), _p(f['W12']), _p(f['b12']), _p(out), 64, n, _stream(u)), 'irn_tail')
-    return out
-
-
-def irn_block_child64(parent_nbr, x, params, tables):
-    """C = 64 InceptionResNet on a children level, both passes through the PARENT level's map (k_child_irn_a<64>, k_child_irn_b64);
-    bit-identical to irn_block / irn_block_mfma64."""
-    _f32(x, 'x')
-    n, n_p = x.shape[0], parent_nbr.shape[1]
-    ta, tb = tables
-    t = torch.empty((n, 32), dtype=torch.float32, device=x.device)
-    out = torch.empty((n, 64), dtype=torch.float32, device=x.device)
-    P = [p.data_ptr() for p in params]
-    s = _stream(x)
-    if PROFILE.counting:
-        PROFILE.count_children(parent_nbr)
-    tiles = (n_p + 15) // 16
-    forms = _irn_pass_formulas(n, 64, 27 * n_p * 4, ('k_child_irn_a<64>', 'k_child_irn_b64'))
-    per_tile = (216 * 16 + 8 * 16, 216 * 12 + 64)            # MFMA instructions per 16-parent tile (pass B incl. the conv1_2 products)
-    calls = (lambda: lib().pcgc_irn_child_pass(_p(parent_nbr), n_p, 64, 1, _p(x), _ld(x), _p(ta), ta.numel() * 4, P[1], P[5], None, None, 0,
-                                               _p(t), 32, s),
-             lambda: lib().pcgc_irn_child_pass(_p(parent_nbr), n_p, 64, 2, _p(t), 32, _p(tb), tb.numel() * 4, P[3], P[7], P[9], _p(x), _ld(x),
-                                               _p(out), 64, s))
-    for (ps, name, bf, ff, comp), call, mf in zip(forms, calls, per_tile):
-        prof = PROFILE.want((name, n))
-        if prof:
-            e0, e1 = PROFILE.bracket((name, n), name + ' (fused InceptionResNet pass on a children level, parent-map halo gather + fp32 MFMA)', n, bf, ff,
-                                     compulsory=comp, mfma_issued=tiles * mf * 2048)
-            e0.record()
-        check(call(), 'irn_child_pass')
-        if prof:
-            e1.record()
-    return out
-
-
 ROWS_IRN64 = _os.environ.get('PCGC_ROWS_IRN64', '1') != '0'         # C = 64 blocks on plain levels: LDS-resident table, one wave per 16-row tile (csrc/rows_irn.hip); A/B switch
-ROWS_IRN64_CHILD = _os.environ.get('PCGC_ROWS_IRN64_CHILD', '1') != '0'    # ... also on the decoder's C = 64 children level when its own map is at hand
 ROWS_IRN64_MIN = 1024     # rows from which that path is taken (tools/rows_gate_ab.py: 65 vs 135 us per block at 1.1-18 k rows, 103 vs 198 at 71 k)
 
 
 def irn_block_rows64(nbr, x, params, tables):
     """C = 64 InceptionResNet on a plain level through its own k3 map (k_rows_irn_a64, k_rows_irn_b64; tables = child_irn_tables(params));
-    bit-identical to irn_block / irn_block_mfma64."""
+    bit-identical to irn_block."""
     _f32(x, 'x')
     n = x.shape[0]
     ta, tb = tables
@@ -749,10 +628,6 @@ def irn_block_rows32(nbr, x, params, tables):
 
 # ------------------------------------------------------------------------------------------------ children-level convs
 CHILD_MFMA = True         # k3 convs on children levels go through the parent map (csrc/child.hip); A/B switch for tests
-
-
-def set_child_tuning(waves=0, depth=0):
-    check(lib().pcgc_set_child_tuning(int(waves), int(depth)), 'set_child_tuning')
 
 
 def _halo_cells():

@@ -22,8 +22,8 @@ def _t(a, dt=None):
 @pytest.fixture(autouse=True)
 def _restore_path_switches():
     """the A/B switches of the rows kernels are module globals some tests flip: whatever a test leaves behind is undone"""
-    names = ('ROWS_IRN64', 'ROWS_IRN64_CHILD', 'ROWS_IRN64_MIN', 'ROWS_IRN32', 'ROWS_IRN32_MIN', 'ROWS_IRN32_MAX', 'ROWS_CONV', 'ROWS_CONV_MIN',
-             'ROWS_DOWN', 'ROWS_DOWN_MIN', 'UNIT_INPUT_CONV', 'CHILD_MFMA', 'MFMA_IRN', 'FUSE_IRN', 'ONE_SWEEP_PRUNE', 'PACKED_CONV64', 'PACKED_CONV64_MIN', 'UNIT_CONV_MAPLESS', 'D1_CELLS')
+    names = ('ROWS_IRN64', 'ROWS_IRN64_MIN', 'ROWS_IRN32', 'ROWS_IRN32_MIN', 'ROWS_IRN32_MAX', 'ROWS_CONV', 'ROWS_CONV_MIN',
+             'ROWS_DOWN', 'ROWS_DOWN_MIN', 'UNIT_INPUT_CONV', 'CHILD_MFMA', 'FUSE_IRN', 'ONE_SWEEP_PRUNE', 'PACKED_CONV64', 'PACKED_CONV64_MIN', 'UNIT_CONV_MAPLESS', 'D1_CELLS')
     keep = {n: getattr(ops, n) for n in names}
     yield
     for n, v in keep.items():
@@ -152,19 +152,12 @@ CONV_SHAPES = [(27, 1, 16), (27, 16, 16), (27, 32, 8), (27, 8, 16), (27, 8, 8), 
                (8, 16, 32), (8, 32, 64), (8, 64, 32), (1, 32, 8), (1, 8, 16), (1, 64, 16), (1, 16, 32), (1, 16, 4), (1, 4, 8)]
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4, 5, 6, 7],
-                ids=['v0_direct', 'v1_ldsdma', 'v2_mfma', 'v2b_mfma_wlds', 'v2c_mfma_pipe', 'v1_burst', 'row_split', 'v2b_mfma_wlds_mt4'])
+@pytest.fixture(params=[0, 2, 6], ids=['valu', 'mfma', 'row_split'])
 def conv_impl(request):
-    """7 = the LDS-shared-weight MFMA kernel with FOUR M tiles per wave (k_conv_gather_mfma_wlds<64,64,4> / <32,32,4>): the
-    instantiation the dispatcher picks from 400 k rows on (the vox11 / vox12 levels of BASELINE configs 4 and 5), forced here on
-    a 12 k-row level so that it is compared with the oracle value for value."""
-    ops.set_conv_impl(3 if request.param == 7 else (request.param if request.param >= 5 else min(request.param, 3)))
-    ops.set_mfma_pipe(1 if request.param == 4 else 0)
-    ops.set_wlds_mt4_rows(0 if request.param == 7 else 1 << 40)
+    """the three families of pcgc_conv_gather, forced (a family that has no kernel for a shape falls through to the VALU one)"""
+    ops.set_conv_impl(request.param)
     yield request.param
     ops.set_conv_impl(-1)
-    ops.set_mfma_pipe(-1)
-    ops.set_wlds_mt4_rows(-1)
 
 
 @pytest.mark.parametrize('K,cin,cout', CONV_SHAPES)
@@ -276,33 +269,28 @@ def test_conv_down_rows_bit_exact(cin, cout):
         ops.ROWS_DOWN_MIN = keep
 
 
-@pytest.mark.parametrize('waves,depth', [(0, 0), (8, 2), (16, 1), (12, 1)])
-def test_conv_rows_bit_exact(waves, depth):
+def test_conv_rows_bit_exact():
     """pcgc_conv_rows (k3 32 -> 32 on a plain level: LDS-resident fragment table, one wave per 16-row tile, csrc/rows_irn.hip) against the
-    oracle's fmaf chain: plain, fused epilogue (residual + relu into a column slice), ragged sizes, every waves / ring-depth build."""
+    oracle's fmaf chain: plain, fused epilogue (residual + relu into a column slice), ragged sizes."""
     rng = np.random.default_rng(32)
     c4 = _coords('shell7')
     W = (rng.standard_normal((27, 32, 32)) / np.sqrt(27 * 32)).astype(np.float32)
     b = rng.standard_normal((1, 32)).astype(np.float32)
     table = ops.child_conv_table(_t(W))
-    ops.set_child_tuning(waves, depth)
-    try:
-        for m in (len(c4), len(c4) - 7, 33, 16, 1):
-            sub = np.ascontiguousarray(c4[:m])
-            nbr = orc.kmap_k3(sub, 1)
-            x = rng.standard_normal((m, 32)).astype(np.float32)
-            want = orc.conv_gather(nbr, x, W, b)
-            got = ops.conv_rows(_t(nbr), _t(x), table, _t(b), 32)
-            np.testing.assert_array_equal(got.cpu().numpy(), want)
-            res = rng.standard_normal((m, 64)).astype(np.float32)
-            buf = torch.zeros((m, 64), device=DEV)
-            wide = torch.zeros((m, 48), device=DEV)                        # input rows wider than the layer (a column slice of another tensor)
-            wide[:, :32] = _t(x)
-            ops.conv_rows(_t(nbr), wide[:, :32], table, _t(b), 32, out=buf[:, 32:], residual=_t(res)[:, 32:], relu=True)
-            np.testing.assert_array_equal(buf[:, 32:].cpu().numpy(), np.maximum(want + res[:, 32:], np.float32(0)))
-            assert not buf[:, :32].any()
-    finally:
-        ops.set_child_tuning(0, 0)
+    for m in (len(c4), len(c4) - 7, 33, 16, 1):
+        sub = np.ascontiguousarray(c4[:m])
+        nbr = orc.kmap_k3(sub, 1)
+        x = rng.standard_normal((m, 32)).astype(np.float32)
+        want = orc.conv_gather(nbr, x, W, b)
+        got = ops.conv_rows(_t(nbr), _t(x), table, _t(b), 32)
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        res = rng.standard_normal((m, 64)).astype(np.float32)
+        buf = torch.zeros((m, 64), device=DEV)
+        wide = torch.zeros((m, 48), device=DEV)                        # input rows wider than the layer (a column slice of another tensor)
+        wide[:, :32] = _t(x)
+        ops.conv_rows(_t(nbr), wide[:, :32], table, _t(b), 32, out=buf[:, 32:], residual=_t(res)[:, 32:], relu=True)
+        np.testing.assert_array_equal(buf[:, 32:].cpu().numpy(), np.maximum(want + res[:, 32:], np.float32(0)))
+        assert not buf[:, :32].any()
     # the module takes this path on its own from ops.ROWS_CONV_MIN rows on, and the general kernels below
     from pcgcv2_amd.nn import MinkowskiConvolution
     conv = MinkowskiConvolution(32, 32, kernel_size=3, stride=1, bias=True, dimension=3).to(DEV)
@@ -321,9 +309,8 @@ def test_conv_rows_bit_exact(waves, depth):
         ops.ROWS_CONV_MIN = keep
 
 
-@pytest.mark.parametrize('rows', [64, 32, 16])
 @pytest.mark.parametrize('C', [16, 32, 64])
-def test_fused_inception_resnet_bit_exact(C, rows):
+def test_fused_inception_resnet_bit_exact(C):
     """pcgc_irn_block (2 gather passes) == the oracle's five-conv InceptionResNet == the unfused HIP composition."""
     from pcgcv2_amd.autoencoder import InceptionResNet
     rng = np.random.default_rng(C)
@@ -352,15 +339,9 @@ def test_fused_inception_resnet_bit_exact(C, rows):
                 xm = SparseTensor(_t(x[:m]), coordinate_map=CoordMap(_t(sub), 1, unique=True))
                 with torch.no_grad():
                     np.testing.assert_array_equal(blk(xm).F.cpu().numpy(), orc.inception_resnet(sd, 'b', orc.Level(sub, 1), x[:m]))
-            if rows == 64:
-                ops.set_child_tuning(8, 0)
-                with torch.no_grad():
-                    np.testing.assert_array_equal(blk(xs).F.cpu().numpy(), want)
         finally:
             ops.ROWS_IRN32_MIN = keep_min
-            ops.set_child_tuning(0, 0)
         ops.ROWS_IRN32 = False
-    ops.set_irn_rows(rows)
     try:
         with torch.no_grad():
             fused = blk(xs).F.cpu().numpy()
@@ -368,43 +349,17 @@ def test_fused_inception_resnet_bit_exact(C, rows):
             unfused = blk(xs).F.cpu().numpy()
     finally:
         ops.FUSE_IRN = True
-        ops.set_irn_rows(0)
     np.testing.assert_array_equal(unfused, want)
     np.testing.assert_array_equal(fused, want)
-    if rows == 16 and C <= 32:                               # lane-per-row form of the 16-row tiles (the default is the row-split form)
-        ops.set_irn_split(0)
-        try:
-            with torch.no_grad():
-                np.testing.assert_array_equal(blk(xs).F.cpu().numpy(), want)
-        finally:
-            ops.set_irn_split(1)
-    if C == 32 and rows == 64:                               # 16-channel sub-step form of pass A (the default above 400 k rows)
-        ops.set_irn_cb16_rows(0)
-        try:
-            with torch.no_grad():
-                np.testing.assert_array_equal(blk(xs).F.cpu().numpy(), want)
-        finally:
-            ops.set_irn_cb16_rows(-1)
     if C == 64:
         # `fused` above ran the LDS-resident-table kernels (csrc/rows_irn.hip: the default from ops.ROWS_IRN64_MIN rows on); with them
-        # switched off, both schedules of the block-sparse MFMA kernels, then the VALU-fused form
+        # switched off, the VALU-fused form
         assert len(c4) >= ops.ROWS_IRN64_MIN and ops.ROWS_IRN64
         ops.ROWS_IRN64 = False
         try:
-            for mode in (0, 1):
-                ops.set_mfma_pipe(mode)
-                try:
-                    with torch.no_grad():
-                        np.testing.assert_array_equal(blk(xs).F.cpu().numpy(), want)
-                finally:
-                    ops.set_mfma_pipe(-1)
-            if rows == 64:
-                ops.MFMA_IRN = False
-                try:
-                    with torch.no_grad():
-                        np.testing.assert_array_equal(blk(xs).F.cpu().numpy(), want)
-                finally:
-                    ops.MFMA_IRN = True
+            assert dispatch.select('irn', (C,), len(c4)).family == 'valu'
+            with torch.no_grad():
+                np.testing.assert_array_equal(blk(xs).F.cpu().numpy(), want)
         finally:
             ops.ROWS_IRN64 = True
         # ragged sizes of the rows kernels: a level that is not a multiple of the 16-row tile, one tile, one row
@@ -680,10 +635,9 @@ def _model(sd):
 @pytest.mark.parametrize('name', ['shell7', 'shell10', 'shell11'])
 def test_encoder_decoder_layers_bit_exact(name, sd, sd_np):
     """Every level output of the encoder and every classification / pruned output of the decoder, bit for bit.  'shell10' is
-    the bench frame (size-gated instantiations a small cloud never reaches: k_conv_gather_mfma_wlds<*,*,2> on 150 k+ rows,
-    k_irn_a<32,64,*>, the children-level kernels' persistent grids); 'shell11' is BASELINE config 4's frame (2.6 M points): its
-    levels of >= 400 k rows run k_conv_gather_mfma_wlds<64,64,4> / <32,32,4> (autoencoder.py:109-115,162-168 at test.py:28-96
-    size) and the 8.5 M-row children level — the whole conv stack of the R-D sweep's workload against the oracle."""
+    the bench frame (size-gated paths a small cloud never reaches: the quad-block children-level kernels from 200 k parents on, the
+    children-level kernels' persistent grids); 'shell11' is BASELINE config 4's frame (2.6 M points) with its 8.5 M-row children
+    level — the whole conv stack of the R-D sweep's workload against the oracle."""
     c4 = _coords(name)
     m = _model(sd)
     x = SparseTensor(torch.ones((len(c4), 1)), coordinates=_t(c4), tensor_stride=1, device=DEV)
@@ -1228,10 +1182,9 @@ def _children_level(name, prune=None):
     return lvl, kids, kids.C.cpu().numpy()
 
 
-@pytest.mark.parametrize('tuning', [(0, 0), (0, 1), (4, 0)], ids=['default', 'unpipelined', 'waves4'])
 @pytest.mark.parametrize('cin,cout', [(16, 16), (32, 32)])
 @pytest.mark.parametrize('name,prune', [('shell7', None), ('shell8', 7), ('shell6', 1)])
-def test_conv_child_bit_exact(name, prune, cin, cout, tuning):
+def test_conv_child_bit_exact(name, prune, cin, cout):
     """pcgc_conv_child (parent-map halo gather + fp32 MFMA) == the oracle's per-row gather conv on the children level's own map."""
     parent, kids, kc = _children_level(name, prune)
     n = len(kc)
@@ -1241,17 +1194,14 @@ def test_conv_child_bit_exact(name, prune, cin, cout, tuning):
     b = rng.standard_normal((1, cout)).astype(np.float32)
     want = orc.conv_gather(orc.kmap_k3(kc, 1), x, W, b)
     Wt = _t(W)
-    ops.set_child_tuning(*tuning)
-    try:
-        got = ops.conv_child(parent.k3, _t(x), ops.child_conv_table(Wt), _t(b), cout)
-        np.testing.assert_array_equal(got.cpu().numpy(), want)
-        res = rng.standard_normal((n, 2 * cout)).astype(np.float32)
-        buf = torch.zeros((n, 2 * cout), device=DEV)
-        ops.conv_child(parent.k3, _t(x), ops.child_conv_table(Wt), _t(b), cout, out=buf[:, cout:], residual=_t(res)[:, cout:], relu=True)
-        np.testing.assert_array_equal(buf[:, cout:].cpu().numpy(), np.maximum(want + res[:, cout:], np.float32(0)))
-        assert not buf[:, :cout].any()
-    finally:
-        ops.set_child_tuning(0, 0)
+    got = ops.conv_child(parent.k3, _t(x), ops.child_conv_table(Wt), _t(b), cout)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    buf = torch.zeros((n, 2 * cout), device=DEV)                           # relu into a column slice of a wider tensor
+    ops.conv_child(parent.k3, _t(x), ops.child_conv_table(Wt), _t(b), cout, out=buf[:, cout:], relu=True)
+    np.testing.assert_array_equal(buf[:, cout:].cpu().numpy(), np.maximum(want, np.float32(0)))
+    assert not buf[:, :cout].any()
+    with pytest.raises(ops.PcgcError):                                     # (no residual form: the module sends such a call to the gather kernels)
+        ops.conv_child(parent.k3, _t(x), ops.child_conv_table(Wt), _t(b), cout, residual=_t(x[:, :cout].copy()))
 
 
 @pytest.mark.parametrize('cin', [16, 32, 64])
@@ -1265,13 +1215,8 @@ def test_cls_head_child_bit_exact(name, prune, cin):
     W = (rng.standard_normal((27, cin, 1)) / np.sqrt(27 * cin)).astype(np.float32)
     b = rng.standard_normal((1, 1)).astype(np.float32)
     want = orc.conv_gather(orc.kmap_k3(kc, 1), x, W, b)
-    for nw, d in ((0, 0), (4, 0), (0, 1)):
-        ops.set_child_tuning(nw, d)
-        try:
-            got = ops.conv_child(parent.k3, _t(x), ops.child_cls_table(_t(W)), _t(b), 1)
-        finally:
-            ops.set_child_tuning(0, 0)
-        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    got = ops.conv_child(parent.k3, _t(x), ops.child_cls_table(_t(W)), _t(b), 1)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
     if cin == 16:        # round 5: the same head in quad-block form (pcgc_cls_child_q4: a 4 x 4 block = 4 parents x the four children of a z half)
         got = ops.cls_child_q4(parent.k3, _t(x), ops.child_q4_cls_table(_t(W)), _t(b))
         np.testing.assert_array_equal(got.cpu().numpy(), want)
@@ -1279,7 +1224,7 @@ def test_cls_head_child_bit_exact(name, prune, cin):
         np.testing.assert_array_equal(got.cpu().numpy(), orc.conv_gather(orc.kmap_k3(kc, 1), x, W, None))
 
 
-@pytest.mark.parametrize('C', [16, 32, 64])
+@pytest.mark.parametrize('C', [16, 32])
 @pytest.mark.parametrize('name,prune', [('shell7', None), ('shell8', 7), ('shell6', 1)])
 def test_inception_resnet_child_bit_exact(name, prune, C):
     """pcgc_irn_child_pass A + B (packed-N MFMA through the parent map) == the oracle's five-conv InceptionResNet."""
@@ -1296,16 +1241,8 @@ def test_inception_resnet_child_bit_exact(name, prune, C):
     want = orc.inception_resnet(sd, 'b', orc.Level(kc, 1), x)
     params = [p for m in (blk.conv0_0, blk.conv0_1, blk.conv1_0, blk.conv1_1, blk.conv1_2) for p in (m.kernel, m.bias)]
     tables = ops.child_irn_tables(params)
-    for nw, d in ((0, 0), (4, 0)):
-        ops.set_child_tuning(nw, d)
-        try:
-            if C == 64:
-                got = ops.irn_block_child64(parent.k3, _t(x), params, tables)
-            else:
-                got = ops.irn_block_child(parent.k3, _t(x), params, tables)
-        finally:
-            ops.set_child_tuning(0, 0)
-        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    got = ops.irn_block_child(parent.k3, _t(x), params, tables)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
 @pytest.mark.parametrize('name,prune', [('shell7', None), ('shell8', 7), ('shell6', 1), ('shell8', None), ('shell9', 5)])
@@ -1756,13 +1693,12 @@ def _conv_module(cin, cout, k, stride, seed):
 
 GATHER_CASES = [
     # (cin, cout, rows, switches to turn off so that the gather family is reached)       one line per side of every gate of dispatch.GATHER_GATES
-    (64, 64, 8191, ('PACKED_CONV64',)), (64, 64, 8192, ('PACKED_CONV64',)), (64, 64, 109999, ('PACKED_CONV64',)), (64, 64, 110000, ('PACKED_CONV64',)), (64, 64, 399999, ('PACKED_CONV64',)), (64, 64, 400000, ('PACKED_CONV64',)),
-    (64, 64, 511, ()), (64, 64, 512, ('PACKED_CONV64',)),
-    (32, 32, 1023, ()), (32, 32, 109999, ('ROWS_CONV',)), (32, 32, 110000, ('ROWS_CONV',)), (32, 32, 400000, ('ROWS_CONV',)),
-    (32, 8, 18732, ()), (32, 8, 149999, ()), (32, 8, 150000, ()),
+    (64, 64, 511, ()), (64, 64, 512, ('PACKED_CONV64',)), (64, 64, 110000, ('PACKED_CONV64',)),
+    (32, 32, 511, ()), (32, 32, 1023, ()), (32, 32, 110000, ('ROWS_CONV',)),
+    (32, 8, 18732, ()), (32, 8, 150000, ()),
     (16, 16, 39999, ()), (16, 16, 40000, ()), (16, 16, 300, ()),
-    (16, 1, 5000, ()), (32, 1, 39999, ()), (32, 1, 40000, ()), (64, 1, 29999, ()), (64, 1, 30000, ()),
-    (1, 16, 20000, ('UNIT_INPUT_CONV',)), (16, 4, 20000, ()), (64, 16, 20000, ()), (64, 32, 600, ()),
+    (16, 1, 5000, ()), (32, 1, 40000, ()), (64, 1, 30000, ()),
+    (1, 16, 20000, ('UNIT_INPUT_CONV',)), (16, 4, 20000, ()), (64, 16, 20000, ()), (64, 32, 511, ()), (64, 32, 600, ()),
 ]
 
 
@@ -1817,18 +1753,17 @@ def test_dispatch_table_children_and_rows_conv_entries():
 IRN_CASES = [
     # (C, level kind, rows (children: parents), own map built first, expected family)
     (16, 'children', 1024, False, 'child'), (16, 'children', 1023, False, 'valu'), (32, 'children', 1024, False, 'child'), (32, 'children', 1023, False, 'rows32'),
-    (64, 'children', 1024, False, 'child64'), (64, 'children', 1024, True, 'rows64'), (64, 'children', 1023, False, 'rows64'),
-    (64, 'plain', 1024, False, 'rows64'), (64, 'plain', 1023, False, 'mfma64'), (64, 'plain', 511, False, 'valu'),
+    (64, 'children', 1024, False, 'rows64'), (64, 'children', 1024, True, 'rows64'), (64, 'children', 1023, False, 'rows64'),
+    (64, 'plain', 1024, False, 'rows64'), (64, 'plain', 1023, False, 'valu'), (64, 'plain', 511, False, 'valu'),
     (32, 'plain', 1024, False, 'rows32'), (32, 'plain', 1023, False, 'valu'),
-    (16, 'plain', 5000, False, 'valu'), (16, 'plain', 39999, False, 'valu'), (16, 'plain', 40000, False, 'valu'), (16, 'plain', 119999, False, 'valu'),
-    (16, 'plain', 120001, False, 'valu'),
+    (16, 'plain', 5000, False, 'valu'), (16, 'plain', 120001, False, 'valu'),
 ]
 
 
 @pytest.mark.parametrize('C,kind,rows,own_map,family', IRN_CASES, ids=[f'C{c}_{k}_{r}{"_ownmap" if o else ""}' for c, k, r, o, _ in IRN_CASES])
 def test_dispatch_table_inception_resnet_entries(C, kind, rows, own_map, family):
-    """every InceptionResNet entry of the table on both sides of its gates (8192 children rows, ROWS_IRN64_MIN / ROWS_IRN32_MIN, 512; the
-    VALU passes at the library's own tile-height gates, pcgc_irn_config) against the oracle's five-conv block."""
+    """every InceptionResNet entry of the table on both sides of its gates (8192 children rows, ROWS_IRN64_MIN / ROWS_IRN32_MIN) against the
+    oracle's five-conv block."""
     from pcgcv2_amd import dispatch
     from pcgcv2_amd.autoencoder import InceptionResNet
     rng = np.random.default_rng(C + rows)
@@ -1844,7 +1779,7 @@ def test_dispatch_table_inception_resnet_entries(C, kind, rows, own_map, family)
     else:
         c4, lvl = _prefix_level(rows)
     n = len(c4)
-    assert dispatch.select('irn', (C,), n, kind, own_map=lvl._k3 is not None).family == family
+    assert dispatch.select('irn', (C,), n, kind).family == family
     x = rng.standard_normal((n, C)).astype(np.float32)
     with torch.no_grad():
         got = blk(SparseTensor(_t(x), coordinate_map=lvl)).F.cpu().numpy()

@@ -21,29 +21,12 @@ def timeit(fn, n=20):
 
 
 def main():
-    only = [int(a) for a in sys.argv[1:4]] if len(sys.argv) >= 4 else None       # C waves ring: one configuration, 5 launches (PMC runs)
+    only = [int(a) for a in sys.argv[1:4]] if len(sys.argv) >= 4 else None       # C 0 0 [conv|cls|irn]: that layer only, 5 launches (PMC runs)
     pts = synthetic.shell('shell10', device=dev)
     c4 = torch.cat([torch.zeros((len(pts), 1), dtype=torch.int32, device=dev), pts], 1).contiguous()
     l1 = CoordMap(c4, 1, unique=True)
     l2 = l1.down()[0]; l4 = l2.down()[0]
     l8 = l4.down()[0]
-    if not only:                                               # C = 64: InceptionResNet on the children of the stride-8 level (149 856 rows)
-        from pcgcv2_amd.autoencoder import InceptionResNet
-        kids = l8.up(); n = len(kids); x = torch.randn((n, 64), device=dev)
-        blk = InceptionResNet(64).to(dev)
-        params = [p for m in (blk.conv0_0, blk.conv0_1, blk.conv1_0, blk.conv1_1, blk.conv1_2) for p in (m.kernel, m.bias)]
-        with torch.no_grad():
-            for p_ in params: p_.normal_(0, 0.1)
-        f = ops.fuse_irn64(params); nbr = kids.k3
-        ref = ops.irn_block_mfma64(nbr, x, f)
-        us_ref = timeit(lambda: ops.irn_block_mfma64(nbr, x, f))
-        tabs64 = ops.child_irn_tables(params)
-        for nw in (0, 4):
-            ops.set_child_tuning(nw, 0)
-            ok = torch.equal(ops.irn_block_child64(l8.k3, x, params, tabs64), ref)
-            us = timeit(lambda: ops.irn_block_child64(l8.k3, x, params, tabs64))
-            print(f'C=64 InceptionResNet on {n} rows: per-row {us_ref:.1f} us, both passes through the parent map (waves={nw or "default"}) {us:.1f} us  bit-exact={ok}')
-        ops.set_child_tuning(0, 0)
     for parent, C in ((l2, 16), (l4, 32)):
         if only and only[0] != C: continue
         kids = parent.up()
@@ -53,7 +36,6 @@ def main():
         b = torch.randn((1, C), device=dev)
         tab = ops.child_conv_table(W)
         if only:
-            ops.set_child_tuning(only[1], only[2])
             what = sys.argv[4] if len(sys.argv) > 4 else 'conv'
             if what == 'conv':
                 for _ in range(5): ops.conv_child(parent.k3, x, tab, b, C)
@@ -75,24 +57,19 @@ def main():
         us_ref = timeit(lambda: ops.conv_gather(nbr, x, W, b))
         tab = ops.child_conv_table(W)
         print(f'children level of {len(parent)} parents: {n} rows, C={C}: per-row kernel {us_ref:.1f} us')
-        for nw, d in ((0, 0), (0, 1), (4, 0)):
-            ops.set_child_tuning(nw, d)
-            got = ops.conv_child(parent.k3, x, tab, b, C)
-            ok = torch.equal(got, ref)
-            us = timeit(lambda: ops.conv_child(parent.k3, x, tab, b, C))
-            print(f'   conv_child waves={nw or "default"} ring={d or "default"}: {us:.1f} us  bit-exact={ok}')
-        ops.set_child_tuning(0, 0)
+        got = ops.conv_child(parent.k3, x, tab, b, C)
+        ok = torch.equal(got, ref)
+        us = timeit(lambda: ops.conv_child(parent.k3, x, tab, b, C))
+        print(f'   conv_child: {us:.1f} us  bit-exact={ok}')
         # classification head and fused InceptionResNet
         Wc = torch.randn((27, C, 1), device=dev) * 0.05
         bc = torch.randn((1, 1), device=dev)
         ref = ops.conv_gather(nbr, x, Wc, bc)
         us_ref = timeit(lambda: ops.conv_gather(nbr, x, Wc, bc))
         tc = ops.child_cls_table(Wc)
-        for nw, d in ((0, 0), (4, 0), (0, 1)):
-            ops.set_child_tuning(nw, d)
-            ok = torch.equal(ops.conv_child(parent.k3, x, tc, bc, 1), ref)
-            us = timeit(lambda: ops.conv_child(parent.k3, x, tc, bc, 1))
-            print(f'   cls head: per-row {us_ref:.1f} us, child waves={nw or "default"} ring={d or "default"} {us:.1f} us  bit-exact={ok}')
+        ok = torch.equal(ops.conv_child(parent.k3, x, tc, bc, 1), ref)
+        us = timeit(lambda: ops.conv_child(parent.k3, x, tc, bc, 1))
+        print(f'   cls head: per-row {us_ref:.1f} us, parent map {us:.1f} us  bit-exact={ok}')
         from pcgcv2_amd.autoencoder import InceptionResNet
         blk = InceptionResNet(C).to(dev)
         params = [p for m in (blk.conv0_0, blk.conv0_1, blk.conv1_0, blk.conv1_1, blk.conv1_2) for p in (m.kernel, m.bias)]
@@ -101,12 +78,9 @@ def main():
         ref = ops.irn_block(nbr, x, params)
         us_ref = timeit(lambda: ops.irn_block(nbr, x, params))
         tabs = ops.child_irn_tables(params)
-        for nw, d in ((0, 0), (4, 0), (0, 1)):
-            ops.set_child_tuning(nw, d)
-            ok = torch.equal(ops.irn_block_child(parent.k3, x, params, tabs), ref)
-            us = timeit(lambda: ops.irn_block_child(parent.k3, x, params, tabs))
-            print(f'   InceptionResNet: per-row {us_ref:.1f} us, child waves={nw or "default"} ring={d or "default"} {us:.1f} us  bit-exact={ok}')
-        ops.set_child_tuning(0, 0)
+        ok = torch.equal(ops.irn_block_child(parent.k3, x, params, tabs), ref)
+        us = timeit(lambda: ops.irn_block_child(parent.k3, x, params, tabs))
+        print(f'   InceptionResNet: per-row {us_ref:.1f} us, parent map {us:.1f} us  bit-exact={ok}')
 
 
 if __name__ == '__main__':

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the two 64 -> 64 convs of a vox10 frame: gather ladder (k_conv_gather_mfma_pipe / _wlds) vs present-row packing (k_conv_packed64)."""
+"""A/B of the two 64 -> 64 convs of a vox10 frame: gather family (k_conv_gather_mfma) vs present-row packing (k_conv_packed64)."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
