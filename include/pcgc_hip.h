@@ -48,11 +48,9 @@ int pcgc_hash_first_mask(const int32_t* coords, int64_t n, int32_t stride, const
                          int64_t cap, uint8_t* keep /*[dev n]*/, int32_t* first_row /*[dev n] or NULL*/, void* stream);
                          /* keep[i] = row i is the first occurrence of its coordinate; first_row[i] = that first row */
 
-/* *bad <- number of rows outside the representable range (negative, >= 2^20, batch >= 16).  ME accepts any int32
- * coordinate; this library does not, so the host layer validates caller-supplied coordinates (SparseTensor ctor,
- * scale_sparse_tensor) and raises instead of silently dropping rows. */
-int pcgc_coords_check(const int32_t* coords /*[dev n,4]*/, int64_t n, int32_t* bad /*[dev 1]*/, void* stream);
-/* The same validation + how ordered the rows are: out2[0] = rows out of range, out2[1] = descents of the (batch, z, y, x) key along the
+/* Validation of caller-supplied coordinates (ME accepts any int32 coordinate; this library keys levels by 4+20+20+20 bits, so the host layer
+ * — SparseTensor ctor, scale_sparse_tensor — raises instead of silently dropping rows) + how ordered the rows are: out2[0] = rows out of range
+ * (negative, >= 2^20, batch >= 16), out2[1] = descents of the (batch, z, y, x) key along the
  * rows (0: the rows are in sort_spare_tensor's order, data_utils.py:91-101).  The reference takes rows in any order (ME hashes them); here
  * the canonical row order of every level follows the input order, so an unordered PLY would drive every encoder gather through a random
  * row order — Coder.encode sorts such a cloud once at ingest (no output byte depends on it: the latent is sorted before coding). */
@@ -84,8 +82,6 @@ int pcgc_compact_feats(const float* in, int C, int in_ld, const uint8_t* mask, c
 /* ---- kernel maps (ME kernel maps, built once per coordinate level and reused by every conv on it) ---- */
 int pcgc_kmap_k3(const int32_t* coords, int64_t n, int32_t stride, const uint64_t* keys, const int32_t* vals,
                  int64_t cap, int32_t* nbr /*[dev 27,n]*/, void* stream);
-int pcgc_kmap_down(const int32_t* coarse, int64_t n_coarse, int32_t stride_fine, const uint64_t* fine_keys,
-                   const int32_t* fine_vals, int64_t fine_cap, int32_t* nbr /*[dev 8,n_coarse]*/, void* stream);
 
 /* Hierarchical kernel maps: a level's 27-neighbourhood is a gather through its PARENT level's map (octree relation), so
  * only the coarsest level of a pyramid probes the hash.  (ME rebuilds a hash-probed map per level ‡.) */
@@ -128,9 +124,6 @@ int pcgc_down_level(const int32_t* fine /*[dev n,4]*/, int64_t n, int32_t stride
 size_t pcgc_pyramid_scratch_bytes(int64_t n, int levels);
 int pcgc_pyramid(const int32_t* fine /*[dev n,4]*/, int64_t n, int32_t stride, int levels, void* scratch, size_t scratch_bytes,
                  int32_t* const* coarse, int32_t* const* parent_of, int32_t* const* down, int64_t* counts /*host*/, void* stream);
-/* A/B switch of pcgc_pyramid: 1 (default) = level l is inserted from the rows level l - 1 kept, 0 = every level from all input rows
- * (round 3).  Same levels, parent_of and down maps either way. */
-int pcgc_set_pyramid_impl(int hierarchical);
 /* orig[prefix[i]] = i for set mask bytes (row indices that survive a compaction) */
 int pcgc_compact_index(const uint8_t* mask, const int32_t* prefix, int64_t n, int32_t* orig /*[dev total]*/, void* stream);
 
@@ -238,8 +231,8 @@ int pcgc_conv_down_rows(const int32_t* down, int64_t n_coarse, const float* in, 
  * output element as pcgc_conv_gather: bit-identical results. */
 int pcgc_conv_packed64(const int32_t* nbr, int64_t n, const float* in, int in_ld, const float* table, int64_t table_bytes,
                        const float* bias, int relu, float* out, int out_ld, void* stream);
-/* A/B switches of pcgc_conv_packed64: rows per workgroup tile (1 .. 128; 0 = chosen per launch from the level size) and waves per
- * workgroup (4 or 8; 0 = default).  Results do not depend on them. */
+/* A/B switch of pcgc_conv_packed64: rows per workgroup tile (1 .. 128; 0 = chosen per launch from the level size); `waves` must be 0 or 4
+ * (the eight-wave form was removed in round 5).  Results do not depend on it. */
 int pcgc_set_packed_tuning(int rows, int waves);
 
 /* ‡ conventions the reference's results depend on but its sources do not pin (un-vendored MinkowskiEngine / torch.topk on ME's row
@@ -314,12 +307,6 @@ int pcgc_quantize_symbols_segments(const float* feats, int C, int nseg, const in
 int pcgc_cdf_table(const float* params /*[dev 352]*/, int C, float min_v, float max_v, uint16_t* cdf_u16 /*[dev]*/,
                    float* cdf_f32 /*[dev] or NULL*/, void* stream);
 
-/* The whole tail of EntropyBottleneck.compress (entropy_model.py:151-176) enqueued without a host round trip:
- * minmax[2] <- symbol range, sym <- int16 symbols, cdf_u16/cdf_f32 <- [C, L+1] tables packed for the actual L,
- * info[0] <- L (0 if L > max_L: use the two-phase calls).  All outputs are device buffers; fetch them with one copy. */
-int pcgc_compress_prepare(const float* feats, int64_t count, const float* params, int C, int max_L, float* minmax /*[dev 2]*/,
-                          int16_t* sym /*[dev count]*/, uint16_t* cdf_u16 /*[dev C*(max_L+1)]*/, float* cdf_f32 /*[dev C*(max_L+1)]*/,
-                          int32_t* info /*[dev 1]*/, void* stream);
 
 /* ---- range coder, bit-compatible with torchac 0.9.3 ‡ encode_float_cdf / decode_float_cdf
  *      (entropy_model.py:174,192).  HOST functions; symbols row-major [point, channel], one CDF row per channel. ---- */

@@ -19,7 +19,6 @@ SIGNATURES = {
     'pcgc_hash_insert_policy': (ci, [vp, i64, i32, vp, vp, i64, ci, vp]),
     'pcgc_set_convention': (ci, [ci, ci]),
     'pcgc_hash_first_mask': (ci, [vp, i64, i32, vp, vp, i64, vp, vp, vp]),
-    'pcgc_coords_check': (ci, [vp, i64, vp, vp]),
     'pcgc_coords_check_order': (ci, [vp, i64, vp, vp]),
     'pcgc_coords_quantize': (ci, [vp, i64, i32, vp, vp]),
     'pcgc_coords_children': (ci, [vp, i64, i32, vp, vp]),
@@ -30,7 +29,6 @@ SIGNATURES = {
     'pcgc_compact_coords': (ci, [vp, vp, vp, i64, vp, vp]),
     'pcgc_compact_feats': (ci, [vp, ci, ci, vp, vp, i64, vp, vp]),
     'pcgc_kmap_k3': (ci, [vp, i64, i32, vp, vp, i64, vp, vp]),
-    'pcgc_kmap_down': (ci, [vp, i64, i32, vp, vp, i64, vp, vp]),
     'pcgc_kmap_k3_children': (ci, [vp, i64, vp, vp]),
     'pcgc_kmap_k3_prune': (ci, [vp, i64, vp, vp, vp, i64, vp, vp]),
     'pcgc_kmap_k3_prune_parent': (ci, [vp, i64, vp, vp, vp, i64, vp, vp]),
@@ -41,7 +39,6 @@ SIGNATURES = {
     'pcgc_down_level': (ci, [vp, i64, i32, vp, vp, vp, i64, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),
     'pcgc_pyramid_scratch_bytes': (sz, [i64, ci]),
     'pcgc_pyramid': (ci, [vp, i64, i32, ci, vp, sz, vp, vp, vp, vp, vp]),
-    'pcgc_set_pyramid_impl': (ci, [ci]),
     'pcgc_compact_index': (ci, [vp, vp, i64, vp, vp]),
     'pcgc_conv_gather': (ci, [vp, ci, i64, vp, i64, ci, ci, ci, vp, vp, vp, ci, ci, ci, vp, ci, ci, ci, vp]),
     'pcgc_conv_gather_unit': (ci, [vp, ci, i64, vp, vp, ci, vp, ci, ci, vp]),
@@ -83,7 +80,6 @@ SIGNATURES = {
     'pcgc_symbolize': (ci, [vp, i64, f32, vp, vp]),
     'pcgc_desymbolize': (ci, [vp, i64, f32, vp, vp]),
     'pcgc_quantize_symbols': (ci, [vp, i64, vp, vp, vp]),
-    'pcgc_compress_prepare': (ci, [vp, i64, vp, ci, ci, vp, vp, vp, vp, vp, vp]),
     'pcgc_cdf_table': (ci, [vp, ci, f32, f32, vp, vp, vp]),
     'pcgc_d1_cell_masks': (ci, [vp, i64, vp, vp, i64, vp, i64, vp]),
     'pcgc_d1_nn_cells': (ci, [vp, i64, vp, vp, i64, vp, vp, ci, i32, vp, vp, vp, vp]),

@@ -219,12 +219,12 @@ int pk_rows(int64_t n, int cus) {
         if (cost_of(R) <= 1.02 * best_cost && pk_occ(R, 4) == pk_occ(best, 4)) return R;
     return best;
 }
-int g_pk_rows = 0, g_pk_waves = 0;                              // A/B: rows per workgroup / waves per workgroup forced (0 = default)
+int g_pk_rows = 0;                                              // A/B: rows per workgroup forced (0 = default)
 
 }  // namespace
 extern "C" int pcgc_set_packed_tuning(int rows, int waves) {
-    if (rows < 0 || rows > PK_RMAX || (waves != 0 && waves != 4 && waves != 8)) return -1;
-    g_pk_rows = rows; g_pk_waves = waves; return 0;
+    if (rows < 0 || rows > PK_RMAX || (waves != 0 && waves != 4)) return -1;      // (four waves per workgroup: the eight-wave form lost everywhere it was measured)
+    g_pk_rows = rows; return 0;
 }
 
 // MinkowskiConvolution k3 64 -> 64 on a level with its own kernel map nbr [27][n] (-1 = absent); table = ops.child_conv_table(kernel)
@@ -243,17 +243,16 @@ extern "C" int pcgc_conv_packed64(const int32_t* nbr, int64_t n, const float* in
     static int cus = 0;
     if (!cus) { hipDeviceProp_t p; cus = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
     const int R = g_pk_rows > 0 ? g_pk_rows : pk_rows(n, cus);
-    const int nw = g_pk_waves > 0 ? g_pk_waves : 4;
+    constexpr int nw = 4;
     const int lds = pk_lds(R, nw);
     if (!granted[dev & 15]) {
-        for (const void* f : {(const void*)k_conv_packed64<4>, (const void*)k_conv_packed64<8>}) {
+        for (const void* f : {(const void*)k_conv_packed64<4>}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, pk_lds(PK_RMAX, 8));
             if (e != hipSuccess) { pcgc_set_error("conv_packed64: cannot raise the LDS limit to %d: %s", pk_lds(PK_RMAX, 8), hipGetErrorString(e)); return -1; }
         }
         granted[dev & 15] = 1;
     }
-    if (nw == 8) hipLaunchKernelGGL(k_conv_packed64<8>, dim3(grid_for(n, R)), dim3(512), lds, S(stream), nbr, n, in, in_ld, table, bias, relu, out, out_ld, R);
-    else hipLaunchKernelGGL(k_conv_packed64<4>, dim3(grid_for(n, R)), dim3(256), lds, S(stream), nbr, n, in, in_ld, table, bias, relu, out, out_ld, R);
+    hipLaunchKernelGGL(k_conv_packed64<4>, dim3(grid_for(n, R)), dim3(256), lds, S(stream), nbr, n, in, in_ld, table, bias, relu, out, out_ld, R);
     PCGC_CHECK_LAUNCH("conv_packed64");
     return 0;
 }

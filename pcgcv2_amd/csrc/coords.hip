@@ -26,7 +26,7 @@ __global__ void k_hash_insert(const int4* __restrict__ coords, int64_t n, uint64
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int4 c = make_int4(-1, -1, -1, -1);               // (b, x, y, z)
     if (i < n) c = coords[i];
-    // rows outside the key range are never found again; the host rejects such input up front (pcgc_coords_check)
+    // rows outside the key range are never found again; the host rejects such input up front (pcgc_coords_check_order)
     const bool ok = i < n && coord_in_range(c.x, c.y, c.z, c.w);
     const uint64_t key = ok ? coord_key(c.x, c.y, c.z, c.w) : PCGC_EMPTY_KEY;
     // a run of equal keys in consecutive lanes (quantised x-neighbours of a raster-ordered cloud) is inserted by its first lane only:
@@ -81,15 +81,9 @@ __global__ void k_hash_first_mask(const int4* __restrict__ coords, int64_t n, co
     if (first_row) first_row[i] = f;
 }
 
-// rows whose coordinates the 4+20+20+20-bit key cannot hold (negative, >= 2^20, batch >= 16): the hash kernels skip such rows,
-// so the host validates every externally supplied coordinate tensor with this before building a level on it
-__global__ void k_coords_check(const int4* __restrict__ coords, int64_t n, int32_t* __restrict__ bad) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool oob = i < n && !coord_in_range(coords[i].x, coords[i].y, coords[i].z, coords[i].w);
-    const unsigned long long b = __ballot(oob);
-    if (b && (threadIdx.x & 63) == 0) atomicAdd(bad, (int32_t)__popcll(b));
-}
-// the same pass, plus the number of DESCENTS of the (batch, z, y, x) key along the rows (0 = the rows are in sort_spare_tensor's order,
+// rows whose coordinates the 4+20+20+20-bit key cannot hold (negative, >= 2^20, batch >= 16): the hash kernels skip such rows, so the host
+// validates every externally supplied coordinate tensor with this pass before building a level on it; plus the number of DESCENTS of the
+// (batch, z, y, x) key along the rows (0 = the rows are in sort_spare_tensor's order,
 // data_utils.py:91-101; about n / 2 = no order at all): the encoder sorts an unordered cloud once at ingest (coder.Coder._ingest) instead
 // of dragging every gather of every encoder level through a random row order
 __global__ void k_coords_check_order(const int4* __restrict__ coords, int64_t n, int32_t* __restrict__ out2) {
@@ -116,14 +110,6 @@ extern "C" int pcgc_coords_check_order(const int32_t* coords, int64_t n, int32_t
     PCGC_CHECK_LAUNCH("coords_check_order");
     return 0;
 }
-extern "C" int pcgc_coords_check(const int32_t* coords, int64_t n, int32_t* bad, void* stream) {
-    PCGC_REQUIRE(bad != nullptr, "null counter");
-    hipMemsetAsync(bad, 0, sizeof(int32_t), S(stream));
-    if (n > 0) hipLaunchKernelGGL(k_coords_check, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, n, bad);
-    PCGC_CHECK_LAUNCH("coords_check");
-    return 0;
-}
-
 extern "C" int pcgc_hash_clear(uint64_t* keys, int32_t* vals, int64_t cap, void* stream) {
     PCGC_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "capacity must be a power of two");
     hipLaunchKernelGGL(k_hash_clear, dim3(grid_for(cap, 256)), dim3(256), 0, S(stream), keys, vals, cap);
@@ -218,17 +204,6 @@ __global__ void __launch_bounds__(256) k_kmap_k3(const int4* __restrict__ coords
     int dx = (k % 3 - 1) * s, dy = ((k / 3) % 3 - 1) * s, dz = (k / 9 - 1) * s;
     nbr[t] = (k == 13) ? (int32_t)o : hash_lookup(keys, vals, cap_mask, c.x, c.y + dx, c.z + dy, c.w + dz);
 }
-__global__ void __launch_bounds__(256) k_kmap_down(const int4* __restrict__ coarse, int64_t n, int32_t s,
-                                                   const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
-                                                   uint64_t cap_mask, int32_t* __restrict__ nbr) {
-    int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= n) return;
-    int4 c = coarse[o];
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-        nbr[(int64_t)k * n + o] = hash_lookup(keys, vals, cap_mask, c.x, c.y + (k & 1) * s, c.z + ((k >> 1) & 1) * s,
-                                              c.w + (k >> 2) * s);
-}
 extern "C" int pcgc_kmap_k3(const int32_t* coords, int64_t n, int32_t stride, const uint64_t* keys, const int32_t* vals,
                             int64_t cap, int32_t* nbr, void* stream) {
     if (n == 0) return 0;
@@ -237,15 +212,6 @@ extern "C" int pcgc_kmap_k3(const int32_t* coords, int64_t n, int32_t stride, co
     PCGC_CHECK_LAUNCH("kmap_k3");
     return 0;
 }
-extern "C" int pcgc_kmap_down(const int32_t* coarse, int64_t n_coarse, int32_t stride_fine, const uint64_t* fine_keys,
-                              const int32_t* fine_vals, int64_t fine_cap, int32_t* nbr, void* stream) {
-    if (n_coarse == 0) return 0;
-    hipLaunchKernelGGL(k_kmap_down, dim3(grid_for(n_coarse, 256)), dim3(256), 0, S(stream), (const int4*)coarse, n_coarse,
-                       stride_fine, fine_keys, fine_vals, (uint64_t)(fine_cap - 1), nbr);
-    PCGC_CHECK_LAUNCH("kmap_down");
-    return 0;
-}
-
 // ---- hierarchical kernel maps ---------------------------------------------------------------------------------
 // A fine voxel at child slot j = (jx,jy,jz) of its parent, displaced by d in {-1,0,1}^3, lands in the parent displaced
 // by p = floor((j+d)/2) at child slot (j+d)&1 — so the fine level's 27-neighbourhood is a pure gather through the
@@ -477,41 +443,6 @@ struct PyrArgs {
     int32_t s[PYR_MAX]; uint64_t cap_mask; int levels;
 };
 __device__ static inline int4 pyr_quantise(int4 c, int32_t s) { return make_int4(c.x, c.y / s * s, c.z / s * s, c.w / s * s); }   // (coordinates are >= 0 here)
-__global__ void k_pyr_insert(const int4* __restrict__ fine, int64_t n, PyrArgs a) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int4 c = make_int4(-1, -1, -1, -1);
-    if (i < n) c = fine[i];
-    const bool ok = i < n && coord_in_range(c.x, c.y, c.z, c.w);
-#pragma unroll
-    for (int l = 0; l < PYR_MAX; ++l) {
-        if (l >= a.levels) break;
-        const int4 q = pyr_quantise(c, a.s[l]);
-        const uint64_t key = ok ? coord_key(q.x, q.y, q.z, q.w) : PCGC_EMPTY_KEY;
-        const uint64_t left = __shfl_up((unsigned long long)key, 1, 64);          // runs of equal keys in consecutive lanes: first lane inserts
-        if (!ok || ((threadIdx.x & 63) != 0 && left == key)) continue;
-        uint64_t* keys = a.keys[l]; int32_t* vals = a.vals[l];
-        uint64_t h = hash_slot(key, a.cap_mask);
-        for (;;) {
-            unsigned long long prev = __builtin_nontemporal_load((const unsigned long long*)&keys[h]);
-            if (prev == PCGC_EMPTY_KEY) prev = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)PCGC_EMPTY_KEY, (unsigned long long)key);
-            if (prev == PCGC_EMPTY_KEY || prev == key) { if (__builtin_nontemporal_load(&vals[h]) > (int32_t)i) atomicMin(&vals[h], (int32_t)i); break; }
-            h = (h + 1) & a.cap_mask;
-        }
-    }
-}
-__global__ void k_pyr_first(const int4* __restrict__ fine, int64_t n, PyrArgs a) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int4 c = fine[i];
-#pragma unroll
-    for (int l = 0; l < PYR_MAX; ++l) {
-        if (l >= a.levels) break;
-        const int4 q = pyr_quantise(c, a.s[l]);
-        const int32_t f = hash_lookup(a.keys[l], a.vals[l], a.cap_mask, q.x, q.y, q.z, q.w);
-        a.first[l][i] = f;
-        a.keep[l][i] = f == (int32_t)i;
-    }
-}
 // Level by level (round 4).  The first input row of a level-l cell is also the first row of its level-(l-1) cell (an earlier row with the
 // same finer cell would map to the same coarser cell), so level l only needs the rows that level l - 1 KEPT: 786 k + 256 k + 71 k
 // hash insertions for a vox10 frame instead of 3 x 786 k, same tables, same firsts — for two short launches more per level.
@@ -542,8 +473,6 @@ __global__ void k_pyr_first_level(const int4* __restrict__ fine, int64_t n, PyrA
     a.first[l][i] = f;
     a.keep[l][i] = f == (int32_t)i;
 }
-static int g_pyr_hier = 1;                                   // A/B: 0 = every level inserted from all input rows (round 3)
-extern "C" int pcgc_set_pyramid_impl(int hierarchical) { g_pyr_hier = hierarchical ? 1 : 0; return 0; }
 
 // After the read-back: for every level at once, the compacted coarse coordinates, and for the level below each (rows = the input rows kept
 // by the previous level's mask, all of them for the first) parent_of and the 8-slot down map (pre-filled with -1).
@@ -600,14 +529,9 @@ extern "C" int pcgc_pyramid(const int32_t* fine, int64_t n, int32_t stride, int 
     if (e != hipSuccess) { pcgc_set_error("pyramid: %s", hipGetErrorString(e)); return -1; }
     hipLaunchKernelGGL(k_hash_clear, dim3(grid_for((int64_t)cap * levels, 256)), dim3(256), 0, s, keys0, vals0, (int64_t)cap * levels);
     const dim3 g(grid_for(n, 256)), b(256);
-    if (g_pyr_hier) {
-        for (int l = 0; l < levels; ++l) {
-            hipLaunchKernelGGL(k_pyr_insert_level, g, b, 0, s, (const int4*)fine, n, a, l);
-            hipLaunchKernelGGL(k_pyr_first_level, g, b, 0, s, (const int4*)fine, n, a, l);
-        }
-    } else {
-        hipLaunchKernelGGL(k_pyr_insert, g, b, 0, s, (const int4*)fine, n, a);
-        hipLaunchKernelGGL(k_pyr_first, g, b, 0, s, (const int4*)fine, n, a);
+    for (int l = 0; l < levels; ++l) {
+        hipLaunchKernelGGL(k_pyr_insert_level, g, b, 0, s, (const int4*)fine, n, a, l);
+        hipLaunchKernelGGL(k_pyr_first_level, g, b, 0, s, (const int4*)fine, n, a, l);
     }
     for (int l = 0; l < levels; ++l)
         if ((rc = pcgc_mask_scan_zeroed(a.keep[l], n, prefix[l], totals + l, scan_ws[l], pcgc_scan_workspace_bytes(n), stream))) return rc;

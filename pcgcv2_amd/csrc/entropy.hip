@@ -175,9 +175,8 @@ extern "C" int pcgc_cdf_table(const float* params, int C, float min_v, float max
     return 0;
 }
 
-// ---- device-resident symbol range: the whole compress() tail (min/max -> symbols -> table) is enqueued without a host
-// round trip; the host then fetches {minmax, symbols, table} with one synchronising copy.  The table buffer is sized for
-// `max_L` symbols; info[0] = L (0 if the alphabet does not fit, the host then falls back to the two-phase calls).
+// ---- device-resident symbol range: min / max -> symbols is enqueued without a host round trip; the host then fetches {minmax, symbols}
+// with one synchronising copy (the CDF table is evaluated on the host in the reference's arithmetic, csrc/reftable.cpp).
 __global__ void k_symbolize_dev(const float* __restrict__ f, int64_t count, const float* __restrict__ minmax, int16_t* __restrict__ sym) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) sym[i] = (int16_t)(rintf(f[i]) - minmax[0]);
@@ -202,52 +201,5 @@ extern "C" int pcgc_quantize_symbols_segments(const float* feats, int C, int nse
         if (rc) return rc;
         off += seg_rows[b];
     }
-    return 0;
-}
-__global__ void k_cdf_likelihood_dev(const float* __restrict__ P, int C, const float* __restrict__ minmax, int max_L,
-                                     float* __restrict__ cdf_f32, int32_t* __restrict__ info) {
-    __shared__ EbShared sh;
-    const float min_v = minmax[0];
-    const int L = (int)(minmax[1] - min_v) + 1;
-    if (blockIdx.x == 0 && threadIdx.x == 0) info[0] = (L >= 1 && L <= max_L) ? L : 0;
-    if (L < 1 || L > max_L) return;
-    if ((int)(blockIdx.x * blockDim.x) >= C * L) return;          // whole block beyond the table (block-uniform)
-    eb_prepare(P, C, sh);
-    __syncthreads();
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= C * L) return;
-    int c = t / L, s = t % L;
-    double v = (double)min_v + s;
-    double lo = eb_logits(P, C, c, v - 0.5, sh), up = eb_logits(P, C, c, v + 0.5, sh);
-    double sum = lo + up, sign = sum > 0 ? -1.0 : (sum < 0 ? 1.0 : 0.0);
-    float p = (float)fabs(eb_sigmoid(sign * up) - eb_sigmoid(sign * lo));
-    cdf_f32[c * (L + 1) + s + 1] = p < 1e-9f ? 1e-9f : p;
-}
-__global__ void k_cdf_finish_dev(int C, const int32_t* __restrict__ info, float* __restrict__ cdf_f32, uint16_t* __restrict__ cdf_u16) {
-    const int L = info[0];
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (L == 0 || c >= C) return;
-    float* row = cdf_f32 + c * (L + 1);
-    uint16_t* q = cdf_u16 + c * (L + 1);
-    const float scale = 65536.0f - (float)L;
-    float run = 0.0f;
-    row[0] = 0.0f; q[0] = 0;
-    for (int s = 1; s <= L; ++s) {
-        run = run + row[s];
-        float v = run > 1.0f ? 1.0f : run;
-        row[s] = v;
-        q[s] = (uint16_t)((int32_t)rintf(v * scale) + s);
-    }
-}
-extern "C" int pcgc_compress_prepare(const float* feats, int64_t count, const float* params, int C, int max_L, float* minmax,
-                                     int16_t* sym, uint16_t* cdf_u16, float* cdf_f32, int32_t* info, void* stream) {
-    PCGC_REQUIRE(count > 0 && max_L >= 1, "empty latent");
-    PCGC_REQUIRE(C >= 1 && C <= EB_MAX_C, "entropy bottleneck: at most 16 channels");
-    hipLaunchKernelGGL(k_round_minmax, dim3(1), dim3(1024), 0, S(stream), feats, count, minmax);
-    hipLaunchKernelGGL(k_symbolize_dev, dim3(grid_for(count, 256)), dim3(256), 0, S(stream), feats, count, minmax, sym);
-    hipLaunchKernelGGL(k_cdf_likelihood_dev, dim3(grid_for((int64_t)C * max_L, 256)), dim3(256), 0, S(stream), params, C, minmax,
-                       max_L, cdf_f32, info);
-    hipLaunchKernelGGL(k_cdf_finish_dev, dim3(1), dim3(64), 0, S(stream), C, info, cdf_f32, cdf_u16);
-    PCGC_CHECK_LAUNCH("compress_prepare");
     return 0;
 }

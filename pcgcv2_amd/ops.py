@@ -395,14 +395,6 @@ def kmap_k3(coords, stride, table):
     return nbr
 
 
-def kmap_down(coarse, stride_fine, fine_table):
-    n = coarse.shape[0]
-    nbr = torch.empty((8, n), dtype=torch.int32, device=coarse.device)
-    check(lib().pcgc_kmap_down(_p(_i32(coarse)), n, int(stride_fine), _p(fine_table.keys), _p(fine_table.vals), fine_table.cap,
-                               _p(nbr), _stream(coarse)), 'kmap_down')
-    return nbr
-
-
 # ------------------------------------------------------------------------------------------------ conv family
 def set_conv_impl(impl):
     """family of pcgc_conv_gather: -1 auto, 0 = direct-load VALU kernel, 2 = LDS-DMA + MFMA, 6 = row-split (bit-identical results)."""
@@ -1236,29 +1228,6 @@ def quantize_symbols_segments(feats, seg_rows):
     host = buf.cpu().numpy()
     mm = host[:4 * B].view(np.float32).reshape(B, 2)
     return [(np.float32(a), np.float32(b)) for a, b in mm], host[4 * B:].reshape(n, C)
-
-
-def compress_prepare(feats, params, C, max_L=1024):
-    """Device-side tail of compress(): -> (min_v, max_v, sym int16 ndarray, cdf uint16 ndarray [C, L+1]) with ONE
-    synchronising device->host transfer, or None if the alphabet exceeds max_L."""
-    feats = _f32(feats).contiguous()
-    n = feats.numel()
-    # one pinned-size staging buffer: [minmax f32 x2 | info i32 | pad | table u16 C*(max_L+1) | sym i16 n]
-    tab_elems = C * (max_L + 1)
-    head = torch.empty(4, dtype=torch.float32, device=feats.device)          # minmax (2 floats) + info (1 int32 viewed) + pad
-    table = torch.empty(tab_elems, dtype=torch.int16, device=feats.device)
-    scratch = torch.empty(tab_elems, dtype=torch.float32, device=feats.device)
-    sym = torch.empty(feats.shape, dtype=torch.int16, device=feats.device)
-    info = head[2:3].view(torch.int32)
-    check(lib().pcgc_compress_prepare(_p(feats), n, _p(_f32(params, 'params')), C, max_L, _p(head), _p(sym), _p(table), _p(scratch),
-                                      _p(info), _stream(feats)), 'compress_prepare')
-    packed = torch.cat([head.view(torch.int16), table, sym.reshape(-1)]).cpu().numpy()        # single D2H + sync
-    min_v, max_v = packed[:4].view(np.float32)[:2]
-    L = int(packed[4:6].view(np.int32)[0])
-    if L == 0:
-        return None
-    tab = packed[8:8 + C * (L + 1)].view(np.uint16).reshape(C, L + 1)
-    return np.float32(min_v), np.float32(max_v), packed[8 + tab_elems:].reshape(feats.shape), tab
 
 
 def cdf_table(params, C, min_v, max_v):
