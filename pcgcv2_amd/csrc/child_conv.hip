@@ -22,10 +22,10 @@ extern "C" int pcgc_conv_child(const int32_t* parent_nbr, int64_t n_parent, cons
     int rc = -2;
     const int tb = (int)table_bytes;
     if (Cout == 1 && (Cin == 16 || Cin == 32 || Cin == 64)) {        // classification head: 8 columns = the 8 children
-        PCGC_REQUIRE(table_bytes == (int64_t)64 * (Cin / 16) * 32 * 4 * 4, "cls table size");
+        PCGC_REQUIRE(table_bytes == (int64_t)(125 * ((Cin / 16) * 64 + 16) + 1023) / 1024 * 1024, "cls table size");
         PCGC_REQUIRE(residual == nullptr && !relu, "cls head has no fused epilogue");
         ChildEpi ep{bias, nullptr, 0, 0, out, out_ld, 0};
-        // <16-channel blocks, waves per group, ring depth>: the table (32 / 64 KB) decides how many waves fit a CU
+        // <16-channel blocks, waves per group, ring depth>: compact tables (10 / 18 / 34 KB), the rings take the rest of the LDS
         if (Cin == 64) rc = pcgc_child_cls64(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
         else if (Cin == 16) rc = launch_child_cls<1, 8, 4>(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);
         else rc = pcgc_child_cls32(parent_nbr, n_parent, in, in_ld, table, tb, ep, s);

@@ -129,15 +129,27 @@ struct PlainConv : HaloGeometry {                     // k3 conv Cin = 16 NB -> 
     static constexpr bool uses_block(int, int) { return true; }
     static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 64 * KS * 4; }      // byte offset in the table
 };
+// k3 conv C -> 1 (classification head): one tile, column j (0..7) = child j.  B fragments are NOT stored per cell (round 4: 64 cells x NB x
+// 512 B = 128 KB at C = 64, which left seven waves one ring slot each — every cell's gather latency exposed, 57 us for 1171 tiles): the
+// weights sit in LDS once, in a 5 x 5 x 5 offset space k' = (kz + 1, ky + 1, kx + 1) with kz, ky, kx in -1 .. 3 whose rows outside 0 .. 2 are
+// ZERO, row k' = [cb][mq][jj] -> W[k][16 cb + 4 jj + mq] (+ 16 bytes of padding: rows start 17 / 9 / 5 sixteen-byte groups apart, and the
+// eight children's rows of one cell — k' offsets {0, 1, 5, 6, 25, 26, 30, 31} — fall on eight different groups).  Child j of the tile sees
+// cell c through k' = cellterm(c) + 31 - j', j' = 25 jz + 5 jy + jx: a lane's fragment of (cell, block) is ONE ds_read_b128 at a per-lane
+// base + a compile-time offset, and a child that does not reach the cell reads a zero row — the same products as the stored fragments.
 template <int NB_>
-struct ClsHead : HaloGeometry {                       // k3 conv C -> 1: one tile, column j (0..7) = child j; one fragment per cell
+struct ClsHead : HaloGeometry {
     static constexpr int NB = NB_, ROWCHUNKS = 4, T = 1, KS = 4;
     static constexpr bool HALF = true;
+    static constexpr int ROWB = NB * 64 + 16;                   // bytes per k' row
+    static constexpr int TABLE_BYTES = (125 * ROWB + 1023) / 1024 * 1024;
     static constexpr int kfirst(int) { return 0; }
     static constexpr bool active(int, int) { return true; }
-    static constexpr int frag(int c, int) { return c; }
     static constexpr bool uses_block(int, int) { return true; }
-    static constexpr int frag_off(int c, int t, int cb) { return (frag(c, t) * NB + cb) * 32 * KS * 4; }
+    static constexpr int frag_off(int c, int, int cb) { return (cz_of(c) * 25 + cy_of(c) * 5 + cx_of(c)) * ROWB + cb * 64; }
+    __device__ static inline int lane_table_off(int mi, int mq) {       // byte offset of the lane's base in the table
+        const int j = mi & 7;
+        return (31 - (25 * (j >> 2) + 5 * ((j >> 1) & 1) + (j & 1))) * ROWB + mq * 16;
+    }
 };
 // InceptionResNet pass A (autoencoder.py:52-57 first half): conv0_0 (k3 C -> Q) and conv1_0 (k1 C -> Q), Q = C/4.
 // Columns pack (child, output channel): 16/Q children per tile.  Tiles [0, T/2) = conv0_0, [T/2, T) = conv1_0 (fed only by the
@@ -366,7 +378,9 @@ __device__ __forceinline__ void child_tile_mainloop_mt(const int32_t* __restrict
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const unsigned tab_lane = (unsigned)(uintptr_t)(lds_void_ptr)((const float*)lds_raw + (V::HALF ? (mq * 8 + (mi & 7)) : lane) * KS);
+    unsigned tab_lane;
+    if constexpr (V::HALF) tab_lane = (unsigned)(uintptr_t)(lds_void_ptr)(lds_raw + V::lane_table_off(mi, mq));
+    else tab_lane = (unsigned)(uintptr_t)(lds_void_ptr)((const float*)lds_raw + lane * KS);
     // A operand straight in MFMA layout: lane (mi, mq) needs channel 4 jj + mq of row mi for K-step jj; chunk jj of row mi sits at
     // slot position jj ^ f(mi >> 2) of the (source-swizzled) image, so four ds_read_b32 — conflict-free: bank = 16 (mi & 3) +
     // 4 (jj ^ f(mi >> 2)) + mq covers all 64 banks — replace the ds_read_b128 + 4x4 lane transpose (4 permlane swaps + moves per
@@ -850,11 +864,11 @@ int child_lds_limit(K kern, size_t lds, ChildLdsGrant& granted) {
 }
 // persistent grid: as many workgroups as stay resident (LDS-limited, at most 16 waves per CU), a multiple of 8 (one share per XCD).
 // n_units: work items of the launch (tiles of 16 MT parents, x 2 for half units)
-static unsigned child_grid_units(int64_t n_units, int nw, size_t lds) {
+static unsigned child_grid_units(int64_t n_units, int nw, size_t lds, int max_waves_per_cu = 16) {
     static int cus = 0;
     if (!cus) { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); cus = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
     int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
-    if (per_cu > 16 / nw) per_cu = 16 / nw;
+    if (per_cu > max_waves_per_cu / nw) per_cu = max_waves_per_cu / nw;
     if (per_cu < 1) per_cu = 1;
     int64_t want = (n_units + nw - 1) / nw;
     int64_t g = (int64_t)cus * per_cu;
@@ -889,10 +903,17 @@ int launch_child_conv_split(const int32_t* pnbr, int64_t n_p, const float* in, i
                             const ChildEpi& ep, hipStream_t s) {
     CHILD_LAUNCH_EX((k_child_conv<NB, NT, NW, D, true, 1, false>), NW, D * NB * 1024, ep, 1, 2);
 }
-template <int NB, int NW, int D, int MT = 1>
+// WPC: waves per CU the persistent grid may count on
+template <int NB, int NW, int D, int MT = 1, int WPC = 16>
 int launch_child_cls(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,
                      const ChildEpi& ep, hipStream_t s) {
-    CHILD_LAUNCH_EX((k_child_cls<NB, NW, D, MT>), NW, D * NB * 1024 * MT, ep, MT, 1);
+    const size_t lds = (size_t)table_bytes + (size_t)NW * (D * NB * 1024 * MT);
+    auto kern = k_child_cls<NB, NW, D, MT>;
+    static ChildLdsGrant granted;
+    if (int rc = child_lds_limit(kern, lds, granted)) return rc;
+    const int64_t units = (n_p + 16 * MT - 1) / (16 * MT);
+    hipLaunchKernelGGL(kern, dim3(child_grid_units(units, NW, lds, WPC)), dim3(NW * 64), lds, s, pnbr, n_p, in, in_ld, table, table_bytes, ep);
+    return 0;
 }
 template <int C, int NW, int D, int MT = 1>
 int launch_child_irn_a(const int32_t* pnbr, int64_t n_p, const float* in, int in_ld, const float* table, int table_bytes,

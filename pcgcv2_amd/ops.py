@@ -680,20 +680,28 @@ def _gather_table(index, flat):
 
 
 def _cls_index(C):
-    W = np.arange(27 * C, dtype=np.int64).reshape(27, C, 1)
-    frags = []
-    for kp, jc, reach in _halo_cells():
-        cols = [None] * 8
-        for j, k in reach:
-            cols[j] = W[k][:, 0]
-        frags.append(_fragment(cols, C // 16, half=True))
-    return np.concatenate([f.reshape(-1) for f in frags])
+    """gather index of the compact classification-head table (csrc/child_kernels.h: ClsHead): 125 rows k' = 25 (kz + 1) + 5 (ky + 1) + (kx + 1),
+    kz, ky, kx in -1 .. 3; a row with all three in 0 .. 2 is kernel[9 kz + 3 ky + kx] as [cb][mq][jj] -> channel 16 cb + 4 jj + mq, every other
+    row is zero; rows are (C / 16) * 64 + 16 bytes apart, the table is padded to a multiple of 1 KB."""
+    nb = C // 16
+    rowf = nb * 16 + 4
+    idx = np.full(((125 * rowf * 4 + 1023) // 1024 * 256,), -1, np.int64)
+    for kz in range(3):
+        for ky in range(3):
+            for kx in range(3):
+                r = 25 * (kz + 1) + 5 * (ky + 1) + (kx + 1)
+                k = 9 * kz + 3 * ky + kx
+                for cb in range(nb):
+                    for mq in range(4):
+                        for jj in range(4):
+                            idx[r * rowf + cb * 16 + mq * 4 + jj] = k * C + 16 * cb + 4 * jj + mq
+    return idx
 
 
 def child_cls_table(W):
-    """Table of the classification head (k3 conv C -> 1) for pcgc_conv_child: one half fragment per halo cell; column j = child j,
-    holding kernel[k(cell, j)][:, 0] where child j reaches the cell, zero elsewhere.  Built by one device gather through a
-    cached index (the geometry is static)."""
+    """Table of the classification head (k3 conv C -> 1) for pcgc_conv_child: the kernel in a zero-padded 5 x 5 x 5 offset space (one
+    ds_read_b128 per lane fetches the weights through which ITS child sees a cell, or zeros).  Built by one device gather through a
+    cached index."""
     C = W.shape[1]
     key = ('cls', C, W.device)
     if key not in _TABLE_INDEX:
