@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase shader-clock cycles of the plain-rows kernels (csrc/rows_irn.hip) per tile and wave, on the encoder's C = 64 level (71 k rows)
-and the decoder's (150 k rows).  Needs the timing build (see tools/child_phase_times.py)."""
+and the decoder's (150 k rows).  Needs the timing build: PCGC_BUILD_VARIANT=timing PCGC_EXTRA_HIPCC_FLAGS=-DPCGC_CHILD_TIMING (pcgcv2_amd/_build.py)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
