@@ -409,6 +409,9 @@ int pcgc_frame_decode(const char* stem, int C, const float* eb_params, pcgc_tabl
 int pcgc_frame_decode_begin(const char* stem, int C, const float* eb_params, pcgc_table_fn table_fn, int use_sidecar, int coord_scale,
                             int64_t cap_rows, int16_t* sym, int32_t* level, int64_t* info, float* range, int threads);
 int pcgc_frame_decode_end(void);
+/* Test hook of the two-halves form: the library's frame worker takes every job `delay_us` late (0 = off; negative = leave unchanged)
+ * -> how many feature-stream jobs `_end` has run on the calling thread because the worker had not taken them yet. */
+int pcgc_frame_worker_test(int delay_us);
 
 /* The CDF-table cache behind pcgc_items_encode / pcgc_items_decode / pcgc_frame_decode (a table is a pure function of the entropy
  * parameters and the symbol range; the reference evaluates it in every compress() and decompress(), entropy_model.py:165-171,185-190).

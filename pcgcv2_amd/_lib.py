@@ -103,6 +103,7 @@ SIGNATURES = {
     'pcgc_frame_decode': (ci, [C.c_char_p, ci, vp, vp, ci, ci, i64, vp, vp, vp, vp, ci]),
     'pcgc_frame_decode_begin': (ci, [C.c_char_p, ci, vp, vp, ci, ci, i64, vp, vp, vp, vp, ci]),
     'pcgc_frame_decode_end': (ci, []),
+    'pcgc_frame_worker_test': (ci, [ci]),
     'pcgc_table_cache': (ci, [ci]),
     'pcgc_crc32': (C.c_uint32, [C.c_uint32, vp, i64]),
     'pcgc_ply_read_ascii_geo': (i64, [C.c_char_p, vp, i64]),

@@ -1565,6 +1565,7 @@ struct FrameAsync {
     std::function<void()> job; bool has_job = false, stop = false;
     std::atomic<int> finished{0};
     std::atomic<int64_t> spin_until{0};
+    std::atomic<int> test_delay_us{0}, stolen{0};
     int rc = 0, coords_rc = 0; std::string err, coords_err;
     static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     void loop() {
@@ -1577,6 +1578,12 @@ struct FrameAsync {
                     cv.wait(lk, [&] { return has_job || stop || now_ns() < spin_until.load(std::memory_order_relaxed); });
                 }
                 if (stop) return;
+                if (const int d = test_delay_us.load(std::memory_order_relaxed)) {      // (tests: a worker that is late to its job)
+                    lk.unlock();
+                    std::this_thread::sleep_for(std::chrono::microseconds(d));
+                    lk.lock();
+                    if (!has_job) continue;                                             // the caller took it back (finish())
+                }
                 j = std::move(job); has_job = false;
             }
             j();
@@ -1601,7 +1608,7 @@ struct FrameAsync {
     void finish() {
         std::function<void()> j;
         { std::lock_guard<std::mutex> lk(m); if (has_job) { j = std::move(job); has_job = false; } }
-        if (j) { j(); finished.store(1, std::memory_order_release); }
+        if (j) { stolen.fetch_add(1, std::memory_order_relaxed); j(); finished.store(1, std::memory_order_release); }
         else wait(finished);
     }
     void ensure() { if (!worker.joinable()) worker = std::thread([this] { loop(); }); }
@@ -1655,6 +1662,12 @@ extern "C" int pcgc_frame_decode_begin(const char* stem, int C, const float* eb_
     // which the calling thread never waits for before it has run out of groups itself
     fa.coords_rc = decode_item_coords(stem_copy, 0, rows, native != 0, level, 1, coord_scale > 0 ? coord_scale : 1, fa.coords_err);
     return 0;
+}
+// Test hook: make the frame worker `delay_us` late to every job (0 = off) -> the number of jobs callers have taken back so far.
+extern "C" int pcgc_frame_worker_test(int delay_us) {
+    FrameAsync& fa = frame_async();
+    if (delay_us >= 0) fa.test_delay_us.store(delay_us, std::memory_order_relaxed);
+    return fa.stolen.load(std::memory_order_relaxed);
 }
 extern "C" int pcgc_frame_decode_end(void) {
     if (!tl_frame_pending) return 0;                      // (the synchronous form: everything happened in _begin)

@@ -1032,6 +1032,24 @@ def test_frame_decode_in_two_halves(tmp_path):
     [t.start() for t in threads]
     [t.join() for t in threads]
     assert not errors, errors
+    # a worker that is late to its job (a busy host): `_end` runs the feature stream on the calling thread; the late worker finds nothing
+    import time
+    before = lib().pcgc_frame_worker_test(20000)
+    try:
+        for _ in range(3):
+            sb, lb = np.full((r, 8), -5, np.int16), np.full((r, 4), -5, np.int32)
+            ops.frame_decode_begin(stem, 8, packed, sb, lb)
+            np.testing.assert_array_equal(lb[:, 1:], want)
+            ops.frame_decode_end()
+            np.testing.assert_array_equal(sb, sym)
+        assert lib().pcgc_frame_worker_test(-1) >= before + 3
+    finally:
+        lib().pcgc_frame_worker_test(0)
+    time.sleep(0.05)                                             # (the late worker wakes up to an empty slot)
+    sb, lb = np.full((r, 8), -5, np.int16), np.full((r, 4), -5, np.int32)
+    ops.frame_decode_begin(stem, 8, packed, sb, lb)
+    ops.frame_decode_end()
+    np.testing.assert_array_equal(sb, sym)
 
 
 def test_dispatch_table_rules_without_a_gpu():

@@ -44,5 +44,22 @@ int main() {
         }
     });
     for (auto& x : th) x.join();
-    printf("threads done, failures %d\n", bad);
+    // the two-halves form from all four threads at once (one is served by the frame worker, the others synchronously), with the worker on time
+    // and 0.3 s late to every job (the caller takes the job back in _end)
+    for (int delay : {0, 300000}) {
+        pcgc_frame_worker_test(delay);
+        th.clear();
+        for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+            std::vector<int16_t> so(rs[t] * C); std::vector<int32_t> lo(rs[t] * 4); int64_t info[6]; float rg[2];
+            for (int it = 0; it < 6; ++it) {
+                std::fill(so.begin(), so.end(), (int16_t)-1);
+                int rc = pcgc_frame_decode_begin(stems[t].c_str(), C, params.data(), table_fn, 1, 8, rs[t], so.data(), lo.data(), info, rg, 0);
+                if (rc == 0) rc = pcgc_frame_decode_end();
+                if (rc != 0 || memcmp(so.data(), syms[t].data(), so.size() * 2) != 0) __atomic_add_fetch(&bad, 1, __ATOMIC_RELAXED);
+            }
+        });
+        for (auto& x : th) x.join();
+    }
+    printf("threads done, failures %d, jobs taken back by callers %d\n", bad, pcgc_frame_worker_test(0));
+    return bad != 0;
 }
