@@ -621,7 +621,7 @@ def attach_pmc_traffic(roof):
     h = hashlib.sha256()
     d = os.path.join(ROOT, 'pcgcv2_amd', 'csrc')
     for f in sorted(os.listdir(d)):
-        if f.endswith(('.hip', '.h', '.cpp')):
+        if f.endswith(('.hip', '.h')):            # device sources (the host codec, ply and table .cpp files launch nothing)
             h.update(f.encode()); h.update(open(os.path.join(d, f), 'rb').read())
     if table.get('kernel_sources_sha16') != h.hexdigest()[:16]:
         roof['traffic_source'] = ('profiles/pmc_traffic.json was collected on other kernel sources (stamp %s, now %s): not replayed; re-run tools/pmc_traffic.sh'

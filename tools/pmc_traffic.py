@@ -36,7 +36,7 @@ def kernel_sources_sha16(root):
     h = hashlib.sha256()
     d = os.path.join(root, 'pcgcv2_amd', 'csrc')
     for f in sorted(os.listdir(d)):
-        if f.endswith(('.hip', '.h', '.cpp')):
+        if f.endswith(('.hip', '.h')):            # device sources (the host codec, ply and table .cpp files launch nothing)
             h.update(f.encode()); h.update(open(os.path.join(d, f), 'rb').read())
     return h.hexdigest()[:16]
 
