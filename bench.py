@@ -233,19 +233,21 @@ def main():
     # finds the dominant (kernel, level) and gives the all-launch aggregate — and one that counts the kernel-map pairs per level
     # for the byte / flop formulas.  The timed region then brackets only the dominant kernel's launches, so the event overhead
     # (~0.6 ms per step with every launch bracketed) stays out of `value`.
-    dominant, warm_all, warm_detail, pairs = None, None, None, None
+    ANALYSIS_STEPS = 3
+    dominant, dominant_keys, warm_all, warm_detail, pairs, families = None, (), None, None, None, None
     if not args.no_events and units:
         ops.PROFILE.reset(enabled=True)
-        step()
-        outs = step()                                # two bracketed steps: the dominant kernel is picked by median launch time
+        for _ in range(ANALYSIS_STEPS):              # three bracketed steps: the dominant kernel NAME is picked by median launch time x launches
+            outs = step()
         ops.PROFILE.enabled = False
         ops.PROFILE.counting = True
         step()
         ops.PROFILE.counting = False
         torch.cuda.synchronize()
-        dominant = ops.PROFILE.dominant_key()
-        warm_all = ops.PROFILE.summary(HBM_PEAK_GBS, 2)
-        warm_detail = ops.PROFILE.detail()
+        dominant, dominant_keys = ops.PROFILE.dominant(ANALYSIS_STEPS, HBM_PEAK_GBS)
+        warm_all = ops.PROFILE.aggregate(HBM_PEAK_GBS, ANALYSIS_STEPS)
+        families = ops.PROFILE.families(ANALYSIS_STEPS, HBM_PEAK_GBS)
+        warm_detail = [{k: v for k, v in d.items() if k != 'key'} for d in ops.PROFILE.detail()]
         pairs = dict(ops.PROFILE.pairs)
     elif outs is None:
         outs = step()
@@ -264,7 +266,7 @@ def main():
             index_bits += os.path.getsize(os.path.join(tmp, f)) * 8
 
     # ---- timed region: exactly K steps, with the dominant kernel bracketed by HIP events on its own stream ----
-    ops.PROFILE.reset(enabled=dominant is not None, only=dominant)
+    ops.PROFILE.reset(enabled=dominant is not None, only=dominant_keys)
     if dominant is not None:
         ops.PROFILE.pairs = pairs
     # the W warm-up steps, under exactly the timed region's instrumentation (the pair-counting pass above leaves allocator and caches in a
@@ -272,7 +274,7 @@ def main():
     for _ in range(args.warmup):
         step()
     if dominant is not None:
-        ops.PROFILE.reset(enabled=True, only=dominant)
+        ops.PROFILE.reset(enabled=True, only=dominant_keys)
         ops.PROFILE.pairs = pairs
     timers = [0.0, 0.0]
     step_ms = []
@@ -286,9 +288,13 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.PROFILE.enabled = False
     torch.cuda.synchronize()
-    roof = ops.PROFILE.summary(HBM_PEAK_GBS, args.steps) if dominant is not None else None
+    roof = ops.PROFILE.summary(HBM_PEAK_GBS, args.steps, name=dominant) if dominant is not None else None
     if roof is not None and warm_all is not None:
-        roof['all_launches'] = dict(warm_all['all_launches'], measured='untimed analysis step before the timed region, every sparse-conv launch bracketed')
+        # the dominant kernel's own figures above are LIVE (its launches bracketed inside the timed region); the all-launch aggregate and the
+        # per-kernel table come from the untimed analysis steps, where EVERY sparse-conv launch is bracketed (that costs ~0.6 ms per step)
+        roof['all_launches'] = dict(warm_all, measured=f'{ANALYSIS_STEPS} untimed analysis steps before the timed region, every sparse-conv launch bracketed '
+                                                       '(k3 / k1 convs, fused InceptionResNet passes, k2 s2 down convs, generative up convs)')
+        roof['families'] = families
 
     # the same K steps on the reference's four files alone (no `_F.idx` sidecar: the feature stream is decoded serially, exactly as a
     # reference-made stream would be) — reported beside `value`, so rate and speed of BOTH configurations are on the line
@@ -366,30 +372,40 @@ def main():
     # symbols have reached the host (nothing is queued on the GPU any more) and before the decoder's first device work is enqueued.  Between
     # the two the GPU idles behind the sequential host stages (range encoder, files, file read, coordinate decode, table); outside them the
     # host launches and the GPU executes concurrently.
-    windows = None
-    if cfg == 'frame' and not args.no_extra and batch is None and rate_sds is None:
+    def step_windows(these=None):
         spans = []
         for _ in range(5):
             coder_mod.TIMELINE = marks = []
             torch.cuda.synchronize()
             t_a = time.perf_counter()
-            step()
+            step(these=these)
             torch.cuda.synchronize()
             t_b = time.perf_counter()
             coder_mod.TIMELINE = None
             m = dict(marks)
             if 'enc_gpu_done' in m and 'dec_gpu_first' in m:
                 spans.append(((m['enc_gpu_done'] - t_a) * 1e3, (m['dec_gpu_first'] - m['enc_gpu_done']) * 1e3, (t_b - m['dec_gpu_first']) * 1e3))
-        if spans:
-            med = lambda i: round(sorted(sp[i] for sp in spans)[len(spans) // 2], 3)
-            windows = {'enc_gpu_window_ms': med(0), 'host_serial_ms': med(1), 'dec_gpu_window_ms': med(2),
-                       'gpu_conv_ms': None if warm_all is None else warm_all['all_launches']['ms_per_step'],
-                       'note': 'medians of 5 untimed steps (host clock, no extra device synchronisation inside the step).  enc_gpu_window: step start -> '
-                               "the latent's symbols are on the host (pyramid, maps, encoder convolutions, sort, quantisation; the host enqueues ahead of the "
-                               'GPU).  host_serial: -> the decoder\'s first device work is enqueued: range encoder, table, files, file read, coordinate-stream '
-                               'decode — the GPU has NOTHING queued in this window.  dec_gpu_window: -> decode complete (level upload, feature-stream decode '
-                               'finishing beside it, decoder convolutions, top-k / pruning).  gpu_conv_ms = sum of the sparse-conv launches of one step (HIP '
-                               'events, analysis pass); the GPU-busy total incl. the non-conv kernels is in profiles/r05_kernel_trace.txt'}
+        if not spans:
+            return None
+        med = lambda i: round(sorted(sp[i] for sp in spans)[len(spans) // 2], 3)
+        return {'enc_gpu_window_ms': med(0), 'host_serial_ms': med(1), 'dec_gpu_window_ms': med(2)}
+
+    windows = None
+    if cfg == 'frame' and not args.no_extra and batch is None and rate_sds is None:
+        windows = step_windows()
+        if windows:
+            windows.update(gpu_conv_ms=None if warm_all is None else warm_all['ms_per_step'],
+                           note='medians of 5 untimed steps (host clock, no extra device synchronisation inside the step).  enc_gpu_window: step start -> '
+                                "the latent's symbols are on the host (pyramid, maps, encoder convolutions, sort, quantisation; the host enqueues ahead of the "
+                                'GPU).  host_serial: -> the decoder\'s first device work is enqueued: range encoder, table, files, file read, coordinate-stream '
+                                'decode — the GPU has NOTHING queued in this window.  dec_gpu_window: -> decode complete (level upload, feature-stream decode '
+                                'finishing beside it, decoder convolutions, top-k / pruning).  gpu_conv_ms = sum of ALL sparse-conv launches of one step (HIP '
+                                'events, analysis pass); the GPU-busy total incl. the non-conv kernels is in profiles/r06_kernel_trace.txt')
+        if geom_sens:
+            for nm in ('noisy10', 'multi10', 'solid_ball'):
+                if nm in geom_sens:
+                    geom_sens[nm]['step_windows'] = step_windows(these=[(nm, cloud(nm))])
+            step()
 
     # one rank on a TWO-CPU budget (eight ranks of a node that share a 16-CPU quota get exactly that): the same command in a child process
     # whose affinity mask holds two CPUs — configure_host_threads then budgets one range-decoder thread (the lane-parallel decoder), no pools
@@ -551,7 +567,8 @@ def main():
         value = total_coded * args.steps / elapsed / 1e6
         nbar = None
         if roof is not None:
-            nbar = round(roof['pairs'] / roof['n_out'], 2)
+            big = max(warm_detail, key=lambda d: d['n_out'] if 'pairs' in d and d['name'].startswith(('k_child', 'k3', 'k_conv_packed', 'k_rows_irn', 'k_rows_conv')) else -1)
+            nbar = round(big['pairs'] / big['n_out'], 2)
         line = {
             'metric': 'encode+decode Mpoints/sec at fixed bpp (r3 ckpt), vox10 frame',
             'value': round(value, 4), 'unit': 'Mpoints/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -627,23 +644,23 @@ def attach_pmc_traffic(roof):
         roof['traffic_source'] = ('profiles/pmc_traffic.json was collected on other kernel sources (stamp %s, now %s): not replayed; re-run tools/pmc_traffic.sh'
                                   % (table.get('kernel_sources_sha16'), h.hexdigest()[:16]))
         return
-    short = roof['kernel'].split(' (')[0].rstrip('>')                     # e.g. "k_child_irn_a<16" or "k_conv_gather_mfma_wlds<64, 32, 2"
-    import math
+    short = roof['kernel'].split(' (')[0].rstrip('>')                     # e.g. "k_child_irn_a<16" or "k_rows_irn_a64"
     cands = []
     for e in table.get('kernels', []):
         name = e['kernel'].replace('(anonymous namespace)::', '').replace('void ', '')
-        if name.startswith(short + ',') or name.startswith(short + '>') or name.startswith(short + '<'):
+        if name == short or name.startswith(short + ',') or name.startswith(short + '>') or name.startswith(short + '<'):
             cands.append(e)
-    # the same template may run on several levels: take the launch geometry closest to this level (grid threads ~ 1-2 x rows;
-    # the persistent children-level kernels have one entry each)
-    cands.sort(key=lambda e: abs(math.log2(max(e.get('grid_size', 1), 1) / max(roof['n_out'], 1)) - 0.5))
-    for e in cands[:1]:
-        roof['traffic'] = e['hbm_bytes_per_launch']
-        roof['traffic_source'] = 'replayed from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command); not measured in this run'
-        roof['traffic_rate'] = {'GBps': round(e['hbm_bytes_per_launch'] / (roof['avg_launch_us'] * 1e-6) / 1e9, 1),
-                                'frac_of_hbm_peak': round(e['hbm_bytes_per_launch'] / (roof['avg_launch_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
-        roof['traffic_detail'] = {k: e[k] for k in ('kernel', 'fetch_bytes_raw', 'fetch_bytes_corrected', 'write_bytes', 'source') if k in e}
+    if not cands:
         return
+    # the roofline object pools the kernel's levels, so does the traffic: mean over the sampled launches of every grid the name ran on
+    n = sum(e['launches_sampled'] for e in cands)
+    per_launch = sum(e['hbm_bytes_per_launch'] * e['launches_sampled'] for e in cands) / n
+    roof['traffic'] = round(per_launch)
+    roof['traffic_source'] = 'replayed from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command); not measured in this run'
+    roof['traffic_rate'] = {'GBps': round(per_launch / (roof['avg_launch_us'] * 1e-6) / 1e9, 1),
+                            'frac_of_hbm_peak': round(per_launch / (roof['avg_launch_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                            'over_compulsory': round(per_launch / max(roof['algorithmic']['compulsory_bytes_per_launch'], 1), 3)}
+    roof['traffic_detail'] = [{k: e[k] for k in ('kernel', 'grid_size', 'launches_sampled', 'fetch_bytes_raw', 'fetch_bytes_corrected', 'write_bytes') if k in e} for e in cands]
 
 
 def cpu_baseline(cfg, sample, sd):

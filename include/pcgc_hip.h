@@ -346,6 +346,10 @@ int pcgc_set_oct_tiled(int on);
  * a context adapts fast on its first visits; 0 = the round-3 versions 2 / 3 (p = 1/2 / sphere-trained prior), kept so that files written
  * by earlier builds stay covered by the format tests.  Replaces nothing in the reference (gpcc.py:6-41 hands `_C.bin` to tmc3). */
 int pcgc_set_oct_model(int model);
+/* Builds the octree coder's trained priors now rather than inside the first encode / decode call of the process (a cold decoder's first
+ * frame would pay tens of milliseconds).  Idempotent and thread-safe; pcgcv2_amd.Coder calls it at construction.  (pcgc_set_oct_model /
+ * pcgc_set_oct_tiled are process-wide A/B and test knobs, not per-call options.)  Replaces nothing in the reference (gpcc.py:6-41). */
+int pcgc_oct_warm(void);
 
 /* ---- D1 point-to-point distortion (pc_error.py:27-74 -> mpeg-pcc-dmetric ‡): sum and max over A of the squared distance to
  *      the nearest point of B, B given by its coordinate hash (stride 1).  offsets: int32 [n,4] = (dx,dy,dz,d2) sorted by d2. ---- */

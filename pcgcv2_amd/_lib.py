@@ -93,6 +93,7 @@ SIGNATURES = {
     'pcgc_set_rc_lanes': (ci, [ci]),
     'pcgc_set_oct_tiled': (ci, [ci]),
     'pcgc_set_oct_model': (ci, [ci]),
+    'pcgc_oct_warm': (ci, []),
     'pcgc_oct_encode': (i64, [vp, i64, vp, i64]),
     'pcgc_oct_decode_count': (i64, [vp, i64]),
     'pcgc_oct_decode': (ci, [vp, i64, vp, i64]),

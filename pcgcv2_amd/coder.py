@@ -217,6 +217,8 @@ class Coder():
         self.filename = filename
         self.coordinate_coder = CoordinateCoder(filename)
         self.feature_coder = FeatureCoder(self.filename, model.entropy_bottleneck)
+        from ._lib import lib
+        lib().pcgc_oct_warm()                                   # the coordinate coder's trained priors: built here, not inside the first frame
 
     @torch.no_grad()
     def encode(self, x, postfix=''):
@@ -241,10 +243,12 @@ class Coder():
         # one sort per cloud, not per encode: an R-D sweep (test.py) encodes the same tensor once per rate, and the sorted level carries the
         # cached pyramid and kernel maps every rate reuses
         # (kept on the coordinate map, so that CoordMap.drop_caches() — "no geometry survives" — drops it with everything else)
-        key = (x.F.data_ptr(), x.F._version, tuple(x.F.shape))
+        # The memo holds the feature tensor ITSELF and hits on identity + version: an address-based key would match a NEW tensor the caching
+        # allocator placed at a freed one's address (same data_ptr, version 0, same shape) and code the previous cloud's sorted features
+        F = x.F
         memo = x.cmap.__dict__.get('_ingested')
-        if memo is not None and memo[0] == key:
-            return memo[1]
+        if memo is not None and memo[0] is F and memo[1] == F._version:
+            return memo[2]
         order = ops.sort_zyx(x.C, batch_major=True)
         cmap = CoordMap(ops.gather_coords(x.C, order), x.cmap.stride, unique=True)
         cmap.descents = 0
@@ -255,7 +259,7 @@ class Coder():
             y.unit_features, y._unit_stamp = True, x._unit_stamp
         else:
             y = SparseTensor(ops.gather_feats(x.F, order), coordinate_map=cmap)
-        x.cmap.__dict__['_ingested'] = (key, y)
+        x.cmap.__dict__['_ingested'] = (F, F._version, y)
         return y
 
     def _encode(self, x, postfix):

@@ -948,15 +948,20 @@ int oct_decode_part(const uint8_t* in, int64_t nbytes, const std::vector<uint64_
 }
 constexpr uint8_t kOctTiled = 3;
 constexpr int64_t kOctTiledMin = 8192;                 // smaller clouds: one stream (version 2)
-int kOctGroups = 8;
+std::atomic<int> kOctGroups{8};
 #ifndef PCGC_OCT_NODES_PER_GROUP
 #define PCGC_OCT_NODES_PER_GROUP 2
 #endif
-int g_oct_tiled = 1;                                   // 0 = always one stream (A/B tests)
-int g_oct_model = 1;                                   // what the ENCODER writes: 1 = versions 4 / 5 (mixed prior + fast start), 0 = the round-3 versions 2 / 3
+std::atomic<int> g_oct_tiled{1};                                 // 0 = always one stream (A/B tests)
+std::atomic<int> g_oct_model{1};                                 // what the ENCODER writes: 1 = versions 4 / 5 (mixed prior + fast start), 0 = the round-3 versions 2 / 3
 constexpr uint8_t kOctVersion1 = 4, kOctTiled1 = 5;    // model 1: one stream / groups of subtrees (the decoder reads all four versions)
 }  // namespace
+// (pcgc_set_oct_model / pcgc_set_oct_tiled are A/B and test knobs: process-wide, read once per encode call — a caller that flips them while
+//  another thread encodes gets one or the other container, never a mixed one; the decoder reads every version whatever they say)
 extern "C" int pcgc_set_oct_model(int model) { if (model != 0 && model != 1) return -1; g_oct_model = model; return 0; }
+// Builds the coder's trained priors now instead of inside the first encode / decode call of the process (4 x 128^3 voxel tests + four training
+// passes: tens of milliseconds a cold decoder would otherwise pay on its first frame).  Idempotent, thread-safe (function-local statics).
+extern "C" int pcgc_oct_warm(void) { (void)oct_prior(); (void)oct_prior_mixed(); return 0; }
 // 0 = one stream, 1 = the default 8 groups, n > 1 = n groups (clamped to the 255 the one-byte group count of the stream can hold)
 extern "C" int pcgc_set_oct_tiled(int on) { g_oct_tiled = on ? 1 : 0; kOctGroups = on > 1 ? (on > 255 ? 255 : on) : 8; return 0; }
 
@@ -1661,6 +1666,16 @@ extern "C" int pcgc_frame_decode_begin(const char* stem, int C, const float* eb_
     // caller needs this result before it can do anything else, so no other thread's wake-up is on its path — only the octree pool's helpers,
     // which the calling thread never waits for before it has run out of groups itself
     fa.coords_rc = decode_item_coords(stem_copy, 0, rows, native != 0, level, 1, coord_scale > 0 ? coord_scale : 1, fa.coords_err);
+    if (fa.coords_rc != 0) {
+        // `level` is stale or uninitialised now: the caller must not upload it and enqueue map kernels on garbage coordinates, so the error
+        // surfaces HERE (the feature task is drained first: it writes into the caller's symbol buffer)
+        fa.finish();
+        const int rc = fa.coords_rc;
+        pcgc_set_error("item 0: %s", fa.coords_err.c_str());
+        tl_frame_pending = false;
+        fa.owner.unlock();
+        return rc;
+    }
     return 0;
 }
 // Test hook: make the frame worker `delay_us` late to every job (0 = off) -> the number of jobs callers have taken back so far.

@@ -84,11 +84,14 @@ class MinkowskiConvolution(_ConvBase):
         return SparseTensor(y, coordinate_map=cmap)
 
     def _table(self, build):
-        """the layer's kernel re-laid-out as MFMA B fragments, rebuilt whenever the parameter tensor was replaced or modified"""
-        stamp = (self.kernel.data_ptr(), self.kernel._version, build.__name__)
-        if getattr(self, '_child_stamp', None) != stamp:
-            self._child_table, self._child_stamp = build(self.kernel), stamp
-        return self._child_table
+        """the layer's kernel re-laid-out as MFMA B fragments, rebuilt whenever the parameter tensor was replaced or modified; one slot per
+        layout (a head whose level sizes straddle a dispatch gate alternates between two layouts: neither evicts the other)"""
+        stamp = (self.kernel.data_ptr(), self.kernel._version)
+        slots = self.__dict__.setdefault('_child_tables', {})
+        hit = slots.get(build.__name__)
+        if hit is None or hit[0] != stamp:
+            hit = slots[build.__name__] = (stamp, build(self.kernel))
+        return hit[1]
 
 
 class MinkowskiGenerativeConvolutionTranspose(_ConvBase):
