@@ -214,6 +214,17 @@ int pcgc_cls_child_q4(const int32_t* parent_nbr, int64_t n_parent, const float* 
 int pcgc_irn_rows_pass(const int32_t* nbr, int64_t n, int C, int pass, const float* in, int in_ld, const float* table,
                        int64_t table_bytes, const float* b0, const float* b1, const float* b2, const float* x, int x_ld, float* out,
                        int out_ld, void* stream);
+/* The two passes at C = 32 on a plain level (the encoder's block0 / block2, autoencoder.py:85-89,123-127) in QUAD-BLOCK form
+ * (csrc/q4x.h, csrc/rows_q4.hip: v_mfma_f32_4x4x1_16b_f32, lane = row, no zero column).  pass 1 (A): in = x [n, >= 32] -> out = t [n, 16]
+ * dense; pass 2 (B): in = t -> out [n, >= 32] with the residual x.  tables = ops.rows_q4_tables(params): pass A 112 fragments [co 4][ci 16]
+ * ordered [k (27 = conv1_0)][channel half][output group], pass B 83 ([k][conv0_1 outputs 0-7, 8-15, conv1_1 0-7], then conv1_2's two).
+ * Same chain as pcgc_irn_rows_pass / pcgc_irn_block: bit-identical. */
+int pcgc_irn_rows_q4_pass(const int32_t* nbr, int64_t n, int C, int pass, const float* in, int in_ld, const float* table,
+                          int64_t table_bytes, const float* b0, const float* b1, const float* b2, const float* x, int x_ld, float* out,
+                          int out_ld, void* stream);
+/* A/B knob of that entry (tools/rows32_ab.py): 0 = the default instantiation (3); 1 = 8 waves x 2 M tiles x ring 2; 2 = 8 x 1 x 4 with paired
+ * half-row gathers; 3 = pass A 16 x 1 x 2, pass B 12 x 1 x 2.  Results do not depend on it.  Replaces nothing in the reference. */
+int pcgc_set_rows_q4_variant(int v);
 /* Plain k3 conv 32 -> 32 on a plain level (the encoder's conv1, autoencoder.py:90-96) by the same kernel family: table =
  * ops.child_conv_table(kernel) (108 KB, LDS-resident); epilogue as pcgc_conv_gather. */
 int pcgc_conv_rows(const int32_t* nbr, int64_t n, const float* in, int Cin, int in_ld, const float* table, int64_t table_bytes,

@@ -55,6 +55,8 @@ SIGNATURES = {
     'pcgc_conv_down_rows': (ci, [vp, i64, vp, i64, ci, ci, vp, i64, vp, ci, vp, ci, ci, vp]),
     'pcgc_conv_rows': (ci, [vp, i64, vp, ci, ci, vp, i64, vp, vp, ci, ci, vp, ci, ci, vp]),
     'pcgc_irn_rows_pass': (ci, [vp, i64, ci, ci, vp, ci, vp, i64, vp, vp, vp, vp, ci, vp, ci, vp]),
+    'pcgc_irn_rows_q4_pass': (ci, [vp, i64, ci, ci, vp, ci, vp, i64, vp, vp, vp, vp, ci, vp, ci, vp]),
+    'pcgc_set_rows_q4_variant': (ci, [ci]),
     'pcgc_conv_packed64': (ci, [vp, i64, vp, ci, vp, i64, vp, ci, vp, ci, vp]),
     'pcgc_set_packed_tuning': (ci, [ci, ci]),
     'pcgc_conv_up2': (ci, [i64, vp, ci, ci, vp, vp, ci, vp, ci, vp]),

@@ -38,6 +38,8 @@ class InceptionResNet(torch.nn.Module):
                 big = x.F.shape[0] >= 8 * ops.CHILD_Q4_MIN_PARENTS
                 q4 = self._tables('q4', ops.child_q4_tables, params) if (c == 16 and ops.CHILD_Q4 and big) else None
                 y = ops.irn_block_child(x.cmap.origin[1].k3, x.F, params, self._tables('child', ops.child_irn_tables, params), q4_table=q4)
+            elif fam == 'rows32q4':      # large plain level, C = 32: the quad-block rows kernels (csrc/rows_q4.hip)
+                y = ops.irn_block_rows32_q4(x.cmap.k3, x.F, params, self._tables('rows_q4', ops.rows_q4_tables, params))
             elif fam == 'rows32':        # plain level, C = 32: the rows kernels instead of the VALU passes
                 y = ops.irn_block_rows32(x.cmap.k3, x.F, params, self._tables('rows32', ops.rows_irn32_tables, params))
             else:                        # 'valu': two fused gather passes

@@ -12,7 +12,7 @@ an instantiation that is reachable is an instantiation that has a parity test.
 Every family of one operator computes the same canonical fmaf chain: the choice affects speed, never a bit of the result.
 Gates are measured (tools/rows_gate_ab.py; numbers in the `why` column).
 
-The A/B switches (ops.CHILD_MFMA, ops.ROWS_*, ops.FUSE_IRN, ops.UNIT_INPUT_CONV) stay what they were — module attributes
+The A/B switches (ops.CHILD_MFMA, ops.ROWS_*, ops.ROWS_Q4, ops.FUSE_IRN, ops.UNIT_INPUT_CONV) stay what they were — module attributes
 the tests flip — and are consulted here, by name, at call time.  Nothing in the product path writes them, and nothing in the product
 path calls a process-wide `pcgc_set_*` knob: concurrent coders cannot race on the policy.
 """
@@ -51,6 +51,9 @@ TABLE = (
     Rule('irn', (64,), None, 'ROWS_IRN64_MIN', INF, 'ROWS_IRN64', 'rows64', 'k_rows_irn_a64<.., RowsPassA64H> + k_rows_irn_b64',
          "through the level's own map, plain or children level (the decoder's 64 -> 64 conv has built it): 65 vs 135 us per block at 1-18 k rows, 103 vs 198 at 71 k; "
          'on the 150 k-row children level 171 vs 197 us for the parent-map form (removed in round 5)'),
+    Rule('irn', (32,), None, 'ROWS_Q4_MIN', 'ROWS_IRN32_MAX+1', 'ROWS_Q4', 'rows32q4', 'k_rows_q4_a32 + k_rows_q4_b32',
+         'quad-block form (4x4x1 fp32 MFMA, lane = row, no zero column: issued / algorithmic 3.9 -> 2.1 in pass A): 120 -> 88 us per block at 256 k rows; '
+         'below ~150 k rows the 64-row tiles are one round of lone waves and the packed-N kernels stay ahead (40 vs 46 us at 71 k)'),
     Rule('irn', (32,), None, 'ROWS_IRN32_MIN', 'ROWS_IRN32_MAX+1', 'ROWS_IRN32', 'rows32', 'k_rows_irn_a32 + k_rows_irn_b32',
          'plain level: 47 vs 74 us per block at 49 k rows, 119 vs 127 at 256 k'),
     Rule('irn', (16, 32, 64), None, 0, INF, 'FUSE_IRN', 'valu', 'k_irn_a_split<C> + k_irn_b_split<C> (C = 16, 32), k_irn_a<64,16> + k_irn_b<64,16>',
@@ -120,7 +123,7 @@ def select(op, shape, rows, level='plain', extent=None, contiguous=True, unit_in
         fam = rule.family
         if fam in ('packed', 'child') and op == 'conv3' and not plain_output:     # (neither has a residual / `out=` form)
             continue
-        if fam in ('child', 'rows', 'rows64', 'rows32', 'rows_down', 'packed') and extent >= LIMIT:
+        if fam in ('child', 'rows', 'rows64', 'rows32', 'rows32q4', 'rows_down', 'packed') and extent >= LIMIT:
             continue                                                     # beyond 32-bit buffer offsets: the generic kernels take it
         if op == 'irn' and fam != 'unfused' and (not ops.FUSE_IRN or rows * 4 * width >= 0xFFFFFFF0):
             continue

@@ -686,6 +686,92 @@ def irn_block_rows32(nbr, x, params, tables):
     return out
 
 
+def rows32_pass(nbr, x, params, tables, ps, t=None):
+    """one pass of irn_block_rows32 on its own (A/B tools): ps = 1 -> t [n, 16]; ps = 2 (t given) -> out [n, 32]"""
+    n = x.shape[0]
+    ta, tb = tables
+    P = [p.data_ptr() for p in params]
+    s = _stream(x)
+    if ps == 1:
+        t = torch.empty((n, 16), dtype=torch.float32, device=x.device)
+        check(lib().pcgc_irn_rows_pass(_p(nbr), n, 32, 1, _p(x), _ld(x), _p(ta), ta.numel() * 4, P[1], P[5], None, None, 0, _p(t), 16, s), 'irn_rows_pass')
+        return t
+    out = torch.empty((n, 32), dtype=torch.float32, device=x.device)
+    check(lib().pcgc_irn_rows_pass(_p(nbr), n, 32, 2, _p(t), 16, _p(tb), tb.numel() * 4, P[3], P[7], P[9], _p(x), _ld(x), _p(out), 32, s), 'irn_rows_pass')
+    return out
+
+
+def rows_q4_tables(params):
+    """(table A 28 672 B, table B 21 248 B) of the quad-block C = 32 InceptionResNet passes on plain levels (csrc/rows_q4.hip); params as in
+    irn_block.  Every fragment is [co 4][16 floats]: a lane's operands of one group are its output channel's 16 values, contiguous.
+      A: [k = 0..26][channel half h][output group g] = W00[k][16 h + j][4 g + co], then [h][g] = W10[16 h + j][4 g + co]
+      B: [k][X0, X1, Y]: X_p[co][8 half + j] = W01[k][j][4 (2 p + half) + co], Y[co][8 half + j] = W11[k][j][4 half + co];
+         then conv1_2's two: [p][co][8 half + j] = W12[j][4 (2 p + half) + co]."""
+    W00, b00, W01, b01, W10, b10, W11, b11, W12, b12 = params
+    C = W00.shape[1]
+    if C != 32:
+        raise PcgcError('rows_q4_tables: C = 32')
+    a0 = W00.detach().reshape(27, 2, 16, 2, 4).permute(0, 1, 3, 4, 2).reshape(-1)                 # [k][h][g][co][j]
+    a1 = W10.detach().reshape(2, 16, 2, 4).permute(0, 2, 3, 1).reshape(-1)                          # [h][g][co][j]
+    x01 = W01.detach().reshape(27, 8, 2, 2, 4).permute(0, 2, 4, 3, 1).reshape(27, 2, 64)            # [k][p][co][half][j]
+    y11 = W11.detach().reshape(27, 8, 2, 4).permute(0, 3, 2, 1).reshape(27, 1, 64)                  # [k][co][half][j]
+    w12 = W12.detach().reshape(8, 2, 2, 4).permute(1, 3, 2, 0).reshape(-1)                          # [p][co][half][j]
+    return torch.cat([a0, a1]).contiguous(), torch.cat([torch.cat([x01, y11], 1).reshape(-1), w12]).contiguous()
+
+
+ROWS_Q4 = _os.environ.get('PCGC_ROWS_Q4', '1') != '0'        # C = 32 blocks on plain levels in quad-block form (csrc/rows_q4.hip); A/B switch
+# the packed-N rows kernels keep the small levels: their 16-row tiles fill the chip where 64-row quad-block tiles are a single round of lone
+# waves (tools/rows32_ab.py, us per block, packed-N vs quad-block: 18.7 k rows 30 vs 43, 71 k rows 40 vs 46, 256 k rows 120 vs 88)
+ROWS_Q4_MIN = 150_000
+
+
+def rows_q4_pass(nbr, x, params, tables, ps, t=None):
+    """one pass of irn_block_rows32_q4 on its own (A/B tools)"""
+    n = x.shape[0]
+    ta, tb = tables
+    P = [p.data_ptr() for p in params]
+    s = _stream(x)
+    if ps == 1:
+        t = torch.empty((n, 16), dtype=torch.float32, device=x.device)
+        check(lib().pcgc_irn_rows_q4_pass(_p(nbr), n, 32, 1, _p(x), _ld(x), _p(ta), ta.numel() * 4, P[1], P[5], None, None, 0, _p(t), 16, s), 'irn_rows_q4_pass')
+        return t
+    out = torch.empty((n, 32), dtype=torch.float32, device=x.device)
+    check(lib().pcgc_irn_rows_q4_pass(_p(nbr), n, 32, 2, _p(t), 16, _p(tb), tb.numel() * 4, P[3], P[7], P[9], _p(x), _ld(x), _p(out), 32, s), 'irn_rows_q4_pass')
+    return out
+
+
+def irn_block_rows32_q4(nbr, x, params, tables):
+    """C = 32 InceptionResNet on a plain level through its own k3 map, quad-block form (k_rows_q4_a32 / _b32); bit-identical to irn_block."""
+    _f32(x, 'x')
+    n = x.shape[0]
+    ta, tb = tables
+    t = torch.empty((n, 16), dtype=torch.float32, device=x.device)
+    out = torch.empty((n, 32), dtype=torch.float32, device=x.device)
+    P = [p.data_ptr() for p in params]
+    s = _stream(x)
+    if PROFILE.counting:
+        PROFILE.count(nbr)
+    tiles = (n + 63) // 64
+    forms = _irn_pass_formulas(n, 32, 27 * n * 4, ('k_rows_q4_a32', 'k_rows_q4_b32'))
+    per_tile = (112 * 16, 81 * 16 + 32)                      # 4x4x1 instructions (512 flops each) per 64-row M tile
+    calls = (lambda: lib().pcgc_irn_rows_q4_pass(_p(nbr), n, 32, 1, _p(x), _ld(x), _p(ta), ta.numel() * 4, P[1], P[5], None, None, 0, _p(t), 16, s),
+             lambda: lib().pcgc_irn_rows_q4_pass(_p(nbr), n, 32, 2, _p(t), 16, _p(tb), tb.numel() * 4, P[3], P[7], P[9], _p(x), _ld(x), _p(out), 32, s))
+    for (ps, name, bf, ff, comp), call, mf in zip(forms, calls, per_tile):
+        prof = PROFILE.want((name, n))
+        if prof:
+            e0, e1 = PROFILE.bracket((name, n), name + ' (fused InceptionResNet pass on a plain level, quad-block 4x4x1 fp32 MFMA, lane = row)', n, bf, ff,
+                                     compulsory=comp, mfma_issued=tiles * mf * 512)
+            e0.record()
+        check(call(), 'irn_rows_q4_pass')
+        if prof:
+            e1.record()
+    return out
+
+
+def set_rows_q4_variant(v):
+    check(lib().pcgc_set_rows_q4_variant(int(v)), 'set_rows_q4_variant')
+
+
 # ------------------------------------------------------------------------------------------------ children-level convs
 CHILD_MFMA = True         # k3 convs on children levels go through the parent map (csrc/child.hip); A/B switch for tests
 

@@ -22,7 +22,7 @@ def _t(a, dt=None):
 @pytest.fixture(autouse=True)
 def _restore_path_switches():
     """the A/B switches of the rows kernels are module globals some tests flip: whatever a test leaves behind is undone"""
-    names = ('ROWS_IRN64', 'ROWS_IRN64_MIN', 'ROWS_IRN32', 'ROWS_IRN32_MIN', 'ROWS_IRN32_MAX', 'ROWS_CONV', 'ROWS_CONV_MIN',
+    names = ('ROWS_IRN64', 'ROWS_IRN64_MIN', 'ROWS_IRN32', 'ROWS_IRN32_MIN', 'ROWS_IRN32_MAX', 'ROWS_Q4', 'ROWS_Q4_MIN', 'ROWS_CONV', 'ROWS_CONV_MIN',
              'ROWS_DOWN', 'ROWS_DOWN_MIN', 'UNIT_INPUT_CONV', 'CHILD_MFMA', 'FUSE_IRN', 'ONE_SWEEP_PRUNE', 'PACKED_CONV64', 'PACKED_CONV64_MIN', 'UNIT_CONV_MAPLESS', 'D1_CELLS')
     keep = {n: getattr(ops, n) for n in names}
     yield
@@ -373,6 +373,37 @@ def test_fused_inception_resnet_bit_exact(C):
                     np.testing.assert_array_equal(blk(xm).F.cpu().numpy(), want_m)
             finally:
                 ops.ROWS_IRN64_MIN = keep_min
+
+
+@pytest.mark.parametrize('variant', [1, 2, 3])
+def test_inception_resnet_rows_quad_block_bit_exact(variant):
+    """C = 32 InceptionResNet on a plain level in quad-block form (csrc/q4x.h, csrc/rows_q4.hip: k_rows_q4_a32 / _b32) against the oracle's
+    five-conv block, every instantiation (waves x M tiles x ring depth, paired half-row gathers), through the module with the gate lowered:
+    a whole level, ragged last tiles (one row short of / one row past a 64- and a 128-row tile), one tile, one row; a noisy cloud whose
+    rows have isolated neighbourhoods (whole gather instructions of absent rows)."""
+    from pcgcv2_amd import dispatch
+    from pcgcv2_amd.autoencoder import InceptionResNet
+    rng = np.random.default_rng(320 + variant)
+    blk = InceptionResNet(32).to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.from_numpy(rng.standard_normal(tuple(p.shape)).astype(np.float32) * 0.2))
+    sd = {'b.' + k: v.detach().cpu().numpy() for k, v in blk.state_dict().items()}
+    ops.ROWS_Q4_MIN = 1
+    ops.set_rows_q4_variant(variant)
+    try:
+        for cloud, sizes in (('shell8', (None, 12805, 129, 128, 127, 65, 64, 63, 1)), ('noisy_s', (None,))):
+            c4 = _cloud4(cloud) if cloud.endswith('_s') else _coords(cloud)
+            x = rng.standard_normal((len(c4), 32)).astype(np.float32)
+            for m in sizes:
+                sub = np.ascontiguousarray(c4 if m is None else c4[:m])
+                assert dispatch.select('irn', (32,), len(sub)).family == 'rows32q4'
+                xm = SparseTensor(_t(x[:len(sub)]), coordinate_map=CoordMap(_t(sub), 1, unique=True))
+                with torch.no_grad():
+                    got = blk(xm).F.cpu().numpy()
+                np.testing.assert_array_equal(got, orc.inception_resnet(sd, 'b', orc.Level(sub, 1), x[:len(sub)]))
+    finally:
+        ops.set_rows_q4_variant(0)
 
 
 @pytest.mark.parametrize('impl', [1, 0], ids=['mfma', 'valu'])
@@ -1245,11 +1276,12 @@ def test_inception_resnet_child_bit_exact(name, prune, C):
     np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize('name,prune', [('shell7', None), ('shell8', 7), ('shell6', 1), ('shell8', None), ('shell9', 5)])
+@pytest.mark.parametrize('name,prune', [('shell7', None), ('shell8', 7), ('shell6', 1), ('shell8', None), ('shell9', 5), ('shell10', None)])
 def test_inception_resnet_child_quad_block_bit_exact(name, prune):
     """Round 5: the C = 16 InceptionResNet with pass A in QUAD-BLOCK form (pcgc_irn_child_q4: v_mfma_f32_4x4x1_16b_f32, one 4 x 4 block
     per (4 parents, cell, child); t in the T2 layout, pass B gathering through it) == the oracle's five-conv block == the packed-N
-    kernels.  Levels of one partial tile (shell6), several 128-parent tiles with a ragged last one, pruned parents (absent neighbours)."""
+    kernels.  Levels of one partial tile (shell6), several 128-parent tiles with a ragged last one, pruned parents (absent neighbours), and the
+    stride-1 level of the bench frame itself (the size the module's gate admits)."""
     from pcgcv2_amd.autoencoder import InceptionResNet
     C = 16
     parent, kids, kc = _children_level(name, prune)
@@ -1268,10 +1300,13 @@ def test_inception_resnet_child_quad_block_bit_exact(name, prune):
     got = ops.irn_block_child(parent.k3, _t(x), params, tables, q4_table=q4)
     packed = ops.irn_block_child(parent.k3, _t(x), params, tables)               # (no quad-block table: both passes packed-N)
     assert torch.equal(got, packed)
-    if n <= 300_000:
-        sd = {'b.' + k: v.detach().cpu().numpy() for k, v in blk.state_dict().items()}
-        want = orc.inception_resnet(sd, 'b', orc.Level(kc, 1), x)
-        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    # the oracle at EVERY size, the level the product's gate admits included (shell10: 255 692 parents >= ops.CHILD_Q4_MIN_PARENTS, 2.05 M rows:
+    # ~15 s of OpenMP oracle) — a comparison of the quad-block kernels with the packed-N kernels alone would be a self-comparison
+    if name == 'shell10':
+        assert len(parent) >= ops.CHILD_Q4_MIN_PARENTS
+    sd = {'b.' + k: v.detach().cpu().numpy() for k, v in blk.state_dict().items()}
+    want = orc.inception_resnet(sd, 'b', orc.Level(kc, 1), x)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
 def test_quad_block_switch_reaches_both_kernel_pairs():
@@ -1755,7 +1790,7 @@ IRN_CASES = [
     (16, 'children', 1024, False, 'child'), (16, 'children', 1023, False, 'valu'), (32, 'children', 1024, False, 'child'), (32, 'children', 1023, False, 'rows32'),
     (64, 'children', 1024, False, 'rows64'), (64, 'children', 1024, True, 'rows64'), (64, 'children', 1023, False, 'rows64'),
     (64, 'plain', 1024, False, 'rows64'), (64, 'plain', 1023, False, 'valu'), (64, 'plain', 511, False, 'valu'),
-    (32, 'plain', 1024, False, 'rows32'), (32, 'plain', 1023, False, 'valu'),
+    (32, 'plain', 1024, False, 'rows32'), (32, 'plain', 1023, False, 'valu'), (32, 'plain', 150000, False, 'rows32q4'), (32, 'plain', 149999, False, 'rows32'),
     (16, 'plain', 5000, False, 'valu'), (16, 'plain', 120001, False, 'valu'),
 ]
 

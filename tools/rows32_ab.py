@@ -40,7 +40,7 @@ def main():
     tabs = ops.rows_irn32_tables(params)
     has_q4 = hasattr(ops, 'irn_block_rows32_q4')
     q4tabs = ops.rows_q4_tables(params) if has_q4 else None
-    for lv in ((l2,) if pmc else (l2, l8)):
+    for lv in ((l2,) if pmc else (l2, l8, l4)):
         n = len(lv)
         nbr = lv.k3
         x = torch.randn((n, 32), device=dev)
@@ -59,16 +59,21 @@ def main():
         print(f'{cloud} level of {n} rows, {P} pairs ({P / n:.2f} per row): rows kernels {us:.1f} us per block = {flops / us / 1e6:.1f} TFLOP/s '
               f'({flops / us / 1e6 / 157.3:.3f} of peak)  bit-exact={torch.equal(got, ref)}')
         if has_q4:
-            got = ops.irn_block_rows32_q4(nbr, x, params, q4tabs)
-            us = timeit(lambda: ops.irn_block_rows32_q4(nbr, x, params, q4tabs))
-            print(f'    quad-block rows kernels {us:.1f} us per block = {flops / us / 1e6:.1f} TFLOP/s ({flops / us / 1e6 / 157.3:.3f} of peak)  '
-                  f'bit-exact={torch.equal(got, ref)}')
-            ta = ops.rows_q4_pass(nbr, x, params, q4tabs, 1)
             t_ref = ops.rows32_pass(nbr, x, params, tabs, 1)
-            print(f'    pass A: rows {timeit(lambda: ops.rows32_pass(nbr, x, params, tabs, 1)):.1f} us, q4 {timeit(lambda: ops.rows_q4_pass(nbr, x, params, q4tabs, 1)):.1f} us'
-                  f'  bit-exact={torch.equal(ta, t_ref)}')
-            print(f'    pass B: rows {timeit(lambda: ops.rows32_pass(nbr, x, params, tabs, 2, t_ref)):.1f} us, q4 {timeit(lambda: ops.rows_q4_pass(nbr, x, params, q4tabs, 2, t_ref)):.1f} us')
-
+            ua = timeit(lambda: ops.rows32_pass(nbr, x, params, tabs, 1))
+            ub = timeit(lambda: ops.rows32_pass(nbr, x, params, tabs, 2, t_ref))
+            print(f'    packed-N rows kernels: pass A {ua:.1f} us, pass B {ub:.1f} us')
+            for v, what in ((1, '8 waves x 2 M tiles x ring 2'), (2, '8 x 1 x 4 paired'), (3, 'A 16 x 1 x 2 / B 12 x 1 x 2'), (0, 'default')):
+                ops.set_rows_q4_variant(v)
+                got = ops.irn_block_rows32_q4(nbr, x, params, q4tabs)
+                ta = ops.rows_q4_pass(nbr, x, params, q4tabs, 1)
+                ok = torch.equal(got, ref) and torch.equal(ta, t_ref)
+                us = timeit(lambda: ops.irn_block_rows32_q4(nbr, x, params, q4tabs))
+                ua = timeit(lambda: ops.rows_q4_pass(nbr, x, params, q4tabs, 1))
+                ub = timeit(lambda: ops.rows_q4_pass(nbr, x, params, q4tabs, 2, t_ref))
+                print(f'    quad-block ({what}): block {us:.1f} us = {flops / us / 1e6:.1f} TFLOP/s ({flops / us / 1e6 / 157.3:.3f} of peak), pass A {ua:.1f} us, '
+                      f'pass B {ub:.1f} us  bit-exact={ok}')
+            ops.set_rows_q4_variant(0)
 
 if __name__ == '__main__':
     main()
