@@ -594,7 +594,7 @@ def main():
                        'entropy_decode': '`_F.bin` (bit-identical to the reference-format stream, decodable without it) comes with a sidecar '
                                          f'`_F.idx` of decoder states at {coder_mod.INDEX_SEGMENTS} row boundaries: its segments are decoded two per thread (two dependency chains per loop) on up to 8 threads; `_C.bin` '
                                          '(native octree, tmc3 absent) is coded as up to 8 independent groups of subtrees',
-                       'path_switches': {k: bool(getattr(ops, k)) for k in ('ONE_SWEEP_PRUNE', 'PACKED_CONV64', 'UNIT_CONV_MAPLESS', 'ROWS_IRN64', 'ROWS_IRN32', 'ROWS_Q4', 'ROWS_CONV', 'ROWS_DOWN', 'CHILD_MFMA', 'CHILD_Q4')},
+                       'path_switches': ops.PATH.switches(),
                        'coord_codec': 'native-octree (tmc3 absent)', 'coord_coder_ms': coord_ms, 'coord_codec_rate': coord_rate, 'serving_throughput': serving,
                        'step_ms_rank0': step_ms,
                        'd1_psnr_rank0_db': None if d1 is None else round(d1['mseF,PSNR (p2point)'], 4),

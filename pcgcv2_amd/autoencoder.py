@@ -35,8 +35,8 @@ class InceptionResNet(torch.nn.Module):
                 y = ops.irn_block_rows64(x.cmap.k3, x.F, params, self._tables('child', ops.child_irn_tables, params))
             elif fam == 'child':
                 # the stride-1 level of a vox10+ frame: pass A in quad-block form (csrc/child_q4.h; smaller levels do not fill its wave slots)
-                big = x.F.shape[0] >= 8 * ops.CHILD_Q4_MIN_PARENTS
-                q4 = self._tables('q4', ops.child_q4_tables, params) if (c == 16 and ops.CHILD_Q4 and big) else None
+                big = x.F.shape[0] >= 8 * ops.PATH.CHILD_Q4_MIN_PARENTS
+                q4 = self._tables('q4', ops.child_q4_tables, params) if (c == 16 and ops.PATH.CHILD_Q4 and big) else None
                 y = ops.irn_block_child(x.cmap.origin[1].k3, x.F, params, self._tables('child', ops.child_irn_tables, params), q4_table=q4)
             elif fam == 'rows32q4':      # large plain level, C = 32: the quad-block rows kernels (csrc/rows_q4.hip)
                 y = ops.irn_block_rows32_q4(x.cmap.k3, x.F, params, self._tables('rows_q4', ops.rows_q4_tables, params))

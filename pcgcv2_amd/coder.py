@@ -272,7 +272,7 @@ class Coder():
         ready.record(torch.cuda.current_stream(x.device))       # the pyramid is complete after this
         # the encoder's kernel maps, coarse to fine, then its ~40 layer launches (the finest level's own map is only read by the first layer,
         # which on the all-ones input derives presence from the level above: sparse.CoordMap.mapless_unit_conv)
-        if x.has_unit_features() and x.cmap.mapless_unit_conv() and ops.UNIT_INPUT_CONV:
+        if x.has_unit_features() and x.cmap.mapless_unit_conv() and ops.PATH.UNIT_INPUT_CONV:
             x.cmap.down()[0].k3
         else:
             x.cmap.k3

@@ -12,9 +12,9 @@ an instantiation that is reachable is an instantiation that has a parity test.
 Every family of one operator computes the same canonical fmaf chain: the choice affects speed, never a bit of the result.
 Gates are measured (tools/rows_gate_ab.py; numbers in the `why` column).
 
-The A/B switches (ops.CHILD_MFMA, ops.ROWS_*, ops.ROWS_Q4, ops.FUSE_IRN, ops.UNIT_INPUT_CONV) stay what they were — module attributes
-the tests flip — and are consulted here, by name, at call time.  Nothing in the product path writes them, and nothing in the product
-path calls a process-wide `pcgc_set_*` knob: concurrent coders cannot race on the policy.
+The A/B switches and row-count gates are the fields of ONE frozen record, `pathconfig.PathConfig`; `select(..., cfg=None)` is a pure function
+of it (default: the process-wide `ops.PATH`).  Nothing in the product path replaces that record, and nothing in the product path calls a
+process-wide `pcgc_set_*` knob: concurrent coders cannot race on the policy.
 """
 from collections import namedtuple
 
@@ -25,8 +25,8 @@ LIMIT = 0xF0000000          # the LDS-DMA kernels address rows with 32-bit buffe
 # op:       'conv3' (k3 s1) | 'irn' (a whole InceptionResNet block) | 'down' (k2 s2) | 'conv1' (k1) | 'up' (generative transpose k2 s2) | 'prune' (top-k + pruning)
 # shape:    (cin, cout) pairs the entry serves, or None = any
 # level:    'children' (rows 8 p + j of a generative transpose: convs can run through the PARENT level's map) | 'plain' | None = any
-# rows:     [rows_min, rows_max) of the level the operator runs on (ints, or names of ops.* attributes the tests move)
-# switch:   name of the ops.* boolean that must be on (None = always)
+# rows:     [rows_min, rows_max) of the level the operator runs on (ints, or names of PathConfig fields)
+# switch:   name of the PathConfig boolean that must be on (None = always)
 # family:   what nn.py / autoencoder.py switch on
 # kernel:   the kernel template(s) behind it
 Rule = namedtuple('Rule', 'op shape level rows_min rows_max switch family kernel why')
@@ -35,7 +35,7 @@ INF = 1 << 62
 TABLE = (
     # ---- k3 s1 convolutions ---------------------------------------------------------------------------------------------------------
     Rule('conv3', ((16, 16), (32, 32), (16, 1), (32, 1), (64, 1)), 'children', 8192, INF, 'CHILD_MFMA', 'child',
-         'k_child_conv<1,1> / k_child_conv<2,2,split> / k_child_cls<NB>; 16->1 with ops.CHILD_Q4: k_child_q4<cls> (quad-block 4x4x1 MFMA)',
+         'k_child_conv<1,1> / k_child_conv<2,2,split> / k_child_cls<NB>; 16->1 with CHILD_Q4: k_child_q4<cls> (quad-block 4x4x1 MFMA)',
          'halo gather through the parent map, packed-N fp32 MFMA: conv 16->16 436 -> 259 us on 2.05 M rows, cls 16->1 209 -> 85 (quad-block form: 83)'),
     Rule('conv3', ((1, 16),), None, 0, INF, 'UNIT_INPUT_CONV', 'unit', 'k_conv_unit<16> / k_conv_unit_coarse<16>',
          'all-ones occupancy input (x.has_unit_features()): sum of kernel slices over the present offsets, no feature gathers: 88 -> 55 us'),
@@ -46,7 +46,7 @@ TABLE = (
     Rule('conv3', None, None, 0, INF, None, 'gather', 'pcgc_conv_gather (see GATHER below)', 'every other shape / size'),
     # ---- InceptionResNet blocks ----------------------------------------------------------------------------------------------------
     Rule('irn', (16, 32), 'children', 8192, INF, 'CHILD_MFMA', 'child',
-         'k_child_irn_a<C> + k_child_irn_b<C> (C = 32: half units); C = 16 with ops.CHILD_Q4: k_child_q4<pass A> (quad-block 4x4x1 MFMA) + k_child_irn_b<16, T2 gather>',
+         'k_child_irn_a<C> + k_child_irn_b<C> (C = 32: half units); C = 16 with CHILD_Q4: k_child_q4<pass A> (quad-block 4x4x1 MFMA) + k_child_irn_b<16, T2 gather>',
          'packed-N MFMA passes through the parent map: C = 16 212/170 -> 118/102 us on 2.05 M rows (quad-block pass A: 97/110), C = 32 174/130 -> 100/81 on 570 k'),
     Rule('irn', (64,), None, 'ROWS_IRN64_MIN', INF, 'ROWS_IRN64', 'rows64', 'k_rows_irn_a64<.., RowsPassA64H> + k_rows_irn_b64',
          "through the level's own map, plain or children level (the decoder's 64 -> 64 conv has built it): 65 vs 135 us per block at 1-18 k rows, 103 vs 198 at 71 k; "
@@ -90,33 +90,35 @@ def gather_impl(K, cin, cout, rows, aligned=True):
     return 0
 
 
-def _value(v):
-    """a gate: an int, or the name of an ops attribute (optionally '+1': an inclusive upper bound turned exclusive)"""
+def _value(v, cfg):
+    """a gate: an int, or the name of a PathConfig field (optionally '+1': an inclusive upper bound turned exclusive)"""
     if isinstance(v, str):
         name, plus, inc = v.partition('+')
-        return getattr(ops, name) + (int(inc) if plus else 0)
+        return getattr(cfg, name) + (int(inc) if plus else 0)
     return v
 
 
-def _switch_on(rule):
+def _switch_on(rule, cfg):
     if rule.switch is None:
         return True
-    return bool(getattr(ops, rule.switch))
+    return bool(getattr(cfg, rule.switch))
 
 
-def select(op, shape, rows, level='plain', extent=None, contiguous=True, unit_input=False, plain_output=True):
+def select(op, shape, rows, level='plain', extent=None, contiguous=True, unit_input=False, plain_output=True, cfg=None):
     """-> the first Rule of TABLE that applies.  shape: (cin, cout), or (C,) for 'irn'; rows: rows of the level the operator runs on
     (the COARSE rows for 'down'); level: 'children' | 'plain'; extent: bytes of the largest tensor the kernel would address with 32-bit
     buffer offsets (rows x leading dimension x 4; default rows x width x 4) — beyond LIMIT the generic kernels take over;
     contiguous: the feature tensor is dense; unit_input: the input is the all-ones
-    occupancy indicator; plain_output: no `out=` / `residual=` (the unit and down kernels have no fused epilogue for those)."""
+    occupancy indicator; plain_output: no `out=` / `residual=` (the unit and down kernels have no fused epilogue for those); cfg: the
+    PathConfig to decide by (default: ops.PATH)."""
+    cfg = ops.PATH if cfg is None else cfg
     width = shape[0]
     extent = rows * 4 * width if extent is None else extent
     key = tuple(shape) if len(shape) > 1 else shape[0]
     for rule in TABLE:
         if rule.op != op or (rule.shape is not None and key not in rule.shape):
             continue
-        if not (_value(rule.rows_min) <= rows < _value(rule.rows_max)) or not _switch_on(rule):
+        if not (_value(rule.rows_min, cfg) <= rows < _value(rule.rows_max, cfg)) or not _switch_on(rule, cfg):
             continue
         if rule.level is not None and level != 'children':
             continue
@@ -125,7 +127,7 @@ def select(op, shape, rows, level='plain', extent=None, contiguous=True, unit_in
             continue
         if fam in ('child', 'rows', 'rows64', 'rows32', 'rows32q4', 'rows_down', 'packed') and extent >= LIMIT:
             continue                                                     # beyond 32-bit buffer offsets: the generic kernels take it
-        if op == 'irn' and fam != 'unfused' and (not ops.FUSE_IRN or rows * 4 * width >= 0xFFFFFFF0):
+        if op == 'irn' and fam != 'unfused' and (not cfg.FUSE_IRN or rows * 4 * width >= 0xFFFFFFF0):
             continue
         if fam == 'child' and op == 'irn' and not contiguous:
             continue
@@ -137,20 +139,22 @@ def select(op, shape, rows, level='plain', extent=None, contiguous=True, unit_in
     raise ops.PcgcError(f'dispatch: no kernel for {op} {shape} on a {level} level of {rows} rows')
 
 
-def entries():
+def entries(cfg=None):
     """(rule, gate row counts) for the exhaustive test: every rule with the row counts just inside its window (both ends)."""
+    cfg = ops.PATH if cfg is None else cfg
     out = []
     for rule in TABLE:
-        lo, hi = _value(rule.rows_min), _value(rule.rows_max)
+        lo, hi = _value(rule.rows_min, cfg), _value(rule.rows_max, cfg)
         out.append((rule, [r for r in (lo, hi - 1) if 0 < r < INF]))
     return out
 
 
-def describe():
+def describe(cfg=None):
     """The table as text (DESIGN.md §5 prints this)."""
+    cfg = ops.PATH if cfg is None else cfg
     lines = []
     for r in TABLE:
-        lo, hi = _value(r.rows_min), _value(r.rows_max)
+        lo, hi = _value(r.rows_min, cfg), _value(r.rows_max, cfg)
         rng = f'{lo}..' + ('' if hi >= INF else str(hi - 1))
         lines.append(f'{r.op:6s} {str(r.shape or "any"):48s} {str(r.level or "any"):18s} rows {rng:16s} -> {r.family:9s} {r.kernel}')
     return '\n'.join(lines)

@@ -42,7 +42,7 @@ class MinkowskiConvolution(_ConvBase):
                                   unit_input=cin == 1 and x.has_unit_features(), plain_output=plain_out).family
             if fam == 'child':
                 # children level (output of a generative transpose): gather through the PARENT level's map, csrc/child_kernels.h
-                if cout == 1 and cin == 16 and ops.CHILD_Q4 and plain_out and not relu and x.F.shape[0] >= 8 * ops.CHILD_Q4_MIN_PARENTS:
+                if cout == 1 and cin == 16 and ops.PATH.CHILD_Q4 and plain_out and not relu and x.F.shape[0] >= 8 * ops.PATH.CHILD_Q4_MIN_PARENTS:
                     # the stride-1 level's classification head in quad-block form (csrc/child_q4.h)
                     y = ops.cls_child_q4(x.cmap.origin[1].k3, x.F, self._table(ops.child_q4_cls_table), self.bias)
                     return SparseTensor(y, coordinate_map=x.cmap)

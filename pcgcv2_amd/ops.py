@@ -242,6 +242,54 @@ class _Profile:
 PROFILE = _Profile()
 
 
+# ------------------------------------------------------------------------------------------------ dispatch policy (pcgcv2_amd/pathconfig.py)
+from .pathconfig import PathConfig, FIELDS as _PATH_FIELDS
+
+PATH = PathConfig.from_env()          # the process-wide default record: frozen; replaced as a whole, never mutated
+
+
+def configure(cfg=None, **changes):
+    """replace the default PathConfig: configure(FIELD=value, ...) or configure(a_record) -> the PREVIOUS record (hand it back to restore)"""
+    global PATH
+    prev = PATH
+    PATH = (PATH if cfg is None else cfg).replace(**changes)
+    return prev
+
+
+class path:
+    """with ops.path(ROWS_Q4=False): ...  — the default record replaced inside the block, the previous one restored on exit"""
+
+    def __init__(self, **changes):
+        self.changes = changes
+
+    def __enter__(self):
+        self.prev = configure(**self.changes)
+        return PATH
+
+    def __exit__(self, *exc):
+        configure(self.prev)
+        return False
+
+
+class _OpsModule(type(_os)):
+    """`ops.FIELD` reads the current record; `ops.FIELD = v` replaces the record (the spelling of the A/B tools and tests of rounds 1-5)"""
+
+    def __getattr__(self, name):
+        if name in _PATH_FIELDS:
+            return getattr(self.__dict__['PATH'], name)
+        raise AttributeError(f"module 'pcgcv2_amd.ops' has no attribute '{name}'")
+
+    def __setattr__(self, name, value):
+        if name in _PATH_FIELDS:
+            self.__dict__['PATH'] = self.__dict__['PATH'].replace(**{name: value})
+        else:
+            super().__setattr__(name, value)
+
+
+import sys as _sys
+_sys.modules[__name__].__class__ = _OpsModule
+
+
 # ------------------------------------------------------------------------------------------------ hash / coords
 class HashTable:
     """Coordinate hash of one level (keys/vals device buffers + the stride its spatial blocking was built with)."""
@@ -493,8 +541,6 @@ def conv_gather(nbr, x, W, bias, out=None, residual=None, relu=False, n_out=None
     return out
 
 
-UNIT_INPUT_CONV = True     # A/B switch: the first layer on an all-ones input skips the feature gathers (bit-identical)
-UNIT_CONV_MAPLESS = _os.environ.get('PCGC_UNIT_CONV_MAPLESS', '1') != '0'      # ... and, on a pyramid level, the level's own kernel map (presence from the parent level's map); A/B switch
 
 
 def conv_gather_unit(nbr, W, bias, relu=False):
@@ -549,7 +595,6 @@ def set_up2_impl(mfma):
     check(lib().pcgc_set_up2_impl(int(mfma)), 'set_up2_impl')
 
 
-FUSE_IRN = True           # tests flip this to compare the fused block against its five-conv composition
 
 
 def _irn_pass_formulas(n, C, map_bytes, names):
@@ -589,8 +634,6 @@ def irn_block(nbr, x, params):
     return out
 
 
-ROWS_IRN64 = _os.environ.get('PCGC_ROWS_IRN64', '1') != '0'         # C = 64 blocks on plain levels: LDS-resident table, one wave per 16-row tile (csrc/rows_irn.hip); A/B switch
-ROWS_IRN64_MIN = 1024     # rows from which that path is taken (tools/rows_gate_ab.py: 65 vs 135 us per block at 1.1-18 k rows, 103 vs 198 at 71 k)
 
 
 def irn_block_rows64(nbr, x, params, tables):
@@ -654,8 +697,6 @@ def rows_irn32_tables(params):
     return _gather_table(ia, flat), _gather_table(ib, flat)
 
 
-ROWS_IRN32 = _os.environ.get('PCGC_ROWS_IRN32', '1') != '0'        # C = 32 blocks on plain levels (the encoder's stride-2 and stride-8 levels); A/B switch
-ROWS_IRN32_MIN, ROWS_IRN32_MAX = 1024, 0xF0000000 // (32 * 4) - 1     # upper bound = the kernels' 32-bit buffer offsets (n * 32 * 4 B < 0xF0000000)                     # (tools/rows_gate_ab.py: ahead of the VALU passes at every size: 47 vs 74 us per block at 49 k rows, 119 vs 127 at 256 k)
 
 
 def irn_block_rows32(nbr, x, params, tables):
@@ -719,10 +760,6 @@ def rows_q4_tables(params):
     return torch.cat([a0, a1]).contiguous(), torch.cat([torch.cat([x01, y11], 1).reshape(-1), w12]).contiguous()
 
 
-ROWS_Q4 = _os.environ.get('PCGC_ROWS_Q4', '1') != '0'        # C = 32 blocks on plain levels in quad-block form (csrc/rows_q4.hip); A/B switch
-# the packed-N rows kernels keep the small levels: their 16-row tiles fill the chip where 64-row quad-block tiles are a single round of lone
-# waves (tools/rows32_ab.py, us per block, packed-N vs quad-block: 18.7 k rows 30 vs 43, 71 k rows 40 vs 46, 256 k rows 120 vs 88)
-ROWS_Q4_MIN = 150_000
 
 
 def rows_q4_pass(nbr, x, params, tables, ps, t=None):
@@ -773,7 +810,6 @@ def set_rows_q4_variant(v):
 
 
 # ------------------------------------------------------------------------------------------------ children-level convs
-CHILD_MFMA = True         # k3 convs on children levels go through the parent map (csrc/child.hip); A/B switch for tests
 
 
 def _halo_cells():
@@ -1022,7 +1058,6 @@ def child_irn_tables(params):
     return _gather_table(ia, flat), (None if ib is None else _gather_table(ib, flat))
 
 
-CHILD_Q4 = _os.environ.get('PCGC_CHILD_Q4', '1') != '0'      # C = 16 InceptionResNet blocks of children levels: pass A in quad-block form (csrc/child_q4.h); A/B switch
 
 
 def child_q4_tables(params):
@@ -1034,10 +1069,6 @@ def child_q4_tables(params):
                       W10.detach().reshape(C, C // 4).t().reshape(-1)]).contiguous()
 
 
-# the quad-block kernels are one 128-parent tile per wave on 2 048 wave slots: below ~1 600 tiles the slots are not filled twice and a lone
-# wave's tile time (78 us at two cells of gather in flight) is what the launch takes — 64 k parents: 78 us against the packed-N pass A's 37,
-# 225 k: 97 against 100, 256 k: 97 against 114 (tools/child_q4_variants.py) — so the module path takes them from this many parents on
-CHILD_Q4_MIN_PARENTS = 200_000
 
 
 def irn_block_child(parent_nbr, x, params, tables, q4_table=None):
@@ -1057,7 +1088,7 @@ def irn_block_child(parent_nbr, x, params, tables, q4_table=None):
     tiles = (n_p + 15) // 16
     per_tile = {16: (416, 248), 32: (1216, 736)}[C]          # MFMA instructions per 16-parent tile (incl. the conv1_2 products of pass B)
     names = (f'k_child_irn_a<{C}>', f'k_child_irn_b<{C}>')
-    q4 = CHILD_Q4 and C == 16 and q4_table is not None
+    q4 = PATH.CHILD_Q4 and C == 16 and q4_table is not None
     if q4:
         # per 16 parents, in units of 2048 flops: 224 groups x 16 4x4x1 instructions (512 flops each) per 64 parents + the 128 transposing ones per 128
         per_tile = ((216 + 8) * 16 // 4 // 4 + 128 // 8 // 4, per_tile[1])
@@ -1116,8 +1147,6 @@ def conv_child(parent_nbr, x, table, bias, Cout, out=None, residual=None, relu=F
     return out
 
 
-ROWS_CONV = _os.environ.get('PCGC_ROWS_CONV', '1') != '0'      # k3 32 -> 32 on plain levels: LDS-resident table, one wave per 16-row tile; A/B switch
-ROWS_CONV_MIN = 1024      # rows from which that path is taken (tools/rows_gate_ab.py: 34 vs 51 us at 1.1-18 k rows, 127 vs 159 at 256 k)
 
 
 def conv_rows(nbr, x, table, bias, Cout, out=None, residual=None, relu=False):
@@ -1144,8 +1173,6 @@ def conv_rows(nbr, x, table, bias, Cout, out=None, residual=None, relu=False):
     return out
 
 
-PACKED_CONV64 = _os.environ.get('PCGC_PACKED_CONV64', '1') != '0'      # k3 64 -> 64 with present-row packing (csrc/conv_packed.hip); A/B switch
-PACKED_CONV64_MIN = 512        # (tools/conv_packed_ab.py gate: 39 vs 86 us at 1-4 k rows, 44 vs 113 at 8 k, 75 vs 115 at 33 k, 112 vs 164 at 66 k)
 
 
 def conv_packed64(nbr, x, table, bias, relu=False):
@@ -1171,8 +1198,6 @@ def conv_packed64(nbr, x, table, bias, relu=False):
     return out
 
 
-ROWS_DOWN = _os.environ.get('PCGC_ROWS_DOWN', '1') != '0'      # k2 s2 down convs: LDS-resident table, one wave per 16 coarse rows; A/B switch
-ROWS_DOWN_MIN = 1024
 
 
 def conv_down_rows(down, x, table, bias, Cout, relu=False):
@@ -1283,7 +1308,6 @@ def topk_mask_segments(logits, seg_rows, seg_k):
     return mask
 
 
-ONE_SWEEP_PRUNE = _os.environ.get('PCGC_ONE_SWEEP_PRUNE', '1') != '0'      # prune_voxel as radix passes + one scan (csrc/select.hip, pcgc_topk_select); A/B switch
 
 
 def topk_select(logits, seg_rows, seg_k, coords=None, parent_coords=None, parent_stride=0):
@@ -1445,7 +1469,6 @@ def _d1_offsets(device, radius=12):
     return _D1_OFFSETS[key]
 
 
-D1_CELLS = _os.environ.get('PCGC_D1_CELLS', '1') != '0'       # nearest neighbours through 4 x 4 x 4 cells with occupancy masks (A/B switch: 0 = one probe per lattice offset)
 _D1_CELL_OFFSETS = {}
 
 
@@ -1469,7 +1492,7 @@ def d1_nn(a, b, radius=12):
     s = torch.empty(1, dtype=torch.float64, device=a.device)
     m = torch.empty(1, dtype=torch.int64, device=a.device)
     u = torch.empty(1, dtype=torch.int32, device=a.device)
-    if D1_CELLS and b.shape[0] > 0:
+    if PATH.D1_CELLS and b.shape[0] > 0:
         # cloud B as stride-4 cells: hash of the cells + a 64-bit occupancy mask per cell; reach: cells up to 4 away, i.e. every voxel nearer
         # than 4 * 5 - 3 = 17 has been seen when the search ends
         reach_cells = max(1, (int(radius) + 3) // 4 + 1)

@@ -105,7 +105,7 @@ class CoordMap:
         """True when a unit-input k3 conv on this level should derive presence from the parent level's map instead of this level's own
         (ops.conv_unit_from_coarse): a raw level that would derive its map from its strided pyramid anyway, and whose map nobody has
         built so far."""
-        return (ops.UNIT_CONV_MAPLESS and self._k3 is None and self.origin is None and len(self) > HASH_LEVEL_MAX and self.stride <= (1 << 18))
+        return (ops.PATH.UNIT_CONV_MAPLESS and self._k3 is None and self.origin is None and len(self) > HASH_LEVEL_MAX and self.stride <= (1 << 18))
 
     def down(self):
         """-> (coarse CoordMap at 2*stride, [8, N_coarse] kernel map): MinkowskiConvolution(kernel_size=2, stride=2).

@@ -20,14 +20,12 @@ def _t(a, dt=None):
 
 
 @pytest.fixture(autouse=True)
-def _restore_path_switches():
-    """the A/B switches of the rows kernels are module globals some tests flip: whatever a test leaves behind is undone"""
-    names = ('ROWS_IRN64', 'ROWS_IRN64_MIN', 'ROWS_IRN32', 'ROWS_IRN32_MIN', 'ROWS_IRN32_MAX', 'ROWS_Q4', 'ROWS_Q4_MIN', 'ROWS_CONV', 'ROWS_CONV_MIN',
-             'ROWS_DOWN', 'ROWS_DOWN_MIN', 'UNIT_INPUT_CONV', 'CHILD_MFMA', 'FUSE_IRN', 'ONE_SWEEP_PRUNE', 'PACKED_CONV64', 'PACKED_CONV64_MIN', 'UNIT_CONV_MAPLESS', 'D1_CELLS')
-    keep = {n: getattr(ops, n) for n in names}
+def _restore_path_config():
+    """the dispatch policy is ONE frozen record (pcgcv2_amd/pathconfig.py); a test that replaces it (`ops.FIELD = v`, ops.configure, ops.path)
+    gets the previous record back afterwards"""
+    keep = ops.PATH
     yield
-    for n, v in keep.items():
-        setattr(ops, n, v)
+    ops.configure(keep)
 
 
 def _coords(name):
@@ -1949,16 +1947,20 @@ def test_unit_conv_without_a_map_of_its_own(cloud, monkeypatch):
 
 def test_dispatch_table_is_the_only_policy():
     """every family the table can name is handled by nn.py / autoencoder.py, every entry has a window, and the text of the two modules
-    holds no row-count literal of its own (the gates live in dispatch.py / ops constants)."""
+    holds no row-count literal of its own (the gates are fields of pathconfig.PathConfig); select() is a pure function of the record it is
+    handed."""
     import inspect, re
     from pcgcv2_amd import dispatch, nn, autoencoder
     src = inspect.getsource(nn.MinkowskiConvolution.forward) + inspect.getsource(autoencoder.InceptionResNet.forward)
     for rule in dispatch.TABLE:
         if rule.op in ('conv3', 'irn', 'down') and rule.family not in ('gather', 'valu', 'unfused'):
             assert f"'{rule.family}'" in src, rule.family
-        assert dispatch._value(rule.rows_min) < dispatch._value(rule.rows_max)
+        assert dispatch._value(rule.rows_min, ops.PATH) < dispatch._value(rule.rows_max, ops.PATH)
     assert not re.search(r'\b(8192|1024|512|110000|40000|150000|0xF0000000)\b', src)
     assert len(dispatch.describe().splitlines()) == len(dispatch.TABLE)
+    off = ops.PATH.replace(ROWS_Q4=False, ROWS_IRN32=False)
+    assert dispatch.select('irn', (32,), 200000, cfg=off).family == 'valu' and dispatch.select('irn', (32,), 200000).family == 'rows32q4'
+    assert ops.PATH.ROWS_Q4 and ops.PATH.ROWS_IRN32                           # (the default record is untouched)
 
 
 def test_ingest_sort_changes_no_byte(sd, sd_np, tmp_path):
