@@ -154,7 +154,7 @@ int pcgc_conv_unit_from_coarse(const int32_t* fine /*[n_fine,4]*/, int64_t n_fin
                                const float* W /*[27,1,Cout]*/, const float* bias, int relu, float* out, int Cout, int out_ld, void* stream);
 /* force a family of pcgc_conv_gather: -1 auto (default) | 0 VALU | 2 MFMA | 6 row-split (A/B tests; bit-identical) */
 int pcgc_set_conv_impl(int impl);
-/* generative transpose 64->32 / 32->16: 1 fp32-MFMA kernel (default), 0 VALU kernel.  Bit-identical. */
+/* generative transpose 64->32 / 32->16: 2 fp32-MFMA kernel with the weight fragments resident in LDS (default), 1 fragments read from L2, 0 VALU kernel.  Bit-identical. */
 int pcgc_set_up2_impl(int mfma);
 /* Fused InceptionResNet block (autoencoder.py:7-57):  out = cat(conv0_1(relu(conv0_0 x)), conv1_2(relu(conv1_1(relu(conv1_0 x))))) + x
  * in two gather passes.  params[10] = {conv0_0.kernel, .bias, conv0_1.kernel, .bias, conv1_0.kernel, .bias, conv1_1.kernel,

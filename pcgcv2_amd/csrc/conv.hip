@@ -1139,7 +1139,124 @@ static int launch_up2_mfma(int64_t n_in, const float* in, int in_ld, const int32
     hipLaunchKernelGGL((k_conv_up2_mfma<CIN, COUT, 1>), dim3(grid_for(n_in, 64)), dim3(256), 0, s, n_in, in, in_ld, rows, W, bias, relu, out);
     return 0;
 }
-static int g_up2_mfma = 1;          // 0 = VALU form (A/B tests)
+// Third form (round 6): the same GEMMs with the eight weight slices staged ONCE per persistent workgroup in LDS as lane-linear B fragments —
+// fragment (k, n, cb): lane (mi, mq) holds W[k][16 cb + 4 jj + mq][16 n + mi], jj = 0..3: one ds_read_b128 per four MFMAs — where the form above
+// reads 4 NB NT dwords per k and wave from L2 (a load latency in front of every k's MFMAs: 52 us for 2.3 GFLOP and 73 MB of output at 64 -> 32,
+// 0.27 of the matrix peak at issued / algorithmic 1.0), and FOUR k per store phase: the 4 COUT floats of (parent, k .. k + 3) are contiguous in
+// memory (512 bytes at 64 -> 32).  Same products in the same order per output element (cb, jj, K index ascending): bit-identical.
+template <int CIN, int COUT, int NW>
+__global__ void __launch_bounds__(NW * 64)
+k_conv_up2_tab(int64_t n_in, const float* __restrict__ in, int in_ld, const int32_t* __restrict__ rows, const float* __restrict__ W,
+               const float* __restrict__ bias, int relu, float* __restrict__ out) {
+    constexpr int NB = CIN / 16, NT = COUT / 16, NFRAG = 8 * NT * NB, LDW = COUT + 4, F4 = COUT / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char up2_lds[];
+    float4* tab = (float4*)up2_lds;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mi = lane & 15, mq = lane >> 4;
+    // W [8][CIN][COUT] read linearly (16 bytes per thread, every load independent of the others), scattered into the fragments: element
+    // (k, ci, co) -> fragment (k, co / 16, ci / 16), lane (mi = co % 16, mq = ci % 4), component (ci % 16) / 4
+    for (int e = threadIdx.x; e < 8 * CIN * F4; e += NW * 64) {
+        const float4 w = ((const float4*)W)[e];
+        const int c4 = e % F4, ci = (e / F4) % CIN, k = e / (F4 * CIN), co = 4 * c4;
+        float* dst = (float*)tab + ((((k * NT + co / 16) * NB + ci / 16) * 64 + (ci & 3) * 16 + (co & 15)) * 4 + ((ci & 15) >> 2));
+        dst[0] = w.x; dst[4] = w.y; dst[8] = w.z; dst[12] = w.w;
+    }
+    __syncthreads();
+    float* stage = (float*)(up2_lds + NFRAG * 1024) + wave * (4 * 16 * LDW);
+    float bv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bv[n] = bias ? bias[16 * n + mi] : 0.0f;
+    const int64_t ntiles = (n_in + 15) >> 4;
+    const int64_t tstep = (int64_t)gridDim.x * NW;
+    // the tile's rows (lane (mi, mq): chunk mq of row mi of each 16-channel block), requested one tile ahead: a wave runs ~2 tiles and two waves
+    // share a SIMD, so a load latency in front of every tile would be a fifth of its time
+    auto fetch = [&](int64_t tile, float4 (&raw)[NB]) {
+        const int64_t p = tile * 16 + mi;
+        const bool ok = tile < ntiles && p < n_in;
+        const int64_t src = (rows && ok) ? (int64_t)rows[p] : p;                  // (rows: input row p is row rows[p] of `in` — a pruned level read in place)
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) raw[cb] = ok ? *(const float4*)(in + src * in_ld + 16 * cb + 4 * mq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    float4 nxt[NB];
+    fetch((int64_t)blockIdx.x * NW + wave, nxt);
+    for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += tstep) {
+        const int64_t p0 = tile * 16;
+        float4 a[NB];
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) { a[cb] = nxt[cb]; lane_transpose4(a[cb]); }
+        fetch(tile + tstep, nxt);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = 4 * kh + kk;
+                f32x4 acc[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) {
+                    float4 b[NT];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) b[n] = tab[((k * NT + n) * NB + cb) * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            const float av = j == 0 ? a[cb].x : (j == 1 ? a[cb].y : (j == 2 ? a[cb].z : a[cb].w));
+                            const float bw = j == 0 ? b[n].x : (j == 1 ? b[n].y : (j == 2 ? b[n].z : b[n].w));
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw, acc[n], 0, 0, 0);
+                        }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        float v = acc[n][r];
+                        if (bias) v = v + bv[n];
+                        if (relu) v = fmaxf(v, 0.0f);
+                        stage[(kk * 16 + 4 * mq + r) * LDW + 16 * n + mi] = v;
+                    }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < (16 * 4 * F4) / 64; ++it) {
+                const int f = lane + 64 * it, pr = f / (4 * F4), rem = f % (4 * F4), kk = rem / F4, c4 = rem % F4;
+                const float4 v = *(const float4*)(stage + (kk * 16 + pr) * LDW + 4 * c4);
+                if (p0 + pr < n_in) *(float4*)(out + (8 * (p0 + pr) + 4 * kh) * COUT + 4 * rem) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+template <int CIN, int COUT>
+static int launch_up2_tab(int64_t n_in, const float* in, int in_ld, const int32_t* rows, const float* W, const float* bias, int relu, float* out,
+                          hipStream_t s) {
+    constexpr int NW = 8, NB = CIN / 16, NT = COUT / 16;
+    constexpr size_t lds = (size_t)8 * NT * NB * 1024 + (size_t)NW * 4 * 16 * (COUT + 4) * 4;
+    static_assert(lds <= 160 * 1024, "table + staging fit one workgroup");
+    auto kern = k_conv_up2_tab<CIN, COUT, NW>;
+    static bool granted[16] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (lds > 48 * 1024 && !granted[dev & 15]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { pcgc_set_error("conv_up2: cannot raise the LDS limit to %zu: %s", lds, hipGetErrorString(e)); return -1; }
+        granted[dev & 15] = true;
+    }
+    static int cus = 0;
+    if (!cus) { hipDeviceProp_t p; cus = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+    const int64_t ntiles = (n_in + 15) >> 4;
+    const int per_cu = (int)((160 * 1024) / lds) > 2 ? 2 : ((160 * 1024) / lds < 1 ? 1 : (int)((160 * 1024) / lds));      // (16 waves per CU at most)
+    int64_t g = (ntiles + NW - 1) / NW;
+    if (g > (int64_t)cus * per_cu) g = (int64_t)cus * per_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NW * 64), lds, s, n_in, in, in_ld, rows, W, bias, relu, out);
+    return 0;
+}
+static int g_up2_mfma = 2;          // 2 = LDS-resident fragment table (default), 1 = fragments from L2, 0 = VALU form (A/B tests)
 extern "C" int pcgc_set_up2_impl(int mfma) { g_up2_mfma = mfma; return 0; }
 
 // the same on a PRUNED level read in place: input row p = row rows[p] of `in` (rows = the survivors' candidate rows, pcgc_topk_select) —
@@ -1150,9 +1267,11 @@ extern "C" int pcgc_conv_up2_gather(int64_t n_in, const float* in, int Cin, int 
     PCGC_REQUIRE(rows != nullptr, "null row list");
     if (n_in == 0) return 0;
     if (!g_up2_mfma || (in_ld & 3) != 0 || (((uintptr_t)in | (uintptr_t)W | (uintptr_t)out | (uintptr_t)bias) & 15) != 0) return -3;
-    if (Cin == 64 && Cout == 32) launch_up2_mfma<64, 32>(n_in, in, in_ld, rows, W, bias, relu, out, S(stream));
-    else if (Cin == 32 && Cout == 16) launch_up2_mfma<32, 16>(n_in, in, in_ld, rows, W, bias, relu, out, S(stream));
+    int rc = 0;
+    if (Cin == 64 && Cout == 32) rc = g_up2_mfma == 2 ? launch_up2_tab<64, 32>(n_in, in, in_ld, rows, W, bias, relu, out, S(stream)) : launch_up2_mfma<64, 32>(n_in, in, in_ld, rows, W, bias, relu, out, S(stream));
+    else if (Cin == 32 && Cout == 16) rc = g_up2_mfma == 2 ? launch_up2_tab<32, 16>(n_in, in, in_ld, rows, W, bias, relu, out, S(stream)) : launch_up2_mfma<32, 16>(n_in, in, in_ld, rows, W, bias, relu, out, S(stream));
     else return -3;
+    if (rc) return rc;
     PCGC_CHECK_LAUNCH("conv_up2_gather");
     return 0;
 }
@@ -1162,6 +1281,8 @@ extern "C" int pcgc_conv_up2(int64_t n_in, const float* in, int Cin, int in_ld, 
     if ((in_ld & 3) == 0 && (((uintptr_t)in | (uintptr_t)W | (uintptr_t)out | (uintptr_t)bias) & 15) == 0) {
         bool done = true;
         if (Cin == 8 && Cout == 64) launch_up2_rows<8, 64>(n_in, in, in_ld, W, bias, relu, out, S(stream));
+        else if (g_up2_mfma == 2 && Cin == 64 && Cout == 32) { if (int rc = launch_up2_tab<64, 32>(n_in, in, in_ld, nullptr, W, bias, relu, out, S(stream))) return rc; }
+        else if (g_up2_mfma == 2 && Cin == 32 && Cout == 16) { if (int rc = launch_up2_tab<32, 16>(n_in, in, in_ld, nullptr, W, bias, relu, out, S(stream))) return rc; }
         else if (g_up2_mfma && Cin == 64 && Cout == 32) launch_up2_mfma<64, 32>(n_in, in, in_ld, nullptr, W, bias, relu, out, S(stream));
         else if (g_up2_mfma && Cin == 32 && Cout == 16) launch_up2_mfma<32, 16>(n_in, in, in_ld, nullptr, W, bias, relu, out, S(stream));
         else if (Cin == 64 && Cout == 32) launch_up2_rows<64, 32>(n_in, in, in_ld, W, bias, relu, out, S(stream));

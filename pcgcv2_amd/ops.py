@@ -591,7 +591,7 @@ def conv_unit_from_coarse(fine, stride_fine, parent_of, coarse_nbr, down, W, bia
 
 
 def set_up2_impl(mfma):
-    """generative transpose conv kernel for 64->32 / 32->16: 1 fp32 MFMA (default), 0 VALU."""
+    """generative transpose conv kernel for 64->32 / 32->16: 2 fp32 MFMA with LDS-resident fragments (default), 1 fragments from L2, 0 VALU."""
     check(lib().pcgc_set_up2_impl(int(mfma)), 'set_up2_impl')
 
 

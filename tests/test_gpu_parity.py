@@ -404,14 +404,14 @@ def test_inception_resnet_rows_quad_block_bit_exact(variant):
         ops.set_rows_q4_variant(0)
 
 
-@pytest.mark.parametrize('impl', [1, 0], ids=['mfma', 'valu'])
+@pytest.mark.parametrize('impl', [2, 1, 0], ids=['mfma_lds_table', 'mfma', 'valu'])
 @pytest.mark.parametrize('cin,cout', [(8, 64), (64, 32), (32, 16)])
 def test_conv_up2_bit_exact(cin, cout, impl):
     ops.set_up2_impl(impl)
     try:
         _conv_up2_case(cin, cout)
     finally:
-        ops.set_up2_impl(1)
+        ops.set_up2_impl(2)
 
 
 def _conv_up2_case(cin, cout):

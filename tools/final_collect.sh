@@ -1,12 +1,11 @@
 set -x
-# Round-end collection on the GPU box: PMC traffic (FETCH_SIZE / WRITE_SIZE passes), rocprofv3 kernel trace of the bench command, SQ counters
-# of the dominant children-level kernels, FETCH_SIZE calibration, and the bench lines of every config.  Everything lands in gpurun_out/final/.
+# Round-end collection on the GPU box: PMC traffic (FETCH_SIZE / WRITE_SIZE passes), rocprofv3 kernel traces of the bench command (frame, sweep, blocks,
+# noisy10), SQ / TCC counters of the children-level and rows kernels, FETCH_SIZE calibration, and the bench lines of every config.  -> gpurun_out/final/
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/final
 timeout 600 bash $R/tools/pmc_traffic.sh > $R/gpurun_out/final/pmc.log 2>&1
 cp $R/profiles/pmc_traffic.json $R/gpurun_out/final/pmc_traffic.json
 cd /tmp && export TMPDIR=/tmp
-# kernel traces of the three bench configurations: summaries of the TIMED steps by timestamp window (at::native / rocclr kernels inside a step included)
 for cfg in frame:10:1 sweep:2:7 blocks:3:8; do
   c=${cfg%%:*}; rest=${cfg#*:}; st=${rest%%:*}; per=${rest##*:}
   cd /tmp
@@ -14,10 +13,10 @@ for cfg in frame:10:1 sweep:2:7 blocks:3:8; do
   cd $R
   python tools/trace_window_summary.py gpurun_out/final/kt_$c/*/*kernel_trace.csv $st $per > gpurun_out/final/kernel_trace_$c.txt 2>&1 || true
   python tools/rocprof_summary.py gpurun_out/final/kt_$c/*/*kernel_stats.csv > gpurun_out/final/kernel_stats_$c.txt 2>&1 || true
+  [ $c = frame ] && python tools/trace_gaps.py gpurun_out/final/kt_$c/*/*kernel_trace.csv > gpurun_out/final/gpu_idle_gaps.txt 2>&1
   find gpurun_out/final/kt_$c -name '*kernel_trace.csv' -delete
 done
 bash tools/fetch_calib.sh > /dev/null 2>&1; cp gpurun_out/fetch_calibration.txt gpurun_out/final/fetch_calibration.txt 2>/dev/null
-# a second geometry family: kernel trace of the frame config on noisy10
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/kt_noisy10 -- python $R/bench.py --workload noisy10 --steps 10 --warmup 2 --no-cpu-baseline --no-events --serving-frames 0 --no-extra > $R/gpurun_out/final/kt_noisy10.log 2>&1
 cd $R
