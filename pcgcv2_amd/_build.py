@@ -14,7 +14,7 @@ OBJ = os.path.join(CSRC, '_obj' + ('_' + VARIANT if VARIANT else ''))
 LIB = os.path.join(HERE, 'libpcgc_hip' + ('_' + VARIANT if VARIANT else '') + '.so')
 SOURCES = ['coords.hip', 'select.hip', 'conv.hip', 'child_conv.hip', 'child_conv32.hip', 'child_cls_w.hip', 'child_irn.hip', 'child_irn_a16.hip', 'child_irn_b16.hip',
            'child_irn_a32.hip', 'child_irn_b32.hip', 'child_q4.hip', 'rows_irn.hip', 'rows_q4.hip', 'conv_packed.hip', 'entropy.hip', 'hostcodec.cpp', 'ply.cpp']
-HEADERS = [os.path.join(CSRC, 'pcgc_common.h'), os.path.join(CSRC, 'mfma_util.h'), os.path.join(CSRC, 'child_kernels.h'), os.path.join(CSRC, 'child_q4.h'), os.path.join(CSRC, 'q4x.h'), os.path.join(HERE, '..', 'include', 'pcgc_hip.h')]
+HEADERS = [os.path.join(CSRC, 'pcgc_common.h'), os.path.join(CSRC, 'mfma_util.h'), os.path.join(CSRC, 'child_kernels.h'), os.path.join(CSRC, 'child_q4.h'), os.path.join(CSRC, 'q4x.h'), os.path.join(CSRC, 'q4x_sched.h'), os.path.join(CSRC, 'rows_q4_policy.h'), os.path.join(HERE, '..', 'include', 'pcgc_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-Wall', '-Wno-unused-result'] + \
         os.environ.get('PCGC_EXTRA_HIPCC_FLAGS', '').split()          # (experiments only, e.g. -DPCGC_EXP_...)
 

@@ -1074,3 +1074,69 @@ def test_dispatch_table_rules_without_a_gpu():
         for k, v in keep.items():
             setattr(ops, k, v)
     assert len(dispatch.describe().splitlines()) == len(dispatch.TABLE)
+
+
+def test_q4x_schedules_counted_waits(tmp_path):
+    """The quad-block engine (csrc/q4x.h) waits for its LDS-DMA gathers with COUNTED `s_waitcnt vmcnt(N)` taken from a compile-time simulation
+    of the VMEM issue order (csrc/q4x_sched.h): N too large is a data race on the gather ring, N too small a stall.  The schedules of every
+    instantiation the library launches are dumped by a g++ build of the same headers and checked against an independent re-simulation of the
+    engine's issue order: every cell gathered exactly once, into a ring slot whose previous rows are already in registers; every wait
+    exactly the number of gather instructions issued after the awaited cell's; counts within vmcnt's 6 bits; per accumulator the weight
+    fragments in the order of the canonical chain (ascending offset, then ascending channel half)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / 'q4x_dump')
+    subprocess.run(['g++', '-std=c++17', '-O1', '-o', exe, os.path.join(root, 'tests', 'native', 'q4x_sched_dump.cpp')], check=True)
+    lines = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.splitlines()
+    assert len(lines) == 6
+    for line in lines:
+        S = json.loads(line)
+        MT, D, nc, groups = S['MT'], S['D'], S['ncells'], S['groups']
+        per = 4 * MT                                              # gather instructions per cell
+        # structure: cells in order, first / last flags
+        cells_of = [g['cell'] for g in groups]
+        assert cells_of == sorted(cells_of) and set(cells_of) == set(range(nc))
+        for i, g in enumerate(groups):
+            assert g['first'] == (i == 0 or groups[i - 1]['cell'] != g['cell'])
+            assert g['last'] == (i == len(groups) - 1 or groups[i + 1]['cell'] != g['cell'])
+        first_group = {g['cell']: i for i, g in reversed(list(enumerate(groups)))}
+        last_group = {g['cell']: i for i, g in enumerate(groups)}
+        # the engine's order: prologue gathers cells 0 .. D-1; per group: (first: the cell's planned gathers) then (last: wait for cell + 1, read it)
+        issued_at, order, ops = {}, [], 0                         # cell -> (group index or -1, ops count after its last instruction)
+        for c in range(min(D, nc)):
+            ops += per; issued_at[c] = (-1, ops); order.append(c)
+        rows_in_regs = {0: -1}                                    # cell -> group index at whose START its rows are requested into registers (-1: prologue)
+        for i, g in enumerate(groups):
+            c = g['cell']
+            if g['first']:
+                for tgt in S['cells'][c][3:5]:
+                    if tgt >= 0:
+                        assert tgt not in issued_at, 'a cell gathered twice'
+                        # its ring slot held cell tgt - D: those rows must be in registers — requested in an EARLIER group and waited for (lgkmcnt(0)) at this group's start
+                        assert tgt - D in rows_in_regs and rows_in_regs[tgt - D] < i
+                        ops += per; issued_at[tgt] = (i, ops); order.append(tgt)
+            if g['last'] and c + 1 < nc:
+                assert c + 1 in issued_at, 'waiting for a cell that was never gathered'
+                want = ops - issued_at[c + 1][1]                  # instructions issued after the awaited cell's last one
+                assert g['vm_wait'] == want, (S['name'], MT, D, i, g['vm_wait'], want)
+                assert 0 <= want < 64
+                rows_in_regs[c + 1] = i
+        assert sorted(issued_at) == list(range(nc))
+        # chain order per accumulator: (offset, half) ascending; slots of one group ascending in (row quarter) per accumulator
+        seen = {}
+        for g in groups:
+            kp, _, byte_off = S['cells'][g['cell']][:3]
+            for e in range(4):
+                if g['acc'][e] < 0:
+                    continue
+                key = (kp, byte_off, g['rowq'][e])
+                assert seen.get(g['acc'][e], (-1, -1, -1)) < key, (S['name'], g)
+                seen[g['acc'][e]] = key
+        if S['name'] == 'A32':
+            assert len(groups) == 112 and nc == 54 and sorted(seen) == [0, 1, 2, 3]
+            assert [g['frag'] for g in groups if g['acc'][0] == 0] == [(k * 2 + h) * 2 for k in range(27) for h in range(2)]
+            assert [g['frag'] for g in groups if g['acc'][0] == 3] == [(27 * 2 + h) * 2 + 1 for h in range(2)]
+        else:
+            assert len(groups) == 81 and nc == 27 and sorted(seen) == [0, 1, 2, 3, 4, 5]
+            assert all(g['frag'] == 3 * g['cell'] + j for g, j in zip(groups, [0, 1, 2] * 27))
