@@ -350,6 +350,10 @@ int launch_rows(K kern, int nw, size_t lds, const int32_t* nbr, int64_t n, const
 
 }  // namespace
 
+// C = 32 levels of up to this many rows (one round of 8-wave workgroups on 256 CUs) take the deep-ring instantiations: 18.7 k rows 31 -> 20 us per
+// block, 4.6 k rows 25 -> 19; at 55 k rows (two rounds) the 16-wave form is ahead, 34 vs 36 (tools/rows32_small_ab.py)
+constexpr int64_t ROWS32_DEEP_MAX = 32768;
+
 // Fused InceptionResNet passes at C = 64 on a plain level through its own k3 map nbr [27][n].  pass 1 (A): in = x [n, 64] -> out = t [n, 32];
 // pass 2 (B): in = t -> out [n, 64] with the residual x.  tables: ops.child_irn_tables(params) (112 KB / 83 KB).
 extern "C" int pcgc_irn_rows_pass(const int32_t* nbr, int64_t n, int C, int pass, const float* in, int in_ld, const float* table,
@@ -372,7 +376,11 @@ extern "C" int pcgc_irn_rows_pass(const int32_t* nbr, int64_t n, int C, int pass
     int rc;
     static ChildLdsGrant granted[8];
 #define ROWS_GO(SLOT, KERN, NW_, RINGBYTES) launch_rows(KERN, NW_, (size_t)table_bytes + (size_t)(NW_) * (RINGBYTES), nbr, n, in, in_ld, table, (int)table_bytes, ep, s, granted[SLOT])
-    if (C == 32) {                                             // 54 KB / 27.5 KB tables; 16 waves, ring slots of 2 KB / 1 KB (pass B: scratch 2.5 KB)
+    if (C == 32 && n <= ROWS32_DEEP_MAX) {
+        // small levels (the encoder's stride-8 level: 1 171 sixteen-row tiles for 4 096 wave slots — every wave runs ONE tile, and the launch takes a
+        // tile's chain of 27 gather latencies): half the waves, rings two to four times as deep (LDS is plentiful when every CU holds one workgroup)
+        rc = pass == 1 ? ROWS_GO(4, (k_rows_irn_a32<8, 4>), 8, 4 * 2048) : ROWS_GO(5, (k_rows_irn_b32<8, 8>), 8, 8 * 1024);
+    } else if (C == 32) {                                      // 54 KB / 27.5 KB tables; 16 waves, ring slots of 2 KB / 1 KB (pass B: scratch 2.5 KB)
         rc = pass == 1 ? ROWS_GO(0, (k_rows_irn_a32<16, 2>), 16, 2 * 2048) : ROWS_GO(1, (k_rows_irn_b32<16, 4>), 16, 4 * 1024);
     } else if (pass == 1) {                                    // 112 KB table: 48 KB for the rings (12 waves, two 2 KB slots each)
         rc = ROWS_GO(2, (k_rows_irn_a64<12, 2, RowsPassA64H>), 12, 2 * 2048);
@@ -437,7 +445,7 @@ extern "C" int pcgc_conv_down_rows(const int32_t* down, int64_t n_coarse, const 
     } while (0)
     if (Cin == 16) DOWN_GO(0, 1, 2, 16, 2);
     else if (Cin == 32) DOWN_GO(1, 2, 4, 12, 2);
-    else DOWN_GO(2, 4, 2, 12, 1);
+    else DOWN_GO(2, 4, 2, 8, 2);            // (eight waves with two ring slots each: 16.3 -> 12.2 us at 18.7 k coarse rows, 26 -> 23 at 55 k, against twelve waves with one)
 #undef DOWN_GO
     if (rc) return rc;
     PCGC_CHECK_LAUNCH("conv_down_rows");
